@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE -- generates tests/golden/*.npz from the REAL reference.
+
+Run in the build container only (needs /root/reference and `make -C oracle ref`):
+
+    python oracle/make_golden.py
+
+What it does
+  * runs oracle/_ref/cpu (= /root/reference/cpu_launcher.cpp built exactly as the
+    reference Makefile:38 says) as `cpu 1 0` in a scratch directory, once with the
+    cat OBJ reachable and once without (spheres-only), decodes the PNGs and stores
+    the RGB bytes + SHA-256;
+  * runs oracle/_ref/ref_harness (oracle/ref_harness.cpp + the reference TU) to dump
+    the parsed mesh, the BVH, primitive known-answer tests, float renders (direct
+    lighting, and mt19937(0)-replayable stochastic renders) and a statistical mean;
+  * packs everything as numpy .npz (no pickles) under tests/golden/.
+
+The fixtures are data: inputs and the reference's outputs.  No reference source
+text is stored.  The cat mesh (cadnav.com, see tests/golden/README.md for the
+attribution its readme asks for) is stored as the float32 vertex array and the
+int32 index array the reference's own parser produced.
+"""
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+from PIL import Image
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get("RT_REFERENCE", "/root/reference")
+GOLD = os.path.join(ROOT, "tests", "golden")
+CPU = os.path.join(HERE, "_ref", "cpu")
+HARNESS = os.path.join(HERE, "_ref", "ref_harness")
+
+
+def run(cmd, cwd, env=None):
+    e = dict(os.environ)
+    if env:
+        e.update(env)
+    r = subprocess.run(cmd, cwd=cwd, env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        print(r.stdout)
+        raise SystemExit(f"{cmd} failed with {r.returncode}")
+    return r.stdout
+
+
+def f32(path, cols=None):
+    a = np.fromfile(path, dtype="<f4")
+    return a.reshape(-1, cols) if cols else a
+
+
+def i32(path, cols=None):
+    a = np.fromfile(path, dtype="<i4")
+    return a.reshape(-1, cols) if cols else a
+
+
+def norm_rows(v):
+    """float32 normalisation in the reference's operation order (cpu:58-63)."""
+    v = v.astype(np.float32)
+    n2 = (v[:, 0] * v[:, 0] + v[:, 1] * v[:, 1]).astype(np.float32) + v[:, 2] * v[:, 2]
+    n = np.sqrt(n2.astype(np.float32)).astype(np.float32)
+    return (v / n[:, None]).astype(np.float32)
+
+
+def make_kat_inputs(rng, verts, tris):
+    cam = np.array([0, 0, 55], np.float32)
+    # ---- spheres: [C R O u]
+    walls = np.array([[0, 0, -1000, 940], [0, -1000, 0, 990], [0, 1000, 0, 940], [-1000, 0, 0, 940],
+                      [1000, 0, 0, 940], [0, 0, 1000, 940], [0, 0, 0, 10], [-20, 0, 0, 10], [20, 0, 0, 9]], np.float32)
+    rows = []
+    for _ in range(4000):
+        s = walls[rng.integers(len(walls))]
+        O = cam if rng.random() < 0.5 else rng.uniform(-50, 50, 3).astype(np.float32)
+        u = norm_rows(rng.normal(size=(1, 3)))[0]
+        rows.append(np.concatenate([s, O, u]))
+    for s in walls[6:]:  # tangent / through-centre / inside / behind
+        C, Rr = s[:3], s[3]
+        for O in (cam, C.copy(), (C + np.array([0, 0, Rr / 2], np.float32)).astype(np.float32)):
+            for tgt in (C, C + np.array([Rr, 0, 0], np.float32), C + np.array([0, Rr, 0], np.float32),
+                        C + np.array([Rr * 1.0000001, 0, 0], np.float32)):
+                d = (tgt - O).astype(np.float32)
+                if not d.any():
+                    d = np.array([0, 0, -1], np.float32)
+                u = norm_rows(d[None])[0]
+                rows.append(np.concatenate([s, O, u]))
+                rows.append(np.concatenate([s, O, -u]))
+    sph = np.array(rows, np.float32)
+    # ---- boxes: [mn mx O u]
+    rows = []
+    for _ in range(6000):
+        a = rng.uniform(-30, 30, 3); b = a + rng.uniform(0, 20, 3) * (rng.random(3) > 0.1)
+        O = cam if rng.random() < 0.5 else rng.uniform(-60, 60, 3)
+        u = norm_rows(rng.normal(size=(1, 3)))[0].astype(np.float64)
+        if rng.random() < 0.7:   # aim at a point in (or just around) the box so that hits are common
+            tgt = a + (b - a) * rng.uniform(-0.15, 1.15, 3)
+            u = norm_rows((tgt - O)[None])[0].astype(np.float64)
+        k = rng.random()
+        if k < 0.15:
+            u[rng.integers(3)] = 0.0  # axis-parallel slab => inf / nan
+        if k < 0.03:
+            u[:] = 0; u[rng.integers(3)] = 1.0
+        if 0.15 <= k < 0.25:  # origin exactly on a slab plane with zero direction component => 0/0
+            ax = rng.integers(3); O = np.array(O, np.float64); O[ax] = a[ax]; u[ax] = 0.0
+        if 0.25 <= k < 0.35:  # aim exactly at a corner
+            corner = np.where(rng.random(3) < 0.5, a, b)
+            u = norm_rows((corner - O)[None])[0]
+        rows.append(np.concatenate([a, b, O, u]))
+    box = np.array(rows, np.float32)
+    # ---- triangles: [A B C O u]
+    rows = []
+    for _ in range(6000):
+        A, B, C = rng.uniform(-20, 20, (3, 3)).astype(np.float32)
+        O = cam if rng.random() < 0.5 else rng.uniform(-60, 60, 3).astype(np.float32)
+        k = rng.random()
+        if k < 0.5:   # aim inside the triangle
+            w = rng.dirichlet([1, 1, 1]); tgt = w[0] * A + w[1] * B + w[2] * C
+        elif k < 0.6:  # exactly at a vertex
+            tgt = (A, B, C)[rng.integers(3)]
+        elif k < 0.75:  # exactly on an edge
+            s = rng.random(); tgt = s * A + (1 - s) * B
+        else:
+            tgt = rng.uniform(-25, 25, 3)
+        u = norm_rows((np.asarray(tgt, np.float32) - O)[None])[0]
+        if k > 0.97:   # ray parallel to the plane: u = e1 direction
+            u = norm_rows((B - A)[None])[0]
+        if k > 0.985:  # degenerate triangle
+            C = A.copy()
+        rows.append(np.concatenate([A, B, C, O, u]))
+    # real cat triangles hit through vertices / edge midpoints from the camera
+    for ti in rng.integers(0, len(tris), 800):
+        A, B, C = verts[tris[ti]]
+        for tgt in (A, ((A + B) / 2).astype(np.float32), ((A + B + C) / 3).astype(np.float32)):
+            u = norm_rows((tgt - cam)[None])[0]
+            rows.append(np.concatenate([A, B, C, cam, u]))
+    tri = np.array(rows, np.float32)
+    # ---- whole mesh: [O u]
+    rows = []
+    L = np.array([-10, 20, 40], np.float32)
+    for _ in range(3000):
+        tgt = verts[rng.integers(len(verts))] + rng.normal(scale=0.3, size=3).astype(np.float32)
+        u = norm_rows((tgt - cam)[None])[0]
+        rows.append(np.concatenate([cam, u]))
+    for vi in rng.integers(0, len(verts), 600):   # exactly through mesh vertices
+        u = norm_rows((verts[vi] - cam)[None])[0]
+        rows.append(np.concatenate([cam, u]))
+    for _ in range(2000):                          # shadow-like rays towards the light
+        O = rng.uniform([-30, -10, -10], [30, 30, 20]).astype(np.float32)
+        u = norm_rows((L - O)[None])[0]
+        rows.append(np.concatenate([O, u]))
+    for _ in range(1000):                          # axis-parallel and random
+        u = np.zeros(3, np.float32); u[rng.integers(3)] = rng.choice([-1, 1])
+        O = rng.uniform(-30, 30, 3).astype(np.float32)
+        rows.append(np.concatenate([O, u]))
+    mesh = np.array(rows, np.float32)
+    return sph, box, tri, mesh
+
+
+def main():
+    if not (os.path.exists(CPU) and os.path.exists(HARNESS)):
+        raise SystemExit("build the reference first: make -C oracle ref")
+    os.makedirs(GOLD, exist_ok=True)
+    tmp = tempfile.mkdtemp(prefix="rt_golden_")
+    try:
+        with_cat = os.path.join(tmp, "with_cat"); os.makedirs(with_cat)
+        no_cat = os.path.join(tmp, "no_cat"); os.makedirs(no_cat)
+        os.symlink(os.path.join(REF, "cadnav.com_model"), os.path.join(with_cat, "cadnav.com_model"))
+
+        # 1. the unmodified reference binary, deterministic setting `1 0`
+        imgs = {}
+        for name, cwd in (("cat", with_cat), ("spheres", no_cat)):
+            run([CPU, "1", "0"], cwd, {"OMP_NUM_THREADS": "8"})
+            rgb = np.array(Image.open(os.path.join(cwd, "image.png")).convert("RGB"), np.uint8)
+            imgs[name] = rgb
+            print(name, rgb.shape, hashlib.sha256(rgb.tobytes()).hexdigest())
+        np.savez_compressed(os.path.join(GOLD, "ref_cpu_png_1_0.npz"),
+                            cat=imgs["cat"], spheres=imgs["spheres"],
+                            cat_sha256=np.frombuffer(hashlib.sha256(imgs["cat"].tobytes()).digest(), np.uint8),
+                            spheres_sha256=np.frombuffer(hashlib.sha256(imgs["spheres"].tobytes()).digest(), np.uint8))
+
+        # 2. mesh + BVH as the reference parses / builds them
+        md = os.path.join(tmp, "mesh"); os.makedirs(md)
+        print(run([HARNESS, "mesh", md], with_cat).strip())
+        verts = f32(os.path.join(md, "vertices.f32"), 3)
+        tri_obj = i32(os.path.join(md, "tri_obj_order.i32"), 3)
+        tri_bvh = i32(os.path.join(md, "tri_bvh_order.i32"), 3)
+        arr10 = f32(os.path.join(md, "bvh_arr10.f32"), 10)
+        np.savez_compressed(os.path.join(GOLD, "cat_mesh.npz"), vertices=verts, tri_obj_order=tri_obj,
+                            tri_bvh_order=tri_bvh, bvh_arr10=arr10)
+
+        # 3. primitive KATs
+        rng = np.random.default_rng(20261004)
+        sph, box, tri, mesh = make_kat_inputs(rng, verts, tri_obj)
+        kd = os.path.join(tmp, "kat"); os.makedirs(kd)
+        sph.tofile(os.path.join(kd, "kat_sphere_in.f32")); box.tofile(os.path.join(kd, "kat_box_in.f32"))
+        tri.tofile(os.path.join(kd, "kat_tri_in.f32")); mesh.tofile(os.path.join(kd, "kat_mesh_in.f32"))
+        run([HARNESS, "kat", kd], with_cat)
+        np.savez_compressed(os.path.join(GOLD, "kat.npz"),
+                            sphere_in=sph, sphere_out=f32(os.path.join(kd, "kat_sphere_out.f32"), 5),
+                            box_in=box, box_out=f32(os.path.join(kd, "kat_box_out.f32")),
+                            tri_in=tri, tri_out=f32(os.path.join(kd, "kat_tri_out.f32"), 5),
+                            mesh_in=mesh, mesh_out=f32(os.path.join(kd, "kat_mesh_out.f32"), 5))
+
+        # 4. float renders through the reference's Scene::getColor (single thread, mt19937(0))
+        renders = [  # name, scene, W, H, spp, bounce, stride
+            ("cpu_512_direct", "cpu", 512, 512, 1, 0, 4),
+            ("cpu_1080p_direct", "cpu", 1920, 1080, 1, 0, 8),
+            ("spheres_512_direct", "spheres", 512, 512, 1, 0, 4),
+            ("cpu_512_b3_spp2", "cpu", 512, 512, 2, 3, 8),
+            ("demo10_256_b5", "demo10", 256, 256, 1, 5, 2),
+            ("demo10_256_direct", "demo10", 256, 256, 1, 0, 2),
+        ]
+        out = {}
+        for name, scene, W, H, spp, b, stride in renders:
+            base = os.path.join(tmp, name)
+            run([HARNESS, "render", scene, str(W), str(H), str(spp), str(b), str(stride), base], with_cat,
+                {"OMP_NUM_THREADS": "1"})
+            nh, nw = (H + stride - 1) // stride, (W + stride - 1) // stride
+            out[name + "_color"] = f32(base + ".color.f32").reshape(nh, nw, 3)
+            out[name + "_hit"] = f32(base + ".hit.f32").reshape(nh, nw, 7)
+            out[name + "_cfg"] = np.array([W, H, spp, b, stride], np.int32)
+            print("render", name, out[name + "_color"].shape)
+        np.savez_compressed(os.path.join(GOLD, "ref_render.npz"), **out)
+
+        # 5. statistical golden of the stochastic estimator (reference RNG, 8 threads)
+        base = os.path.join(tmp, "stat")
+        W, H, spp, b, stride = 512, 512, 256, 3, 8
+        run([HARNESS, "stat", str(W), str(H), str(spp), str(b), str(stride), base], with_cat, {"OMP_NUM_THREADS": "8"})
+        nh, nw = (H + stride - 1) // stride, (W + stride - 1) // stride
+        np.savez_compressed(os.path.join(GOLD, "ref_stat.npz"),
+                            mean=f32(base + ".mean.f32").reshape(nh, nw, 3),
+                            sem=f32(base + ".sem.f32").reshape(nh, nw, 3),
+                            cfg=np.array([W, H, spp, b, stride], np.int32))
+        print("stat done")
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    for fn in sorted(os.listdir(GOLD)):
+        print(f"{os.path.getsize(os.path.join(GOLD, fn)):9d}  {fn}")
+
+
+if __name__ == "__main__":
+    sys.exit(main())
