@@ -1,0 +1,157 @@
+/*
+ * raytrace_hip.h -- C-ABI of libraytrace_hip.so: the MI355X (gfx950) render path.
+ *
+ * Drop-in boundary for the per-pixel render of souhhcong/RaytracingGPU.  The
+ * reference has no library interface: its render path is the CUDA sequence in
+ * optimized.cu main() --
+ *     cudaMalloc/cudaMemcpy of arr_bvh, indices, vertices      (optimized.cu:811-826)
+ *     KernelLaunch<<<H*W/128,128,smem>>>(d_colors, W, H, num_rays, num_bounce,
+ *                  d_indices, ni, d_vertices, nv, d_arr_bvh)   (optimized.cu:828-847)
+ *     cudaDeviceSynchronize + cudaMemcpy D2H of the image      (optimized.cu:849-856)
+ * -- and, on the CPU, the pixel loop of cpu_launcher.cpp:693-718.  Each entry point
+ * below names the reference lines it replaces.  Plain pointers and sizes only; no
+ * HIP, torch or C++ types cross this boundary.  Every function returns RT_OK (0) or
+ * a negative rt_status, never exits and never throws (the reference's gpuErrchk
+ * prints and calls exit(), optimized.cu:24-30).
+ *
+ * Result contract: for sigma == 0 the linear float colour written by rt_render* is
+ * bit-identical to cpu_launcher.cpp's Scene::getColor average (color_avg, cpu:713)
+ * when the reference's uniform() is replaced by the counter RNG of DESIGN.md; the
+ * 8-bit image is cpu:714-716.  There is no CPU fallback in this library.
+ */
+#ifndef RAYTRACE_HIP_H
+#define RAYTRACE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+#define RT_MAX_SPHERES 16      /* reference: Geometry* objects[10], optimized.cu:663 */
+#define RT_MAX_SEGMENTS 16     /* reference: MAX_RAY_DEPTH 10, optimized.cu:22       */
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,       /* bad argument (message in rt_last_error)            */
+    RT_ERR_NO_DEVICE = -2,     /* no gfx950 device / HIP runtime unusable            */
+    RT_ERR_HIP = -3,           /* a HIP call failed (message in rt_last_error)       */
+    RT_ERR_NO_SCENE = -4,      /* render before rt_scene_upload                      */
+    RT_ERR_UNSUPPORTED = -5    /* e.g. LDS variant that does not fit the mesh        */
+} rt_status;
+
+/* kernel variants (BASELINE.json configs 3/4); all produce identical results */
+typedef enum rt_variant {
+    RT_VARIANT_AUTO = 0,       /* library picks the fastest variant that fits       */
+    RT_VARIANT_GLOBAL = 1,     /* SoA nodes + packed triangles read from HBM/L2      */
+    RT_VARIANT_LDS_VERTS = 2,  /* vertex array staged in LDS per workgroup
+                                  (different-versions/optimized_vertices-in-shared.cu:681-686) */
+    RT_VARIANT_LDS_TOP = 3,    /* + top BVH levels staged in LDS                     */
+    RT_VARIANT_LDS_ALL = 4     /* whole BVH + vertices + indices resident in LDS     */
+} rt_variant;
+
+typedef struct rt_ctx rt_ctx;
+
+/* Sphere(C, R, albedo, mirror, n_in, n_out): cpu_launcher.cpp:505-511, Geometry cpu:106-118 */
+typedef struct rt_sphere {
+    float   center[3];
+    float   radius;
+    float   albedo[3];
+    int32_t mirror;
+    float   in_refraction_index;
+    float   out_refraction_index;
+} rt_sphere;
+
+/* The mesh exactly as optimized.cu hands it to KernelLaunch (optimized.cu:670, 811-826):
+ * Vector vertices[nv] (3 x f32), TriangleIndices indices[nt] in BVH order (only
+ * vtxi,vtxj,vtxk are read, optimized.cu:271) and the bvhTreeToArray float[10] node array
+ * (optimized.cu:512-534: [0]=left [1]=right(-1 leaf) [2..4]=mn [5..7]=mx [8]=tri_start [9]=tri_end). */
+typedef struct rt_mesh {
+    const float   *vertices;       /* n_vertices * 3                                          */
+    int32_t        n_vertices;
+    const int32_t *indices;        /* vtxi,vtxj,vtxk of triangle t at indices[t*index_stride] */
+    int32_t        index_stride;   /* 3 = compact, 10 = sizeof(TriangleIndices)/4             */
+    int32_t        n_triangles;
+    const float   *bvh_arr10;      /* n_nodes * 10                                            */
+    int32_t        n_nodes;
+    float          albedo[3];      /* mesh_ptr->albedo, cpu:683                               */
+    int32_t        object_slot;    /* position in Scene::objects (cpu_launcher: 6 = last,
+                                      optimized.cu:690-700: 1); decides exact-tie order cpu:554 */
+} rt_mesh;
+
+/* Scene::L / Scene::intensity (cpu:650-651), camera C and alpha (cpu:666,691) */
+typedef struct rt_light  { float position[3]; float intensity; } rt_light;
+typedef struct rt_camera { float position[3]; float fov; } rt_camera;
+
+typedef struct rt_params {
+    int32_t  width, height;        /* W,H (reference: 512, cpu:661-662)                       */
+    int32_t  num_rays;             /* argv[1], cpu:659                                        */
+    int32_t  num_bounce;           /* argv[2], cpu:659                                        */
+    int32_t  depth_convention;     /* 0: cpu_launcher, b => b+1 segments (cpu:567)
+                                      1: optimized.cu, b => b segments (optimized.cu:566)     */
+    float    sigma;                /* anti-aliasing jitter: 0 (cpu:704) / 0.2 (optimized.cu:753) */
+    float    eps;                  /* 1e-3 (cpu:575) / 1e-4 (optimized.cu:575)                */
+    float    tri_tmin;             /* 1e-4f (cpu:301) / 0 (optimized.cu:275)                  */
+    uint32_t seed;                 /* counter RNG seed; optimized.cu:745 uses 123456          */
+    int32_t  variant;              /* rt_variant                                              */
+} rt_params;
+
+/* Which rows a call renders.  Local row r (0 <= r < n_rows) is image row
+ *     row0 + (r / tile_rows) * tile_rows * tile_step + (r % tile_rows).
+ * Contiguous range [a,b): {a, b-a, b-a, 1}.  Interleaved tiles of rank k of G
+ * (SURVEY 8e): {k*R, n_local_rows, R, G}. */
+typedef struct rt_rows {
+    int32_t row0;
+    int32_t n_rows;
+    int32_t tile_rows;
+    int32_t tile_step;
+} rt_rows;
+
+typedef struct rt_stats {
+    float    kernel_ms;            /* HIP-event time of the last render kernel                */
+    float    tonemap_ms;           /* of the last tonemap kernel (0 if none)                  */
+    uint64_t pixels;               /* pixels of the last render call                          */
+    int32_t  variant;              /* variant that actually ran                               */
+    int32_t  lds_bytes;            /* dynamic + static LDS per workgroup                      */
+    int32_t  block_threads;
+    int32_t  grid_blocks;
+} rt_stats;
+
+/* --- device / context -------------------------------------------------------- */
+/* replaces the implicit CUDA device 0 of optimized.cu */
+int rt_abi_version(void);
+int rt_device_count(int *count);
+int rt_ctx_create(rt_ctx **ctx, int device_id);
+int rt_ctx_destroy(rt_ctx *ctx);
+const char *rt_last_error(const rt_ctx *ctx);          /* ctx may be NULL: last global error */
+int rt_device_name(const rt_ctx *ctx, char *buf, size_t buflen);
+
+/* --- scene upload: replaces optimized.cu:811-826 (H2D of arr_bvh/indices/vertices)
+ *     and the in-kernel scene construction optimized.cu:679-726 --------------------
+ * All host arrays are copied; the caller keeps ownership.  mesh may be NULL
+ * (spheres only: what the reference renders when the OBJ is missing, cpu:322-325). */
+int rt_scene_upload(rt_ctx *ctx, const rt_sphere *spheres, int n_spheres, const rt_mesh *mesh,
+                    const rt_light *light, const rt_camera *camera);
+
+/* --- render: replaces KernelLaunch + cudaDeviceSynchronize + D2H, optimized.cu:828-856,
+ *     i.e. the pixel loop cpu:693-713.  Output: n_rows*width float4, .xyz = linear
+ *     colour average (color_avg, cpu:713), .w = rays traced for the pixel. ------- */
+int rt_render(rt_ctx *ctx, const rt_params *p, int row_begin, int row_end, float *out_rgba_host);
+/* same, into device memory, asynchronous on `stream` (a hipStream_t, NULL = the
+ * context's own stream); rows may be interleaved tiles (multi-GPU) */
+int rt_render_device(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *out_rgba_dev, void *stream);
+
+/* --- tonemap: cpu:714-716 (gamma 1/2.2 in binary64, min 255, truncate) ------- */
+int rt_tonemap_device(rt_ctx *ctx, const void *rgba_dev, int64_t n_pixels, void *rgb8_dev, void *stream);
+/* render + tonemap + D2H of the interleaved RGB8 image (what stbi_write_png gets, cpu:719) */
+int rt_render_rgb8(rt_ctx *ctx, const rt_params *p, int row_begin, int row_end, uint8_t *out_rgb8_host);
+
+int rt_synchronize(rt_ctx *ctx);
+int rt_get_stats(rt_ctx *ctx, rt_stats *stats);        /* waits for the last render to finish */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAYTRACE_HIP_H */

@@ -1,0 +1,210 @@
+"""ctypes binding of libraytrace_hip.so (include/raytrace_hip.h).
+
+Plumbing only: the render path is the HIP library.  There is no CPU fallback --
+if the shared library is missing or no gfx950 device is visible this module
+raises instead of rendering with something else.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libraytrace_hip.so")
+
+RT_OK = 0
+VARIANT_AUTO, VARIANT_GLOBAL, VARIANT_LDS_VERTS, VARIANT_LDS_TOP, VARIANT_LDS_ALL = range(5)
+VARIANTS = {"auto": 0, "global": 1, "lds_verts": 2, "lds_top": 3, "lds_all": 4}
+
+# every symbol include/raytrace_hip.h declares (tests check the .so exports each)
+EXPORTS = ["rt_abi_version", "rt_device_count", "rt_ctx_create", "rt_ctx_destroy", "rt_last_error",
+           "rt_device_name", "rt_scene_upload", "rt_render", "rt_render_device", "rt_tonemap_device",
+           "rt_render_rgb8", "rt_synchronize", "rt_get_stats"]
+
+
+class RtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libraytrace_hip: status {code}: {msg}")
+        self.code = code
+
+
+class Sphere(C.Structure):
+    _fields_ = [("center", C.c_float * 3), ("radius", C.c_float), ("albedo", C.c_float * 3), ("mirror", C.c_int32),
+                ("in_refraction_index", C.c_float), ("out_refraction_index", C.c_float)]
+
+
+class Mesh(C.Structure):
+    _fields_ = [("vertices", C.POINTER(C.c_float)), ("n_vertices", C.c_int32),
+                ("indices", C.POINTER(C.c_int32)), ("index_stride", C.c_int32), ("n_triangles", C.c_int32),
+                ("bvh_arr10", C.POINTER(C.c_float)), ("n_nodes", C.c_int32),
+                ("albedo", C.c_float * 3), ("object_slot", C.c_int32)]
+
+
+class Light(C.Structure):
+    _fields_ = [("position", C.c_float * 3), ("intensity", C.c_float)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("position", C.c_float * 3), ("fov", C.c_float)]
+
+
+class Params(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("num_rays", C.c_int32), ("num_bounce", C.c_int32),
+                ("depth_convention", C.c_int32), ("sigma", C.c_float), ("eps", C.c_float), ("tri_tmin", C.c_float),
+                ("seed", C.c_uint32), ("variant", C.c_int32)]
+
+
+class Rows(C.Structure):
+    _fields_ = [("row0", C.c_int32), ("n_rows", C.c_int32), ("tile_rows", C.c_int32), ("tile_step", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("kernel_ms", C.c_float), ("tonemap_ms", C.c_float), ("pixels", C.c_uint64), ("variant", C.c_int32),
+                ("lds_bytes", C.c_int32), ("block_threads", C.c_int32), ("grid_blocks", C.c_int32)]
+
+
+_lib = None
+
+
+def load():
+    """Load libraytrace_hip.so; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.rt_abi_version.restype = C.c_int
+    L.rt_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.rt_ctx_create.argtypes = [C.POINTER(vp), C.c_int]
+    L.rt_ctx_destroy.argtypes = [vp]
+    L.rt_last_error.argtypes = [vp]
+    L.rt_last_error.restype = C.c_char_p
+    L.rt_device_name.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.rt_scene_upload.argtypes = [vp, C.POINTER(Sphere), C.c_int, C.POINTER(Mesh), C.POINTER(Light), C.POINTER(Camera)]
+    L.rt_render.argtypes = [vp, C.POINTER(Params), C.c_int, C.c_int, C.POINTER(C.c_float)]
+    L.rt_render_device.argtypes = [vp, C.POINTER(Params), C.POINTER(Rows), vp, vp]
+    L.rt_tonemap_device.argtypes = [vp, vp, C.c_int64, vp, vp]
+    L.rt_render_rgb8.argtypes = [vp, C.POINTER(Params), C.c_int, C.c_int, C.POINTER(C.c_uint8)]
+    L.rt_synchronize.argtypes = [vp]
+    L.rt_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    _lib = L
+    return L
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = load().rt_device_count(C.byref(n))
+    return n.value if rc == RT_OK else 0
+
+
+def make_params(width, height, num_rays=1, num_bounce=0, depth_convention=0, sigma=0.0, eps=1e-3, tri_tmin=1e-4,
+                seed=123456, variant="auto"):
+    p = Params()
+    p.width, p.height, p.num_rays, p.num_bounce = width, height, num_rays, num_bounce
+    p.depth_convention, p.sigma, p.eps, p.tri_tmin, p.seed = depth_convention, sigma, eps, tri_tmin, seed
+    p.variant = VARIANTS[variant] if isinstance(variant, str) else int(variant)
+    return p
+
+
+def interleaved_rows(height, tile_rows, rank, world):
+    """Row tiles k*world+rank of `tile_rows` rows each.  Returns (Rows, image row indices)."""
+    n_tiles = (height + tile_rows - 1) // tile_rows
+    mine = list(range(rank, n_tiles, world))
+    idx = np.concatenate([np.arange(t * tile_rows, min((t + 1) * tile_rows, height)) for t in mine]) if mine \
+        else np.zeros(0, np.int64)
+    r = Rows(rank * tile_rows, len(idx), tile_rows, world)
+    return r, idx
+
+
+class Context:
+    """One rt_ctx = one GPU.  Methods mirror the C-ABI one to one."""
+
+    def __init__(self, device_id=0):
+        self._L = load()
+        self._h = C.c_void_p()
+        rc = self._L.rt_ctx_create(C.byref(self._h), device_id)
+        if rc != RT_OK:
+            raise RtError(rc, self._L.rt_last_error(None).decode())
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.rt_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc != RT_OK:
+            raise RtError(rc, self._L.rt_last_error(self._h).decode())
+
+    @property
+    def device_name(self):
+        buf = C.create_string_buffer(256)
+        self._check(self._L.rt_device_name(self._h, buf, 256))
+        return buf.value.decode()
+
+    def scene_upload(self, spheres, mesh=None, light=((-10.0, 20.0, 40.0), 3e10), camera=((0.0, 0.0, 55.0), None)):
+        """spheres: iterable of (center, radius, albedo[, mirror, n_in, n_out]);
+        mesh: dict(vertices, indices, bvh_arr10, albedo, object_slot) with the reference's array layouts."""
+        arr = (Sphere * max(len(spheres), 1))()
+        for i, s in enumerate(spheres):
+            c, r, a = s[0], s[1], s[2]
+            arr[i].center[:] = c
+            arr[i].radius = r
+            arr[i].albedo[:] = a
+            arr[i].mirror = int(s[3]) if len(s) > 3 else 0
+            arr[i].in_refraction_index = s[4] if len(s) > 4 else 1.0
+            arr[i].out_refraction_index = s[5] if len(s) > 5 else 1.0
+        m = None
+        if mesh is not None:
+            v = np.ascontiguousarray(mesh["vertices"], np.float32).reshape(-1, 3)
+            ix = np.ascontiguousarray(mesh["indices"], np.int32)
+            stride = ix.shape[1] if ix.ndim == 2 else 3
+            bv = np.ascontiguousarray(mesh["bvh_arr10"], np.float32).reshape(-1, 10)
+            m = Mesh()
+            m.vertices = v.ctypes.data_as(C.POINTER(C.c_float)); m.n_vertices = len(v)
+            m.indices = ix.ctypes.data_as(C.POINTER(C.c_int32)); m.index_stride = stride
+            m.n_triangles = ix.size // stride
+            m.bvh_arr10 = bv.ctypes.data_as(C.POINTER(C.c_float)); m.n_nodes = len(bv)
+            m.albedo[:] = mesh.get("albedo", (0.25, 0.25, 0.25))
+            m.object_slot = mesh.get("object_slot", len(spheres))
+            self._keep = (v, ix, bv)
+        lt = Light(); lt.position[:] = light[0]; lt.intensity = light[1]
+        cam = Camera(); cam.position[:] = camera[0]
+        # float alpha = PI/3 (cpu:666)
+        cam.fov = np.float32(np.pi / 3) if camera[1] is None else np.float32(camera[1])
+        self._check(self._L.rt_scene_upload(self._h, arr, len(spheres), C.byref(m) if m is not None else None,
+                                            C.byref(lt), C.byref(cam)))
+
+    def render(self, params, row_begin=0, row_end=None):
+        row_end = params.height if row_end is None else row_end
+        out = np.empty((max(row_end - row_begin, 0), params.width, 4), np.float32)
+        self._check(self._L.rt_render(self._h, C.byref(params), row_begin, row_end, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def render_rgb8(self, params, row_begin=0, row_end=None):
+        row_end = params.height if row_end is None else row_end
+        out = np.empty((max(row_end - row_begin, 0), params.width, 3), np.uint8)
+        self._check(self._L.rt_render_rgb8(self._h, C.byref(params), row_begin, row_end, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
+
+    def render_device(self, params, rows, out_ptr, stream=None):
+        """Asynchronous render into device memory (e.g. a torch tensor's data_ptr())."""
+        self._check(self._L.rt_render_device(self._h, C.byref(params), C.byref(rows), C.c_void_p(out_ptr),
+                                             C.c_void_p(stream) if stream else None))
+
+    def tonemap_device(self, rgba_ptr, n_pixels, rgb8_ptr, stream=None):
+        self._check(self._L.rt_tonemap_device(self._h, C.c_void_p(rgba_ptr), n_pixels, C.c_void_p(rgb8_ptr),
+                                              C.c_void_p(stream) if stream else None))
+
+    def synchronize(self):
+        self._check(self._L.rt_synchronize(self._h))
+
+    def stats(self):
+        s = Stats()
+        self._check(self._L.rt_get_stats(self._h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in Stats._fields_}

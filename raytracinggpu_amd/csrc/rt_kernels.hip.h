@@ -1,0 +1,349 @@
+// rt_kernels.hip.h -- gfx950 render kernels of libraytrace_hip.so.
+//
+// One lane per pixel, one wave64 per 8x8 pixel tile, four waves (32x8 pixels) per
+// workgroup.  Replaces KernelLaunch (optimized.cu:670-772) / the pixel loop of
+// cpu_launcher.cpp:693-718.  Written for CDNA4 only; compiled with
+// -ffp-contract=off and IEEE-correct f32 divide/sqrt so that every arithmetic
+// operation is the same single rounding the reference performs (DESIGN.md
+// "Numerics").  No MFMA: there is no dense contraction on this path.
+//
+// Data layout (built by rt_scene_upload, rt_capi.hip):
+//   node_lo[n], node_hi[n]  float4 SoA, nodes in TRAVERSAL order (pre-order,
+//        right child first = the order cpu_launcher.cpp:284-293 pops them).
+//        lo = (mn.x, mn.y, mn.z, bits(next-on-miss | tri_start))
+//        hi = (mx.x, mx.y, mx.z, bits(-1 internal | tri_end leaf))
+//        Because the reference never prunes by distance the visit set
+//        is a pure function of the ray, so traversal needs no stack: on a box hit
+//        go to node+1, on a miss of an internal node jump past its subtree.
+//   tri[3*t .. 3*t+2]       float4 x3 per triangle in the reference's BVH order:
+//        (A.xyz, e1.x) (e1.yz, e2.xy) (e2.z, N.xyz), e1=B-A, e2=C-A, N=e1 x e2
+//        computed on the host with the same IEEE operations cpu:227-229 performs.
+//   verts[nv] float4, tidx[nt] int4   (LDS-staged variants)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rtk {
+
+constexpr int kMaxSpheres = 16;
+constexpr int kMaxSegments = 16;
+constexpr int kBlockThreads = 256;   // 4 waves: 32 x 8 pixels
+constexpr int kTileW = 32, kTileH = 8;
+
+struct Sphere {           // rt_sphere, cpu:505-511
+    float cx, cy, cz, R;
+    float ar, ag, ab;
+    int mirror;
+    float n_in, n_out;
+};
+
+struct Scene {
+    Sphere sph[kMaxSpheres];
+    int n_spheres;
+    int n_objects;        // spheres + (mesh ? 1 : 0)
+    int mesh_slot;        // object index of the mesh, -1 = none
+    float mar, mag, mab;  // mesh albedo
+    float Lx, Ly, Lz, intensity;
+    float camx, camy, camz, fov;
+    const float4 *node_lo, *node_hi;
+    const float4 *tri;
+    const float4 *verts;
+    const int4 *tidx;
+    int n_nodes, n_tris, n_verts;
+};
+
+struct Frame {
+    int W, H, spp, segs;
+    float sigma, eps, tri_tmin, z;
+    uint32_t seed;
+    int row0, n_rows, tile_rows, tile_step;
+    float4 *out;
+};
+
+struct f3 { float x, y, z; };
+__device__ __forceinline__ f3 mk(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 operator-(f3 a) { return mk(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ f3 operator*(float s, f3 b) { return mk(s * b.x, s * b.y, s * b.z); }
+__device__ __forceinline__ f3 operator*(f3 a, f3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ f3 operator/(f3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
+__device__ __forceinline__ float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ f3 cross(f3 a, f3 b) {
+    return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ float norm2(f3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+__device__ __forceinline__ f3 normalize(f3 a) {   // cpu:58-63: three divisions by sqrt(norm2)
+    float n = __fsqrt_rn(norm2(a));
+    return mk(a.x / n, a.y / n, a.z / n);
+}
+
+// counter RNG, DESIGN.md "RNG" (same definition as the oracle's or_uniform)
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float uniform01(uint32_t hs, uint32_t depth, uint32_t dim) {
+    uint32_t h = mix32(hs ^ ((depth * 4U + dim) * 0x85EBCA77U));
+    return (float)((h >> 8) + 1U) * 0x1p-24f;
+}
+
+// BoundingBox::intersect, cpu:146-157, literal (division by u, swap, min_element/max_element order)
+__device__ __forceinline__ bool slab(float4 lo, float4 hi, f3 O, f3 u) {
+    float t0x = (lo.x - O.x) / u.x, t0y = (lo.y - O.y) / u.y, t0z = (lo.z - O.z) / u.z;
+    float t1x = (hi.x - O.x) / u.x, t1y = (hi.y - O.y) / u.y, t1z = (hi.z - O.z) / u.z;
+    float tmp;
+    if (t0x > t1x) { tmp = t0x; t0x = t1x; t1x = tmp; }
+    if (t0y > t1y) { tmp = t0y; t0y = t1y; t1y = tmp; }
+    if (t0z > t1z) { tmp = t0z; t0z = t1z; t1z = tmp; }
+    float mn = t1x; if (t1y < mn) mn = t1y; if (t1z < mn) mn = t1z;
+    float mx = t0x; if (mx < t0y) mx = t0y; if (mx < t0z) mx = t0z;
+    return mn > mx;
+}
+
+// TriangleMesh::intersect, cpu:277-311.  Returns true iff some triangle was accepted
+// (SURVEY H4); t/Nraw are the nearest accepted t and its unnormalised e1 x e2.
+__device__ __forceinline__ bool mesh_intersect(const Scene &sc, f3 O, f3 u, float tri_tmin, float &t_out, f3 &N_out) {
+    float t_min = 1e9f;   // INF (1e9+9) narrowed to float, cpu:283
+    bool any = false;
+    f3 Nb = mk(0, 0, 0);
+    int node = 0;
+    const int n_nodes = sc.n_nodes;
+    while (node < n_nodes) {
+        const float4 lo = sc.node_lo[node];
+        const float4 hi = sc.node_hi[node];
+        const int hiw = __float_as_int(hi.w);
+        const int low = __float_as_int(lo.w);
+        if (slab(lo, hi, O, u)) {
+            if (hiw >= 0) {   // leaf: triangles [low, hiw), ascending (cpu:295)
+                for (int i = low; i < hiw; ++i) {
+                    const float4 q0 = sc.tri[3 * i + 0], q1 = sc.tri[3 * i + 1], q2 = sc.tri[3 * i + 2];
+                    const f3 A = mk(q0.x, q0.y, q0.z), e1 = mk(q0.w, q1.x, q1.y), e2 = mk(q1.z, q1.w, q2.x);
+                    const f3 N = mk(q2.y, q2.z, q2.w);
+                    // moller_trumbore, cpu:226-236
+                    const float det = dot(u, N);
+                    if (det == 0) continue;
+                    const f3 AO = A - O;
+                    const f3 c = cross(AO, u);
+                    const float beta = dot(e2, c) / det;
+                    const float gamma = -dot(e1, c) / det;
+                    if (!(0 <= beta && beta <= 1) || !(0 <= gamma && gamma <= 1)) continue;
+                    const float t = dot(AO, N) / det;
+                    if (!(beta + gamma <= 1 && t > 0)) continue;
+                    if (t > tri_tmin && t < t_min) { t_min = t; Nb = N; any = true; }   // cpu:301
+                }
+            }
+            node = node + 1;
+        } else {
+            node = (hiw < 0) ? low : node + 1;
+        }
+    }
+    t_out = t_min;
+    N_out = Nb;
+    return any;
+}
+
+// Scene::intersect_all, cpu:545-564.  Objects are visited in insertion order with a
+// strict '<' (exact-tie behaviour); the winner's normal is evaluated once at the end
+// (it is a pure function of the winner, so this is bit-identical to cpu:524-525/308).
+__device__ __forceinline__ bool intersect_all(const Scene &sc, f3 O, f3 u, float tri_tmin, f3 &P, f3 &N, int &objectId) {
+    float t_min = 1e9f;
+    int id_min = -1;
+    int sph_min = -1;
+    f3 Nmesh = mk(0, 0, 0);
+    int si = 0;
+    for (int obj = 0; obj < sc.n_objects; ++obj) {
+        if (obj == sc.mesh_slot) {
+            float t; f3 Nr;
+            if (mesh_intersect(sc, O, u, tri_tmin, t, Nr) && t < t_min) { t_min = t; id_min = obj; sph_min = -1; Nmesh = Nr; }
+            continue;
+        }
+        const Sphere &s = sc.sph[si++];
+        // Sphere::intersect, cpu:512-527
+        const f3 C = mk(s.cx, s.cy, s.cz);
+        const f3 OC = O - C;
+        const float d = dot(u, OC);
+        const float delta = d * d - (norm2(OC) - s.R * s.R);
+        if (delta < 0) continue;
+        const float sq = __fsqrt_rn(delta);
+        const float b = dot(u, C - O);
+        const float t1 = b - sq, t2 = b + sq;
+        if (t2 < 0) continue;
+        const float t = t1 < 0 ? t2 : t1;
+        if (t < t_min) { t_min = t; id_min = obj; sph_min = si - 1; }
+    }
+    P = O + t_min * u;   // cpu:560 (also on a miss)
+    objectId = id_min;
+    if (id_min < 0) { N = mk(0, 0, 0); return false; }
+    if (sph_min >= 0) {
+        const Sphere &s = sc.sph[sph_min];
+        N = normalize(O + t_min * u - mk(s.cx, s.cy, s.cz));   // cpu:524-525
+    } else {
+        N = normalize(Nmesh);                                  // cpu:308
+    }
+    return true;
+}
+
+struct Material { float ar, ag, ab; int mirror; float n_in, n_out; };
+__device__ __forceinline__ Material material_of(const Scene &sc, int obj) {
+    Material m;
+    if (obj == sc.mesh_slot) { m.ar = sc.mar; m.ag = sc.mag; m.ab = sc.mab; m.mirror = 0; m.n_in = 1.f; m.n_out = 1.f; return m; }   // cpu:110
+    const int si = (sc.mesh_slot >= 0 && obj > sc.mesh_slot) ? obj - 1 : obj;
+    const Sphere &s = sc.sph[si];
+    m.ar = s.ar; m.ag = s.ag; m.ab = s.ab; m.mirror = s.mirror; m.n_in = s.n_in; m.n_out = s.n_out;
+    return m;
+}
+
+// Scene::getColor, cpu:566-648, made iterative: the path is walked front to back recording for each
+// diffuse segment the scalar l (cpu:623) and the object id, then folded back to front exactly as the
+// recursion returns (color = direct + albedo (.) child, cpu:642-644).  Mirror/refraction segments return
+// the child unchanged (cpu:579,594,601) and a miss returns black (cpu:571).
+// lstack: per-lane LDS column, lstack[d * kBlockThreads].
+__device__ __forceinline__ f3 get_color(const Scene &sc, const Frame &fr, f3 O, f3 u, uint32_t hs, float *lstack, float &rays) {
+    const float PI_F = (float)3.14159265358979323846;
+    const double PI_D = 3.14159265358979323846;
+    const f3 L = mk(sc.Lx, sc.Ly, sc.Lz);
+    float refr = 1.f;             // Ray::refraction_index, cpu:100
+    uint64_t ids = 0;             // 4 bits of object id per segment
+    uint32_t diffuse_mask = 0;
+    int nseg = 0;
+    for (int d = 0; d < fr.segs; ++d) {
+        f3 P, N; int id;
+        rays += 1.f;
+        if (!intersect_all(sc, O, u, fr.tri_tmin, P, N, id)) break;
+        nseg = d + 1;
+        const Material m = material_of(sc, id);
+        if (m.mirror) {                                             // cpu:573-579
+            O = P + fr.eps * N;
+            u = u - (2 * dot(u, N)) * N;
+        } else if (m.n_in != m.n_out) {                             // cpu:580-604
+            float ratio;
+            const bool out2in = refr == m.n_out;
+            if (out2in) ratio = m.n_out / m.n_in;
+            else { ratio = m.n_in / m.n_out; N = -N; }
+            const float un = dot(u, N);
+            if (((out2in && refr > m.n_in) || (!out2in && refr > m.n_out)) && (ratio * ratio) * (1 - un * un) > 1) {
+                O = P + fr.eps * N;
+                u = u - (2 * un) * N;
+            } else {
+                O = P - fr.eps * N;
+                const f3 Nc = (-__fsqrt_rn(1 - (ratio * ratio) * (1 - un * un))) * N;
+                const f3 Tc = ratio * (u - un * N);
+                u = Nc + Tc;
+                refr = out2in ? m.n_in : m.n_out;
+            }
+        } else {                                                    // cpu:605-645
+            const f3 Pa = P + fr.eps * N;
+            const f3 toL = L - Pa;
+            const f3 sdir = toL / __fsqrt_rn(norm2(toL));           // NORMED_VEC, cpu:30,614
+            f3 Pp, Np; int ids_;
+            rays += 1.f;
+            (void)intersect_all(sc, Pa, sdir, fr.tri_tmin, Pp, Np, ids_);
+            float l = 0.f;
+            if (!(norm2(Pp - Pa) <= norm2(L - Pa))) {               // cpu:615
+                const f3 wl = normalize(L - P);
+                const float dn = dot(N, wl);
+                const float mx = (dn < 0.f) ? 0.f : dn;             // std::max(dn, 0.f)
+                l = (float)((double)sc.intensity / (4 * PI_D * (double)norm2(L - P)) * (double)mx);   // cpu:623
+            }
+            lstack[d * kBlockThreads] = l;
+            ids |= (uint64_t)(id & 15) << (4 * d);
+            diffuse_mask |= 1u << d;
+            const float r1 = uniform01(hs, (uint32_t)d, 0);         // cpu:628-629
+            const float r2 = uniform01(hs, (uint32_t)d, 1);
+            double sn, cs;
+            sincos(2 * PI_D * (double)r1, &sn, &cs);
+            const float s1 = __fsqrt_rn(1 - r2);
+            const float x = (float)(cs * (double)s1);               // cpu:630
+            const float y = (float)(sn * (double)s1);               // cpu:631
+            const float zz = __fsqrt_rn(r2);                        // cpu:632
+            f3 T1;
+            if (N.y != 0 && N.x != 0) T1 = mk(-N.y, N.x, 0);        // cpu:634-638
+            else T1 = mk(-N.z, 0, N.x);
+            T1 = normalize(T1);
+            const f3 T2 = cross(N, T1);
+            u = x * T1 + y * T2 + zz * N;                           // cpu:641
+            O = Pa;
+            refr = 1.f;                                             // Ray(P_adjusted, random_direction), cpu:642
+        }
+    }
+    f3 ans = mk(0, 0, 0);
+    for (int d = nseg - 1; d >= 0; --d) {
+        if (diffuse_mask & (1u << d)) {
+            const Material m = material_of(sc, (int)((ids >> (4 * d)) & 15));
+            const float l = lstack[d * kBlockThreads];
+            const f3 alb = mk(m.ar, m.ag, m.ab);
+            const f3 direct = (l * alb) / PI_F;                     // cpu:624
+            ans = direct + alb * ans;                               // cpu:642,644
+        }
+    }
+    return ans;
+}
+
+__global__ __launch_bounds__(kBlockThreads) void render_kernel(const Scene sc, const Frame fr) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int px = blockIdx.x * kTileW + wave * 8 + (lane & 7);
+    const int lrow = blockIdx.y * kTileH + (lane >> 3);
+    if (px >= fr.W || lrow >= fr.n_rows) return;
+    const int row = fr.row0 + (lrow / fr.tile_rows) * fr.tile_rows * fr.tile_step + (lrow % fr.tile_rows);
+    if (row >= fr.H) return;
+    float *lstack = smem + tid;
+
+    // cpu:699: +0.5/-0.5 are double literals, narrowed by the Vector constructor
+    const f3 uc = mk((float)((double)((float)px - (float)fr.W / 2) + 0.5),
+                     (float)((double)((float)fr.H / 2 - (float)row) - 0.5), fr.z);
+    const f3 C = mk(sc.camx, sc.camy, sc.camz);
+    const uint32_t pixel = (uint32_t)row * (uint32_t)fr.W + (uint32_t)px;
+    const uint32_t hp = mix32(pixel ^ mix32(fr.seed));
+    f3 total = mk(0, 0, 0);
+    float rays = 0.f;
+    for (int s = 0; s < fr.spp; ++s) {
+        const uint32_t hs = mix32(hp ^ ((uint32_t)s * 0x9E3779B1U));
+        f3 uu = uc;
+        if (fr.sigma != 0.f) {   // cpu:705-707; with sigma == 0 the jitter is exactly +-0 and uc is unchanged
+            const float r1 = uniform01(hs, 0, 2), r2 = uniform01(hs, 0, 3);
+            const float bm = fr.sigma * __fsqrt_rn(-2 * logf(r1));
+            double sn, cs;
+            sincos(2 * 3.14159265358979323846 * (double)r2, &sn, &cs);
+            uu = uc + mk((float)((double)bm * cs), (float)((double)bm * sn), 0.f);
+        }
+        const f3 u = normalize(uu);
+        const f3 col = get_color(sc, fr, C, u, hs, lstack, rays);
+        total = total + col;
+    }
+    const f3 avg = total / (float)fr.spp;                           // cpu:713
+    fr.out[(size_t)lrow * fr.W + px] = make_float4(avg.x, avg.y, avg.z, rays);
+}
+
+// cpu:714-716: std::min(std::pow(c, 1./2.2), 255.) -> unsigned char.  4 pixels per lane,
+// 12 output bytes written as three dwords.
+__device__ __forceinline__ uint32_t tone1(float c) {
+    double v = pow((double)c, 1. / 2.2);
+    if (255. < v) v = 255.;
+    if (!(v == v)) return 0u;
+    return (uint32_t)(int)v;
+}
+__global__ __launch_bounds__(256) void tonemap_kernel(const float4 *__restrict__ rgba, int64_t npix, uint8_t *__restrict__ out) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t p0 = q * 4;
+    if (p0 >= npix) return;
+    uint32_t b[12];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float4 c = (p0 + k < npix) ? rgba[p0 + k] : make_float4(0, 0, 0, 0);
+        b[3 * k + 0] = tone1(c.x); b[3 * k + 1] = tone1(c.y); b[3 * k + 2] = tone1(c.z);
+    }
+    if (p0 + 4 <= npix) {
+        uint32_t *o = reinterpret_cast<uint32_t *>(out + 3 * p0);   // 12*q bytes: 4-byte aligned
+        o[0] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+        o[1] = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+        o[2] = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
+    } else {
+        for (int64_t k = 0; p0 + k < npix; ++k)
+            for (int ch = 0; ch < 3; ++ch) out[3 * (p0 + k) + ch] = (uint8_t)b[3 * k + ch];
+    }
+}
+
+}  // namespace rtk

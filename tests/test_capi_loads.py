@@ -1,0 +1,57 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every declared symbol, and refuses to
+work without a GPU instead of falling back to anything."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import raytracinggpu_amd as rt
+from raytracinggpu_amd import _capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "raytrace_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _capi.load()
+    names = declared_symbols()
+    assert len(names) >= 13
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(_capi.EXPORTS) == names
+    assert lib.rt_abi_version() == 1
+
+
+def test_struct_sizes_match_header():
+    assert ctypes.sizeof(_capi.Sphere) == 40
+    assert ctypes.sizeof(_capi.Params) == 40
+    assert ctypes.sizeof(_capi.Rows) == 16
+    assert ctypes.sizeof(_capi.Light) == 16 and ctypes.sizeof(_capi.Camera) == 16
+
+
+def test_no_cpu_fallback_without_a_gpu():
+    if rt.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(rt.RtError) as e:
+        rt.Context(0)
+    assert e.value.code in (-2, -3)
+
+
+def test_interleaved_rows_partition_the_image():
+    for H, R, G in ((1080, 8, 8), (1080, 8, 3), (250, 8, 4), (7, 8, 2), (4320, 16, 8)):
+        seen = np.zeros(H, int)
+        for k in range(G):
+            rows, idx = rt.interleaved_rows(H, R, k, G)
+            assert rows.n_rows == len(idx)
+            local = np.arange(rows.n_rows)
+            mapped = rows.row0 + (local // rows.tile_rows) * rows.tile_rows * rows.tile_step + local % rows.tile_rows
+            np.testing.assert_array_equal(mapped, idx)      # the formula documented in raytrace_hip.h
+            seen[idx] += 1
+        assert (seen == 1).all()

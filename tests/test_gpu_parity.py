@@ -1,0 +1,139 @@
+"""HIP render path (through the C-ABI) vs the CPU oracle on the same inputs.  -m gpu.
+
+Tolerance (BASELINE.json / SURVEY 8d): per-channel L-inf <= 1e-4 on g = min(pow(c,1/2.2),255)/255.
+For sigma == 0 the linear float colour is expected to be bit-identical (same single IEEE roundings);
+where it is not (binary64 sin/cos of the ROCm device library vs glibc on the bounce directions), the
+test states the measured fraction and still enforces the 1e-4 bound.
+"""
+import numpy as np
+import pytest
+
+import raytracinggpu_amd as rt
+from .conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = rt.Context(0)
+    yield c
+    c.close()
+
+
+def upload(ctx, scene, cat_golden, ref_arrays=True):
+    mesh = None
+    if scene in ("cpu", "optimized"):
+        mesh = dict(vertices=cat_golden["vertices"], indices=cat_golden["tri_bvh_order"], bvh_arr10=cat_golden["bvh_arr10"],
+                    albedo=rt.scenes.CAT_ALBEDO, object_slot=rt.scenes.mesh_slot(scene))
+    ctx.scene_upload(rt.scenes.spheres(scene), mesh)
+
+
+def linf(oracle, a, b):
+    return float(np.abs(oracle.gamma_unit(a[..., :3]) - oracle.gamma_unit(b[..., :3])).max())
+
+
+def values_equal(a, b):
+    return (a == b) | (np.isnan(a) & np.isnan(b))
+
+
+@pytest.mark.parametrize("scene,W,H", [("cpu", 512, 512), ("spheres", 512, 512), ("demo10", 256, 256), ("cpu", 333, 77)])
+def test_direct_lighting_bit_exact(ctx, oracle, oracle_cat, cat_golden, scene, W, H):
+    """num_bounce=0, sigma=0: deterministic in the reference too -> bit-exact linear colour."""
+    upload(ctx, scene, cat_golden)
+    got = ctx.render(rt.make_params(W, H, 1, 0, **rt.scenes.CPU_LAUNCHER))
+    exp, exp8, _ = oracle.Scene.preset(scene, oracle_cat if scene == "cpu" else None).render(W, H, 1, 0)
+    assert values_equal(got[..., :3], exp[..., :3]).all()
+    np.testing.assert_array_equal(got[..., 3], exp[..., 3])          # rays per pixel
+    assert linf(oracle, got, exp) == 0.0
+    got8 = ctx.render_rgb8(rt.make_params(W, H, 1, 0, **rt.scenes.CPU_LAUNCHER))
+    np.testing.assert_array_equal(got8, exp8)
+
+
+def test_png_bytes_equal_unmodified_reference_binary(ctx, cat_golden):
+    """GPU 8-bit image == bytes of `./cpu 1 0` (the reference program itself)."""
+    g = load_golden("ref_cpu_png_1_0.npz")
+    upload(ctx, "cpu", cat_golden)
+    np.testing.assert_array_equal(ctx.render_rgb8(rt.make_params(512, 512, 1, 0, **rt.scenes.CPU_LAUNCHER)), g["cat"])
+    upload(ctx, "spheres", cat_golden)
+    np.testing.assert_array_equal(ctx.render_rgb8(rt.make_params(512, 512, 1, 0, **rt.scenes.CPU_LAUNCHER)), g["spheres"])
+
+
+def test_reference_getColor_floats_1080p(ctx, cat_golden):
+    """Linear floats of the reference's own Scene::getColor at 1920x1080 (every 8th pixel), bit-exact."""
+    g = load_golden("ref_render.npz")
+    W, H, spp, b, stride = (int(x) for x in g["cpu_1080p_direct_cfg"])
+    upload(ctx, "cpu", cat_golden)
+    got = ctx.render(rt.make_params(W, H, spp, b, **rt.scenes.CPU_LAUNCHER))
+    np.testing.assert_array_equal(got[::stride, ::stride, :3], g["cpu_1080p_direct_color"])
+
+
+@pytest.mark.parametrize("scene,W,H,spp,b", [("cpu", 512, 512, 2, 3), ("demo10", 256, 256, 2, 5), ("spheres", 320, 200, 4, 2),
+                                             ("cpu", 256, 256, 1, 10)])
+def test_bounces_within_tolerance(ctx, oracle, oracle_cat, cat_golden, scene, W, H, spp, b):
+    upload(ctx, scene, cat_golden)
+    got = ctx.render(rt.make_params(W, H, spp, b, **rt.scenes.CPU_LAUNCHER))
+    exp, _, _ = oracle.Scene.preset(scene, oracle_cat if scene == "cpu" else None).render(W, H, spp, b, want_rgb8=False)
+    same = values_equal(got[..., :3], exp[..., :3]).mean()
+    err = linf(oracle, got, exp)
+    print(f"{scene} {W}x{H} spp={spp} b={b}: bit-identical channels {same:.6f}, Linf(gamma) {err:.3g}")
+    assert err <= TOL
+    assert same > 0.999
+    np.testing.assert_array_equal(got[..., 3], exp[..., 3])
+
+
+def test_optimized_cu_conventions(ctx, oracle, cat_golden):
+    """optimized.cu's scene: mesh at slot 1 rescaled 0.6/(0,-4,0), eps 1e-4, t>0, b segments."""
+    m = oracle.Mesh.from_arrays(cat_golden["vertices"], cat_golden["tri_obj_order"])
+    m.rescale(0.6, (0, -4, 0))
+    m.build_bvh()
+    ctx.scene_upload(rt.scenes.spheres("optimized"),
+                     dict(vertices=m.vertices, indices=m.triangles, bvh_arr10=m.bvh_array(), albedo=rt.scenes.CAT_ALBEDO, object_slot=1))
+    kw = dict(rt.scenes.OPTIMIZED_CU, sigma=0.0)
+    got = ctx.render(rt.make_params(384, 384, 2, 3, **kw))
+    exp, _, _ = oracle.Scene.preset("optimized", m).render(384, 384, 2, 2, eps=1e-4, tri_tmin=0.0, want_rgb8=False)
+    assert linf(oracle, got, exp) <= TOL
+    np.testing.assert_array_equal(got[..., 3], exp[..., 3])
+
+
+def test_row_ranges_and_interleaved_tiles_are_bitwise_the_full_frame(ctx, cat_golden):
+    import torch
+    upload(ctx, "cpu", cat_golden)
+    W, H = 400, 250          # neither a multiple of the 32x8 workgroup tile
+    p = rt.make_params(W, H, 2, 2, **rt.scenes.CPU_LAUNCHER)
+    full = ctx.render(p)
+    part = ctx.render(p, 37, 121)
+    np.testing.assert_array_equal(part.view(np.uint32), full[37:121].view(np.uint32))
+    assert ctx.render(p, 5, 5).shape == (0, W, 4)
+    for world in (2, 3, 8):
+        frame = np.zeros_like(full)
+        for rank in range(world):
+            rows, idx = rt.interleaved_rows(H, 8, rank, world)
+            buf = torch.empty((max(rows.n_rows, 1), W, 4), dtype=torch.float32, device="cuda:0")
+            ctx.render_device(p, rows, buf.data_ptr())
+            ctx.synchronize()
+            frame[idx] = buf[:rows.n_rows].cpu().numpy()
+        np.testing.assert_array_equal(frame.view(np.uint32), full.view(np.uint32))
+
+
+def test_error_paths(ctx, cat_golden):
+    upload(ctx, "cpu", cat_golden)
+    with pytest.raises(rt.RtError):
+        ctx.render(rt.make_params(0, 10))
+    with pytest.raises(rt.RtError):
+        ctx.render(rt.make_params(64, 64, 0, 0))
+    with pytest.raises(rt.RtError):
+        ctx.render(rt.make_params(64, 64, 1, 40))
+    with pytest.raises(rt.RtError):
+        ctx.render(rt.make_params(64, 64), 10, 200)
+    bad = np.array(cat_golden["bvh_arr10"]); bad[0, 0] = 5000
+    with pytest.raises(rt.RtError):
+        ctx.scene_upload(rt.scenes.spheres("cpu"), dict(vertices=cat_golden["vertices"], indices=cat_golden["tri_bvh_order"], bvh_arr10=bad))
+    fresh = rt.Context(0)
+    with pytest.raises(rt.RtError):
+        fresh.render(rt.make_params(64, 64))
+    fresh.close()
+    # the context is still usable after errors
+    upload(ctx, "spheres", cat_golden)
+    assert np.isfinite(ctx.render(rt.make_params(64, 64))).all()
