@@ -74,6 +74,15 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so (SONAME libamdhip64.so.7) and
+    # its libraries ask for it as "libamdhip64.so", so a system copy loaded first is NOT reused and the second
+    # runtime then finds no GPU.  Loading torch first makes this library's NEEDED libamdhip64.so.7 resolve to
+    # the copy torch already mapped.  (The C++ launcher, which has no torch, uses /opt/rocm's.)
+    if os.environ.get("RT_WITHOUT_TORCH") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.rt_abi_version.restype = C.c_int

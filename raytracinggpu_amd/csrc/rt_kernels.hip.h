@@ -72,9 +72,12 @@ __device__ __forceinline__ float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y 
 __device__ __forceinline__ f3 cross(f3 a, f3 b) {
     return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
+// IEEE-754 correctly rounded binary32 square root.  NOT __fsqrt_rn: ROCm 7.2 maps that to the native
+// (1-ulp) v_sqrt_f32; sqrtf under -fhip-fp32-correctly-rounded-divide-sqrt gets the fix-up sequence.
+__device__ __forceinline__ float rt_sqrtf(float x) { return __builtin_sqrtf(x); }
 __device__ __forceinline__ float norm2(f3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
 __device__ __forceinline__ f3 normalize(f3 a) {   // cpu:58-63: three divisions by sqrt(norm2)
-    float n = __fsqrt_rn(norm2(a));
+    float n = rt_sqrtf(norm2(a));
     return mk(a.x / n, a.y / n, a.z / n);
 }
 
@@ -165,7 +168,7 @@ __device__ __forceinline__ bool intersect_all(const Scene &sc, f3 O, f3 u, float
         const float d = dot(u, OC);
         const float delta = d * d - (norm2(OC) - s.R * s.R);
         if (delta < 0) continue;
-        const float sq = __fsqrt_rn(delta);
+        const float sq = rt_sqrtf(delta);
         const float b = dot(u, C - O);
         const float t1 = b - sq, t2 = b + sq;
         if (t2 < 0) continue;
@@ -227,7 +230,7 @@ __device__ __forceinline__ f3 get_color(const Scene &sc, const Frame &fr, f3 O, 
                 u = u - (2 * un) * N;
             } else {
                 O = P - fr.eps * N;
-                const f3 Nc = (-__fsqrt_rn(1 - (ratio * ratio) * (1 - un * un))) * N;
+                const f3 Nc = (-rt_sqrtf(1 - (ratio * ratio) * (1 - un * un))) * N;
                 const f3 Tc = ratio * (u - un * N);
                 u = Nc + Tc;
                 refr = out2in ? m.n_in : m.n_out;
@@ -235,7 +238,7 @@ __device__ __forceinline__ f3 get_color(const Scene &sc, const Frame &fr, f3 O, 
         } else {                                                    // cpu:605-645
             const f3 Pa = P + fr.eps * N;
             const f3 toL = L - Pa;
-            const f3 sdir = toL / __fsqrt_rn(norm2(toL));           // NORMED_VEC, cpu:30,614
+            const f3 sdir = toL / rt_sqrtf(norm2(toL));           // NORMED_VEC, cpu:30,614
             f3 Pp, Np; int ids_;
             rays += 1.f;
             (void)intersect_all(sc, Pa, sdir, fr.tri_tmin, Pp, Np, ids_);
@@ -253,10 +256,10 @@ __device__ __forceinline__ f3 get_color(const Scene &sc, const Frame &fr, f3 O, 
             const float r2 = uniform01(hs, (uint32_t)d, 1);
             double sn, cs;
             sincos(2 * PI_D * (double)r1, &sn, &cs);
-            const float s1 = __fsqrt_rn(1 - r2);
+            const float s1 = rt_sqrtf(1 - r2);
             const float x = (float)(cs * (double)s1);               // cpu:630
             const float y = (float)(sn * (double)s1);               // cpu:631
-            const float zz = __fsqrt_rn(r2);                        // cpu:632
+            const float zz = rt_sqrtf(r2);                        // cpu:632
             f3 T1;
             if (N.y != 0 && N.x != 0) T1 = mk(-N.y, N.x, 0);        // cpu:634-638
             else T1 = mk(-N.z, 0, N.x);
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(const Scene sc, c
         f3 uu = uc;
         if (fr.sigma != 0.f) {   // cpu:705-707; with sigma == 0 the jitter is exactly +-0 and uc is unchanged
             const float r1 = uniform01(hs, 0, 2), r2 = uniform01(hs, 0, 3);
-            const float bm = fr.sigma * __fsqrt_rn(-2 * logf(r1));
+            const float bm = fr.sigma * rt_sqrtf(-2 * logf(r1));
             double sn, cs;
             sincos(2 * 3.14159265358979323846 * (double)r2, &sn, &cs);
             uu = uc + mk((float)((double)bm * cs), (float)((double)bm * sn), 0.f);
