@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the render hot path (BASELINE.json: Mrays/s + ms/frame, cat mesh
+1920x1080, at 1/2/4/8 MI355X).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one frame of the workload: the cat scene of cpu_launcher.cpp (walls + cat mesh + array BVH),
+1920x1080, num_rays=1, num_bounce=3 (CPU convention: 4 segments), rendered by the HIP kernel through the
+C-ABI with the scene already resident in HBM.  With N > 1 the frame is split into interleaved 8-row tiles
+(tile k -> rank k mod N), every rank renders its tiles, and ONE RCCL gather per frame brings the float4
+tiles to rank 0, which de-interleaves them (all inside the timed region).  Total work is fixed => "strong".
+
+Rank 0 prints one JSON line.  `value` = rays traced per second (1 ray = 1 Scene::intersect_all call:
+primary, shadow or bounce segment; counted exactly by the kernel in the framebuffer's .w channel).
+`roofline` prices the render kernel against the HBM roofline with the ALGORITHMIC bytes of SURVEY 8d
+(24 B/box test + 16 B/node + 48 B/triangle test + 16 B/pixel).  `cpu_baseline` is the CPU restatement of
+cpu_launcher.cpp (oracle/, OpenMP schedule(dynamic,1) over rows like cpu:695) timed on this host.
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+TILE_ROWS = 8
+
+# Traversal work per frame for the default workload, frozen from the oracle's counting pass
+# (oracle.or_render counters; regenerated and cross-checked whenever the cpu_baseline leg runs).
+FROZEN_COUNTS = {
+    "cat_1920x1080_spp1_b3": None,   # filled in by tools/freeze_counts.py -> profiles/algorithmic_counts.json
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=1)
+    ap.add_argument("--bounces", type=int, default=3)
+    ap.add_argument("--scene", default="cpu", choices=["cpu", "spheres", "demo10"])
+    ap.add_argument("--variant", default="auto")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    return ap.parse_args()
+
+
+def build_scene(rt, ctx, scene):
+    """Upload the preset through the C-ABI.  The mesh arrays are the reference's own layouts."""
+    from raytracinggpu_amd import hostlib
+    mesh = None
+    if scene == "cpu":
+        verts, tris = rt.scenes.load_cat_arrays()
+        mesh = hostlib.build_mesh(verts, tris, albedo=rt.scenes.CAT_ALBEDO, object_slot=rt.scenes.mesh_slot(scene))
+    ctx.scene_upload(rt.scenes.spheres(scene), mesh)
+
+
+def cpu_baseline(args, rays_per_frame):
+    """The oracle (CPU restatement of cpu_launcher.cpp) on this host's cores; rank 0, N=1 only."""
+    from oracle import oracle_py as orc
+    threads = args.cpu_threads or len(os.sched_getaffinity(0))
+    mesh = None
+    if args.scene == "cpu":
+        verts, tris = __import__("raytracinggpu_amd").scenes.load_cat_arrays()
+        mesh = orc.Mesh.from_arrays(verts, tris).build_bvh()
+    sc = orc.Scene.preset(args.scene, mesh)
+    # probe on every 16th tile to size the sample (tiles are interleaved => representative)
+    H = args.height
+    t0 = time.perf_counter()
+    probe_rows = [(r, min(r + TILE_ROWS, H)) for r in range(0, H, TILE_ROWS * 16)]
+    for a, b in probe_rows:
+        sc.render(args.width, H, args.spp, args.bounces, rows=(a, b), threads=threads, want_rgb8=False)
+    probe = time.perf_counter() - t0
+    est_full = probe * 16
+    if est_full <= 12.0:
+        reps = 3 if est_full <= 4.0 else 1
+        times, cnt = [], None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            _, _, cnt = sc.render(args.width, H, args.spp, args.bounces, threads=threads, want_rgb8=False)
+            times.append(time.perf_counter() - t0)
+        sec = statistics.median(times)
+        rays = cnt["rays"]
+        sample = f"full {args.width}x{H} frame, num_rays={args.spp}, num_bounce={args.bounces}, median of {reps}"
+        counts = cnt
+    else:
+        step = max(2, int(np.ceil(est_full / 10.0)))
+        rows = [(r, min(r + TILE_ROWS, H)) for r in range(0, H, TILE_ROWS * step)]
+        rays, counts = 0, None
+        t0 = time.perf_counter()
+        for a, b in rows:
+            _, _, c = sc.render(args.width, H, args.spp, args.bounces, rows=(a, b), threads=threads, want_rgb8=False)
+            rays += c["rays"]
+        sec = time.perf_counter() - t0
+        sample = f"every {step}th 8-row tile of the {args.width}x{H} frame ({len(rows)} tiles), num_rays={args.spp}, num_bounce={args.bounces}"
+    out = {"value": round(rays / sec / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+           "sample": sample, "seconds": round(sec, 4),
+           "ms_per_frame_equiv": round(1e3 * rays_per_frame / (rays / sec), 2)}
+    return out, counts
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import raytracinggpu_amd as rt
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    ctx = rt.Context(local_rank)
+    build_scene(rt, ctx, args.scene)
+    W, H = args.width, args.height
+    p = rt.make_params(W, H, args.spp, args.bounces, variant=args.variant, **rt.scenes.CPU_LAUNCHER)
+    rows, idx = rt.interleaved_rows(H, TILE_ROWS, rank, world)
+    n_tiles = (H + TILE_ROWS - 1) // TILE_ROWS
+    tiles_local = (n_tiles + world - 1) // world
+    local = torch.zeros((tiles_local * TILE_ROWS, W, 4), dtype=torch.float32, device=dev)
+    gathered = [torch.empty_like(local) for _ in range(world)] if (world > 1 and rank == 0) else None
+    frame = None
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        nonlocal frame
+        ctx.render_device(p, rows, local.data_ptr(), stream)
+        if world > 1:
+            dist.gather(local, gathered, dst=0)
+            if rank == 0:
+                # [G, T, R, W, 4] -> [T, G, R, W, 4]: tile k of rank r is image tile k*G + r
+                g = torch.stack(gathered).view(world, tiles_local, TILE_ROWS, W, 4)
+                frame = g.permute(1, 0, 2, 3, 4).reshape(-1, W, 4)[:H]
+        else:
+            frame = local[:H]
+
+    # exact ray count of one frame (deterministic; outside the timed region)
+    step()
+    torch.cuda.synchronize()
+    rays_local = torch.tensor([float(local[:rows.n_rows, :, 3].double().sum().item())], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(rays_local)
+    rays_per_frame = int(rays_local.item())
+
+    for _ in range(args.warmup):
+        step()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        ctx.render_device(p, rows, local.data_ptr(), stream)
+        ev[k][1].record()
+        if world > 1:
+            dist.gather(local, gathered, dst=0)
+            if rank == 0:
+                g = torch.stack(gathered).view(world, tiles_local, TILE_ROWS, W, 4)
+                frame = g.permute(1, 0, 2, 3, 4).reshape(-1, W, 4)[:H]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = statistics.mean(a.elapsed_time(b) for a, b in ev)
+    tmax = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed, kernel_ms_max = float(tmax[0]), float(tmax[1])
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = rays_per_frame / (elapsed / args.steps) / 1e6
+        workload = f"cat_{W}x{H}_spp{args.spp}_b{args.bounces}" if args.scene == "cpu" else f"{args.scene}_{W}x{H}_spp{args.spp}_b{args.bounces}"
+        res = {"metric": "Mrays/s, cat mesh 1920x1080 (ms/frame in ms_per_step)", "value": round(value, 2), "unit": "Mrays/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": workload, "scene": "cpu_launcher.cpp walls + cat.obj (3954 tris, 2019-node array BVH)",
+                          "num_rays": args.spp, "num_bounce": args.bounces, "depth_convention": "cpu_launcher (b+1 segments)",
+                          "rays_per_frame": rays_per_frame, "tiling": f"{TILE_ROWS}-row tiles interleaved over {world} rank(s)"
+                          + (", RCCL gather to rank 0 per frame" if world > 1 else ""),
+                          "variant": ctx.stats()["variant"], "device": ctx.device_name}}
+        counts = None
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"], counts = cpu_baseline(args, rays_per_frame)
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                res["cpu_baseline"] = {"value": None, "unit": "Mrays/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        if counts is None:
+            cpath = os.path.join(ROOT, "profiles", "algorithmic_counts.json")
+            if os.path.exists(cpath):
+                counts = json.load(open(cpath)).get(workload)
+        if counts is not None:
+            alg = 24 * counts["box_tests"] + 16 * counts["nodes"] + 48 * counts["tri_tests"] + 16 * W * H
+            if world > 1:
+                alg_launch = alg / world      # per-launch share of one rank (interleaved tiles: even split)
+            else:
+                alg_launch = alg
+            ach = alg_launch / (kernel_ms_max * 1e-3) / 1e9
+            res["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                               "kernel": "rtk::render_kernel", "kernel_ms": round(kernel_ms_max, 4),
+                               "algorithmic_bytes_per_launch": int(alg_launch),
+                               "note": "algorithmic bytes (SURVEY 8d); the ~150 KB scene is L2/LDS resident, see DESIGN.md"}
+            tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+            if os.path.exists(tpath):
+                t = json.load(open(tpath)).get(workload)
+                if t:
+                    res["roofline"]["traffic"] = t
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,100 @@
+"""The product's C++ host API (include/raytracer.hpp via libraytrace_host.so): OBJ reader, BVH builder,
+bvhTreeToArray layout, PNG writer, and the cpu_launcher-compatible CLI.  CPU only."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from raytracinggpu_amd import hostlib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_OBJ = "/root/reference/cadnav.com_model/Models_F0202A090/cat.obj"
+LAUNCHER = os.path.join(ROOT, "raytracinggpu_amd", "rt_launcher")
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def test_host_library_exports():
+    lib = hostlib.load()
+    for n in hostlib.EXPORTS:
+        assert hasattr(lib, n), n
+
+
+def test_bvh_builder_reproduces_reference_tree(cat_golden):
+    """buildBVH + bvhTreeToArray on the reference parser's output == the reference's own tree, bit for bit."""
+    m = hostlib.HostMesh.from_arrays(cat_golden["vertices"], cat_golden["tri_obj_order"]).build_bvh()
+    np.testing.assert_array_equal(m.indices10[:, :3], cat_golden["tri_bvh_order"])
+    np.testing.assert_array_equal(bits(m.bvh_arr10), bits(cat_golden["bvh_arr10"]))
+    assert (m.indices10[:, 3:] == -1).all()
+
+
+def test_rescaled_bvh_matches_oracle(oracle, cat_golden):
+    """optimized.cu's rescale(0.6,(0,-4,0)) then build: product builder vs the oracle's restatement."""
+    m = hostlib.HostMesh.from_arrays(cat_golden["vertices"], cat_golden["tri_obj_order"])
+    m.rescale(0.6, (0, -4, 0))
+    m.build_bvh()
+    o = oracle.Mesh.from_arrays(cat_golden["vertices"], cat_golden["tri_obj_order"])
+    o.rescale(0.6, (0, -4, 0))
+    o.build_bvh()
+    np.testing.assert_array_equal(bits(m.vertices), bits(o.vertices))
+    np.testing.assert_array_equal(m.indices10[:, :3], o.triangles)
+    np.testing.assert_array_equal(bits(m.bvh_arr10), bits(o.bvh_array()))
+
+
+@pytest.mark.skipif(not os.path.exists(REF_OBJ), reason="reference asset not present (GPU box)")
+def test_obj_reader_matches_reference_parser(cat_golden):
+    m = hostlib.HostMesh.from_obj(REF_OBJ)
+    assert m.status == 0
+    np.testing.assert_array_equal(bits(m.vertices), bits(cat_golden["vertices"]))
+    np.testing.assert_array_equal(m.indices10[:, :3], cat_golden["tri_obj_order"])
+
+
+def test_obj_reader_forms_match_oracle_parser(oracle, tmp_path):
+    p = tmp_path / "t.obj"
+    p.write_text("# comment\nusemtl a\nv 0 0 0\r\nv 1 0 0\r\nv 1 1 0\r\nv 0 1 0\r\nv 0.5 2 0 1 0 0\r\nvn 0 0 1\r\nvt 0 0\r\n"
+                 "f 1/1/1 2/1/1 3/1/1 4/1/1\r\nf 1/1 2/1 3/1\r\nf 1 2 3 4 5\r\nf 1//1 2//1 3//1\r\nf -5 -4 -3\r\n")
+    m = hostlib.HostMesh.from_obj(str(p), scale=2.0, offset=(1, 0, 0))
+    o = oracle.Mesh.from_obj(str(p), scale=2.0, offset=(1, 0, 0))
+    np.testing.assert_array_equal(bits(m.vertices), bits(o.vertices))
+    np.testing.assert_array_equal(m.indices10[:, :3], o.triangles)
+    assert len(o.triangles) == 8
+
+
+def test_obj_missing_file_leaves_mesh_empty(capfd):
+    m = hostlib.HostMesh.from_obj("/nonexistent/cat.obj")        # cpu_launcher.cpp:322-325
+    assert m.status == -1 and len(m.vertices) == 0 and len(m.indices10) == 0
+    assert "Error opening file!" in capfd.readouterr().out
+    assert m.build_bvh().bvh_arr10.shape == (1, 10)              # one empty root, as the reference builds
+
+
+def test_png_writer_roundtrip(tmp_path):
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    path = tmp_path / "o.png"
+    hostlib.write_png(str(path), img)
+    back = np.array(Image.open(path))
+    assert back.shape == img.shape and back.dtype == np.uint8
+    np.testing.assert_array_equal(back, img)
+
+
+def test_launcher_usage_message_and_exit_code():
+    """Wrong argument count: the reference prints a usage message and returns 0 (cpu_launcher.cpp:655-658)."""
+    r = subprocess.run([LAUNCHER], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0
+    assert r.stdout.startswith("Invalid number of arguments!")
+    r = subprocess.run([LAUNCHER, "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0 and "number of bounces" in r.stdout
+
+
+def test_launcher_fails_loudly_without_gpu(tmp_path):
+    import raytracinggpu_amd as rt
+    if rt.device_count() > 0:
+        pytest.skip("a GPU is present")
+    r = subprocess.run([LAUNCHER, "1", "0", "--scene", "spheres", "--out", str(tmp_path / "x.png")],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 1 and "rt_ctx_create" in r.stderr
+    assert not (tmp_path / "x.png").exists()
