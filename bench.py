@@ -32,13 +32,6 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 TILE_ROWS = 8
 
-# Traversal work per frame for the default workload, frozen from the oracle's counting pass
-# (oracle.or_render counters; regenerated and cross-checked whenever the cpu_baseline leg runs).
-FROZEN_COUNTS = {
-    "cat_1920x1080_spp1_b3": None,   # filled in by tools/freeze_counts.py -> profiles/algorithmic_counts.json
-}
-
-
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -65,48 +58,48 @@ def build_scene(rt, ctx, scene):
     ctx.scene_upload(rt.scenes.spheres(scene), mesh)
 
 
+def host_cores():
+    """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(np.ceil(int(q) / int(per)))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(args, rays_per_frame):
-    """The oracle (CPU restatement of cpu_launcher.cpp) on this host's cores; rank 0, N=1 only."""
+    """The oracle (CPU restatement of cpu_launcher.cpp: recursive getColor, pointer BVH + explicit stack,
+    OpenMP schedule(dynamic,1) over rows) on this host's cores; rank 0, N=1 only; bounded sample."""
     from oracle import oracle_py as orc
-    threads = args.cpu_threads or len(os.sched_getaffinity(0))
+    import raytracinggpu_amd as rt
+    threads = args.cpu_threads or host_cores()
     mesh = None
     if args.scene == "cpu":
-        verts, tris = __import__("raytracinggpu_amd").scenes.load_cat_arrays()
+        verts, tris = rt.scenes.load_cat_arrays()
         mesh = orc.Mesh.from_arrays(verts, tris).build_bvh()
     sc = orc.Scene.preset(args.scene, mesh)
-    # probe on every 16th tile to size the sample (tiles are interleaved => representative)
-    H = args.height
+    W, H = args.width, args.height
+    kw = dict(threads=threads, want_rgb8=False, tile_rows=TILE_ROWS)
+    # probe: every 16th 8-row tile (interleaved => representative of the frame), one parallel region
     t0 = time.perf_counter()
-    probe_rows = [(r, min(r + TILE_ROWS, H)) for r in range(0, H, TILE_ROWS * 16)]
-    for a, b in probe_rows:
-        sc.render(args.width, H, args.spp, args.bounces, rows=(a, b), threads=threads, want_rgb8=False)
+    _, _, c = sc.render(W, H, args.spp, args.bounces, tile_step=16, **kw)
     probe = time.perf_counter() - t0
-    est_full = probe * 16
-    if est_full <= 12.0:
-        reps = 3 if est_full <= 4.0 else 1
-        times, cnt = [], None
-        for _ in range(reps):
-            t0 = time.perf_counter()
-            _, _, cnt = sc.render(args.width, H, args.spp, args.bounces, threads=threads, want_rgb8=False)
-            times.append(time.perf_counter() - t0)
-        sec = statistics.median(times)
-        rays = cnt["rays"]
-        sample = f"full {args.width}x{H} frame, num_rays={args.spp}, num_bounce={args.bounces}, median of {reps}"
-        counts = cnt
-    else:
-        step = max(2, int(np.ceil(est_full / 10.0)))
-        rows = [(r, min(r + TILE_ROWS, H)) for r in range(0, H, TILE_ROWS * step)]
-        rays, counts = 0, None
+    est_full = probe * rays_per_frame / max(c["rays"], 1)
+    step = 1 if est_full <= 10.0 else int(np.ceil(est_full / 10.0))
+    reps = 3 if est_full * 3 <= 12.0 else 1
+    times = []
+    for _ in range(reps):
         t0 = time.perf_counter()
-        for a, b in rows:
-            _, _, c = sc.render(args.width, H, args.spp, args.bounces, rows=(a, b), threads=threads, want_rgb8=False)
-            rays += c["rays"]
-        sec = time.perf_counter() - t0
-        sample = f"every {step}th 8-row tile of the {args.width}x{H} frame ({len(rows)} tiles), num_rays={args.spp}, num_bounce={args.bounces}"
-    out = {"value": round(rays / sec / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-           "sample": sample, "seconds": round(sec, 4),
-           "ms_per_frame_equiv": round(1e3 * rays_per_frame / (rays / sec), 2)}
-    return out, counts
+        _, _, c = sc.render(W, H, args.spp, args.bounces, tile_step=step, **kw)
+        times.append(time.perf_counter() - t0)
+    sec = statistics.median(times)
+    what = f"full {W}x{H} frame" if step == 1 else f"every {step}th 8-row tile of the {W}x{H} frame"
+    return {"value": round(c["rays"] / sec / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"{what}, num_rays={args.spp}, num_bounce={args.bounces}, {c['rays']} rays, median of {reps} run(s), pixel loop only",
+            "seconds": round(sec, 4), "ms_per_frame_equiv": round(1e3 * rays_per_frame / (c["rays"] / sec), 2)}
 
 
 def main():
@@ -158,6 +151,8 @@ def main():
     if world > 1:
         dist.all_reduce(rays_local)
     rays_per_frame = int(rays_local.item())
+    # traversal work of one frame from the counting instantiation of the kernel, rank 0
+    counts = ctx.count_work(p) if rank == 0 else None
 
     for _ in range(args.warmup):
         step()
@@ -197,17 +192,13 @@ def main():
                           "rays_per_frame": rays_per_frame, "tiling": f"{TILE_ROWS}-row tiles interleaved over {world} rank(s)"
                           + (", RCCL gather to rank 0 per frame" if world > 1 else ""),
                           "variant": ctx.stats()["variant"], "device": ctx.device_name}}
-        counts = None
         if world == 1 and not args.no_cpu_baseline:
             try:
-                res["cpu_baseline"], counts = cpu_baseline(args, rays_per_frame)
+                res["cpu_baseline"] = cpu_baseline(args, rays_per_frame)
             except Exception as e:  # the baseline must never take the GPU number down with it
                 res["cpu_baseline"] = {"value": None, "unit": "Mrays/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
-        if counts is None:
-            cpath = os.path.join(ROOT, "profiles", "algorithmic_counts.json")
-            if os.path.exists(cpath):
-                counts = json.load(open(cpath)).get(workload)
         if counts is not None:
+            assert counts["rays"] == rays_per_frame, (counts, rays_per_frame)
             alg = 24 * counts["box_tests"] + 16 * counts["nodes"] + 48 * counts["tri_tests"] + 16 * W * H
             if world > 1:
                 alg_launch = alg / world      # per-launch share of one rank (interleaved tiles: even split)
@@ -218,6 +209,7 @@ def main():
                                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                                "kernel": "rtk::render_kernel", "kernel_ms": round(kernel_ms_max, 4),
                                "algorithmic_bytes_per_launch": int(alg_launch),
+                               "per_ray": {k: round(counts[k] / counts["rays"], 3) for k in ("box_tests", "nodes", "tri_tests")},
                                "note": "algorithmic bytes (SURVEY 8d); the ~150 KB scene is L2/LDS resident, see DESIGN.md"}
             tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
             if os.path.exists(tpath):

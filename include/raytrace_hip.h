@@ -148,6 +148,17 @@ int rt_tonemap_device(rt_ctx *ctx, const void *rgba_dev, int64_t n_pixels, void 
 /* render + tonemap + D2H of the interleaved RGB8 image (what stbi_write_png gets, cpu:719) */
 int rt_render_rgb8(rt_ctx *ctx, const rt_params *p, int row_begin, int row_end, uint8_t *out_rgb8_host);
 
+/* --- work accounting: renders rows [row_begin,row_end) with the counting instantiation of
+ *     the kernel and returns the traversal work; 1 ray = 1 Scene::intersect_all call (cpu:545).  The
+ *     algorithmic bytes of the roofline are 24 B*box_tests + 16 B*nodes + 48 B*tri_tests + 16 B*pixels. */
+typedef struct rt_work {
+    uint64_t rays;                 /* intersect_all calls (primary + shadow + bounce)         */
+    uint64_t box_tests;            /* BoundingBox::intersect calls, root included             */
+    uint64_t nodes;                /* BVH nodes whose box was hit (= nodes the reference pops) */
+    uint64_t tri_tests;            /* moller_trumbore calls                                   */
+} rt_work;
+int rt_count_work(rt_ctx *ctx, const rt_params *p, int row_begin, int row_end, rt_work *out);
+
 int rt_synchronize(rt_ctx *ctx);
 int rt_get_stats(rt_ctx *ctx, rt_stats *stats);        /* waits for the last render to finish */
 

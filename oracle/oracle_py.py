@@ -26,7 +26,7 @@ class Params(C.Structure):
                 ("row_begin", C.c_int32), ("row_end", C.c_int32),
                 ("sigma", C.c_float), ("eps", C.c_float), ("tri_tmin", C.c_float), ("fov", C.c_float),
                 ("cam", C.c_float * 3), ("seed", C.c_uint32), ("threads", C.c_int32),
-                ("rng_mode", C.c_int32), ("stride", C.c_int32)]
+                ("rng_mode", C.c_int32), ("stride", C.c_int32), ("tile_rows", C.c_int32), ("tile_step", C.c_int32)]
 
 
 def build(force=False):
@@ -211,7 +211,8 @@ class Scene:
         return bool(hit), oid.value, P, N
 
     def render(self, W, H, num_rays=1, num_bounce=0, rows=None, sigma=0.0, eps=1e-3, tri_tmin=1e-4,
-               fov=None, cam=(0, 0, 55), seed=123456, threads=0, rng_mode=0, stride=1, want_rgb8=True):
+               fov=None, cam=(0, 0, 55), seed=123456, threads=0, rng_mode=0, stride=1, want_rgb8=True,
+               tile_rows=0, tile_step=0):
         p = Params()
         p.W, p.H, p.num_rays, p.num_bounce = W, H, num_rays, num_bounce
         p.row_begin, p.row_end = rows if rows else (0, H)
@@ -221,7 +222,11 @@ class Scene:
         p.cam[:] = cam
         p.seed, p.threads, p.rng_mode, p.stride = seed, threads, rng_mode, stride
         st = max(stride, 1)
-        nr = (p.row_end - p.row_begin + st - 1) // st
+        p.tile_rows, p.tile_step = tile_rows, tile_step
+        if tile_step > 1 and tile_rows > 0:
+            nr = sum(1 for r in range(p.row_begin, p.row_end, st) if ((r - p.row_begin) // tile_rows) % tile_step == 0)
+        else:
+            nr = (p.row_end - p.row_begin + st - 1) // st
         nc = (W + st - 1) // st
         rgba = np.zeros((nr, nc, 4), np.float32)
         rgb8 = np.zeros((nr, nc, 3), np.uint8) if want_rgb8 else None

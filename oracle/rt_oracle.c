@@ -677,8 +677,14 @@ int or_render(const or_scene *s, const or_params *p, float *out_rgba, uint8_t *o
     const int W = p->W, H = p->H;
     if (W <= 0 || H <= 0 || p->num_rays <= 0 || p->row_begin < 0 || p->row_end > H || p->row_begin > p->row_end) return -1;
     const int stride = p->stride > 1 ? p->stride : 1;
-    const int nrows = (p->row_end - p->row_begin + stride - 1) / stride;
     const int ncols = (W + stride - 1) / stride;
+    /* list of image rows to render */
+    int *rowlist = (int *)malloc(sizeof(int) * (size_t)(p->row_end - p->row_begin + 1));
+    int nrows = 0;
+    for (int r = p->row_begin; r < p->row_end; r += stride) {
+        if (p->tile_step > 1 && p->tile_rows > 0 && ((r - p->row_begin) / p->tile_rows) % p->tile_step != 0) continue;
+        rowlist[nrows++] = r;
+    }
     const float alpha = p->fov;
     /* cpu:694 `-W / (2 * tan(alpha/2))`: alpha is a compile-time constant in the reference, so g++ -O3
      * folds tan(float) with MPFR => the CORRECTLY ROUNDED binary32 tangent (0x1.279a74p-1 for pi/3/2),
@@ -699,7 +705,7 @@ int or_render(const or_scene *s, const or_params *p, float *out_rgba, uint8_t *o
         or_counters local = {0, 0, 0, 0, 0};
 #pragma omp for schedule(dynamic, 1)
         for (int ii = 0; ii < nrows; ii++) {
-            const int i = p->row_begin + ii * stride;
+            const int i = rowlist[ii];
             for (int jj = 0; jj < ncols; jj++) {
                 const int j = jj * stride;
                 /* cpu:699: the +0.5 / -0.5 are double literals, narrowed by Vector(float,...) */
@@ -737,6 +743,7 @@ int or_render(const or_scene *s, const or_params *p, float *out_rgba, uint8_t *o
 #pragma omp critical
         cnt_add(&total, &local);
     }
+    free(rowlist);
     if (cnt) *cnt = total;
     return 0;
 }

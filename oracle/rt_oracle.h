@@ -52,6 +52,9 @@ typedef struct or_params {
                                    reference's own uniform() (cpu:531-536) with clock()==0   */
     int32_t stride;          /* render every stride-th row/column only (<=1: all);
                                 the output is then dense ceil(rows/stride) x ceil(W/stride) */
+    int32_t tile_rows;       /* with tile_step > 1: only rows of every tile_step-th tile of      */
+    int32_t tile_step;       /* tile_rows rows (counted from row_begin) are rendered, densely
+                                packed in the output (the interleaved tiling of SURVEY 8e)     */
 } or_params;
 
 /* ---- mesh (TriangleMesh, cpu:167-502) ---- */

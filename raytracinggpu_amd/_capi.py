@@ -19,7 +19,7 @@ VARIANTS = {"auto": 0, "global": 1, "lds_verts": 2, "lds_top": 3, "lds_all": 4}
 # every symbol include/raytrace_hip.h declares (tests check the .so exports each)
 EXPORTS = ["rt_abi_version", "rt_device_count", "rt_ctx_create", "rt_ctx_destroy", "rt_last_error",
            "rt_device_name", "rt_scene_upload", "rt_render", "rt_render_device", "rt_tonemap_device",
-           "rt_render_rgb8", "rt_synchronize", "rt_get_stats"]
+           "rt_render_rgb8", "rt_synchronize", "rt_get_stats", "rt_count_work"]
 
 
 class RtError(RuntimeError):
@@ -56,6 +56,10 @@ class Params(C.Structure):
 
 class Rows(C.Structure):
     _fields_ = [("row0", C.c_int32), ("n_rows", C.c_int32), ("tile_rows", C.c_int32), ("tile_step", C.c_int32)]
+
+
+class Work(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("box_tests", C.c_uint64), ("nodes", C.c_uint64), ("tri_tests", C.c_uint64)]
 
 
 class Stats(C.Structure):
@@ -97,6 +101,7 @@ def load():
     L.rt_render_device.argtypes = [vp, C.POINTER(Params), C.POINTER(Rows), vp, vp]
     L.rt_tonemap_device.argtypes = [vp, vp, C.c_int64, vp, vp]
     L.rt_render_rgb8.argtypes = [vp, C.POINTER(Params), C.c_int, C.c_int, C.POINTER(C.c_uint8)]
+    L.rt_count_work.argtypes = [vp, C.POINTER(Params), C.c_int, C.c_int, C.POINTER(Work)]
     L.rt_synchronize.argtypes = [vp]
     L.rt_get_stats.argtypes = [vp, C.POINTER(Stats)]
     _lib = L
@@ -209,6 +214,13 @@ class Context:
     def tonemap_device(self, rgba_ptr, n_pixels, rgb8_ptr, stream=None):
         self._check(self._L.rt_tonemap_device(self._h, C.c_void_p(rgba_ptr), n_pixels, C.c_void_p(rgb8_ptr),
                                               C.c_void_p(stream) if stream else None))
+
+    def count_work(self, params, row_begin=0, row_end=None):
+        """Traversal work of a frame from the counting instantiation of the kernel."""
+        row_end = params.height if row_end is None else row_end
+        w = Work()
+        self._check(self._L.rt_count_work(self._h, C.byref(params), row_begin, row_end, C.byref(w)))
+        return {k: int(getattr(w, k)) for k, _ in Work._fields_}
 
     def synchronize(self):
         self._check(self._L.rt_synchronize(self._h))

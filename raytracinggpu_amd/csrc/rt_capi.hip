@@ -29,7 +29,7 @@ struct rt_ctx {
     hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
     bool have_scene = false, have_kernel_time = false, have_tonemap_time = false;
     rtk::Scene scene{};
-    DevBuf node_lo, node_hi, tri, verts, tidx, scratch_rgba, scratch_rgb8;
+    DevBuf node_lo, node_hi, tri, verts, tidx, scratch_rgba, scratch_rgb8, work;
     rt_stats stats{};
     std::string err;
     char name[256] = {0};
@@ -142,7 +142,8 @@ int check_params(rt_ctx *ctx, const rt_params *p, int &segs) {
     return RT_OK;
 }
 
-int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *out_dev, hipStream_t stream) {
+int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *out_dev, hipStream_t stream,
+                  unsigned long long *work_dev = nullptr) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
     if (!ctx->have_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_scene_upload has not been called");
     int segs = 0;
@@ -169,6 +170,7 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
     fr.seed = p->seed;
     fr.row0 = rows->row0; fr.n_rows = rows->n_rows; fr.tile_rows = rows->tile_rows; fr.tile_step = rows->tile_step;
     fr.out = static_cast<float4 *>(out_dev);
+    fr.work = work_dev;
 
     ctx->stats.pixels = (uint64_t)rows->n_rows * p->width;
     ctx->stats.variant = variant;
@@ -179,7 +181,8 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
     ctx->stats.lds_bytes = (int)lds;
     ctx->stats.grid_blocks = (int)(grid.x * grid.y);
     RT_HIP(ctx, hipEventRecord(ctx->ev_k0, stream));
-    hipLaunchKernelGGL(rtk::render_kernel, grid, dim3(rtk::kBlockThreads), lds, stream, ctx->scene, fr);
+    if (work_dev) hipLaunchKernelGGL(rtk::render_kernel<true>, grid, dim3(rtk::kBlockThreads), lds, stream, ctx->scene, fr);
+    else hipLaunchKernelGGL(rtk::render_kernel<false>, grid, dim3(rtk::kBlockThreads), lds, stream, ctx->scene, fr);
     RT_HIP(ctx, hipGetLastError());
     RT_HIP(ctx, hipEventRecord(ctx->ev_k1, stream));
     ctx->have_kernel_time = true;
@@ -255,7 +258,7 @@ int rt_ctx_destroy(rt_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ctx->node_lo.release(); ctx->node_hi.release(); ctx->tri.release(); ctx->verts.release(); ctx->tidx.release();
-    ctx->scratch_rgba.release(); ctx->scratch_rgb8.release();
+    ctx->scratch_rgba.release(); ctx->scratch_rgb8.release(); ctx->work.release();
     if (ctx->ev_k0) (void)hipEventDestroy(ctx->ev_k0);
     if (ctx->ev_k1) (void)hipEventDestroy(ctx->ev_k1);
     if (ctx->ev_t0) (void)hipEventDestroy(ctx->ev_t0);
@@ -390,6 +393,26 @@ int rt_render_rgb8(rt_ctx *ctx, const rt_params *p, int row_begin, int row_end, 
     if ((rc = launch_tonemap(ctx, ctx->scratch_rgba.p, npix, ctx->scratch_rgb8.p, ctx->stream)) != RT_OK) return rc;
     RT_HIP(ctx, hipMemcpyAsync(out_rgb8_host, ctx->scratch_rgb8.p, (size_t)npix * 3, hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_count_work(rt_ctx *ctx, const rt_params *p, int row_begin, int row_end, rt_work *out) {
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    if (!p || !out) return fail(ctx, RT_ERR_INVALID, "params/out is NULL");
+    if (row_begin < 0 || row_end < row_begin || row_end > p->height) return fail(ctx, RT_ERR_INVALID, "bad row range [%d,%d)", row_begin, row_end);
+    const int n = row_end - row_begin;
+    int rc = ensure(ctx, ctx->scratch_rgba, (size_t)n * (p->width > 0 ? p->width : 0) * sizeof(float4));
+    if (rc != RT_OK) return rc;
+    if ((rc = ensure(ctx, ctx->work, 4 * sizeof(unsigned long long))) != RT_OK) return rc;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipMemsetAsync(ctx->work.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
+    rt_rows rows{row_begin, n, n > 0 ? n : 1, 1};
+    rc = launch_render(ctx, p, &rows, ctx->scratch_rgba.p, ctx->stream, static_cast<unsigned long long *>(ctx->work.p));
+    if (rc != RT_OK) return rc;
+    unsigned long long h[4];
+    RT_HIP(ctx, hipMemcpyAsync(h, ctx->work.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    out->rays = h[0]; out->box_tests = h[1]; out->nodes = h[2]; out->tri_tests = h[3];
     return RT_OK;
 }
 

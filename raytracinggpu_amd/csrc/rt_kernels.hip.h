@@ -58,7 +58,11 @@ struct Frame {
     uint32_t seed;
     int row0, n_rows, tile_rows, tile_step;
     float4 *out;
+    unsigned long long *work;   // STATS kernels only: {rays, box_tests, nodes, tri_tests}
 };
+
+// per-lane traversal work counters (STATS instantiation only; SURVEY 8d accounting)
+struct Work { uint32_t box = 0, nodes = 0, tris = 0; };
 
 struct f3 { float x, y, z; };
 __device__ __forceinline__ f3 mk(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
@@ -106,7 +110,8 @@ __device__ __forceinline__ bool slab(float4 lo, float4 hi, f3 O, f3 u) {
 
 // TriangleMesh::intersect, cpu:277-311.  Returns true iff some triangle was accepted
 // (SURVEY H4); t/Nraw are the nearest accepted t and its unnormalised e1 x e2.
-__device__ __forceinline__ bool mesh_intersect(const Scene &sc, f3 O, f3 u, float tri_tmin, float &t_out, f3 &N_out) {
+template <bool STATS>
+__device__ __forceinline__ bool mesh_intersect(const Scene &sc, f3 O, f3 u, float tri_tmin, float &t_out, f3 &N_out, Work &wk) {
     float t_min = 1e9f;   // INF (1e9+9) narrowed to float, cpu:283
     bool any = false;
     f3 Nb = mk(0, 0, 0);
@@ -117,8 +122,11 @@ __device__ __forceinline__ bool mesh_intersect(const Scene &sc, f3 O, f3 u, floa
         const float4 hi = sc.node_hi[node];
         const int hiw = __float_as_int(hi.w);
         const int low = __float_as_int(lo.w);
+        if (STATS) wk.box++;
         if (slab(lo, hi, O, u)) {
+            if (STATS) wk.nodes++;
             if (hiw >= 0) {   // leaf: triangles [low, hiw), ascending (cpu:295)
+                if (STATS) wk.tris += (uint32_t)(hiw - low);
                 for (int i = low; i < hiw; ++i) {
                     const float4 q0 = sc.tri[3 * i + 0], q1 = sc.tri[3 * i + 1], q2 = sc.tri[3 * i + 2];
                     const f3 A = mk(q0.x, q0.y, q0.z), e1 = mk(q0.w, q1.x, q1.y), e2 = mk(q1.z, q1.w, q2.x);
@@ -149,7 +157,8 @@ __device__ __forceinline__ bool mesh_intersect(const Scene &sc, f3 O, f3 u, floa
 // Scene::intersect_all, cpu:545-564.  Objects are visited in insertion order with a
 // strict '<' (exact-tie behaviour); the winner's normal is evaluated once at the end
 // (it is a pure function of the winner, so this is bit-identical to cpu:524-525/308).
-__device__ __forceinline__ bool intersect_all(const Scene &sc, f3 O, f3 u, float tri_tmin, f3 &P, f3 &N, int &objectId) {
+template <bool STATS>
+__device__ __forceinline__ bool intersect_all(const Scene &sc, f3 O, f3 u, float tri_tmin, f3 &P, f3 &N, int &objectId, Work &wk) {
     float t_min = 1e9f;
     int id_min = -1;
     int sph_min = -1;
@@ -158,7 +167,7 @@ __device__ __forceinline__ bool intersect_all(const Scene &sc, f3 O, f3 u, float
     for (int obj = 0; obj < sc.n_objects; ++obj) {
         if (obj == sc.mesh_slot) {
             float t; f3 Nr;
-            if (mesh_intersect(sc, O, u, tri_tmin, t, Nr) && t < t_min) { t_min = t; id_min = obj; sph_min = -1; Nmesh = Nr; }
+            if (mesh_intersect<STATS>(sc, O, u, tri_tmin, t, Nr, wk) && t < t_min) { t_min = t; id_min = obj; sph_min = -1; Nmesh = Nr; }
             continue;
         }
         const Sphere &s = sc.sph[si++];
@@ -202,7 +211,8 @@ __device__ __forceinline__ Material material_of(const Scene &sc, int obj) {
 // recursion returns (color = direct + albedo (.) child, cpu:642-644).  Mirror/refraction segments return
 // the child unchanged (cpu:579,594,601) and a miss returns black (cpu:571).
 // lstack: per-lane LDS column, lstack[d * kBlockThreads].
-__device__ __forceinline__ f3 get_color(const Scene &sc, const Frame &fr, f3 O, f3 u, uint32_t hs, float *lstack, float &rays) {
+template <bool STATS>
+__device__ __forceinline__ f3 get_color(const Scene &sc, const Frame &fr, f3 O, f3 u, uint32_t hs, float *lstack, float &rays, Work &wk) {
     const float PI_F = (float)3.14159265358979323846;
     const double PI_D = 3.14159265358979323846;
     const f3 L = mk(sc.Lx, sc.Ly, sc.Lz);
@@ -213,7 +223,7 @@ __device__ __forceinline__ f3 get_color(const Scene &sc, const Frame &fr, f3 O, 
     for (int d = 0; d < fr.segs; ++d) {
         f3 P, N; int id;
         rays += 1.f;
-        if (!intersect_all(sc, O, u, fr.tri_tmin, P, N, id)) break;
+        if (!intersect_all<STATS>(sc, O, u, fr.tri_tmin, P, N, id, wk)) break;
         nseg = d + 1;
         const Material m = material_of(sc, id);
         if (m.mirror) {                                             // cpu:573-579
@@ -241,7 +251,7 @@ __device__ __forceinline__ f3 get_color(const Scene &sc, const Frame &fr, f3 O, 
             const f3 sdir = toL / rt_sqrtf(norm2(toL));           // NORMED_VEC, cpu:30,614
             f3 Pp, Np; int ids_;
             rays += 1.f;
-            (void)intersect_all(sc, Pa, sdir, fr.tri_tmin, Pp, Np, ids_);
+            (void)intersect_all<STATS>(sc, Pa, sdir, fr.tri_tmin, Pp, Np, ids_, wk);
             float l = 0.f;
             if (!(norm2(Pp - Pa) <= norm2(L - Pa))) {               // cpu:615
                 const f3 wl = normalize(L - P);
@@ -283,15 +293,24 @@ __device__ __forceinline__ f3 get_color(const Scene &sc, const Frame &fr, f3 O, 
     return ans;
 }
 
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+template <bool STATS>
 __global__ __launch_bounds__(kBlockThreads) void render_kernel(const Scene sc, const Frame fr) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int px = blockIdx.x * kTileW + wave * 8 + (lane & 7);
     const int lrow = blockIdx.y * kTileH + (lane >> 3);
-    if (px >= fr.W || lrow >= fr.n_rows) return;
     const int row = fr.row0 + (lrow / fr.tile_rows) * fr.tile_rows * fr.tile_step + (lrow % fr.tile_rows);
-    if (row >= fr.H) return;
+    const bool active = px < fr.W && lrow < fr.n_rows && row < fr.H;
+    Work wk;
+    float rays = 0.f;
+    if (active) {
     float *lstack = smem + tid;
 
     // cpu:699: +0.5/-0.5 are double literals, narrowed by the Vector constructor
@@ -301,7 +320,6 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(const Scene sc, c
     const uint32_t pixel = (uint32_t)row * (uint32_t)fr.W + (uint32_t)px;
     const uint32_t hp = mix32(pixel ^ mix32(fr.seed));
     f3 total = mk(0, 0, 0);
-    float rays = 0.f;
     for (int s = 0; s < fr.spp; ++s) {
         const uint32_t hs = mix32(hp ^ ((uint32_t)s * 0x9E3779B1U));
         f3 uu = uc;
@@ -313,11 +331,19 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(const Scene sc, c
             uu = uc + mk((float)((double)bm * cs), (float)((double)bm * sn), 0.f);
         }
         const f3 u = normalize(uu);
-        const f3 col = get_color(sc, fr, C, u, hs, lstack, rays);
+        const f3 col = get_color<STATS>(sc, fr, C, u, hs, lstack, rays, wk);
         total = total + col;
     }
     const f3 avg = total / (float)fr.spp;                           // cpu:713
     fr.out[(size_t)lrow * fr.W + px] = make_float4(avg.x, avg.y, avg.z, rays);
+    }
+    if (STATS) {   // one atomic per wave and counter
+        const uint32_t r = wave_sum((uint32_t)rays), b = wave_sum(wk.box), n = wave_sum(wk.nodes), t = wave_sum(wk.tris);
+        if (lane == 0) {
+            atomicAdd(&fr.work[0], (unsigned long long)r); atomicAdd(&fr.work[1], (unsigned long long)b);
+            atomicAdd(&fr.work[2], (unsigned long long)n); atomicAdd(&fr.work[3], (unsigned long long)t);
+        }
+    }
 }
 
 // cpu:714-716: std::min(std::pow(c, 1./2.2), 255.) -> unsigned char.  4 pixels per lane,

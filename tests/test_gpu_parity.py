@@ -179,3 +179,13 @@ def test_product_builder_feeds_the_kernel(ctx, oracle, oracle_cat, cat_golden):
     exp, _, _ = oracle.Scene.preset("cpu", oracle_cat).render(640, 360, 1, 1, want_rgb8=False)
     assert linf(oracle, got, exp) <= TOL
     assert values_equal(got[..., :3], exp[..., :3]).mean() > 0.999
+
+
+def test_work_counters_equal_oracle_counters(ctx, oracle, oracle_cat, cat_golden):
+    """rt_count_work (counting instantiation of the kernel) == the oracle's counting pass: same rays, box tests,
+    nodes and triangle tests, i.e. the stackless traversal visits exactly what cpu:277-311 visits."""
+    upload(ctx, "cpu", cat_golden)
+    for W, H, spp, b in ((512, 512, 1, 0), (320, 180, 2, 3)):
+        got = ctx.count_work(rt.make_params(W, H, spp, b, **rt.scenes.CPU_LAUNCHER))
+        _, _, exp = oracle.Scene.preset("cpu", oracle_cat).render(W, H, spp, b, want_rgb8=False)
+        assert got == {k: exp[k] for k in ("rays", "box_tests", "nodes", "tri_tests")}
