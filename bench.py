@@ -130,7 +130,12 @@ def main():
     local = torch.zeros((tiles_local * TILE_ROWS, W, 4), dtype=torch.float32, device=dev)
     gathered = [torch.empty_like(local) for _ in range(world)] if (world > 1 and rank == 0) else None
     frame = None
-    stream = torch.cuda.current_stream().cuda_stream
+    # a non-default torch stream: its handle is non-NULL (NULL means "the context's own stream" in the C-ABI),
+    # so the render kernel, torch's timing events and the RCCL gather are all ordered on ONE stream
+    side = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(side)
+    stream = side.cuda_stream
+    assert stream != 0
 
     def step():
         nonlocal frame
