@@ -204,18 +204,28 @@ def main():
                 res["cpu_baseline"] = {"value": None, "unit": "Mrays/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         if counts is not None:
             assert counts["rays"] == rays_per_frame, (counts, rays_per_frame)
-            alg = 24 * counts["box_tests"] + 16 * counts["nodes"] + 48 * counts["tri_tests"] + 16 * W * H
-            if world > 1:
-                alg_launch = alg / world      # per-launch share of one rank (interleaved tiles: even split)
+            st = ctx.stats()
+            trav_bytes = 24 * counts["box_tests"] + 16 * counts["nodes"] + 48 * counts["tri_tests"]
+            fb_bytes = 16 * W * H
+            if st["trav_launches"] > 0:
+                # wavefront variant: the dominant kernel is the traversal kernel; its launches of the last timed
+                # frame are bracketed by HIP events inside the library, on the stream they run on
+                kname = "rtk::wf_trav<false>"
+                launches = st["trav_launches"]
+                k_ms = st["trav_ms"] / launches
+                alg_launch = trav_bytes / world / launches
             else:
-                alg_launch = alg
-            ach = alg_launch / (kernel_ms_max * 1e-3) / 1e9
+                kname = "rtk::render_persistent<false>" if st["variant"] == 1 else "rtk::render_kernel<false>"
+                launches, k_ms, alg_launch = 1, kernel_ms_max, (trav_bytes + fb_bytes) / world
+            ach = alg_launch / (k_ms * 1e-3) / 1e9
             res["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                               "kernel": "rtk::render_kernel", "kernel_ms": round(kernel_ms_max, 4),
+                               "kernel": kname, "kernel_ms": round(k_ms, 4), "launches_per_frame": launches,
                                "algorithmic_bytes_per_launch": int(alg_launch),
+                               "frame_algorithmic_bytes": int(trav_bytes + fb_bytes), "frame_kernels_ms": round(kernel_ms_max, 4),
                                "per_ray": {k: round(counts[k] / counts["rays"], 3) for k in ("box_tests", "nodes", "tri_tests")},
-                               "note": "algorithmic bytes (SURVEY 8d); the ~150 KB scene is L2/LDS resident, see DESIGN.md"}
+                               "note": "algorithmic bytes (SURVEY 8d: 24 B/box test + 16 B/node + 48 B/triangle test); "
+                                       "the ~150 KB scene is cache resident, see DESIGN.md"}
             tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
             if os.path.exists(tpath):
                 t = json.load(open(tpath)).get(workload)

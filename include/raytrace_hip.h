@@ -42,14 +42,20 @@ typedef enum rt_status {
     RT_ERR_UNSUPPORTED = -5    /* e.g. LDS variant that does not fit the mesh        */
 } rt_status;
 
-/* kernel variants (BASELINE.json configs 3/4); all produce identical results */
+/* kernel variants (BASELINE.json configs 3/4); all produce bit-identical results */
 typedef enum rt_variant {
-    RT_VARIANT_AUTO = 0,       /* library picks the fastest variant that fits       */
-    RT_VARIANT_GLOBAL = 1,     /* SoA nodes + packed triangles read from HBM/L2      */
-    RT_VARIANT_LDS_VERTS = 2,  /* vertex array staged in LDS per workgroup
-                                  (different-versions/optimized_vertices-in-shared.cu:681-686) */
-    RT_VARIANT_LDS_TOP = 3,    /* + top BVH levels staged in LDS                     */
-    RT_VARIANT_LDS_ALL = 4     /* whole BVH + vertices + indices resident in LDS     */
+    RT_VARIANT_AUTO = 0,       /* library picks the fastest variant that fits                       */
+    RT_VARIANT_GLOBAL = 1,     /* persistent lanes (micro-op scheduler); SoA nodes + packed
+                                  triangles read from HBM through L2/L1                             */
+    RT_VARIANT_LDS_VERTS = 2,  /* + vertex array staged in LDS per workgroup
+                                  (different-versions/optimized_vertices-in-shared.cu:681-686)      */
+    RT_VARIANT_LDS_TOP = 3,    /* + top BVH levels staged in LDS                                    */
+    RT_VARIANT_LDS_ALL = 4,    /* whole BVH + vertices + indices resident in LDS                    */
+    RT_VARIANT_LOCKSTEP = 5,   /* one lane bound to one pixel for the whole frame, lock-step ray
+                                  queries: the structure of KernelLaunch (optimized.cu:670-772);
+                                  kept as the baseline the other variants are measured against      */
+    RT_VARIANT_WAVEFRONT = 6   /* uniform per-pixel shade/generate kernels alternating with a lean
+                                  persistent traversal kernel; path state as float4 SoA in HBM      */
 } rt_variant;
 
 typedef struct rt_ctx rt_ctx;
@@ -117,6 +123,9 @@ typedef struct rt_stats {
     int32_t  lds_bytes;            /* dynamic + static LDS per workgroup                      */
     int32_t  block_threads;
     int32_t  grid_blocks;
+    float    trav_ms;              /* wavefront variant: summed HIP-event time of the traversal kernel
+                                      launches of the last sample of the last frame, and how many    */
+    int32_t  trav_launches;
 } rt_stats;
 
 /* --- device / context -------------------------------------------------------- */

@@ -3,6 +3,8 @@
 // from the reference's arrays to the kernel's SoA layout), launches, timing.
 #include "../../include/raytrace_hip.h"
 #include "rt_kernels.hip.h"
+#include "rt_persistent.hip.h"
+#include "rt_wavefront.hip.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -29,7 +31,14 @@ struct rt_ctx {
     hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
     bool have_scene = false, have_kernel_time = false, have_tonemap_time = false;
     rtk::Scene scene{};
-    DevBuf node_lo, node_hi, tri, verts, tidx, scratch_rgba, scratch_rgb8, work;
+    DevBuf node_lo, node_hi, nodes2, tri, verts, tidx, scratch_rgba, scratch_rgb8, work, queue;
+    int n_cus = 0;
+    DevBuf wfR0, wfR1, wfM, wfS0, wfS1, wfT, wfF, wfLS, wfQ;   // wavefront path state (HBM)
+    int trav_blocks_per_cu[2] = {0, 0};
+    static constexpr int kMaxTravEvents = 2 * RT_MAX_SEGMENTS;
+    hipEvent_t ev_trav[2 * kMaxTravEvents] = {};
+    int n_trav_events = 0;
+    int persist_blocks_per_cu[2] = {0, 0};   // [STATS]
     rt_stats stats{};
     std::string err;
     char name[256] = {0};
@@ -78,8 +87,9 @@ inline h3 hcross(h3 a, h3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * 
 // Converts the reference's bvhTreeToArray layout (optimized.cu:512-534) into traversal order.
 // The reference pops the right child first (cpu:291-292 push left then right), so the
 // pre-order here descends right before left.
-int build_threaded(rt_ctx *ctx, const rt_mesh *m, std::vector<float4> &lo, std::vector<float4> &hi) {
+int build_threaded(rt_ctx *ctx, const rt_mesh *m, std::vector<float4> &lo, std::vector<float4> &hi, std::vector<int> &perm) {
     const int n = m->n_nodes;
+    perm.clear();
     lo.assign(n, make_float4(0, 0, 0, 0));
     hi.assign(n, make_float4(0, 0, 0, 0));
     if (n == 0) return RT_OK;
@@ -105,8 +115,14 @@ int build_threaded(rt_ctx *ctx, const rt_mesh *m, std::vector<float4> &lo, std::
             if (left == -1 || right == -1) {   // leaf (cpu:287 tests `left` only; the builder sets both or none)
                 if (left != -1 || right != -1)
                     return fail(ctx, RT_ERR_INVALID, "bvh_arr10: node %d has exactly one child", it.ref);
-                lo[it.out].w = __builtin_bit_cast(float, ts);
-                hi[it.out].w = __builtin_bit_cast(float, te);
+                // triangles are re-stored in VISIT order (leaves as the traversal reaches them, ascending inside a
+                // leaf, cpu:295), so a triangle's index is its rank in the reference's scan: the strict '<' of
+                // cpu:301 keeps, among equal t, the smallest index -- which is what lets sub-ranges of one ray
+                // be traversed independently and merged by min over (t, index)
+                const int first = (int)perm.size();
+                for (int q = ts; q < te; ++q) perm.push_back(q);
+                lo[it.out].w = __builtin_bit_cast(float, first);
+                hi[it.out].w = __builtin_bit_cast(float, (int)perm.size());
                 st.pop_back();
                 continue;
             }
@@ -138,7 +154,7 @@ int check_params(rt_ctx *ctx, const rt_params *p, int &segs) {
         return fail(ctx, RT_ERR_INVALID, "depth_convention must be 0 (cpu_launcher) or 1 (optimized.cu)");
     segs = p->depth_convention == 0 ? p->num_bounce + 1 : p->num_bounce;
     if (segs > RT_MAX_SEGMENTS) return fail(ctx, RT_ERR_INVALID, "more than %d ray segments", RT_MAX_SEGMENTS);
-    if (p->variant < RT_VARIANT_AUTO || p->variant > RT_VARIANT_LDS_ALL) return fail(ctx, RT_ERR_INVALID, "unknown variant %d", p->variant);
+    if (p->variant < RT_VARIANT_AUTO || p->variant > RT_VARIANT_WAVEFRONT) return fail(ctx, RT_ERR_INVALID, "unknown variant %d", p->variant);
     return RT_OK;
 }
 
@@ -157,8 +173,9 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
         const int64_t last_row = rows->row0 + (last / rows->tile_rows) * rows->tile_rows * (int64_t)rows->tile_step + (last % rows->tile_rows);
         if (last_row >= p->height) return fail(ctx, RT_ERR_INVALID, "rows reach image row %lld >= height %d", (long long)last_row, p->height);
     }
-    int variant = p->variant == RT_VARIANT_AUTO ? RT_VARIANT_GLOBAL : p->variant;
-    if (variant != RT_VARIANT_GLOBAL) return fail(ctx, RT_ERR_UNSUPPORTED, "variant %d is not available in this build", variant);
+    int variant = p->variant == RT_VARIANT_AUTO ? RT_VARIANT_WAVEFRONT : p->variant;
+    if (variant != RT_VARIANT_GLOBAL && variant != RT_VARIANT_LOCKSTEP && variant != RT_VARIANT_WAVEFRONT)
+        return fail(ctx, RT_ERR_UNSUPPORTED, "variant %d is not available in this build", variant);
 
     RT_HIP(ctx, hipSetDevice(ctx->device));
     rtk::Frame fr{};
@@ -174,15 +191,129 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
 
     ctx->stats.pixels = (uint64_t)rows->n_rows * p->width;
     ctx->stats.variant = variant;
-    ctx->stats.block_threads = rtk::kBlockThreads;
     if (rows->n_rows == 0) { ctx->stats.grid_blocks = 0; ctx->have_kernel_time = false; return RT_OK; }
-    dim3 grid((p->width + rtk::kTileW - 1) / rtk::kTileW, (rows->n_rows + rtk::kTileH - 1) / rtk::kTileH);
-    const size_t lds = (size_t)(segs > 0 ? segs : 1) * rtk::kBlockThreads * sizeof(float);
-    ctx->stats.lds_bytes = (int)lds;
-    ctx->stats.grid_blocks = (int)(grid.x * grid.y);
-    RT_HIP(ctx, hipEventRecord(ctx->ev_k0, stream));
-    if (work_dev) hipLaunchKernelGGL(rtk::render_kernel<true>, grid, dim3(rtk::kBlockThreads), lds, stream, ctx->scene, fr);
-    else hipLaunchKernelGGL(rtk::render_kernel<false>, grid, dim3(rtk::kBlockThreads), lds, stream, ctx->scene, fr);
+    const int nseg = segs > 0 ? segs : 1;
+    ctx->n_trav_events = 0;
+    if (variant == RT_VARIANT_WAVEFRONT) {
+        // begin, (trav, advance) x 2*segments per sample; path state SoA in HBM, tile-order path index
+        rtk::WfState st{};
+        st.tiles_x = (p->width + 7) / 8;
+        const int64_t n_paths64 = (int64_t)st.tiles_x * ((rows->n_rows + 7) / 8) * 64;
+        if (n_paths64 >= ((int64_t)1 << 31) - 65536) return fail(ctx, RT_ERR_INVALID, "image too large");
+        st.n_paths = (int)n_paths64;
+        const size_t np = (size_t)st.n_paths;
+        int rc2;
+        if ((rc2 = ensure(ctx, ctx->wfR0, np * 16)) != RT_OK || (rc2 = ensure(ctx, ctx->wfR1, np * 16)) != RT_OK ||
+            (rc2 = ensure(ctx, ctx->wfM, np * 8)) != RT_OK || (rc2 = ensure(ctx, ctx->wfS0, np * 16)) != RT_OK ||
+            (rc2 = ensure(ctx, ctx->wfS1, np * 16)) != RT_OK || (rc2 = ensure(ctx, ctx->wfT, np * 16)) != RT_OK ||
+            (rc2 = ensure(ctx, ctx->wfF, np * 16)) != RT_OK || (rc2 = ensure(ctx, ctx->wfLS, np * 4 * (size_t)nseg)) != RT_OK ||
+            false)
+            return rc2;
+        st.R0 = static_cast<float4 *>(ctx->wfR0.p); st.R1 = static_cast<float4 *>(ctx->wfR1.p);
+        st.M = static_cast<unsigned long long *>(ctx->wfM.p); st.S0 = static_cast<float4 *>(ctx->wfS0.p);
+        st.S1 = static_cast<float4 *>(ctx->wfS1.p); st.T = static_cast<float4 *>(ctx->wfT.p);
+        st.F = static_cast<int4 *>(ctx->wfF.p); st.LS = static_cast<float *>(ctx->wfLS.p);
+        const int si = work_dev ? 1 : 0;
+        if (ctx->trav_blocks_per_cu[si] == 0) {
+            int nb = 0;
+            if (work_dev) RT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtk::wf_trav<true>, rtk::kTravBlock, 0));
+            else RT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtk::wf_trav<false>, rtk::kTravBlock, 0));
+            ctx->trav_blocks_per_cu[si] = nb > 0 ? nb : 1;
+        }
+        const bool have_mesh = ctx->scene.mesh_slot >= 0 && ctx->scene.n_nodes > 0;
+        static DevBuf dbgbuf;
+        const char *dbg_env = getenv("RT_DEBUG_TRAV");
+        const int dbg_it = dbg_env ? atoi(dbg_env) : -1;
+        if (dbg_env) { rc2 = ensure(ctx, dbgbuf, 6 * 8 * 65536); if (rc2 != RT_OK) return rc2; }
+        // traversal launch geometry: waves_per_simd (env RT_TRAV_WAVES for experiments) persistent waves per SIMD,
+        // each owning an equal, spatially scrambled share of the ray slots (no queue, no atomics)
+        int wps = ctx->trav_blocks_per_cu[si];                       // 256-thread blocks per CU == waves per SIMD
+        if (const char *e = getenv("RT_TRAV_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= wps) wps = v; }
+        int64_t tblocks = (int64_t)ctx->n_cus * wps;
+        st.n_groups = st.n_paths / 4;
+        // scramble: consecutive group-slots of one wave must land on groups spread over the WHOLE image, so the
+        // stride pattern's period S is the largest power of two not above a wave's number of groups
+        int64_t n_waves = tblocks * (rtk::kTravBlock / 64);
+        int64_t groups_per_wave = (st.n_groups + n_waves - 1) / n_waves;
+        if (groups_per_wave < 16) {                                   // small image: fewer waves, >= 64 rays each
+            n_waves = (st.n_groups + 15) / 16;
+            tblocks = (n_waves + 3) / 4; n_waves = tblocks * 4;
+            groups_per_wave = (st.n_groups + n_waves - 1) / n_waves;
+        }
+        st.log2S = 0;
+        while ((2 << st.log2S) <= groups_per_wave && st.log2S < 12) ++st.log2S;
+        const int S = 1 << st.log2S;
+        st.Q = (st.n_groups + S - 1) / S;
+        const int64_t total_slots = (int64_t)S * st.Q * 4;
+        st.slots_per_wave = (int)(((total_slots + n_waves - 1) / n_waves + 3) / 4 * 4);
+        const unsigned pblocks = (unsigned)((np + 255) / 256);
+        ctx->stats.lds_bytes = 0;
+        ctx->stats.block_threads = rtk::kTravBlock;
+        ctx->stats.grid_blocks = (int)tblocks;
+        RT_HIP(ctx, hipEventRecord(ctx->ev_k0, stream));
+        for (int s = 0; s < fr.spp; ++s) {
+            if (work_dev) hipLaunchKernelGGL(rtk::wf_begin<true>, dim3(pblocks), dim3(256), 0, stream, ctx->scene, fr, st, s);
+            else hipLaunchKernelGGL(rtk::wf_begin<false>, dim3(pblocks), dim3(256), 0, stream, ctx->scene, fr, st, s);
+            for (int it = 0; it < 2 * segs; ++it) {
+                if (have_mesh) {
+                    st.dbg = (dbg_env && it == dbg_it) ? static_cast<unsigned long long *>(dbgbuf.p) : nullptr;
+                    const bool timed = s == fr.spp - 1;      // time the traversal launches of the last sample
+                    if (timed) RT_HIP(ctx, hipEventRecord(ctx->ev_trav[2 * it], stream));
+                    if (work_dev) hipLaunchKernelGGL(rtk::wf_trav<true>, dim3((unsigned)tblocks), dim3(rtk::kTravBlock), 0, stream, ctx->scene, fr, st);
+                    else hipLaunchKernelGGL(rtk::wf_trav<false>, dim3((unsigned)tblocks), dim3(rtk::kTravBlock), 0, stream, ctx->scene, fr, st);
+                    if (timed) { RT_HIP(ctx, hipEventRecord(ctx->ev_trav[2 * it + 1], stream)); ctx->n_trav_events = it + 1; }
+                    st.dbg = nullptr;
+                }
+                if (work_dev) hipLaunchKernelGGL(rtk::wf_advance<true>, dim3(pblocks), dim3(256), 0, stream, ctx->scene, fr, st, s);
+                else hipLaunchKernelGGL(rtk::wf_advance<false>, dim3(pblocks), dim3(256), 0, stream, ctx->scene, fr, st, s);
+            }
+        }
+        if (dbg_env) {
+            std::vector<unsigned long long> h(6 * (size_t)(tblocks * 4));
+            (void)hipStreamSynchronize(stream);
+            (void)hipMemcpy(h.data(), dbgbuf.p, h.size() * 8, hipMemcpyDeviceToHost);
+            FILE *f = fopen("gpurun_out/trav_dbg.bin", "wb");
+            if (f) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+        }
+    } else if (variant == RT_VARIANT_LOCKSTEP) {
+        dim3 grid((p->width + rtk::kTileW - 1) / rtk::kTileW, (rows->n_rows + rtk::kTileH - 1) / rtk::kTileH);
+        const size_t lds = (size_t)nseg * rtk::kBlockThreads * sizeof(float);
+        ctx->stats.lds_bytes = (int)lds;
+        ctx->stats.block_threads = rtk::kBlockThreads;
+        ctx->stats.grid_blocks = (int)(grid.x * grid.y);
+        RT_HIP(ctx, hipEventRecord(ctx->ev_k0, stream));
+        if (work_dev) hipLaunchKernelGGL(rtk::render_kernel<true>, grid, dim3(rtk::kBlockThreads), lds, stream, ctx->scene, fr);
+        else hipLaunchKernelGGL(rtk::render_kernel<false>, grid, dim3(rtk::kBlockThreads), lds, stream, ctx->scene, fr);
+    } else {
+        // persistent lanes: as many workgroups as are co-resident, pixels drawn from a global queue
+        rtk::PFrame pf{};
+        pf.f = fr;
+        pf.tiles_x = (p->width + 7) / 8;
+        const int64_t slots = (int64_t)pf.tiles_x * ((rows->n_rows + 7) / 8) * 64;
+        if (slots >= ((int64_t)1 << 32) - 65536) return fail(ctx, RT_ERR_INVALID, "image too large for the pixel queue");
+        pf.n_slots = (unsigned int)slots;
+        int rc2 = ensure(ctx, ctx->queue, sizeof(unsigned int));
+        if (rc2 != RT_OK) return rc2;
+        pf.queue = static_cast<unsigned int *>(ctx->queue.p);
+        const size_t lds = (size_t)nseg * rtk::kPBlock * sizeof(float);
+        const int si = work_dev ? 1 : 0;
+        if (ctx->persist_blocks_per_cu[si] == 0) {
+            int nb = 0;
+            if (work_dev) RT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtk::render_persistent<true>, rtk::kPBlock, (size_t)RT_MAX_SEGMENTS * rtk::kPBlock * sizeof(float)));
+            else RT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtk::render_persistent<false>, rtk::kPBlock, (size_t)RT_MAX_SEGMENTS * rtk::kPBlock * sizeof(float)));
+            ctx->persist_blocks_per_cu[si] = nb > 0 ? nb : 1;
+        }
+        int64_t blocks = (int64_t)ctx->n_cus * ctx->persist_blocks_per_cu[si];
+        const int64_t useful = (slots + rtk::kPBlock - 1) / rtk::kPBlock;
+        if (blocks > useful) blocks = useful;
+        ctx->stats.lds_bytes = (int)lds;
+        ctx->stats.block_threads = rtk::kPBlock;
+        ctx->stats.grid_blocks = (int)blocks;
+        RT_HIP(ctx, hipMemsetAsync(pf.queue, 0, sizeof(unsigned int), stream));
+        RT_HIP(ctx, hipEventRecord(ctx->ev_k0, stream));
+        if (work_dev) hipLaunchKernelGGL(rtk::render_persistent<true>, dim3((unsigned)blocks), dim3(rtk::kPBlock), lds, stream, ctx->scene, pf);
+        else hipLaunchKernelGGL(rtk::render_persistent<false>, dim3((unsigned)blocks), dim3(rtk::kPBlock), lds, stream, ctx->scene, pf);
+    }
     RT_HIP(ctx, hipGetLastError());
     RT_HIP(ctx, hipEventRecord(ctx->ev_k1, stream));
     ctx->have_kernel_time = true;
@@ -238,12 +369,14 @@ int rt_ctx_create(rt_ctx **out, int device_id) {
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_k1);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_t0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_t1);
+    for (hipEvent_t &ev : ctx->ev_trav) if (e == hipSuccess) e = hipEventCreate(&ev);
     if (e != hipSuccess) {
         int code = fail(nullptr, RT_ERR_HIP, "context creation: %s", hipGetErrorString(e));
         rt_ctx_destroy(ctx);
         return code;
     }
     snprintf(ctx->name, sizeof(ctx->name), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    ctx->n_cus = prop.multiProcessorCount;
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
         int code = fail(nullptr, RT_ERR_NO_DEVICE, "device %d is %s; this library contains gfx950 code only", device_id, prop.gcnArchName);
         rt_ctx_destroy(ctx);
@@ -257,8 +390,11 @@ int rt_ctx_destroy(rt_ctx *ctx) {
     if (!ctx) return RT_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    ctx->node_lo.release(); ctx->node_hi.release(); ctx->tri.release(); ctx->verts.release(); ctx->tidx.release();
-    ctx->scratch_rgba.release(); ctx->scratch_rgb8.release(); ctx->work.release();
+    ctx->node_lo.release(); ctx->node_hi.release(); ctx->nodes2.release(); ctx->tri.release(); ctx->verts.release(); ctx->tidx.release();
+    ctx->scratch_rgba.release(); ctx->scratch_rgb8.release(); ctx->work.release(); ctx->queue.release();
+    ctx->wfR0.release(); ctx->wfR1.release(); ctx->wfM.release(); ctx->wfS0.release(); ctx->wfS1.release();
+    ctx->wfT.release(); ctx->wfF.release(); ctx->wfLS.release(); ctx->wfQ.release();
+    for (hipEvent_t &e : ctx->ev_trav) if (e) (void)hipEventDestroy(e);
     if (ctx->ev_k0) (void)hipEventDestroy(ctx->ev_k0);
     if (ctx->ev_k1) (void)hipEventDestroy(ctx->ev_k1);
     if (ctx->ev_t0) (void)hipEventDestroy(ctx->ev_t0);
@@ -311,12 +447,21 @@ int rt_scene_upload(rt_ctx *ctx, const rt_sphere *spheres, int n_spheres, const 
         if (mesh->n_nodes >= (1 << 24)) return fail(ctx, RT_ERR_INVALID, "node indices are stored as floats: < 2^24 nodes");
         sc.mesh_slot = mesh->object_slot;
         sc.mar = mesh->albedo[0]; sc.mag = mesh->albedo[1]; sc.mab = mesh->albedo[2];
-        int rc = build_threaded(ctx, mesh, lo, hi);
+        std::vector<int> perm;
+        int rc = build_threaded(ctx, mesh, lo, hi, perm);
         if (rc != RT_OK) return rc;
-        tri.resize((size_t)mesh->n_triangles * 3);
-        tidx.resize(mesh->n_triangles);
+        if (perm.size() >= ((size_t)1 << 31)) return fail(ctx, RT_ERR_INVALID, "too many leaf triangles");
         for (int t = 0; t < mesh->n_triangles; ++t) {
             const int32_t *ix = mesh->indices + (size_t)t * mesh->index_stride;
+            for (int k = 0; k < 3; ++k)
+                if (ix[k] < 0 || ix[k] >= mesh->n_vertices)
+                    return fail(ctx, RT_ERR_INVALID, "triangle %d references vertex %d outside [0,%d)", t, ix[k], mesh->n_vertices);
+        }
+        const int n_int = (int)perm.size();
+        tri.resize((size_t)n_int * 3);
+        tidx.resize(n_int);
+        for (int t = 0; t < n_int; ++t) {
+            const int32_t *ix = mesh->indices + (size_t)perm[t] * mesh->index_stride;
             for (int k = 0; k < 3; ++k)
                 if (ix[k] < 0 || ix[k] >= mesh->n_vertices)
                     return fail(ctx, RT_ERR_INVALID, "triangle %d references vertex %d outside [0,%d)", t, ix[k], mesh->n_vertices);
@@ -331,18 +476,23 @@ int rt_scene_upload(rt_ctx *ctx, const rt_sphere *spheres, int n_spheres, const 
         verts.resize(mesh->n_vertices);
         for (int i = 0; i < mesh->n_vertices; ++i)
             verts[i] = make_float4(mesh->vertices[3 * (size_t)i], mesh->vertices[3 * (size_t)i + 1], mesh->vertices[3 * (size_t)i + 2], 0);
-        sc.n_nodes = mesh->n_triangles > 0 ? mesh->n_nodes : 0;
-        sc.n_tris = mesh->n_triangles;
+        sc.n_nodes = n_int > 0 ? mesh->n_nodes : 0;
+        sc.n_tris = n_int;
+        if (sc.n_nodes > 0) { sc.root_lo = lo[0]; sc.root_hi = hi[0]; }
         sc.n_verts = mesh->n_vertices;
     }
     int rc;
     if ((rc = upload(ctx, ctx->node_lo, lo.data(), lo.size() * sizeof(float4))) != RT_OK) return rc;
     if ((rc = upload(ctx, ctx->node_hi, hi.data(), hi.size() * sizeof(float4))) != RT_OK) return rc;
+    std::vector<float4> inter(lo.size() * 2);
+    for (size_t k = 0; k < lo.size(); ++k) { inter[2 * k] = lo[k]; inter[2 * k + 1] = hi[k]; }
+    if ((rc = upload(ctx, ctx->nodes2, inter.data(), inter.size() * sizeof(float4))) != RT_OK) return rc;
     if ((rc = upload(ctx, ctx->tri, tri.data(), tri.size() * sizeof(float4))) != RT_OK) return rc;
     if ((rc = upload(ctx, ctx->verts, verts.data(), verts.size() * sizeof(float4))) != RT_OK) return rc;
     if ((rc = upload(ctx, ctx->tidx, tidx.data(), tidx.size() * sizeof(int4))) != RT_OK) return rc;
     sc.node_lo = static_cast<const float4 *>(ctx->node_lo.p);
     sc.node_hi = static_cast<const float4 *>(ctx->node_hi.p);
+    sc.nodes = static_cast<const float4 *>(ctx->nodes2.p);
     sc.tri = static_cast<const float4 *>(ctx->tri.p);
     sc.verts = static_cast<const float4 *>(ctx->verts.p);
     sc.tidx = static_cast<const int4 *>(ctx->tidx.p);
@@ -411,8 +561,12 @@ int rt_count_work(rt_ctx *ctx, const rt_params *p, int row_begin, int row_end, r
     if (rc != RT_OK) return rc;
     unsigned long long h[4];
     RT_HIP(ctx, hipMemcpyAsync(h, ctx->work.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<float> fb((size_t)n * (size_t)p->width * 4);
+    RT_HIP(ctx, hipMemcpyAsync(fb.data(), ctx->scratch_rgba.p, fb.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    out->rays = h[0]; out->box_tests = h[1]; out->nodes = h[2]; out->tri_tests = h[3];
+    double rays = 0;                                  // .w of every pixel = rays traced for it (exact in binary32)
+    for (size_t k = 3; k < fb.size(); k += 4) rays += fb[k];
+    out->rays = (uint64_t)rays; out->box_tests = h[1]; out->nodes = h[2]; out->tri_tests = h[3];
     return RT_OK;
 }
 
@@ -428,9 +582,17 @@ int rt_get_stats(rt_ctx *ctx, rt_stats *stats) {
     RT_HIP(ctx, hipSetDevice(ctx->device));
     ctx->stats.kernel_ms = 0.f;
     ctx->stats.tonemap_ms = 0.f;
+    ctx->stats.trav_ms = 0.f;
+    ctx->stats.trav_launches = 0;
     if (ctx->have_kernel_time) {
         RT_HIP(ctx, hipEventSynchronize(ctx->ev_k1));
         RT_HIP(ctx, hipEventElapsedTime(&ctx->stats.kernel_ms, ctx->ev_k0, ctx->ev_k1));
+        for (int k = 0; k < ctx->n_trav_events; ++k) {
+            float ms = 0.f;
+            RT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_trav[2 * k], ctx->ev_trav[2 * k + 1]));
+            ctx->stats.trav_ms += ms;
+        }
+        ctx->stats.trav_launches = ctx->n_trav_events;
     }
     if (ctx->have_tonemap_time) {
         RT_HIP(ctx, hipEventSynchronize(ctx->ev_t1));

@@ -46,10 +46,12 @@ struct Scene {
     float Lx, Ly, Lz, intensity;
     float camx, camy, camz, fov;
     const float4 *node_lo, *node_hi;
+    const float4 *nodes;      // the same nodes interleaved: nodes[2i] = lo, nodes[2i+1] = hi (one address per visit)
     const float4 *tri;
     const float4 *verts;
     const int4 *tidx;
     int n_nodes, n_tris, n_verts;
+    float4 root_lo, root_hi;   // node 0 again, as kernel arguments (SGPRs) for the uniform root-box pre-test
 };
 
 struct Frame {
@@ -62,7 +64,7 @@ struct Frame {
 };
 
 // per-lane traversal work counters (STATS instantiation only; SURVEY 8d accounting)
-struct Work { uint32_t box = 0, nodes = 0, tris = 0; };
+struct Work { uint32_t box = 0, nodes = 0, tris = 0, rays = 0; };
 
 struct f3 { float x, y, z; };
 __device__ __forceinline__ f3 mk(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
@@ -108,6 +110,50 @@ __device__ __forceinline__ bool slab(float4 lo, float4 hi, f3 O, f3 u) {
     return mn > mx;
 }
 
+// ---- error-bounded filters (DESIGN.md "Filtered exact arithmetic") ------------------------------------
+// The reference decides box and barycentric tests on correctly rounded quotients a/b.  A correctly
+// rounded f32 division costs ~12 instructions on gfx950, and a box test needs six.  The filters below
+// evaluate the same quotients as a * rcp(b) (v_rcp_f32: <= 1 ulp), bound the distance to the exactly
+// rounded quotient by kRel*|q| + kAbs, and decide the comparison only when it cannot depend on that
+// distance; otherwise (and for any non-finite, huge or denormal-range operand) the literal code runs.
+// The decision is therefore bit-identical to the literal code by construction, not by sampling.
+//   |a*rcp(b) - RN(a/b)| <= (2^-23 [rcp] + 2^-24 [mul] + 2^-24 [RN]) |a/b| = 2^-22 |a/b|;  kRel = 2^-21.
+constexpr float kRel = 0x1p-21f;
+constexpr float kAbs = 1e-35f;     // covers the absolute error of results in the denormal range
+constexpr float kBig = 1e30f;      // beyond this the product may overflow where the quotient does not
+constexpr float kTiny = 1e-30f;    // divisors below this are not trusted to v_rcp_f32
+
+struct RayInv { float x, y, z; bool safe; };
+__device__ __forceinline__ RayInv ray_inv(f3 u) {
+    RayInv r;
+    r.x = __builtin_amdgcn_rcpf(u.x); r.y = __builtin_amdgcn_rcpf(u.y); r.z = __builtin_amdgcn_rcpf(u.z);
+    const float m = fminf(fminf(fabsf(u.x), fabsf(u.y)), fabsf(u.z));
+    r.safe = m > kTiny && fmaxf(fmaxf(fabsf(u.x), fabsf(u.y)), fabsf(u.z)) < kBig;   // false for 0, denormal, inf, NaN
+    return r;
+}
+
+// BoundingBox::intersect through the filter.  For finite quotients the literal swap/min_element/max_element
+// sequence (cpu:153-156) equals min over axes of max(t0,t1) > max over axes of min(t0,t1).
+__device__ __forceinline__ bool slab_filtered(float4 lo, float4 hi, f3 O, f3 u, const RayInv &r) {
+    if (r.safe) {
+        const float ax = (lo.x - O.x) * r.x, bx = (hi.x - O.x) * r.x;
+        const float ay = (lo.y - O.y) * r.y, by = (hi.y - O.y) * r.y;
+        const float az = (lo.z - O.z) * r.z, bz = (hi.z - O.z) * r.z;
+        const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+        const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+        const float M = fmaxf(fmaxf(fmaxf(fabsf(ax), fabsf(bx)), fmaxf(fabsf(ay), fabsf(by))), fmaxf(fabsf(az), fabsf(bz)));
+        const float d = tf - tn;
+        // every quotient is within kRel*M+kAbs of its exact value and min/max are 1-Lipschitz, so both tn and tf
+        // are; d > 2*band  =>  exact (min > max) is true, d < -2*band => false.  (r.safe => no NaN can occur.)
+        const float band = 2.f * (M * kRel + kAbs);
+        if (M < kBig) {
+            if (d > band) return true;
+            if (d < -band) return false;
+        }
+    }
+    return slab(lo, hi, O, u);
+}
+
 // TriangleMesh::intersect, cpu:277-311.  Returns true iff some triangle was accepted
 // (SURVEY H4); t/Nraw are the nearest accepted t and its unnormalised e1 x e2.
 template <bool STATS>
@@ -117,13 +163,14 @@ __device__ __forceinline__ bool mesh_intersect(const Scene &sc, f3 O, f3 u, floa
     f3 Nb = mk(0, 0, 0);
     int node = 0;
     const int n_nodes = sc.n_nodes;
+    const RayInv ri = ray_inv(u);
     while (node < n_nodes) {
         const float4 lo = sc.node_lo[node];
         const float4 hi = sc.node_hi[node];
         const int hiw = __float_as_int(hi.w);
         const int low = __float_as_int(lo.w);
         if (STATS) wk.box++;
-        if (slab(lo, hi, O, u)) {
+        if (slab_filtered(lo, hi, O, u, ri)) {
             if (STATS) wk.nodes++;
             if (hiw >= 0) {   // leaf: triangles [low, hiw), ascending (cpu:295)
                 if (STATS) wk.tris += (uint32_t)(hiw - low);
@@ -136,11 +183,27 @@ __device__ __forceinline__ bool mesh_intersect(const Scene &sc, f3 O, f3 u, floa
                     if (det == 0) continue;
                     const f3 AO = A - O;
                     const f3 c = cross(AO, u);
-                    const float beta = dot(e2, c) / det;
-                    const float gamma = -dot(e1, c) / det;
-                    if (!(0 <= beta && beta <= 1) || !(0 <= gamma && gamma <= 1)) continue;
-                    const float t = dot(AO, N) / det;
-                    if (!(beta + gamma <= 1 && t > 0)) continue;
+                    const float bn = dot(e2, c);
+                    const float gn = -dot(e1, c);
+                    bool pass = false;
+                    if (fabsf(det) > kTiny) {   // filter on beta, gamma, beta+gamma (same bound as the box filter)
+                        const float rd = __builtin_amdgcn_rcpf(det);
+                        const float b = bn * rd, g = gn * rd;
+                        const float eb = fabsf(b) * kRel + kAbs, eg = fabsf(g) * kRel + kAbs;
+                        if (b < -eb || b > 1.f + eb || g < -eg || g > 1.f + eg) continue;        // certainly outside [0,1]
+                        const float sum = b + g;
+                        const float es = eb + eg + fabsf(sum) * 0x1p-22f;
+                        if (sum > 1.f + es) continue;                                             // certainly beta+gamma > 1
+                        pass = b >= eb && b <= 1.f - eb && g >= eg && g <= 1.f - eg && sum <= 1.f - es;
+                    }
+                    if (!pass) {   // undecided (or NaN/inf/tiny det): the literal tests
+                        const float beta = bn / det;
+                        const float gamma = gn / det;
+                        if (!(0 <= beta && beta <= 1) || !(0 <= gamma && gamma <= 1)) continue;
+                        if (!(beta + gamma <= 1)) continue;
+                    }
+                    const float t = dot(AO, N) / det;   // exact: t is compared and returned
+                    if (!(t > 0)) continue;
                     if (t > tri_tmin && t < t_min) { t_min = t; Nb = N; any = true; }   // cpu:301
                 }
             }

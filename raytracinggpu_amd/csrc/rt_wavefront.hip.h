@@ -1,0 +1,586 @@
+// rt_wavefront.hip.h -- wavefront render pipeline for gfx950 (default variant).
+//
+// The per-pixel render of cpu_launcher.cpp:693-718 / KernelLaunch (optimized.cu:670-772) split by
+// divergence behaviour instead of by pixel:
+//
+//   wf_begin   one lane per pixel, uniform: camera ray of sample s (cpu:699-709), its ray/sphere tests
+//              (cpu:512-527) and the mesh's root-box test (cpu:279); path state initialised
+//   wf_trav    persistent lanes, one RAY (or a sub-range of one ray's traversal) per lane: stackless BVH walk
+//              (BoundingBox::intersect cpu:146-157, moller_trumbore cpu:226-236, traversal cpu:277-311).
+//              Two micro-ops (BOX, TRI) chosen by wave vote; lanes refill from the wave's own, spatially
+//              scrambled, share of the rays; when that runs out busy lanes hand parts of their traversal
+//              to idle lanes (see "work splitting" below).
+//   wf_advance one lane per pixel, uniform: closes the query (Scene::intersect_all cpu:545-564), then
+//              Scene::getColor's branch for it -- material / shadow ray (cpu:573-614) or direct light +
+//              cosine bounce (cpu:615-642) -- writes the next ray with its sphere and root-box tests, or
+//              folds the finished path (cpu:642-644), accumulates the sample (cpu:711) and, after the last
+//              sample, stores the pixel as one float4 (cpu:713)
+//
+// run as  begin, (trav, advance) x 2*segments  per sample.  Path state lives in HBM as float4 SoA indexed
+// by a TILE-ORDER path index (8x8 pixel tiles: a wave's 64 consecutive paths are one tile, and every state
+// access of wf_begin/wf_advance is a fully coalesced 1 KiB wave transaction).
+//
+// Work splitting.  The reference never prunes by distance, so which nodes and triangles a ray
+// visits does not depend on what it has hit so far, and the nearest hit is  min over visited triangles of
+// (t, visit rank)  -- the strict '<' of cpu:301 keeps the earliest of equal t.  In the stackless layout the
+// traversal of node range [a,b) that starts at a is self-contained whenever a is a node the walk is certain
+// to reach: the node after any subtree (skip(X)) is such a node.  So a lane at node X owning [X,b) can keep
+// [X,skip(X)) and give [skip(X),b) to an idle lane; a lane inside a leaf can give away everything after the
+// leaf, or half of the leaf's triangles.  Triangles are stored in visit order, so rank == triangle index,
+// and sub-results meet in one 64-bit atomic min on (bits(t) << 32 | index).  Results stay bit-identical.
+#pragma once
+#include "rt_kernels.hip.h"
+
+namespace rtk {
+
+// path flags (int per path)
+constexpr int WF_ALIVE = 1 << 8;      // path still being traced
+constexpr int WF_SHADOW = 1 << 9;     // the ray in flight is a shadow ray
+constexpr int WF_MESH = 1 << 20;      // the ray in flight passed the mesh's root box: traversal needed
+constexpr int WF_DEPTH = 0xff;        // segment index d
+constexpr unsigned long long WF_NOHIT = ~0ull;
+
+struct WfState {
+    float4 *R0, *R1;      // ray: (O.xyz, u.x) (u.yz, tA, tB): tA/tB = nearest sphere before/after the mesh slot
+    unsigned long long *M;   // traversal result: bits(t) << 32 | triangle index (visit order); WF_NOHIT if none
+    float4 *S0, *S1;      // surface being shaded: (P.xyz, bits(object id)) (N.xyz, refraction index of the ray)
+    float4 *T;            // (sum of sample colours .xyz, rays traced)
+    int4 *F;              // (flags, diffuse mask, object ids lo, object ids hi); wins packed in flags bits 10..19
+    float *LS;            // l of every diffuse segment: LS[d * n_paths + i]
+    int n_paths;          // tiles_x * tiles_y * 64
+    int tiles_x;
+    // traversal scheduling: ray-slot q in [0, slots) maps to path 4*g + (q & 3), g = ((q>>2) & (S-1)) * Q + ((q>>2) >> log2S)
+    int log2S, Q, n_groups;   // n_groups = n_paths / 4;  S * Q >= n_groups
+    int slots_per_wave;       // multiple of 4
+    unsigned long long *dbg;  // optional per-wave debug record
+};
+
+__device__ __forceinline__ void wf_decode(const WfState &st, const Frame &fr, int i, int &px, int &lrow, bool &valid) {
+    const int tile = i >> 6, p = i & 63;
+    px = (tile % st.tiles_x) * 8 + (p & 7);
+    lrow = (tile / st.tiles_x) * 8 + (p >> 3);
+    valid = px < fr.W && lrow < fr.n_rows;
+}
+
+struct SphereHit { float tA; int winA; float tB; int winB; };
+
+// ray/sphere tests of Scene::intersect_all for one ray, split at the mesh's slot so that the strict '<'
+// of cpu:554 can be replayed later as  A, mesh, B  (see wf_advance).
+__device__ __forceinline__ SphereHit spheres_split(const Scene &sc, f3 O, f3 u) {
+    SphereHit h; h.tA = 1e9f; h.winA = -1; h.tB = 1e9f; h.winB = -1;
+    const int nb = sc.mesh_slot < 0 ? sc.n_spheres : sc.mesh_slot;
+    for (int k = 0; k < sc.n_spheres; ++k) {
+        const Sphere &s = sc.sph[k];
+        const f3 C = mk(s.cx, s.cy, s.cz);
+        const f3 OC = O - C;
+        const float d = dot(u, OC);
+        const float delta = d * d - (norm2(OC) - s.R * s.R);       // cpu:513
+        if (delta < 0) continue;
+        const float sq = rt_sqrtf(delta);
+        const float b = dot(u, C - O);
+        const float t1 = b - sq, t2 = b + sq;                      // cpu:516-517
+        if (t2 < 0) continue;
+        const float t = t1 < 0 ? t2 : t1;
+        if (k < nb) { if (t < h.tA) { h.tA = t; h.winA = k; } }
+        else        { if (t < h.tB) { h.tB = t; h.winB = k + 1; } }   // object id = sphere index + 1 after the mesh
+    }
+    return h;
+}
+__device__ __forceinline__ int wf_pack_wins(const SphereHit &h) { return ((h.winA + 1) & 31) << 10 | ((h.winB + 1) & 31) << 15; }
+
+// Emit a ray: record, sphere tests, root-box test (cpu:279; wave-uniform node data from kernel arguments).
+template <bool STATS>
+__device__ __forceinline__ int wf_emit_ray(const Scene &sc, const WfState &st, int i, f3 O, f3 u, Work &wk) {
+    const SphereHit h = spheres_split(sc, O, u);
+    st.R0[i] = make_float4(O.x, O.y, O.z, u.x);
+    st.R1[i] = make_float4(u.y, u.z, h.tA, h.tB);
+    int f = wf_pack_wins(h);
+    if (sc.mesh_slot >= 0 && sc.n_nodes > 0) {
+        if (STATS) wk.box++;
+        if (slab_filtered(sc.root_lo, sc.root_hi, O, u, ray_inv(u))) {
+            if (STATS) wk.nodes++;
+            f |= WF_MESH;
+            st.M[i] = WF_NOHIT;
+        }
+    }
+    return f;
+}
+
+template <bool STATS>
+__device__ __forceinline__ void wf_flush_work(const Frame &fr, Work &wk) {
+    if (STATS) {
+        const uint32_t b = wave_sum(wk.box), n = wave_sum(wk.nodes), t = wave_sum(wk.tris);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&fr.work[1], (unsigned long long)b);
+            atomicAdd(&fr.work[2], (unsigned long long)n); atomicAdd(&fr.work[3], (unsigned long long)t);
+        }
+    }
+}
+
+// ---- wf_begin: camera rays of sample `samp` ---------------------------------------------------------
+template <bool STATS>
+__global__ __launch_bounds__(256) void wf_begin(const Scene sc, const Frame fr, const WfState st, int samp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    Work wk;
+    if (i < st.n_paths) {
+        int px, lrow; bool valid;
+        wf_decode(st, fr, i, px, lrow, valid);
+        if (!valid || fr.segs <= 0) {
+            st.F[i] = make_int4(0, 0, 0, 0);
+            if (samp == 0) st.T[i] = make_float4(0, 0, 0, 0);
+            if (valid && samp == fr.spp - 1) {   // segs == 0 (optimized.cu convention with num_bounce 0): black
+                const float4 t = samp == 0 ? make_float4(0, 0, 0, 0) : st.T[i];
+                fr.out[(size_t)lrow * fr.W + px] = make_float4(t.x / (float)fr.spp, t.y / (float)fr.spp, t.z / (float)fr.spp, t.w);
+            }
+        } else {
+            const int row = fr.row0 + (lrow / fr.tile_rows) * fr.tile_rows * fr.tile_step + (lrow % fr.tile_rows);
+            // cpu:699: +0.5/-0.5 are double literals, narrowed by the Vector constructor
+            const f3 uc = mk((float)((double)((float)px - (float)fr.W / 2) + 0.5),
+                             (float)((double)((float)fr.H / 2 - (float)row) - 0.5), fr.z);
+            f3 uu = uc;
+            if (fr.sigma != 0.f) {   // cpu:705-707; with sigma == 0 the jitter is exactly +-0
+                const uint32_t hp = mix32(((uint32_t)row * (uint32_t)fr.W + (uint32_t)px) ^ mix32(fr.seed));
+                const uint32_t hs = mix32(hp ^ ((uint32_t)samp * 0x9E3779B1U));
+                const float r1 = uniform01(hs, 0, 2), r2 = uniform01(hs, 0, 3);
+                const float bm = fr.sigma * rt_sqrtf(-2 * logf(r1));
+                double sn, cs;
+                sincos(2 * 3.14159265358979323846 * (double)r2, &sn, &cs);
+                uu = uc + mk((float)((double)bm * cs), (float)((double)bm * sn), 0.f);
+            }
+            const f3 u = normalize(uu);
+            const f3 O = mk(sc.camx, sc.camy, sc.camz);
+            const int f = wf_emit_ray<STATS>(sc, st, i, O, u, wk);
+            st.F[i] = make_int4(WF_ALIVE | f, 0, 0, 0);
+            st.S1[i] = make_float4(0, 0, 0, 1.f);                  // Ray::refraction_index = 1 (cpu:100)
+            float4 t = samp == 0 ? make_float4(0, 0, 0, 0) : st.T[i];
+            t.w += 1.f;                                            // this ray
+            st.T[i] = t;
+        }
+    }
+    wf_flush_work<STATS>(fr, wk);
+}
+
+// ---- wf_trav: persistent stackless traversal -----------------------------------------------------------
+// Hot loop = BOX steps only.  A lane that hits a leaf appends (first, count) to its private LDS leaf list and
+// keeps walking; nothing else happens in the loop but one wave vote.  When fewer than kBoxMin lanes can
+// still walk, a SERVICE pass runs: leaf lists are expanded into the wave's LDS ring of (owner lane, triangle)
+// entries, the ring is consumed 64 entries at a time by full-occupancy TRI steps (ray data from the owners'
+// LDS copies, results merged by a 64-bit LDS min on bits(t) << 32 | triangle), finished tasks retire, idle
+// lanes refill from the wave's scrambled share of the rays or take a split from a busy lane.
+constexpr int kTravBlock = 256;
+constexpr int kQCap = 512;                  // ring entries per wave (power of two)
+constexpr int kLeafCap = 8;                 // leaf-list entries per lane
+constexpr int kBoxMin = 44;                 // service when fewer lanes than this can take a BOX step
+
+struct TravLds {
+    float4 ray0[kTravBlock], ray1[kTravBlock];      // (O.xyz, u.x) (u.yz, -, -) of the lane's current task
+    unsigned long long best[kTravBlock];            // nearest accepted triangle of the lane's current task
+    unsigned int q[kTravBlock / 64][kQCap];         // owner lane << 26 | triangle index
+    unsigned int leaf[kTravBlock / 64][kLeafCap][64];   // count << 26 | first triangle
+};
+
+__device__ __forceinline__ int wf_slot_to_path(const WfState &st, int q) {
+    const int gs = q >> 2;
+    const int g = (gs & ((1 << st.log2S) - 1)) * st.Q + (gs >> st.log2S);
+    return g < st.n_groups ? 4 * g + (q & 3) : -1;
+}
+
+// single-instruction min/max (the operands are results of arithmetic, never signalling NaNs; IEEE-mode
+// v_min/v_max return the other operand for a quiet NaN, which the callers exclude beforehand)
+__device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float vmax3abs(float a, float b, float c) { float r; asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
+// Per-ray constants of the fused box filter.  q~ = fma(bound, r, -fl(O*r)) differs from the reference's
+// RN((bound - O)/u) by at most 2^-21 |q| + 2^-24 |O*r| (+ denormal slack): r carries 2^-23, fl(O*r) 2^-24 of
+// |O*r|, the fma 2^-24, the reference's own subtraction and division 2^-24 each.
+struct RayBox { float rx, ry, rz, ox, oy, oz, c0; bool safe; };
+__device__ __forceinline__ RayBox ray_box(f3 O, f3 u) {
+    RayBox b;
+    b.rx = __builtin_amdgcn_rcpf(u.x); b.ry = __builtin_amdgcn_rcpf(u.y); b.rz = __builtin_amdgcn_rcpf(u.z);
+    b.ox = O.x * b.rx; b.oy = O.y * b.ry; b.oz = O.z * b.rz;
+    const float omax = vmax3abs(b.ox, b.oy, b.oz);
+    b.c0 = 2.f * (omax * 0x1p-24f + kAbs);
+    const float umin = fminf(fminf(fabsf(u.x), fabsf(u.y)), fabsf(u.z)), umax = fmaxf(fmaxf(fabsf(u.x), fabsf(u.y)), fabsf(u.z));
+    b.safe = umin > kTiny && umax < kBig && omax < kBig;      // false for 0, denormal, inf, NaN anywhere
+    return b;
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(kTravBlock) void wf_trav(const Scene sc, const Frame fr, const WfState st) {
+    __shared__ TravLds lds;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wib = tid >> 6;                       // wave in block
+    const int wbase = wib * 64;
+    const int wave = (blockIdx.x * blockDim.x + tid) >> 6;
+    unsigned int *const q = lds.q[wib];
+    unsigned int *const leaf = &lds.leaf[wib][0][lane];     // leaf[k * 64]
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    // lane state: a task = traversal of node range [node, nend) of ray `ray`
+    int ray = -1;                       // path index, -1 = idle
+    f3 O = mk(0, 0, 0), u = mk(0, 0, 1);
+    RayBox rb = ray_box(O, u);
+    int node = 0, nend = 0, sk = 0;
+    int nl = 0;                         // entries in the lane's leaf list
+    int pend_first = 0, pend_cnt = 0;   // triangle range currently being queued
+    unsigned int last_pos = 0;          // ring position after this task's last queued entry
+    bool shared = false;                // this ray's traversal was split: merge with a global atomic
+    // wave-uniform: the wave's own ray slots and its ring cursors (monotonic positions)
+    int cur = __builtin_amdgcn_readfirstlane(wave * st.slots_per_wave);
+    const int end = __builtin_amdgcn_readfirstlane(cur + st.slots_per_wave);
+    unsigned int qhead = 0, qtail = 0;
+    Work wk;
+    const unsigned long long dbg_t0 = st.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    unsigned int dbg_steps = 0, dbg_lanes = 0, dbg_splits = 0, dbg_tsteps = 0;
+    const float4 *const nodes = sc.nodes;
+
+    bool boxable = false;
+    for (;;) {
+        int nB = __popcll(__ballot(boxable));
+        if (nB < kBoxMin) {
+            // =============================== SERVICE ===============================
+            for (;;) {
+                // ---- (1) expand leaf lists into the ring, one entry per lane and round ----
+                for (;;) {
+                    if (pend_cnt == 0 && nl > 0) {
+                        nl--;
+                        const unsigned int e = leaf[nl * 64];
+                        pend_first = (int)(e & 0x3ffffffu); pend_cnt = (int)(e >> 26);
+                    }
+                    const unsigned long long pm = __ballot(pend_cnt > 0);
+                    if (!pm || (unsigned int)kQCap - (qtail - qhead) < 64u) break;
+                    if (pend_cnt > 0) {
+                        const unsigned int pos = qtail + (unsigned int)__popcll(pm & lane_lt);
+                        q[pos & (kQCap - 1)] = (unsigned int)lane << 26 | (unsigned int)pend_first;
+                        pend_first++; pend_cnt--;
+                        last_pos = pos + 1u;
+                    }
+                    qtail += (unsigned int)__popcll(pm);
+                }
+                // ---- (2) TRI steps: 64 queued (owner, triangle) pairs, one per lane ----
+                const bool walkable = ray >= 0 && node < nend && nl < kLeafCap && pend_cnt == 0;
+                const int nW = __popcll(__ballot(walkable));
+                for (;;) {
+                    const unsigned int count = qtail - qhead;
+                    if (count < 64u && !(count > 0u && nW < kBoxMin)) break;
+                    const unsigned int n = count < 64u ? count : 64u;
+                    dbg_tsteps++; dbg_steps++; dbg_lanes += n;
+                    if ((unsigned int)lane < n) {
+                        const unsigned int e = q[(qhead + (unsigned int)lane) & (kQCap - 1)];
+                        const int o = wbase + (int)(e >> 26);
+                        const int i = (int)(e & 0x3ffffffu);
+                        const float4 *tp = sc.tri + 3 * i;
+                        const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+                        const float4 r0 = lds.ray0[o], r1 = lds.ray1[o];
+                        const f3 Oo = mk(r0.x, r0.y, r0.z), uo = mk(r0.w, r1.x, r1.y);
+                        const f3 A = mk(q0.x, q0.y, q0.z), e1 = mk(q0.w, q1.x, q1.y), e2 = mk(q1.z, q1.w, q2.x);
+                        const f3 N = mk(q2.y, q2.z, q2.w);
+                        const float det = dot(uo, N);               // moller_trumbore, cpu:226-236
+                        const f3 AO = A - Oo;
+                        const f3 c = cross(AO, uo);
+                        const float bn = dot(e2, c);
+                        const float gn = -dot(e1, c);
+                        const float rd = __builtin_amdgcn_rcpf(det);
+                        const float b = bn * rd, g = gn * rd;
+                        const float eb = fmaf(fabsf(b), kRel, kAbs), eg = fmaf(fabsf(g), kRel, kAbs);
+                        const float sum = b + g;
+                        const float es = fmaf(fabsf(sum), 0x1p-22f, eb + eg);
+                        const bool trust = fabsf(det) > kTiny;      // also false for det == 0 and NaN
+                        const bool reject = trust && (b < -eb || b > 1.f + eb || g < -eg || g > 1.f + eg || sum > 1.f + es);
+                        bool ok = trust && b >= eb && b <= 1.f - eb && g >= eg && g <= 1.f - eg && sum <= 1.f - es;
+                        if (!reject && !ok && det != 0) {           // undecided: the literal tests (rare)
+                            const float beta = bn / det;
+                            const float gamma = gn / det;
+                            ok = (0 <= beta && beta <= 1) && (0 <= gamma && gamma <= 1) && (beta + gamma <= 1);
+                        }
+                        if (ok) {
+                            const float t = dot(AO, N) / det;
+                            if (t > 0 && t > fr.tri_tmin && t < 1e9f)    // cpu:235,301; the min is the strict '<' scan
+                                atomicMin(&lds.best[o], (unsigned long long)__float_as_uint(t) << 32 | (unsigned int)i);
+                        }
+                    }
+                    qhead += n;
+                }
+                // ---- (3) retire tasks whose nodes are walked and whose queued triangles have all been tested ----
+                if (ray >= 0 && node >= nend && nl == 0 && pend_cnt == 0 && (int)(qhead - last_pos) >= 0) {
+                    const unsigned long long key = lds.best[tid];
+                    if (key != WF_NOHIT) {
+                        if (shared) atomicMin(&st.M[ray], key);
+                        else st.M[ray] = key;
+                    }
+                    ray = -1;
+                }
+                // ---- (4) refill idle lanes from the wave's slots, or split ----
+                const unsigned long long idle = __ballot(ray < 0);
+                const int n_idle = __popcll(idle);
+                if (n_idle && cur < end) {
+                    if (ray < 0) {
+                        const int qs = cur + __popcll(idle & lane_lt);
+                        const int path = qs < end ? wf_slot_to_path(st, qs) : -1;
+                        if (path >= 0) {
+                            const int f = st.F[path].x;
+                            if ((f & (WF_ALIVE | WF_MESH)) == (WF_ALIVE | WF_MESH)) {
+                                const float4 r0 = st.R0[path], r1 = st.R1[path];
+                                O = mk(r0.x, r0.y, r0.z); u = mk(r0.w, r1.x, r1.y);
+                                rb = ray_box(O, u);
+                                lds.ray0[tid] = r0; lds.ray1[tid] = r1; lds.best[tid] = WF_NOHIT;
+                                // the root box was tested when the ray was emitted; start below it
+                                const int rw = __float_as_int(sc.root_hi.w);
+                                node = rw < 0 ? 1 : sc.n_nodes; nend = sc.n_nodes; sk = 0; nl = 0;
+                                pend_first = rw < 0 ? 0 : __float_as_int(sc.root_lo.w);
+                                pend_cnt = rw < 0 ? 0 : rw - pend_first;
+                                if (STATS && rw >= 0) wk.tris += (uint32_t)pend_cnt;
+                                last_pos = qhead; shared = false;
+                                ray = path;
+                            }
+                        }
+                    }
+                    cur = min(cur + n_idle, end);
+                } else if (n_idle >= 4 && n_idle < 64) {
+                    // a busy lane below a hit internal node X keeps [node, skip(X)) and gives [skip(X), nend) away
+                    const bool d_skip = ray >= 0 && sk > node && sk < nend;
+                    const unsigned long long donors = __ballot(d_skip);
+                    if (donors) {
+                        const int n_pairs = min(n_idle, __popcll(donors));
+                        const int my_idle_rank = __popcll(idle & lane_lt);
+                        const int my_donor_rank = __popcll(donors & lane_lt);
+                        int partner = -1;
+                        if (ray < 0 && my_idle_rank < n_pairs) {   // lane id of the my_idle_rank-th donor
+                            unsigned long long m = donors;
+                            for (int k = 0; k < my_idle_rank; ++k) m &= m - 1;
+                            partner = __ffsll((long long)m) - 1;
+                        }
+                        const bool is_donor = ((donors >> lane) & 1ull) && my_donor_rank < n_pairs;
+                        int g_node = 0, g_nend = 0;
+                        if (is_donor) { g_node = sk; g_nend = nend; nend = sk; shared = true; }
+                        const int src = partner >= 0 ? partner : lane;
+                        const int r_ray = __shfl(ray, src, 64);
+                        const float r_ox = __shfl(O.x, src, 64), r_oy = __shfl(O.y, src, 64), r_oz = __shfl(O.z, src, 64);
+                        const float r_ux = __shfl(u.x, src, 64), r_uy = __shfl(u.y, src, 64), r_uz = __shfl(u.z, src, 64);
+                        const int r_node = __shfl(g_node, src, 64), r_nend = __shfl(g_nend, src, 64);
+                        if (partner >= 0) {
+                            ray = r_ray; O = mk(r_ox, r_oy, r_oz); u = mk(r_ux, r_uy, r_uz); rb = ray_box(O, u);
+                            lds.ray0[tid] = make_float4(O.x, O.y, O.z, u.x); lds.ray1[tid] = make_float4(u.y, u.z, 0, 0);
+                            lds.best[tid] = WF_NOHIT;
+                            node = r_node; nend = r_nend; sk = 0; nl = 0; pend_cnt = 0;
+                            last_pos = qhead; shared = true;
+                        }
+                        dbg_splits += n_pairs;
+                    }
+                }
+                // ---- done servicing? ----
+                boxable = ray >= 0 && node < nend && nl < kLeafCap && pend_cnt == 0;
+                nB = __popcll(__ballot(boxable));
+                if (nB >= kBoxMin) break;
+                const bool more = (qtail != qhead) || __ballot(pend_cnt > 0 || nl > 0) != 0ull || (cur < end);
+                if (more) continue;                                  // queue to drain / lists to expand / rays to fetch
+                if (nB > 0) break;                                   // run with the lanes we have
+                if (__ballot(ray >= 0) == 0ull) goto finished;       // nothing left anywhere
+                // busy lanes that are neither walkable nor retired can only be waiting for the ring, which is empty,
+                // so the next pass retires them
+            }
+        }
+        // =============================== BOX step ===============================
+        dbg_steps++; dbg_lanes += nB;
+        if (boxable) {
+            const float4 *np = nodes + 2 * node;
+            const float4 lo = np[0], hi = np[1];
+            const int hiw = __float_as_int(hi.w);
+            const int low = __float_as_int(lo.w);
+            if (STATS) wk.box++;
+            // BoundingBox::intersect (cpu:146-157) through the fused filter
+            const float ax = fmaf(lo.x, rb.rx, -rb.ox), bx = fmaf(hi.x, rb.rx, -rb.ox);
+            const float ay = fmaf(lo.y, rb.ry, -rb.oy), by = fmaf(hi.y, rb.ry, -rb.oy);
+            const float az = fmaf(lo.z, rb.rz, -rb.oz), bz = fmaf(hi.z, rb.rz, -rb.oz);
+            const float tn = vmax3(vmin(ax, bx), vmin(ay, by), vmin(az, bz));
+            const float tf = vmin3(vmax(ax, bx), vmax(ay, by), vmax(az, bz));
+            const float M = vmax(vmax3abs(ax, bx, ay), vmax3abs(by, az, bz));
+            const float d = tf - tn;
+            const float band = fmaf(M, 2.f * kRel, rb.c0);
+            bool hit = d > band;
+            const bool decided = rb.safe && M < kBig && (hit || d < -band);
+            if (!decided) hit = slab(lo, hi, O, u);            // literal arithmetic (rare)
+            int next = node + 1;
+            if (hit) {
+                if (STATS) wk.nodes++;
+                if (hiw >= 0) {                                // leaf: triangles [low, hiw)
+                    const int cnt = hiw - low;
+                    if (STATS) wk.tris += (uint32_t)cnt;
+                    if (cnt <= 63) { leaf[nl * 64] = (unsigned int)cnt << 26 | (unsigned int)low; nl++; }
+                    else { pend_first = low; pend_cnt = cnt; }
+                } else {
+                    sk = low;                                  // everything from skip(node) on can be given away
+                }
+            } else if (hiw < 0) {
+                next = low;
+            }
+            node = next;
+            boxable = next < nend && nl < kLeafCap && pend_cnt == 0;
+        }
+    }
+finished:
+    if (st.dbg && lane == 0) {
+        st.dbg[6 * wave + 0] = dbg_t0; st.dbg[6 * wave + 1] = __builtin_amdgcn_s_memrealtime();
+        st.dbg[6 * wave + 2] = dbg_steps; st.dbg[6 * wave + 3] = dbg_lanes; st.dbg[6 * wave + 4] = dbg_splits; st.dbg[6 * wave + 5] = dbg_tsteps;
+    }
+    wf_flush_work<STATS>(fr, wk);
+}
+
+// ---- wf_advance: close the query, shade, emit the next ray ------------------------------------------------
+template <bool STATS>
+__global__ __launch_bounds__(256) void wf_advance(const Scene sc, const Frame fr, const WfState st, int samp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    Work wk;
+    int4 F = i < st.n_paths ? st.F[i] : make_int4(0, 0, 0, 0);
+    if (F.x & WF_ALIVE) {
+        const float PI_F = (float)3.14159265358979323846;
+        const double PI_D = 3.14159265358979323846;
+        const f3 L = mk(sc.Lx, sc.Ly, sc.Lz);
+        const float4 r0 = st.R0[i], r1 = st.R1[i];
+        f3 O = mk(r0.x, r0.y, r0.z), u = mk(r0.w, r1.x, r1.y);
+        int d = F.x & WF_DEPTH;
+        const bool shadow = (F.x & WF_SHADOW) != 0;
+        // Scene::intersect_all's running minimum, replayed in object order: spheres before the mesh, mesh, spheres after
+        float t_min = r1.z; int win = ((F.x >> 10) & 31) - 1;
+        int tri_win = -1;
+        if (F.x & WF_MESH) {
+            const unsigned long long m = st.M[i];
+            if (m != WF_NOHIT) {
+                const float tmesh = __uint_as_float((unsigned int)(m >> 32));
+                if (tmesh < t_min) { t_min = tmesh; win = sc.mesh_slot; tri_win = (int)(unsigned int)m; }
+            }
+        }
+        if (r1.w < t_min) { t_min = r1.w; win = ((F.x >> 15) & 31) - 1; }
+        float refr = st.S1[i].w;
+        bool path_done = false;
+        bool new_ray = false;
+        int flags = WF_ALIVE;
+
+        if (!shadow) {
+            if (win < 0) {
+                path_done = true;                                    // miss: black (cpu:571)
+            } else {
+                const f3 P = O + t_min * u;                          // cpu:560
+                f3 N;
+                if (win == sc.mesh_slot) {
+                    const float4 q2 = sc.tri[3 * tri_win + 2];
+                    N = normalize(mk(q2.y, q2.z, q2.w));             // cpu:308
+                } else {
+                    const Sphere &s = sc.sph[(sc.mesh_slot >= 0 && win > sc.mesh_slot) ? win - 1 : win];
+                    N = normalize(P - mk(s.cx, s.cy, s.cz));         // cpu:524-525
+                }
+                const Material m = material_of(sc, win);
+                if (m.mirror) {                                      // cpu:573-579
+                    O = P + fr.eps * N;
+                    u = u - (2 * dot(u, N)) * N;
+                    d = d + 1; new_ray = d < fr.segs; path_done = !new_ray;
+                } else if (m.n_in != m.n_out) {                      // cpu:580-604
+                    float ratio;
+                    const bool out2in = refr == m.n_out;
+                    if (out2in) ratio = m.n_out / m.n_in;
+                    else { ratio = m.n_in / m.n_out; N = -N; }
+                    const float un = dot(u, N);
+                    if (((out2in && refr > m.n_in) || (!out2in && refr > m.n_out)) && (ratio * ratio) * (1 - un * un) > 1) {
+                        O = P + fr.eps * N;
+                        u = u - (2 * un) * N;
+                    } else {
+                        O = P - fr.eps * N;
+                        const f3 Nc = (-rt_sqrtf(1 - (ratio * ratio) * (1 - un * un))) * N;
+                        const f3 Tc = ratio * (u - un * N);
+                        u = Nc + Tc;
+                        refr = out2in ? m.n_in : m.n_out;
+                    }
+                    d = d + 1; new_ray = d < fr.segs; path_done = !new_ray;
+                } else {                                             // cpu:605-614: shadow ray
+                    st.S0[i] = make_float4(P.x, P.y, P.z, __int_as_float(win));
+                    const f3 Pa = P + fr.eps * N;
+                    const f3 toL = L - Pa;
+                    u = toL / rt_sqrtf(norm2(toL));                  // NORMED_VEC
+                    O = Pa;
+                    st.S1[i] = make_float4(N.x, N.y, N.z, refr);
+                    flags |= WF_SHADOW;
+                    new_ray = true;
+                }
+                if (!(flags & WF_SHADOW)) st.S1[i].w = refr;
+            }
+        } else {
+            const float4 s0 = st.S0[i], s1 = st.S1[i];
+            const f3 Ps = mk(s0.x, s0.y, s0.z), Ns = mk(s1.x, s1.y, s1.z);
+            const int sid = __float_as_int(s0.w);
+            const f3 Pp = O + t_min * u;                             // cpu:560 (O is P_adjusted)
+            float l = 0.f;
+            if (!(norm2(Pp - O) <= norm2(L - O))) {                  // cpu:615
+                const f3 wl = normalize(L - Ps);
+                const float dn = dot(Ns, wl);
+                const float mx = (dn < 0.f) ? 0.f : dn;
+                l = (float)((double)sc.intensity / (4 * PI_D * (double)norm2(L - Ps)) * (double)mx);   // cpu:623
+            }
+            st.LS[(size_t)d * st.n_paths + i] = l;
+            const uint64_t ids = ((uint64_t)(uint32_t)F.w << 32 | (uint32_t)F.z) | (uint64_t)(sid & 15) << (4 * d);
+            F.z = (int)(uint32_t)ids; F.w = (int)(uint32_t)(ids >> 32);
+            F.y |= 1 << d;
+            if (d + 1 < fr.segs) {                                   // the bounce ray (cpu:627-642)
+                int px, lrow; bool valid;
+                wf_decode(st, fr, i, px, lrow, valid);
+                const int row = fr.row0 + (lrow / fr.tile_rows) * fr.tile_rows * fr.tile_step + (lrow % fr.tile_rows);
+                const uint32_t hp = mix32(((uint32_t)row * (uint32_t)fr.W + (uint32_t)px) ^ mix32(fr.seed));
+                const uint32_t hs = mix32(hp ^ ((uint32_t)samp * 0x9E3779B1U));
+                const float r1u = uniform01(hs, (uint32_t)d, 0);
+                const float r2u = uniform01(hs, (uint32_t)d, 1);
+                double sn, cs;
+                sincos(2 * PI_D * (double)r1u, &sn, &cs);
+                const float s1f = rt_sqrtf(1 - r2u);
+                const float x = (float)(cs * (double)s1f);
+                const float y = (float)(sn * (double)s1f);
+                const float zz = rt_sqrtf(r2u);
+                f3 T1;
+                if (Ns.y != 0 && Ns.x != 0) T1 = mk(-Ns.y, Ns.x, 0);
+                else T1 = mk(-Ns.z, 0, Ns.x);
+                T1 = normalize(T1);
+                const f3 T2 = cross(Ns, T1);
+                u = x * T1 + y * T2 + zz * Ns;                       // O stays P_adjusted
+                st.S1[i].w = 1.f;                                    // Ray(P_adjusted, random_direction): index 1
+                d = d + 1;
+                new_ray = true;
+            } else {
+                d = d + 1;
+                path_done = true;
+            }
+        }
+
+        if (new_ray) {
+            const int f = wf_emit_ray<STATS>(sc, st, i, O, u, wk);
+            st.F[i] = make_int4(flags | d | f, F.y, F.z, F.w);
+            st.T[i].w += 1.f;
+        } else if (path_done) {   // fold the path back to front (cpu:642-644), accumulate the sample (cpu:711)
+            f3 ans = mk(0, 0, 0);
+            const int nseg = d < fr.segs ? d : fr.segs;
+            const uint64_t ids = (uint64_t)(uint32_t)F.w << 32 | (uint32_t)F.z;
+            for (int k = nseg - 1; k >= 0; --k) {
+                if (F.y & (1 << k)) {
+                    const Material m = material_of(sc, (int)((ids >> (4 * k)) & 15));
+                    const float l = st.LS[(size_t)k * st.n_paths + i];
+                    const f3 alb = mk(m.ar, m.ag, m.ab);
+                    ans = (l * alb) / PI_F + alb * ans;
+                }
+            }
+            float4 t = st.T[i];
+            t.x += ans.x; t.y += ans.y; t.z += ans.z;
+            st.F[i] = make_int4(0, 0, 0, 0);
+            if (samp == fr.spp - 1) {                                // cpu:713 + the framebuffer store
+                int px, lrow; bool valid;
+                wf_decode(st, fr, i, px, lrow, valid);
+                const float n = (float)fr.spp;
+                fr.out[(size_t)lrow * fr.W + px] = make_float4(t.x / n, t.y / n, t.z / n, t.w);
+            } else {
+                st.T[i] = t;
+            }
+        }
+    }
+    wf_flush_work<STATS>(fr, wk);
+}
+
+}  // namespace rtk

@@ -38,11 +38,15 @@ def values_equal(a, b):
     return (a == b) | (np.isnan(a) & np.isnan(b))
 
 
+VARIANTS = ["wavefront", "global", "lockstep"]
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("scene,W,H", [("cpu", 512, 512), ("spheres", 512, 512), ("demo10", 256, 256), ("cpu", 333, 77)])
-def test_direct_lighting_bit_exact(ctx, oracle, oracle_cat, cat_golden, scene, W, H):
+def test_direct_lighting_bit_exact(ctx, oracle, oracle_cat, cat_golden, scene, W, H, variant):
     """num_bounce=0, sigma=0: deterministic in the reference too -> bit-exact linear colour."""
     upload(ctx, scene, cat_golden)
-    got = ctx.render(rt.make_params(W, H, 1, 0, **rt.scenes.CPU_LAUNCHER))
+    got = ctx.render(rt.make_params(W, H, 1, 0, variant=variant, **rt.scenes.CPU_LAUNCHER))
     exp, exp8, _ = oracle.Scene.preset(scene, oracle_cat if scene == "cpu" else None).render(W, H, 1, 0)
     assert values_equal(got[..., :3], exp[..., :3]).all()
     np.testing.assert_array_equal(got[..., 3], exp[..., 3])          # rays per pixel
@@ -69,11 +73,12 @@ def test_reference_getColor_floats_1080p(ctx, cat_golden):
     np.testing.assert_array_equal(got[::stride, ::stride, :3], g["cpu_1080p_direct_color"])
 
 
+@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("scene,W,H,spp,b", [("cpu", 512, 512, 2, 3), ("demo10", 256, 256, 2, 5), ("spheres", 320, 200, 4, 2),
                                              ("cpu", 256, 256, 1, 10)])
-def test_bounces_within_tolerance(ctx, oracle, oracle_cat, cat_golden, scene, W, H, spp, b):
+def test_bounces_within_tolerance(ctx, oracle, oracle_cat, cat_golden, scene, W, H, spp, b, variant):
     upload(ctx, scene, cat_golden)
-    got = ctx.render(rt.make_params(W, H, spp, b, **rt.scenes.CPU_LAUNCHER))
+    got = ctx.render(rt.make_params(W, H, spp, b, variant=variant, **rt.scenes.CPU_LAUNCHER))
     exp, _, _ = oracle.Scene.preset(scene, oracle_cat if scene == "cpu" else None).render(W, H, spp, b, want_rgb8=False)
     same = values_equal(got[..., :3], exp[..., :3]).mean()
     err = linf(oracle, got, exp)
@@ -186,6 +191,21 @@ def test_work_counters_equal_oracle_counters(ctx, oracle, oracle_cat, cat_golden
     nodes and triangle tests, i.e. the stackless traversal visits exactly what cpu:277-311 visits."""
     upload(ctx, "cpu", cat_golden)
     for W, H, spp, b in ((512, 512, 1, 0), (320, 180, 2, 3)):
-        got = ctx.count_work(rt.make_params(W, H, spp, b, **rt.scenes.CPU_LAUNCHER))
         _, _, exp = oracle.Scene.preset("cpu", oracle_cat).render(W, H, spp, b, want_rgb8=False)
-        assert got == {k: exp[k] for k in ("rays", "box_tests", "nodes", "tri_tests")}
+        for variant in VARIANTS:
+            got = ctx.count_work(rt.make_params(W, H, spp, b, variant=variant, **rt.scenes.CPU_LAUNCHER))
+            assert got == {k: exp[k] for k in ("rays", "box_tests", "nodes", "tri_tests")}, variant
+
+
+def test_variants_are_bitwise_identical_at_full_size(ctx, cat_golden):
+    """BASELINE size 1920x1080, 4 segments: every kernel variant writes the same bits (incl. the ray counts)."""
+    upload(ctx, "cpu", cat_golden)
+    ref = None
+    for variant in VARIANTS:
+        got = ctx.render(rt.make_params(1920, 1080, 1, 3, variant=variant, **rt.scenes.CPU_LAUNCHER))
+        assert np.isfinite(got).all()
+        if ref is None:
+            ref = got
+        else:
+            np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
+    assert int(ref[..., 3].sum()) == 16588799

@@ -16,5 +16,5 @@ for grp in \
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/p$i -o pmc -- python3 bench.py --no-cpu-baseline --steps 4 --warmup 1 "$@" > $out/p$i.json 2> $out/p$i.err || { echo "pass $i ($grp) failed"; tail -5 $out/p$i.err; }
 done
-python3 tools/pmc_summary.py $out > $out/summary.json
+python3 tools/pmc_summary.py $out "${PMC_KERNEL:-render_}" > $out/summary.json
 cat $out/summary.json

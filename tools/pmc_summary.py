@@ -1,11 +1,12 @@
 """Averages rocprofv3 --pmc counter rows of the render kernel over its dispatches (GPU box helper)."""
 import csv, glob, json, os, sys
 out = sys.argv[1]
+pat = sys.argv[2] if len(sys.argv) > 2 else "render_"
 acc, n = {}, {}
 for f in glob.glob(os.path.join(out, "p*", "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
-        if "render_kernel<false>" not in k and "render_kernel" not in k:
+        if pat not in k:
             continue
         if "<true>" in k:
             continue
