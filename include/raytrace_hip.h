@@ -44,7 +44,7 @@ typedef enum rt_status {
 
 /* kernel variants (BASELINE.json configs 3/4); all produce bit-identical results */
 typedef enum rt_variant {
-    RT_VARIANT_AUTO = 0,       /* library picks the fastest variant that fits                       */
+    RT_VARIANT_AUTO = 0,       /* the fastest measured variant: RT_VARIANT_WAVEFRONT                */
     RT_VARIANT_GLOBAL = 1,     /* persistent lanes (micro-op scheduler); SoA nodes + packed
                                   triangles read from HBM through L2/L1                             */
     RT_VARIANT_LDS_VERTS = 2,  /* + vertex array staged in LDS per workgroup
@@ -54,8 +54,12 @@ typedef enum rt_variant {
     RT_VARIANT_LOCKSTEP = 5,   /* one lane bound to one pixel for the whole frame, lock-step ray
                                   queries: the structure of KernelLaunch (optimized.cu:670-772);
                                   kept as the baseline the other variants are measured against      */
-    RT_VARIANT_WAVEFRONT = 6   /* uniform per-pixel shade/generate kernels alternating with a lean
-                                  persistent traversal kernel; path state as float4 SoA in HBM      */
+    RT_VARIANT_WAVEFRONT = 6,  /* uniform per-pixel shade/generate kernels alternating with a lean
+                                  persistent traversal kernel; path state as float4 SoA in HBM;
+                                  BVH nodes and triangles read from HBM through L2/L1               */
+    RT_VARIANT_WAVEFRONT_LDS = 7 /* the same with every BVH node staged in LDS (one 1024-thread
+                                  workgroup per CU shares the copy); RT_ERR_UNSUPPORTED when the
+                                  nodes do not fit the 160 KB                                       */
 } rt_variant;
 
 typedef struct rt_ctx rt_ctx;

@@ -34,7 +34,8 @@ struct rt_ctx {
     DevBuf node_lo, node_hi, nodes2, tri, verts, tidx, scratch_rgba, scratch_rgb8, work, queue;
     int n_cus = 0;
     DevBuf wfR0, wfR1, wfM, wfS0, wfS1, wfT, wfF, wfLS, wfQ;   // wavefront path state (HBM)
-    int trav_blocks_per_cu[2] = {0, 0};
+    int trav_blocks_per_cu[4] = {0, 0, 0, 0};
+    bool trav_attr_set = false;
     static constexpr int kMaxTravEvents = 2 * RT_MAX_SEGMENTS;
     hipEvent_t ev_trav[2 * kMaxTravEvents] = {};
     int n_trav_events = 0;
@@ -154,7 +155,7 @@ int check_params(rt_ctx *ctx, const rt_params *p, int &segs) {
         return fail(ctx, RT_ERR_INVALID, "depth_convention must be 0 (cpu_launcher) or 1 (optimized.cu)");
     segs = p->depth_convention == 0 ? p->num_bounce + 1 : p->num_bounce;
     if (segs > RT_MAX_SEGMENTS) return fail(ctx, RT_ERR_INVALID, "more than %d ray segments", RT_MAX_SEGMENTS);
-    if (p->variant < RT_VARIANT_AUTO || p->variant > RT_VARIANT_WAVEFRONT) return fail(ctx, RT_ERR_INVALID, "unknown variant %d", p->variant);
+    if (p->variant < RT_VARIANT_AUTO || p->variant > RT_VARIANT_WAVEFRONT_LDS) return fail(ctx, RT_ERR_INVALID, "unknown variant %d", p->variant);
     return RT_OK;
 }
 
@@ -173,8 +174,18 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
         const int64_t last_row = rows->row0 + (last / rows->tile_rows) * rows->tile_rows * (int64_t)rows->tile_step + (last % rows->tile_rows);
         if (last_row >= p->height) return fail(ctx, RT_ERR_INVALID, "rows reach image row %lld >= height %d", (long long)last_row, p->height);
     }
-    int variant = p->variant == RT_VARIANT_AUTO ? RT_VARIANT_WAVEFRONT : p->variant;
-    if (variant != RT_VARIANT_GLOBAL && variant != RT_VARIANT_LOCKSTEP && variant != RT_VARIANT_WAVEFRONT)
+    // LDS budget of the node-staging traversal kernel: all nodes + 16 per-wave carves in one 1024-thread workgroup
+    const size_t lds_nodes_bytes = (size_t)ctx->scene.n_nodes * 32 + (rtk::kTravBlockLds / 64) * (size_t)rtk::TravCarve<256, 4>::kBytes;
+    const bool lds_fits = ctx->scene.n_nodes > 0 && lds_nodes_bytes <= 160 * 1024;
+    int variant = p->variant;
+    // measured on MI355X (cat, 1080p): nodes through L2/L1 at 6 waves/SIMD beat LDS-staged nodes at 4 waves/SIMD
+    // (the traversal is latency-bound; occupancy wins), so AUTO is the HBM/L2 variant
+    if (variant == RT_VARIANT_AUTO) variant = RT_VARIANT_WAVEFRONT;
+    if (variant == RT_VARIANT_WAVEFRONT_LDS && !lds_fits) {
+        if (ctx->scene.n_nodes == 0) variant = RT_VARIANT_WAVEFRONT;      // no mesh: nothing to stage
+        else return fail(ctx, RT_ERR_UNSUPPORTED, "%d BVH nodes need %zu bytes of LDS (> 160 KiB)", ctx->scene.n_nodes, lds_nodes_bytes);
+    }
+    if (variant != RT_VARIANT_GLOBAL && variant != RT_VARIANT_LOCKSTEP && variant != RT_VARIANT_WAVEFRONT && variant != RT_VARIANT_WAVEFRONT_LDS)
         return fail(ctx, RT_ERR_UNSUPPORTED, "variant %d is not available in this build", variant);
 
     RT_HIP(ctx, hipSetDevice(ctx->device));
@@ -194,7 +205,8 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
     if (rows->n_rows == 0) { ctx->stats.grid_blocks = 0; ctx->have_kernel_time = false; return RT_OK; }
     const int nseg = segs > 0 ? segs : 1;
     ctx->n_trav_events = 0;
-    if (variant == RT_VARIANT_WAVEFRONT) {
+    if (variant == RT_VARIANT_WAVEFRONT || variant == RT_VARIANT_WAVEFRONT_LDS) {
+        const bool ldsn = variant == RT_VARIANT_WAVEFRONT_LDS;
         // begin, (trav, advance) x 2*segments per sample; path state SoA in HBM, tile-order path index
         rtk::WfState st{};
         st.tiles_x = (p->width + 7) / 8;
@@ -213,31 +225,40 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
         st.M = static_cast<unsigned long long *>(ctx->wfM.p); st.S0 = static_cast<float4 *>(ctx->wfS0.p);
         st.S1 = static_cast<float4 *>(ctx->wfS1.p); st.T = static_cast<float4 *>(ctx->wfT.p);
         st.F = static_cast<int4 *>(ctx->wfF.p); st.LS = static_cast<float *>(ctx->wfLS.p);
-        const int si = work_dev ? 1 : 0;
+        const int tb = ldsn ? rtk::kTravBlockLds : rtk::kTravBlock;
+        const size_t trav_lds = ldsn ? lds_nodes_bytes : (size_t)(rtk::kTravBlock / 64) * rtk::TravCarve<512, 8>::kBytes;
+        if (!ctx->trav_attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(rtk::wf_trav<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(rtk::wf_trav<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            ctx->trav_attr_set = true;
+        }
+        const int si = (work_dev ? 1 : 0) + (ldsn ? 2 : 0);
         if (ctx->trav_blocks_per_cu[si] == 0) {
             int nb = 0;
-            if (work_dev) RT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtk::wf_trav<true>, rtk::kTravBlock, 0));
-            else RT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtk::wf_trav<false>, rtk::kTravBlock, 0));
+            if (ldsn) nb = 1;
+            else if (work_dev) RT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtk::wf_trav<true, false>, rtk::kTravBlock, trav_lds));
+            else RT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtk::wf_trav<false, false>, rtk::kTravBlock, trav_lds));
             ctx->trav_blocks_per_cu[si] = nb > 0 ? nb : 1;
         }
         const bool have_mesh = ctx->scene.mesh_slot >= 0 && ctx->scene.n_nodes > 0;
         static DevBuf dbgbuf;
         const char *dbg_env = getenv("RT_DEBUG_TRAV");
         const int dbg_it = dbg_env ? atoi(dbg_env) : -1;
-        if (dbg_env) { rc2 = ensure(ctx, dbgbuf, 6 * 8 * 65536); if (rc2 != RT_OK) return rc2; }
+        if (dbg_env) { rc2 = ensure(ctx, dbgbuf, 10 * 8 * 65536); if (rc2 != RT_OK) return rc2; }
         // traversal launch geometry: waves_per_simd (env RT_TRAV_WAVES for experiments) persistent waves per SIMD,
         // each owning an equal, spatially scrambled share of the ray slots (no queue, no atomics)
-        int wps = ctx->trav_blocks_per_cu[si];                       // 256-thread blocks per CU == waves per SIMD
-        if (const char *e = getenv("RT_TRAV_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= wps) wps = v; }
-        int64_t tblocks = (int64_t)ctx->n_cus * wps;
+        int bpc = ctx->trav_blocks_per_cu[si];                       // blocks per CU
+        if (const char *e = getenv("RT_TRAV_WAVES")) { const int v = atoi(e); if (!ldsn && v >= 1 && v <= bpc) bpc = v; }
+        int64_t tblocks = (int64_t)ctx->n_cus * bpc;
         st.n_groups = st.n_paths / 4;
         // scramble: consecutive group-slots of one wave must land on groups spread over the WHOLE image, so the
         // stride pattern's period S is the largest power of two not above a wave's number of groups
-        int64_t n_waves = tblocks * (rtk::kTravBlock / 64);
+        const int wpb = tb / 64;
+        int64_t n_waves = tblocks * wpb;
         int64_t groups_per_wave = (st.n_groups + n_waves - 1) / n_waves;
         if (groups_per_wave < 16) {                                   // small image: fewer waves, >= 64 rays each
             n_waves = (st.n_groups + 15) / 16;
-            tblocks = (n_waves + 3) / 4; n_waves = tblocks * 4;
+            tblocks = (n_waves + wpb - 1) / wpb; n_waves = tblocks * wpb;
             groups_per_wave = (st.n_groups + n_waves - 1) / n_waves;
         }
         st.log2S = 0;
@@ -247,8 +268,8 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
         const int64_t total_slots = (int64_t)S * st.Q * 4;
         st.slots_per_wave = (int)(((total_slots + n_waves - 1) / n_waves + 3) / 4 * 4);
         const unsigned pblocks = (unsigned)((np + 255) / 256);
-        ctx->stats.lds_bytes = 0;
-        ctx->stats.block_threads = rtk::kTravBlock;
+        ctx->stats.lds_bytes = (int)trav_lds;
+        ctx->stats.block_threads = tb;
         ctx->stats.grid_blocks = (int)tblocks;
         RT_HIP(ctx, hipEventRecord(ctx->ev_k0, stream));
         for (int s = 0; s < fr.spp; ++s) {
@@ -259,8 +280,13 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
                     st.dbg = (dbg_env && it == dbg_it) ? static_cast<unsigned long long *>(dbgbuf.p) : nullptr;
                     const bool timed = s == fr.spp - 1;      // time the traversal launches of the last sample
                     if (timed) RT_HIP(ctx, hipEventRecord(ctx->ev_trav[2 * it], stream));
-                    if (work_dev) hipLaunchKernelGGL(rtk::wf_trav<true>, dim3((unsigned)tblocks), dim3(rtk::kTravBlock), 0, stream, ctx->scene, fr, st);
-                    else hipLaunchKernelGGL(rtk::wf_trav<false>, dim3((unsigned)tblocks), dim3(rtk::kTravBlock), 0, stream, ctx->scene, fr, st);
+                    if (ldsn) {
+                        if (work_dev) hipLaunchKernelGGL((rtk::wf_trav<true, true>), dim3((unsigned)tblocks), dim3(tb), trav_lds, stream, ctx->scene, fr, st);
+                        else hipLaunchKernelGGL((rtk::wf_trav<false, true>), dim3((unsigned)tblocks), dim3(tb), trav_lds, stream, ctx->scene, fr, st);
+                    } else {
+                        if (work_dev) hipLaunchKernelGGL((rtk::wf_trav<true, false>), dim3((unsigned)tblocks), dim3(tb), trav_lds, stream, ctx->scene, fr, st);
+                        else hipLaunchKernelGGL((rtk::wf_trav<false, false>), dim3((unsigned)tblocks), dim3(tb), trav_lds, stream, ctx->scene, fr, st);
+                    }
                     if (timed) { RT_HIP(ctx, hipEventRecord(ctx->ev_trav[2 * it + 1], stream)); ctx->n_trav_events = it + 1; }
                     st.dbg = nullptr;
                 }
@@ -269,7 +295,7 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
             }
         }
         if (dbg_env) {
-            std::vector<unsigned long long> h(6 * (size_t)(tblocks * 4));
+            std::vector<unsigned long long> h(10 * (size_t)65536);
             (void)hipStreamSynchronize(stream);
             (void)hipMemcpy(h.data(), dbgbuf.p, h.size() * 8, hipMemcpyDeviceToHost);
             FILE *f = fopen("gpurun_out/trav_dbg.bin", "wb");

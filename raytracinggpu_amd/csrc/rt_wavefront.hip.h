@@ -167,22 +167,20 @@ __global__ __launch_bounds__(256) void wf_begin(const Scene sc, const Frame fr, 
 // entries, the ring is consumed 64 entries at a time by full-occupancy TRI steps (ray data from the owners'
 // LDS copies, results merged by a 64-bit LDS min on bits(t) << 32 | triangle), finished tasks retire, idle
 // lanes refill from the wave's scrambled share of the rays or take a split from a busy lane.
-constexpr int kTravBlock = 256;
-constexpr int kQCap = 512;                  // ring entries per wave (power of two)
-constexpr int kLeafCap = 8;                 // leaf-list entries per lane
+constexpr int kTravBlock = 256;             // nodes from HBM/L2: 256-thread blocks, several per CU
+constexpr int kTravBlockLds = 1024;         // nodes staged in LDS: ONE 1024-thread block per CU shares the copy
 constexpr int kBoxMin = 44;                 // service when fewer lanes than this can take a BOX step
 
-struct TravLds {
-    float4 ray0[kTravBlock], ray1[kTravBlock];      // (O.xyz, u.x) (u.yz, -, -) of the lane's current task
-    unsigned long long best[kTravBlock];            // nearest accepted triangle of the lane's current task
-    unsigned int q[kTravBlock / 64][kQCap];         // owner lane << 26 | triangle index
-    unsigned int leaf[kTravBlock / 64][kLeafCap][64];   // count << 26 | first triangle
+// per-wave LDS carve: ray0[64] ray1[64] (float4) | best[64] (u64) | ring[QCAP] (u32) | leaf[LEAFCAP][64] (u32)
+template <int QCAP, int LEAFCAP> struct TravCarve {
+    static constexpr int kRay = 0, kBest = 2048, kRing = 2560, kLeaf = kRing + 4 * QCAP, kBytes = kLeaf + 256 * LEAFCAP;
 };
 
 __device__ __forceinline__ int wf_slot_to_path(const WfState &st, int q) {
     const int gs = q >> 2;
-    const int g = (gs & ((1 << st.log2S) - 1)) * st.Q + (gs >> st.log2S);
-    return g < st.n_groups ? 4 * g + (q & 3) : -1;
+    const int col = gs >> st.log2S;                  // >= Q for the padding slots of the last waves
+    const int g = (gs & ((1 << st.log2S) - 1)) * st.Q + col;
+    return (col < st.Q && g < st.n_groups) ? 4 * g + (q & 3) : -1;
 }
 
 // single-instruction min/max (the operands are results of arithmetic, never signalling NaNs; IEEE-mode
@@ -208,16 +206,32 @@ __device__ __forceinline__ RayBox ray_box(f3 O, f3 u) {
     return b;
 }
 
-template <bool STATS>
-__global__ __launch_bounds__(kTravBlock) void wf_trav(const Scene sc, const Frame fr, const WfState st) {
-    __shared__ TravLds lds;
+template <bool STATS, bool LDSN>
+__global__ __launch_bounds__(LDSN ? kTravBlockLds : kTravBlock) void wf_trav(const Scene sc, const Frame fr, const WfState st) {
+    constexpr int kQCap = LDSN ? 256 : 512;         // ring entries per wave (power of two)
+    constexpr int kLeafCap = LDSN ? 4 : 8;          // leaf-list entries per lane
+    using Carve = TravCarve<kQCap, kLeafCap>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char trav_smem[];
+    unsigned char *const smem = trav_smem;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wib = tid >> 6;                       // wave in block
-    const int wbase = wib * 64;
     const int wave = (blockIdx.x * blockDim.x + tid) >> 6;
-    unsigned int *const q = lds.q[wib];
-    unsigned int *const leaf = &lds.leaf[wib][0][lane];     // leaf[k * 64]
+    // LDS: [LDSN: every node, 2 x float4 each] then one carve per wave
+    const float4 *nodes = sc.nodes;
+    unsigned char *wl = smem + wib * Carve::kBytes;
+    if (LDSN) {
+        float4 *ln = reinterpret_cast<float4 *>(smem);
+        for (int k = tid; k < 2 * sc.n_nodes; k += blockDim.x) ln[k] = sc.nodes[k];
+        __syncthreads();
+        nodes = ln;
+        wl += (size_t)sc.n_nodes * 32;
+    }
+    float4 *const lray0 = reinterpret_cast<float4 *>(wl + Carve::kRay);
+    float4 *const lray1 = lray0 + 64;
+    unsigned long long *const lbest = reinterpret_cast<unsigned long long *>(wl + Carve::kBest);
+    unsigned int *const q = reinterpret_cast<unsigned int *>(wl + Carve::kRing);
+    unsigned int *const leaf = reinterpret_cast<unsigned int *>(wl + Carve::kLeaf) + lane;     // leaf[k * 64]
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
     // lane state: a task = traversal of node range [node, nend) of ray `ray`
     int ray = -1;                       // path index, -1 = idle
@@ -235,14 +249,17 @@ __global__ __launch_bounds__(kTravBlock) void wf_trav(const Scene sc, const Fram
     Work wk;
     const unsigned long long dbg_t0 = st.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
     unsigned int dbg_steps = 0, dbg_lanes = 0, dbg_splits = 0, dbg_tsteps = 0;
-    const float4 *const nodes = sc.nodes;
-
+    unsigned long long cy_box = 0, cy_tri = 0, cy_exp = 0, cy_ref = 0, stamp = 0;
+    const bool dbg_on = st.dbg != nullptr;
+#define WF_STAMP(acc) do { if (dbg_on) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - stamp; stamp = t_; } } while (0)
+    if (dbg_on) stamp = __builtin_amdgcn_s_memtime();
     bool boxable = false;
     for (;;) {
         int nB = __popcll(__ballot(boxable));
         if (nB < kBoxMin) {
             // =============================== SERVICE ===============================
             for (;;) {
+                WF_STAMP(cy_box);
                 // ---- (1) expand leaf lists into the ring, one entry per lane and round ----
                 for (;;) {
                     if (pend_cnt == 0 && nl > 0) {
@@ -260,6 +277,7 @@ __global__ __launch_bounds__(kTravBlock) void wf_trav(const Scene sc, const Fram
                     }
                     qtail += (unsigned int)__popcll(pm);
                 }
+                WF_STAMP(cy_exp);
                 // ---- (2) TRI steps: 64 queued (owner, triangle) pairs, one per lane ----
                 const bool walkable = ray >= 0 && node < nend && nl < kLeafCap && pend_cnt == 0;
                 const int nW = __popcll(__ballot(walkable));
@@ -270,11 +288,11 @@ __global__ __launch_bounds__(kTravBlock) void wf_trav(const Scene sc, const Fram
                     dbg_tsteps++; dbg_steps++; dbg_lanes += n;
                     if ((unsigned int)lane < n) {
                         const unsigned int e = q[(qhead + (unsigned int)lane) & (kQCap - 1)];
-                        const int o = wbase + (int)(e >> 26);
+                        const int o = (int)(e >> 26);
                         const int i = (int)(e & 0x3ffffffu);
                         const float4 *tp = sc.tri + 3 * i;
                         const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
-                        const float4 r0 = lds.ray0[o], r1 = lds.ray1[o];
+                        const float4 r0 = lray0[o], r1 = lray1[o];
                         const f3 Oo = mk(r0.x, r0.y, r0.z), uo = mk(r0.w, r1.x, r1.y);
                         const f3 A = mk(q0.x, q0.y, q0.z), e1 = mk(q0.w, q1.x, q1.y), e2 = mk(q1.z, q1.w, q2.x);
                         const f3 N = mk(q2.y, q2.z, q2.w);
@@ -299,14 +317,15 @@ __global__ __launch_bounds__(kTravBlock) void wf_trav(const Scene sc, const Fram
                         if (ok) {
                             const float t = dot(AO, N) / det;
                             if (t > 0 && t > fr.tri_tmin && t < 1e9f)    // cpu:235,301; the min is the strict '<' scan
-                                atomicMin(&lds.best[o], (unsigned long long)__float_as_uint(t) << 32 | (unsigned int)i);
+                                atomicMin(&lbest[o], (unsigned long long)__float_as_uint(t) << 32 | (unsigned int)i);
                         }
                     }
                     qhead += n;
                 }
+                WF_STAMP(cy_tri);
                 // ---- (3) retire tasks whose nodes are walked and whose queued triangles have all been tested ----
                 if (ray >= 0 && node >= nend && nl == 0 && pend_cnt == 0 && (int)(qhead - last_pos) >= 0) {
-                    const unsigned long long key = lds.best[tid];
+                    const unsigned long long key = lbest[lane];
                     if (key != WF_NOHIT) {
                         if (shared) atomicMin(&st.M[ray], key);
                         else st.M[ray] = key;
@@ -326,7 +345,7 @@ __global__ __launch_bounds__(kTravBlock) void wf_trav(const Scene sc, const Fram
                                 const float4 r0 = st.R0[path], r1 = st.R1[path];
                                 O = mk(r0.x, r0.y, r0.z); u = mk(r0.w, r1.x, r1.y);
                                 rb = ray_box(O, u);
-                                lds.ray0[tid] = r0; lds.ray1[tid] = r1; lds.best[tid] = WF_NOHIT;
+                                lray0[lane] = r0; lray1[lane] = r1; lbest[lane] = WF_NOHIT;
                                 // the root box was tested when the ray was emitted; start below it
                                 const int rw = __float_as_int(sc.root_hi.w);
                                 node = rw < 0 ? 1 : sc.n_nodes; nend = sc.n_nodes; sk = 0; nl = 0;
@@ -363,14 +382,15 @@ __global__ __launch_bounds__(kTravBlock) void wf_trav(const Scene sc, const Fram
                         const int r_node = __shfl(g_node, src, 64), r_nend = __shfl(g_nend, src, 64);
                         if (partner >= 0) {
                             ray = r_ray; O = mk(r_ox, r_oy, r_oz); u = mk(r_ux, r_uy, r_uz); rb = ray_box(O, u);
-                            lds.ray0[tid] = make_float4(O.x, O.y, O.z, u.x); lds.ray1[tid] = make_float4(u.y, u.z, 0, 0);
-                            lds.best[tid] = WF_NOHIT;
+                            lray0[lane] = make_float4(O.x, O.y, O.z, u.x); lray1[lane] = make_float4(u.y, u.z, 0, 0);
+                            lbest[lane] = WF_NOHIT;
                             node = r_node; nend = r_nend; sk = 0; nl = 0; pend_cnt = 0;
                             last_pos = qhead; shared = true;
                         }
                         dbg_splits += n_pairs;
                     }
                 }
+                WF_STAMP(cy_ref);
                 // ---- done servicing? ----
                 boxable = ray >= 0 && node < nend && nl < kLeafCap && pend_cnt == 0;
                 nB = __popcll(__ballot(boxable));
@@ -402,7 +422,11 @@ __global__ __launch_bounds__(kTravBlock) void wf_trav(const Scene sc, const Fram
             const float band = fmaf(M, 2.f * kRel, rb.c0);
             bool hit = d > band;
             const bool decided = rb.safe && M < kBig && (hit || d < -band);
-            if (!decided) hit = slab(lo, hi, O, u);            // literal arithmetic (rare)
+            // literal arithmetic for undecided lanes: behind a wave-uniform branch so that the six IEEE divisions are
+            // skipped, not if-converted, when (as almost always) every lane decided
+            if (__builtin_expect(__ballot(!decided) != 0ull, 0)) {
+                if (!decided) hit = slab(lo, hi, O, u);
+            }
             int next = node + 1;
             if (hit) {
                 if (STATS) wk.nodes++;
@@ -425,7 +449,10 @@ finished:
     if (st.dbg && lane == 0) {
         st.dbg[6 * wave + 0] = dbg_t0; st.dbg[6 * wave + 1] = __builtin_amdgcn_s_memrealtime();
         st.dbg[6 * wave + 2] = dbg_steps; st.dbg[6 * wave + 3] = dbg_lanes; st.dbg[6 * wave + 4] = dbg_splits; st.dbg[6 * wave + 5] = dbg_tsteps;
+        unsigned long long *d2 = st.dbg + 6 * 65536 + 4 * wave;
+        d2[0] = cy_box; d2[1] = cy_exp; d2[2] = cy_tri; d2[3] = cy_ref;
     }
+#undef WF_STAMP
     wf_flush_work<STATS>(fr, wk);
 }
 

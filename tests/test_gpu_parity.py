@@ -38,7 +38,7 @@ def values_equal(a, b):
     return (a == b) | (np.isnan(a) & np.isnan(b))
 
 
-VARIANTS = ["wavefront", "global", "lockstep"]
+VARIANTS = ["wavefront_lds", "wavefront", "global", "lockstep"]
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
