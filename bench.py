@@ -30,7 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-TILE_ROWS = 8
+TILE_ROWS = 8              # == raytracinggpu_amd.tiling.TILE_ROWS
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -107,6 +107,7 @@ def main():
     import torch
     import torch.distributed as dist
     import raytracinggpu_amd as rt
+    from raytracinggpu_amd import tiling
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -125,9 +126,7 @@ def main():
     W, H = args.width, args.height
     p = rt.make_params(W, H, args.spp, args.bounces, variant=args.variant, **rt.scenes.CPU_LAUNCHER)
     rows, idx = rt.interleaved_rows(H, TILE_ROWS, rank, world)
-    n_tiles = (H + TILE_ROWS - 1) // TILE_ROWS
-    tiles_local = (n_tiles + world - 1) // world
-    local = torch.zeros((tiles_local * TILE_ROWS, W, 4), dtype=torch.float32, device=dev)
+    local = tiling.local_buffer(H, W, world, dev)
     gathered = [torch.empty_like(local) for _ in range(world)] if (world > 1 and rank == 0) else None
     frame = None
     # a non-default torch stream: its handle is non-NULL (NULL means "the context's own stream" in the C-ABI),
@@ -140,14 +139,7 @@ def main():
     def step():
         nonlocal frame
         ctx.render_device(p, rows, local.data_ptr(), stream)
-        if world > 1:
-            dist.gather(local, gathered, dst=0)
-            if rank == 0:
-                # [G, T, R, W, 4] -> [T, G, R, W, 4]: tile k of rank r is image tile k*G + r
-                g = torch.stack(gathered).view(world, tiles_local, TILE_ROWS, W, 4)
-                frame = g.permute(1, 0, 2, 3, 4).reshape(-1, W, 4)[:H]
-        else:
-            frame = local[:H]
+        frame = tiling.gather_frame(local, H, world, rank, gathered)
 
     # exact ray count of one frame (deterministic; outside the timed region)
     step()
@@ -170,11 +162,7 @@ def main():
         ev[k][0].record()
         ctx.render_device(p, rows, local.data_ptr(), stream)
         ev[k][1].record()
-        if world > 1:
-            dist.gather(local, gathered, dst=0)
-            if rank == 0:
-                g = torch.stack(gathered).view(world, tiles_local, TILE_ROWS, W, 4)
-                frame = g.permute(1, 0, 2, 3, 4).reshape(-1, W, 4)[:H]
+        frame = tiling.gather_frame(local, H, world, rank, gathered)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -5,5 +5,5 @@ include/raytrace_hip.h) plus the C++ host API of include/raytracer.hpp.  This
 Python package is plumbing for tests and bench.py: a ctypes binding and the scene
 presets of the reference programs.
 """
-from . import _capi, scenes  # noqa: F401
+from . import _capi, scenes  # noqa: F401  (tiling imports torch: import it explicitly where needed)
 from ._capi import Context, RtError, device_count, interleaved_rows, make_params  # noqa: F401

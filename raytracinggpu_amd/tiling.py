@@ -1,0 +1,42 @@
+"""Row-tile partition of a frame over ranks and its reassembly.
+
+Tile k (TILE_ROWS image rows) belongs to rank k mod G: contiguous blocks would be badly imbalanced (the cat
+and its shadow sit in the middle rows).  Every rank renders its tiles into a dense local buffer of
+`tiles_local * TILE_ROWS` rows (the last tile of some ranks may be padding); ONE gather to rank 0 per frame
+moves the float4 tiles, and a single permute restores row order.  Pure torch/torch.distributed: works with
+the nccl (= RCCL over xGMI) backend on GPUs and with gloo on CPU tensors.
+"""
+import torch
+import torch.distributed as dist
+
+TILE_ROWS = 8
+
+
+def tiles_per_rank(height, world, tile_rows=TILE_ROWS):
+    n_tiles = (height + tile_rows - 1) // tile_rows
+    return (n_tiles + world - 1) // world
+
+
+def local_buffer(height, width, world, device, tile_rows=TILE_ROWS):
+    """Dense per-rank buffer [tiles_local * tile_rows, W, 4] (zero-filled so padding tiles are defined)."""
+    return torch.zeros((tiles_per_rank(height, world, tile_rows) * tile_rows, width, 4), dtype=torch.float32, device=device)
+
+
+def assemble(stacked, height, tile_rows=TILE_ROWS):
+    """stacked: [G, tiles_local * R, W, 4] (rank-major) -> [H, W, 4].  Tile k of rank r is image tile k*G + r."""
+    g, rows, w, c = stacked.shape
+    t = rows // tile_rows
+    return stacked.view(g, t, tile_rows, w, c).permute(1, 0, 2, 3, 4).reshape(-1, w, c)[:height]
+
+
+def gather_frame(local, height, world, rank, gather_list=None, tile_rows=TILE_ROWS):
+    """One gather of the float4 tiles to rank 0 (a grouped send/recv under RCCL: each peer uses its own xGMI
+    link to the root).  Returns the assembled [H, W, 4] frame on rank 0, None elsewhere."""
+    if world == 1:
+        return local[:height]
+    if rank == 0 and gather_list is None:
+        gather_list = [torch.empty_like(local) for _ in range(world)]
+    dist.gather(local, gather_list if rank == 0 else None, dst=0)
+    if rank != 0:
+        return None
+    return assemble(torch.stack(gather_list), height, tile_rows)

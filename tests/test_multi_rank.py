@@ -1,0 +1,101 @@
+"""N-rank row-tile path: world_size-2/3 torch.distributed runs.
+
+CPU (gloo): the partition / gather / reassembly code bench.py uses, with the CPU oracle standing in for the
+renderer of each rank's tiles -- the gathered frame must equal the full frame bit for bit.
+GPU (-m gpu): the same with the HIP render path on cuda:0 in every rank (<= 3 ranks on the one card), gloo for
+the exchange; RCCL itself needs one GPU per rank and runs in bench.py on the 8-GPU node.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, mode, W, H, spp, b, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import raytracinggpu_amd as rt
+    from raytracinggpu_amd import tiling
+    g = np.load(rt.scenes.CAT_FIXTURE, allow_pickle=False)
+    rows, idx = rt.interleaved_rows(H, tiling.TILE_ROWS, rank, world)
+    local = tiling.local_buffer(H, W, world, "cpu")
+    if mode == "oracle":
+        from oracle import oracle_py as orc
+        mesh = orc.Mesh.from_arrays(g["vertices"], g["tri_obj_order"]).build_bvh()
+        sc = orc.Scene.preset("cpu", mesh)
+        if rows.n_rows:
+            part, _, _ = sc.render(W, H, spp, b, rows=(rank * tiling.TILE_ROWS, H), tile_rows=tiling.TILE_ROWS, tile_step=world,
+                                   threads=2, want_rgb8=False)
+            assert part.shape[0] == rows.n_rows
+            local[:rows.n_rows] = torch.from_numpy(part)
+    else:
+        from raytracinggpu_amd import hostlib
+        ctx = rt.Context(0)
+        ctx.scene_upload(rt.scenes.spheres("cpu"), hostlib.build_mesh(g["vertices"], g["tri_obj_order"], object_slot=6))
+        dev = torch.zeros(local.shape, dtype=torch.float32, device="cuda:0")
+        ctx.render_device(rt.make_params(W, H, spp, b, **rt.scenes.CPU_LAUNCHER), rows, dev.data_ptr())
+        ctx.synchronize()
+        local.copy_(dev.cpu())
+        ctx.close()
+    frame = tiling.gather_frame(local, H, world, rank)
+    if rank == 0:
+        np.save(out_path, frame.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gathered_tiles_equal_full_frame_gloo_cpu(oracle, oracle_cat, tmp_path, world):
+    W, H, spp, b = 96, 50, 1, 2          # H is not a multiple of the tile height: padding tiles in play
+    out = str(tmp_path / "frame.npy")
+    mp.spawn(_worker, args=(world, _free_port(), "oracle", W, H, spp, b, out), nprocs=world, join=True)
+    got = np.load(out)
+    exp, _, _ = oracle.Scene.preset("cpu", oracle_cat).render(W, H, spp, b, want_rgb8=False)
+    assert got.shape == exp.shape
+    np.testing.assert_array_equal(got.view(np.uint32), exp.view(np.uint32))
+
+
+def test_assemble_is_the_inverse_of_the_partition():
+    from raytracinggpu_amd import tiling
+    import raytracinggpu_amd as rt
+    for H, W, G in ((1080, 8, 8), (50, 4, 3), (7, 3, 2), (64, 2, 4)):
+        frame = torch.arange(H * W * 4, dtype=torch.float32).view(H, W, 4)
+        locs = []
+        for r in range(G):
+            rows, idx = rt.interleaved_rows(H, tiling.TILE_ROWS, r, G)
+            loc = tiling.local_buffer(H, W, G, "cpu")
+            loc[:len(idx)] = frame[torch.as_tensor(idx, dtype=torch.long)]
+            locs.append(loc)
+        assert torch.equal(tiling.assemble(torch.stack(locs), H), frame)
+
+
+@pytest.mark.gpu
+def test_gathered_gpu_tiles_equal_single_gpu_frame(tmp_path):
+    import raytracinggpu_amd as rt
+    from raytracinggpu_amd import hostlib
+    W, H, spp, b = 640, 356, 1, 2
+    out = str(tmp_path / "frame.npy")
+    mp.spawn(_worker, args=(3, _free_port(), "gpu", W, H, spp, b, out), nprocs=3, join=True)
+    got = np.load(out)
+    g = np.load(rt.scenes.CAT_FIXTURE, allow_pickle=False)
+    ctx = rt.Context(0)
+    ctx.scene_upload(rt.scenes.spheres("cpu"), hostlib.build_mesh(g["vertices"], g["tri_obj_order"], object_slot=6))
+    full = ctx.render(rt.make_params(W, H, spp, b, **rt.scenes.CPU_LAUNCHER))
+    np.testing.assert_array_equal(got.view(np.uint32), full.view(np.uint32))
