@@ -218,7 +218,8 @@ def main():
             if os.path.exists(tpath):
                 t = json.load(open(tpath)).get(workload)
                 if t:
-                    res["roofline"]["traffic"] = t
+                    res["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+                    res["roofline"]["traffic_source"] = t["source"]
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
