@@ -201,6 +201,10 @@ def main():
                 kname = "rtk::wf_trav<false>"
                 launches = st["trav_launches"]
                 k_ms = st["trav_ms"] / launches
+                # `parts` sub-frames run concurrently on separate streams; the timed launches are part 0's.  While one of
+                # them runs, the matching launches of the other parts run beside it, so the chip moves the whole step's
+                # bytes (all parts) in that window: achieved = step bytes / launch duration.
+                parts = max(st.get("parts", 1), 1)
                 alg_launch = trav_bytes / world / launches
             else:
                 kname = "rtk::render_persistent<false>" if st["variant"] == 1 else "rtk::render_kernel<false>"
@@ -208,8 +212,8 @@ def main():
             ach = alg_launch / (k_ms * 1e-3) / 1e9
             res["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                               "kernel": kname, "kernel_ms": round(k_ms, 4), "launches_per_frame": launches,
-                               "algorithmic_bytes_per_launch": int(alg_launch),
+                               "kernel": kname, "kernel_ms": round(k_ms, 4), "launches_per_frame": launches * max(st.get("parts", 1), 1), "concurrent_launches": max(st.get("parts", 1), 1),
+                               "algorithmic_bytes_per_launch": int(alg_launch / max(st.get("parts", 1), 1)), "algorithmic_bytes_per_launch_window": int(alg_launch),
                                "frame_algorithmic_bytes": int(trav_bytes + fb_bytes), "frame_kernels_ms": round(kernel_ms_max, 4),
                                "per_ray": {k: round(counts[k] / counts["rays"], 3) for k in ("box_tests", "nodes", "tri_tests")},
                                "note": "algorithmic bytes (SURVEY 8d: 24 B/box test + 16 B/node + 48 B/triangle test); "

@@ -130,6 +130,8 @@ typedef struct rt_stats {
     float    trav_ms;              /* wavefront variant: summed HIP-event time of the traversal kernel
                                       launches of the last sample of the last frame, and how many    */
     int32_t  trav_launches;
+    int32_t  parts;                /* wavefront variant: concurrent sub-frames the call was cut into      */
+    int32_t  reserved;
 } rt_stats;
 
 /* --- device / context -------------------------------------------------------- */

@@ -35,6 +35,10 @@ struct rt_ctx {
     int n_cus = 0;
     DevBuf wfR0, wfR1, wfM, wfS0, wfS1, wfT, wfF, wfLS, wfQ;   // wavefront path state (HBM)
     int trav_blocks_per_cu[4] = {0, 0, 0, 0};
+    static constexpr int kMaxParts = 8;
+    hipStream_t part_stream[kMaxParts] = {};
+    hipEvent_t part_ev[kMaxParts] = {};
+    hipEvent_t fork_ev = nullptr;
     bool trav_attr_set = false;
     static constexpr int kMaxTravEvents = 2 * RT_MAX_SEGMENTS;
     hipEvent_t ev_trav[2 * kMaxTravEvents] = {};
@@ -175,7 +179,7 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
         if (last_row >= p->height) return fail(ctx, RT_ERR_INVALID, "rows reach image row %lld >= height %d", (long long)last_row, p->height);
     }
     // LDS budget of the node-staging traversal kernel: all nodes + 16 per-wave carves in one 1024-thread workgroup
-    const size_t lds_nodes_bytes = (size_t)ctx->scene.n_nodes * 32 + (rtk::kTravBlockLds / 64) * (size_t)rtk::TravCarve<256, 4>::kBytes;
+    const size_t lds_nodes_bytes = (size_t)ctx->scene.n_nodes * 32 + (rtk::kTravBlockLds / 64) * (size_t)rtk::TravCarve<256, 4>::kBytes + 16;
     const bool lds_fits = ctx->scene.n_nodes > 0 && lds_nodes_bytes <= 160 * 1024;
     int variant = p->variant;
     // measured on MI355X (cat, 1080p): nodes through L2/L1 at 6 waves/SIMD beat LDS-staged nodes at 4 waves/SIMD
@@ -199,6 +203,7 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
     fr.row0 = rows->row0; fr.n_rows = rows->n_rows; fr.tile_rows = rows->tile_rows; fr.tile_step = rows->tile_step;
     fr.out = static_cast<float4 *>(out_dev);
     fr.work = work_dev;
+    fr.out_tile0 = 0; fr.out_tile_step = 1;
 
     ctx->stats.pixels = (uint64_t)rows->n_rows * p->width;
     ctx->stats.variant = variant;
@@ -207,26 +212,22 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
     ctx->n_trav_events = 0;
     if (variant == RT_VARIANT_WAVEFRONT || variant == RT_VARIANT_WAVEFRONT_LDS) {
         const bool ldsn = variant == RT_VARIANT_WAVEFRONT_LDS;
-        // begin, (trav, advance) x 2*segments per sample; path state SoA in HBM, tile-order path index
-        rtk::WfState st{};
-        st.tiles_x = (p->width + 7) / 8;
-        const int64_t n_paths64 = (int64_t)st.tiles_x * ((rows->n_rows + 7) / 8) * 64;
-        if (n_paths64 >= ((int64_t)1 << 31) - 65536) return fail(ctx, RT_ERR_INVALID, "image too large");
-        st.n_paths = (int)n_paths64;
-        const size_t np = (size_t)st.n_paths;
-        int rc2;
-        if ((rc2 = ensure(ctx, ctx->wfR0, np * 16)) != RT_OK || (rc2 = ensure(ctx, ctx->wfR1, np * 16)) != RT_OK ||
-            (rc2 = ensure(ctx, ctx->wfM, np * 8)) != RT_OK || (rc2 = ensure(ctx, ctx->wfS0, np * 16)) != RT_OK ||
-            (rc2 = ensure(ctx, ctx->wfS1, np * 16)) != RT_OK || (rc2 = ensure(ctx, ctx->wfT, np * 16)) != RT_OK ||
-            (rc2 = ensure(ctx, ctx->wfF, np * 16)) != RT_OK || (rc2 = ensure(ctx, ctx->wfLS, np * 4 * (size_t)nseg)) != RT_OK ||
-            false)
-            return rc2;
-        st.R0 = static_cast<float4 *>(ctx->wfR0.p); st.R1 = static_cast<float4 *>(ctx->wfR1.p);
-        st.M = static_cast<unsigned long long *>(ctx->wfM.p); st.S0 = static_cast<float4 *>(ctx->wfS0.p);
-        st.S1 = static_cast<float4 *>(ctx->wfS1.p); st.T = static_cast<float4 *>(ctx->wfT.p);
-        st.F = static_cast<int4 *>(ctx->wfF.p); st.LS = static_cast<float *>(ctx->wfLS.p);
+        // begin, (trav, advance) x 2*segments per sample; path state SoA in HBM, tile-order path index.
+        // The rows are cut into `parts` independent sub-frames (interleaved tiles), each running its own kernel
+        // sequence on its own stream: the traversal kernel ends in a latency-bound tail (a few long rays), and
+        // the other parts' kernels fill the SIMDs that a tail leaves idle.  (More than 3 concurrent streams fall off
+        // a cliff on this runtime: 4 hardware queues per process.)
+        int parts = 2;
+        if (const char *e = getenv("RT_PARTS")) { const int v = atoi(e); if (v >= 1 && v <= rt_ctx::kMaxParts) parts = v; }
+        int R = rows->tile_rows, G = rows->tile_step;
+        if (G == 1) R = 8;                                            // contiguous rows: any tile height describes them
+        const int T = (rows->n_rows + R - 1) / R;                     // local tiles of this call
+        if (R % 8 != 0 || work_dev || getenv("RT_DEBUG_TRAV")) parts = 1;
+        if (parts > T) parts = T > 0 ? T : 1;
+        const int tiles_x = (p->width + 7) / 8;
         const int tb = ldsn ? rtk::kTravBlockLds : rtk::kTravBlock;
-        const size_t trav_lds = ldsn ? lds_nodes_bytes : (size_t)(rtk::kTravBlock / 64) * rtk::TravCarve<512, 8>::kBytes;
+        const int wpb = tb / 64;
+        const size_t trav_lds = ldsn ? lds_nodes_bytes : (size_t)(rtk::kTravBlock / 64) * rtk::TravCarve<512, 8>::kBytes + 16;
         if (!ctx->trav_attr_set) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(rtk::wf_trav<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(rtk::wf_trav<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -240,60 +241,108 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
             else RT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtk::wf_trav<false, false>, rtk::kTravBlock, trav_lds));
             ctx->trav_blocks_per_cu[si] = nb > 0 ? nb : 1;
         }
+        int bpc = ctx->trav_blocks_per_cu[si];                       // blocks per CU
+        if (const char *e = getenv("RT_TRAV_WAVES")) { const int v = atoi(e); if (!ldsn && v >= 1 && v <= bpc) bpc = v; }
         const bool have_mesh = ctx->scene.mesh_slot >= 0 && ctx->scene.n_nodes > 0;
         static DevBuf dbgbuf;
         const char *dbg_env = getenv("RT_DEBUG_TRAV");
         const int dbg_it = dbg_env ? atoi(dbg_env) : -1;
+        int rc2;
         if (dbg_env) { rc2 = ensure(ctx, dbgbuf, 10 * 8 * 65536); if (rc2 != RT_OK) return rc2; }
-        // traversal launch geometry: waves_per_simd (env RT_TRAV_WAVES for experiments) persistent waves per SIMD,
-        // each owning an equal, spatially scrambled share of the ray slots (no queue, no atomics)
-        int bpc = ctx->trav_blocks_per_cu[si];                       // blocks per CU
-        if (const char *e = getenv("RT_TRAV_WAVES")) { const int v = atoi(e); if (!ldsn && v >= 1 && v <= bpc) bpc = v; }
-        int64_t tblocks = (int64_t)ctx->n_cus * bpc;
-        st.n_groups = st.n_paths / 4;
-        // scramble: consecutive group-slots of one wave must land on groups spread over the WHOLE image, so the
-        // stride pattern's period S is the largest power of two not above a wave's number of groups
-        const int wpb = tb / 64;
-        int64_t n_waves = tblocks * wpb;
-        int64_t groups_per_wave = (st.n_groups + n_waves - 1) / n_waves;
-        if (groups_per_wave < 16) {                                   // small image: fewer waves, >= 64 rays each
-            n_waves = (st.n_groups + 15) / 16;
-            tblocks = (n_waves + wpb - 1) / wpb; n_waves = tblocks * wpb;
-            groups_per_wave = (st.n_groups + n_waves - 1) / n_waves;
+
+        // per-part geometry
+        struct Part { rtk::Frame fr; rtk::WfState st; int64_t tblocks; unsigned pblocks; size_t base; };
+        std::vector<Part> pv(parts);
+        size_t np_total = 0;
+        for (int j = 0; j < parts; ++j) {
+            Part &pt = pv[j];
+            const int Tj = (T - j + parts - 1) / parts;               // local tiles j, j+parts, ...
+            int nrows_j = Tj * R;
+            if (Tj > 0 && (T - 1) % parts == j) nrows_j -= T * R - rows->n_rows;   // the last local tile may be partial
+            pt.fr = fr;
+            pt.fr.row0 = rows->row0 + j * R * G; pt.fr.n_rows = nrows_j; pt.fr.tile_rows = R; pt.fr.tile_step = G * parts;
+            pt.fr.out_tile0 = j; pt.fr.out_tile_step = parts;
+            pt.st = rtk::WfState{};
+            pt.st.tiles_x = tiles_x;
+            const int64_t n_paths64 = (int64_t)tiles_x * ((nrows_j + 7) / 8) * 64;
+            if (n_paths64 >= ((int64_t)1 << 31) - 65536) return fail(ctx, RT_ERR_INVALID, "image too large");
+            pt.st.n_paths = (int)n_paths64;
+            pt.base = np_total;
+            np_total += (size_t)n_paths64;
+            // every workgroup owns an equal, spatially scrambled share of the ray slots; its waves draw from it on demand
+            rtk::WfState &st = pt.st;
+            st.n_groups = st.n_paths / 4;
+            int64_t tblocks = std::max<int64_t>(1, (int64_t)ctx->n_cus * bpc / parts);   // all parts co-resident
+            int min_groups = 16 * wpb;                                // >= 64 ray slots per wave on average
+            if (const char *e = getenv("RT_TRAV_MIN_GROUPS")) { const int v = atoi(e); if (v >= 4) min_groups = v * wpb; }
+            int64_t groups_per_block = (st.n_groups + tblocks - 1) / tblocks;
+            if (groups_per_block < min_groups) {                      // small launch: fewer, fuller workgroups
+                tblocks = (st.n_groups + min_groups - 1) / min_groups;
+                if (tblocks < 1) tblocks = 1;
+                groups_per_block = (st.n_groups + tblocks - 1) / tblocks;
+            }
+            // scramble: consecutive group-slots of one workgroup must land on groups spread over the WHOLE sub-frame, so
+            // the stride pattern's period S is the largest power of two not above a workgroup's number of groups
+            st.log2S = 0;
+            while ((2 << st.log2S) <= groups_per_block && st.log2S < 16) ++st.log2S;
+            const int S = 1 << st.log2S;
+            st.Q = (st.n_groups + S - 1) / S;
+            const int64_t total_slots = (int64_t)S * st.Q * 4;
+            st.slots_per_block = (int)(((total_slots + tblocks - 1) / tblocks + 3) / 4 * 4);
+            pt.tblocks = tblocks;
+            pt.pblocks = (unsigned)((n_paths64 + 255) / 256);
         }
-        st.log2S = 0;
-        while ((2 << st.log2S) <= groups_per_wave && st.log2S < 12) ++st.log2S;
-        const int S = 1 << st.log2S;
-        st.Q = (st.n_groups + S - 1) / S;
-        const int64_t total_slots = (int64_t)S * st.Q * 4;
-        st.slots_per_wave = (int)(((total_slots + n_waves - 1) / n_waves + 3) / 4 * 4);
-        const unsigned pblocks = (unsigned)((np + 255) / 256);
+        const size_t np = np_total;
+        if ((rc2 = ensure(ctx, ctx->wfR0, np * 16)) != RT_OK || (rc2 = ensure(ctx, ctx->wfR1, np * 16)) != RT_OK ||
+            (rc2 = ensure(ctx, ctx->wfM, np * 8)) != RT_OK || (rc2 = ensure(ctx, ctx->wfS0, np * 16)) != RT_OK ||
+            (rc2 = ensure(ctx, ctx->wfS1, np * 16)) != RT_OK || (rc2 = ensure(ctx, ctx->wfT, np * 16)) != RT_OK ||
+            (rc2 = ensure(ctx, ctx->wfF, np * 16)) != RT_OK || (rc2 = ensure(ctx, ctx->wfLS, np * 4 * (size_t)nseg)) != RT_OK)
+            return rc2;
+        for (Part &pt : pv) {
+            rtk::WfState &st = pt.st;
+            st.R0 = static_cast<float4 *>(ctx->wfR0.p) + pt.base; st.R1 = static_cast<float4 *>(ctx->wfR1.p) + pt.base;
+            st.M = static_cast<unsigned long long *>(ctx->wfM.p) + pt.base; st.S0 = static_cast<float4 *>(ctx->wfS0.p) + pt.base;
+            st.S1 = static_cast<float4 *>(ctx->wfS1.p) + pt.base; st.T = static_cast<float4 *>(ctx->wfT.p) + pt.base;
+            st.F = static_cast<int4 *>(ctx->wfF.p) + pt.base;
+            st.LS = static_cast<float *>(ctx->wfLS.p) + pt.base * (size_t)nseg;   // LS[d * n_paths + i] inside the part's block
+        }
         ctx->stats.lds_bytes = (int)trav_lds;
         ctx->stats.block_threads = tb;
-        ctx->stats.grid_blocks = (int)tblocks;
+        ctx->stats.grid_blocks = (int)pv[0].tblocks;
+        ctx->stats.parts = parts;
         RT_HIP(ctx, hipEventRecord(ctx->ev_k0, stream));
-        for (int s = 0; s < fr.spp; ++s) {
-            if (work_dev) hipLaunchKernelGGL(rtk::wf_begin<true>, dim3(pblocks), dim3(256), 0, stream, ctx->scene, fr, st, s);
-            else hipLaunchKernelGGL(rtk::wf_begin<false>, dim3(pblocks), dim3(256), 0, stream, ctx->scene, fr, st, s);
-            for (int it = 0; it < 2 * segs; ++it) {
-                if (have_mesh) {
-                    st.dbg = (dbg_env && it == dbg_it) ? static_cast<unsigned long long *>(dbgbuf.p) : nullptr;
-                    const bool timed = s == fr.spp - 1;      // time the traversal launches of the last sample
-                    if (timed) RT_HIP(ctx, hipEventRecord(ctx->ev_trav[2 * it], stream));
-                    if (ldsn) {
-                        if (work_dev) hipLaunchKernelGGL((rtk::wf_trav<true, true>), dim3((unsigned)tblocks), dim3(tb), trav_lds, stream, ctx->scene, fr, st);
-                        else hipLaunchKernelGGL((rtk::wf_trav<false, true>), dim3((unsigned)tblocks), dim3(tb), trav_lds, stream, ctx->scene, fr, st);
-                    } else {
-                        if (work_dev) hipLaunchKernelGGL((rtk::wf_trav<true, false>), dim3((unsigned)tblocks), dim3(tb), trav_lds, stream, ctx->scene, fr, st);
-                        else hipLaunchKernelGGL((rtk::wf_trav<false, false>), dim3((unsigned)tblocks), dim3(tb), trav_lds, stream, ctx->scene, fr, st);
+        if (parts > 1) RT_HIP(ctx, hipEventRecord(ctx->fork_ev, stream));
+        for (int j = 0; j < parts; ++j) {
+            Part &pt = pv[j];
+            hipStream_t q = j == 0 ? stream : ctx->part_stream[j];
+            if (j > 0) RT_HIP(ctx, hipStreamWaitEvent(q, ctx->fork_ev, 0));
+            if (pt.st.n_paths == 0) continue;
+            for (int s = 0; s < fr.spp; ++s) {
+                if (work_dev) hipLaunchKernelGGL(rtk::wf_begin<true>, dim3(pt.pblocks), dim3(256), 0, q, ctx->scene, pt.fr, pt.st, s);
+                else hipLaunchKernelGGL(rtk::wf_begin<false>, dim3(pt.pblocks), dim3(256), 0, q, ctx->scene, pt.fr, pt.st, s);
+                for (int it = 0; it < 2 * segs; ++it) {
+                    if (have_mesh) {
+                        pt.st.dbg = (dbg_env && it == dbg_it) ? static_cast<unsigned long long *>(dbgbuf.p) : nullptr;
+                        const bool timed = j == 0 && s == fr.spp - 1;   // time part 0's traversal launches of the last sample
+                        if (timed) RT_HIP(ctx, hipEventRecord(ctx->ev_trav[2 * it], q));
+                        const dim3 tg((unsigned)pt.tblocks), tbd(tb);
+                        if (ldsn) {
+                            if (work_dev) hipLaunchKernelGGL((rtk::wf_trav<true, true>), tg, tbd, trav_lds, q, ctx->scene, pt.fr, pt.st);
+                            else hipLaunchKernelGGL((rtk::wf_trav<false, true>), tg, tbd, trav_lds, q, ctx->scene, pt.fr, pt.st);
+                        } else {
+                            if (work_dev) hipLaunchKernelGGL((rtk::wf_trav<true, false>), tg, tbd, trav_lds, q, ctx->scene, pt.fr, pt.st);
+                            else hipLaunchKernelGGL((rtk::wf_trav<false, false>), tg, tbd, trav_lds, q, ctx->scene, pt.fr, pt.st);
+                        }
+                        if (timed) { RT_HIP(ctx, hipEventRecord(ctx->ev_trav[2 * it + 1], q)); ctx->n_trav_events = it + 1; }
+                        pt.st.dbg = nullptr;
                     }
-                    if (timed) { RT_HIP(ctx, hipEventRecord(ctx->ev_trav[2 * it + 1], stream)); ctx->n_trav_events = it + 1; }
-                    st.dbg = nullptr;
+                    if (work_dev) hipLaunchKernelGGL(rtk::wf_advance<true>, dim3(pt.pblocks), dim3(256), 0, q, ctx->scene, pt.fr, pt.st, s);
+                    else hipLaunchKernelGGL(rtk::wf_advance<false>, dim3(pt.pblocks), dim3(256), 0, q, ctx->scene, pt.fr, pt.st, s);
                 }
-                if (work_dev) hipLaunchKernelGGL(rtk::wf_advance<true>, dim3(pblocks), dim3(256), 0, stream, ctx->scene, fr, st, s);
-                else hipLaunchKernelGGL(rtk::wf_advance<false>, dim3(pblocks), dim3(256), 0, stream, ctx->scene, fr, st, s);
             }
+            if (j > 0) { RT_HIP(ctx, hipEventRecord(ctx->part_ev[j], q)); }
         }
+        for (int j = 1; j < parts; ++j) RT_HIP(ctx, hipStreamWaitEvent(stream, ctx->part_ev[j], 0));
         if (dbg_env) {
             std::vector<unsigned long long> h(10 * (size_t)65536);
             (void)hipStreamSynchronize(stream);
@@ -396,6 +445,9 @@ int rt_ctx_create(rt_ctx **out, int device_id) {
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_t0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_t1);
     for (hipEvent_t &ev : ctx->ev_trav) if (e == hipSuccess) e = hipEventCreate(&ev);
+    for (hipEvent_t &ev : ctx->part_ev) if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    for (hipStream_t &q : ctx->part_stream) if (e == hipSuccess) e = hipStreamCreateWithFlags(&q, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming);
     if (e != hipSuccess) {
         int code = fail(nullptr, RT_ERR_HIP, "context creation: %s", hipGetErrorString(e));
         rt_ctx_destroy(ctx);
@@ -421,6 +473,9 @@ int rt_ctx_destroy(rt_ctx *ctx) {
     ctx->wfR0.release(); ctx->wfR1.release(); ctx->wfM.release(); ctx->wfS0.release(); ctx->wfS1.release();
     ctx->wfT.release(); ctx->wfF.release(); ctx->wfLS.release(); ctx->wfQ.release();
     for (hipEvent_t &e : ctx->ev_trav) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t &e : ctx->part_ev) if (e) (void)hipEventDestroy(e);
+    for (hipStream_t &q : ctx->part_stream) if (q) (void)hipStreamDestroy(q);
+    if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
     if (ctx->ev_k0) (void)hipEventDestroy(ctx->ev_k0);
     if (ctx->ev_k1) (void)hipEventDestroy(ctx->ev_k1);
     if (ctx->ev_t0) (void)hipEventDestroy(ctx->ev_t0);

@@ -61,7 +61,12 @@ struct Frame {
     int row0, n_rows, tile_rows, tile_step;
     float4 *out;
     unsigned long long *work;   // STATS kernels only: {rays, box_tests, nodes, tri_tests}
+    int out_tile0, out_tile_step;   // local row r is stored at output row ((r / tile_rows) * out_tile_step + out_tile0) * tile_rows + r % tile_rows
 };
+__device__ __forceinline__ size_t out_index(const Frame &fr, int lrow, int px) {
+    const int orow = ((lrow / fr.tile_rows) * fr.out_tile_step + fr.out_tile0) * fr.tile_rows + lrow % fr.tile_rows;
+    return (size_t)orow * fr.W + px;
+}
 
 // per-lane traversal work counters (STATS instantiation only; SURVEY 8d accounting)
 struct Work { uint32_t box = 0, nodes = 0, tris = 0, rays = 0; };
@@ -398,7 +403,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(const Scene sc, c
         total = total + col;
     }
     const f3 avg = total / (float)fr.spp;                           // cpu:713
-    fr.out[(size_t)lrow * fr.W + px] = make_float4(avg.x, avg.y, avg.z, rays);
+    fr.out[out_index(fr, lrow, px)] = make_float4(avg.x, avg.y, avg.z, rays);
     }
     if (STATS) {   // one atomic per wave and counter
         const uint32_t r = wave_sum((uint32_t)rays), b = wave_sum(wk.box), n = wave_sum(wk.nodes), t = wave_sum(wk.tris);

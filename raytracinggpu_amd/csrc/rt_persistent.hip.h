@@ -279,7 +279,7 @@ __global__ __launch_bounds__(kPBlock) void render_persistent(const Scene sc, con
             const bool want = phase == PH_NEXT && (!have_pixel || samp >= fr.spp);
             if (phase == PH_NEXT && have_pixel && samp >= fr.spp) {
                 const f3 avg = total / (float)fr.spp;                    // cpu:713
-                fr.out[(size_t)lrow * fr.W + px] = make_float4(avg.x, avg.y, avg.z, rays);
+                fr.out[out_index(fr, lrow, px)] = make_float4(avg.x, avg.y, avg.z, rays);
                 have_pixel = false;
             }
             const unsigned long long wm = __ballot(want);

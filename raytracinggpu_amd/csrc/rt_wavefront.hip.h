@@ -51,7 +51,7 @@ struct WfState {
     int tiles_x;
     // traversal scheduling: ray-slot q in [0, slots) maps to path 4*g + (q & 3), g = ((q>>2) & (S-1)) * Q + ((q>>2) >> log2S)
     int log2S, Q, n_groups;   // n_groups = n_paths / 4;  S * Q >= n_groups
-    int slots_per_wave;       // multiple of 4
+    int slots_per_block;      // multiple of 4: ray slots owned by one workgroup, handed to its waves on demand
     unsigned long long *dbg;  // optional per-wave debug record
 };
 
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void wf_begin(const Scene sc, const Frame fr, 
             if (samp == 0) st.T[i] = make_float4(0, 0, 0, 0);
             if (valid && samp == fr.spp - 1) {   // segs == 0 (optimized.cu convention with num_bounce 0): black
                 const float4 t = samp == 0 ? make_float4(0, 0, 0, 0) : st.T[i];
-                fr.out[(size_t)lrow * fr.W + px] = make_float4(t.x / (float)fr.spp, t.y / (float)fr.spp, t.z / (float)fr.spp, t.w);
+                fr.out[out_index(fr, lrow, px)] = make_float4(t.x / (float)fr.spp, t.y / (float)fr.spp, t.z / (float)fr.spp, t.w);
             }
         } else {
             const int row = fr.row0 + (lrow / fr.tile_rows) * fr.tile_rows * fr.tile_step + (lrow % fr.tile_rows);
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void wf_begin(const Scene sc, const Frame fr, 
 // entries, the ring is consumed 64 entries at a time by full-occupancy TRI steps (ray data from the owners'
 // LDS copies, results merged by a 64-bit LDS min on bits(t) << 32 | triangle), finished tasks retire, idle
 // lanes refill from the wave's scrambled share of the rays or take a split from a busy lane.
-constexpr int kTravBlock = 256;             // nodes from HBM/L2: 256-thread blocks, several per CU
+constexpr int kTravBlock = 512;             // nodes from HBM/L2: 512-thread blocks (8 waves share one slot pool), 3 per CU
 constexpr int kTravBlockLds = 1024;         // nodes staged in LDS: ONE 1024-thread block per CU shares the copy
 constexpr int kBoxMin = 44;                 // service when fewer lanes than this can take a BOX step
 
@@ -227,6 +227,11 @@ __global__ __launch_bounds__(LDSN ? kTravBlockLds : kTravBlock) void wf_trav(con
         nodes = ln;
         wl += (size_t)sc.n_nodes * 32;
     }
+    // the workgroup's slot cursor: waves take slots with one LDS atomic per refill, which evens out the cost
+    // variance between the waves of a workgroup
+    int *const blk_cur = reinterpret_cast<int *>(smem + (LDSN ? (size_t)sc.n_nodes * 32 : 0) + (blockDim.x >> 6) * Carve::kBytes);
+    if (tid == 0) *blk_cur = 0;
+    __syncthreads();
     float4 *const lray0 = reinterpret_cast<float4 *>(wl + Carve::kRay);
     float4 *const lray1 = lray0 + 64;
     unsigned long long *const lbest = reinterpret_cast<unsigned long long *>(wl + Carve::kBest);
@@ -243,12 +248,13 @@ __global__ __launch_bounds__(LDSN ? kTravBlockLds : kTravBlock) void wf_trav(con
     unsigned int last_pos = 0;          // ring position after this task's last queued entry
     bool shared = false;                // this ray's traversal was split: merge with a global atomic
     // wave-uniform: the wave's own ray slots and its ring cursors (monotonic positions)
-    int cur = __builtin_amdgcn_readfirstlane(wave * st.slots_per_wave);
-    const int end = __builtin_amdgcn_readfirstlane(cur + st.slots_per_wave);
+    const int blk_base = blockIdx.x * st.slots_per_block;
+    const int blk_n = st.slots_per_block;
+    bool drained = false;
     unsigned int qhead = 0, qtail = 0;
     Work wk;
     const unsigned long long dbg_t0 = st.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
-    unsigned int dbg_steps = 0, dbg_lanes = 0, dbg_splits = 0, dbg_tsteps = 0;
+    unsigned int dbg_steps = 0, dbg_lanes = 0, dbg_splits = 0;
     unsigned long long cy_box = 0, cy_tri = 0, cy_exp = 0, cy_ref = 0, stamp = 0;
     const bool dbg_on = st.dbg != nullptr;
 #define WF_STAMP(acc) do { if (dbg_on) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - stamp; stamp = t_; } } while (0)
@@ -285,7 +291,7 @@ __global__ __launch_bounds__(LDSN ? kTravBlockLds : kTravBlock) void wf_trav(con
                     const unsigned int count = qtail - qhead;
                     if (count < 64u && !(count > 0u && nW < kBoxMin)) break;
                     const unsigned int n = count < 64u ? count : 64u;
-                    dbg_tsteps++; dbg_steps++; dbg_lanes += n;
+                    dbg_steps++; dbg_lanes += n;
                     if ((unsigned int)lane < n) {
                         const unsigned int e = q[(qhead + (unsigned int)lane) & (kQCap - 1)];
                         const int o = (int)(e >> 26);
@@ -335,10 +341,14 @@ __global__ __launch_bounds__(LDSN ? kTravBlockLds : kTravBlock) void wf_trav(con
                 // ---- (4) refill idle lanes from the wave's slots, or split ----
                 const unsigned long long idle = __ballot(ray < 0);
                 const int n_idle = __popcll(idle);
-                if (n_idle && cur < end) {
+                if (n_idle && !drained) {
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(blk_cur, n_idle);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base + n_idle >= blk_n) drained = true;
                     if (ray < 0) {
-                        const int qs = cur + __popcll(idle & lane_lt);
-                        const int path = qs < end ? wf_slot_to_path(st, qs) : -1;
+                        const int qo = base + __popcll(idle & lane_lt);
+                        const int path = qo < blk_n ? wf_slot_to_path(st, blk_base + qo) : -1;
                         if (path >= 0) {
                             const int f = st.F[path].x;
                             if ((f & (WF_ALIVE | WF_MESH)) == (WF_ALIVE | WF_MESH)) {
@@ -357,7 +367,6 @@ __global__ __launch_bounds__(LDSN ? kTravBlockLds : kTravBlock) void wf_trav(con
                             }
                         }
                     }
-                    cur = min(cur + n_idle, end);
                 } else if (n_idle >= 4 && n_idle < 64) {
                     // a busy lane below a hit internal node X keeps [node, skip(X)) and gives [skip(X), nend) away
                     const bool d_skip = ray >= 0 && sk > node && sk < nend;
@@ -395,7 +404,7 @@ __global__ __launch_bounds__(LDSN ? kTravBlockLds : kTravBlock) void wf_trav(con
                 boxable = ray >= 0 && node < nend && nl < kLeafCap && pend_cnt == 0;
                 nB = __popcll(__ballot(boxable));
                 if (nB >= kBoxMin) break;
-                const bool more = (qtail != qhead) || __ballot(pend_cnt > 0 || nl > 0) != 0ull || (cur < end);
+                const bool more = (qtail != qhead) || __ballot(pend_cnt > 0 || nl > 0) != 0ull || (!drained && __ballot(ray < 0) != 0ull);
                 if (more) continue;                                  // queue to drain / lists to expand / rays to fetch
                 if (nB > 0) break;                                   // run with the lanes we have
                 if (__ballot(ray >= 0) == 0ull) goto finished;       // nothing left anywhere
@@ -448,7 +457,7 @@ __global__ __launch_bounds__(LDSN ? kTravBlockLds : kTravBlock) void wf_trav(con
 finished:
     if (st.dbg && lane == 0) {
         st.dbg[6 * wave + 0] = dbg_t0; st.dbg[6 * wave + 1] = __builtin_amdgcn_s_memrealtime();
-        st.dbg[6 * wave + 2] = dbg_steps; st.dbg[6 * wave + 3] = dbg_lanes; st.dbg[6 * wave + 4] = dbg_splits; st.dbg[6 * wave + 5] = dbg_tsteps;
+        st.dbg[6 * wave + 2] = dbg_steps; st.dbg[6 * wave + 3] = dbg_lanes; st.dbg[6 * wave + 4] = dbg_splits; st.dbg[6 * wave + 5] = 0;
         unsigned long long *d2 = st.dbg + 6 * 65536 + 4 * wave;
         d2[0] = cy_box; d2[1] = cy_exp; d2[2] = cy_tri; d2[3] = cy_ref;
     }
@@ -601,7 +610,7 @@ __global__ __launch_bounds__(256) void wf_advance(const Scene sc, const Frame fr
                 int px, lrow; bool valid;
                 wf_decode(st, fr, i, px, lrow, valid);
                 const float n = (float)fr.spp;
-                fr.out[(size_t)lrow * fr.W + px] = make_float4(t.x / n, t.y / n, t.z / n, t.w);
+                fr.out[out_index(fr, lrow, px)] = make_float4(t.x / n, t.y / n, t.z / n, t.w);
             } else {
                 st.T[i] = t;
             }

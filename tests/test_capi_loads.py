@@ -34,7 +34,7 @@ def test_struct_sizes_match_header():
     assert ctypes.sizeof(_capi.Params) == 40
     assert ctypes.sizeof(_capi.Rows) == 16
     assert ctypes.sizeof(_capi.Light) == 16 and ctypes.sizeof(_capi.Camera) == 16
-    assert ctypes.sizeof(_capi.Stats) == 40 and ctypes.sizeof(_capi.Work) == 32
+    assert ctypes.sizeof(_capi.Stats) == 48 and ctypes.sizeof(_capi.Work) == 32
 
 
 def test_no_cpu_fallback_without_a_gpu():
