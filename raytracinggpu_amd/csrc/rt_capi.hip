@@ -33,7 +33,7 @@ struct rt_ctx {
     rtk::Scene scene{};
     DevBuf node_lo, node_hi, nodes2, tri, verts, tidx, scratch_rgba, scratch_rgb8, work, queue;
     int n_cus = 0;
-    DevBuf wfR0, wfR1, wfM, wfS0, wfS1, wfT, wfF, wfLS, wfQ;   // wavefront path state (HBM)
+    DevBuf wfR0, wfR1, wfM, wfFL, wfS0, wfS1, wfT, wfF, wfLS, wfQ;   // wavefront path state (HBM)
     int trav_blocks_per_cu[4] = {0, 0, 0, 0};
     static constexpr int kMaxParts = 8;
     hipStream_t part_stream[kMaxParts] = {};
@@ -271,7 +271,7 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
             np_total += (size_t)n_paths64;
             // every workgroup owns an equal, spatially scrambled share of the ray slots; its waves draw from it on demand
             rtk::WfState &st = pt.st;
-            st.n_groups = st.n_paths / 4;
+            st.n_groups = 2 * st.n_paths / 4;                         // two ray slots per path (continuation + shadow)
             int64_t tblocks = std::max<int64_t>(1, (int64_t)ctx->n_cus * bpc / parts);   // all parts co-resident
             int min_groups = 16 * wpb;                                // >= 64 ray slots per wave on average
             if (const char *e = getenv("RT_TRAV_MIN_GROUPS")) { const int v = atoi(e); if (v >= 4) min_groups = v * wpb; }
@@ -293,15 +293,17 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
             pt.pblocks = (unsigned)((n_paths64 + 255) / 256);
         }
         const size_t np = np_total;
-        if ((rc2 = ensure(ctx, ctx->wfR0, np * 16)) != RT_OK || (rc2 = ensure(ctx, ctx->wfR1, np * 16)) != RT_OK ||
-            (rc2 = ensure(ctx, ctx->wfM, np * 8)) != RT_OK || (rc2 = ensure(ctx, ctx->wfS0, np * 16)) != RT_OK ||
+        if ((rc2 = ensure(ctx, ctx->wfR0, 2 * np * 16)) != RT_OK || (rc2 = ensure(ctx, ctx->wfR1, 2 * np * 16)) != RT_OK ||
+            (rc2 = ensure(ctx, ctx->wfM, 2 * np * 8)) != RT_OK || (rc2 = ensure(ctx, ctx->wfFL, 2 * np * 4)) != RT_OK ||
+            (rc2 = ensure(ctx, ctx->wfS0, np * 16)) != RT_OK ||
             (rc2 = ensure(ctx, ctx->wfS1, np * 16)) != RT_OK || (rc2 = ensure(ctx, ctx->wfT, np * 16)) != RT_OK ||
             (rc2 = ensure(ctx, ctx->wfF, np * 16)) != RT_OK || (rc2 = ensure(ctx, ctx->wfLS, np * 4 * (size_t)nseg)) != RT_OK)
             return rc2;
         for (Part &pt : pv) {
             rtk::WfState &st = pt.st;
-            st.R0 = static_cast<float4 *>(ctx->wfR0.p) + pt.base; st.R1 = static_cast<float4 *>(ctx->wfR1.p) + pt.base;
-            st.M = static_cast<unsigned long long *>(ctx->wfM.p) + pt.base; st.S0 = static_cast<float4 *>(ctx->wfS0.p) + pt.base;
+            st.R0 = static_cast<float4 *>(ctx->wfR0.p) + 2 * pt.base; st.R1 = static_cast<float4 *>(ctx->wfR1.p) + 2 * pt.base;
+            st.M = static_cast<unsigned long long *>(ctx->wfM.p) + 2 * pt.base; st.FL = static_cast<int *>(ctx->wfFL.p) + 2 * pt.base;
+            st.S0 = static_cast<float4 *>(ctx->wfS0.p) + pt.base;
             st.S1 = static_cast<float4 *>(ctx->wfS1.p) + pt.base; st.T = static_cast<float4 *>(ctx->wfT.p) + pt.base;
             st.F = static_cast<int4 *>(ctx->wfF.p) + pt.base;
             st.LS = static_cast<float *>(ctx->wfLS.p) + pt.base * (size_t)nseg;   // LS[d * n_paths + i] inside the part's block
@@ -320,7 +322,7 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
             for (int s = 0; s < fr.spp; ++s) {
                 if (work_dev) hipLaunchKernelGGL(rtk::wf_begin<true>, dim3(pt.pblocks), dim3(256), 0, q, ctx->scene, pt.fr, pt.st, s);
                 else hipLaunchKernelGGL(rtk::wf_begin<false>, dim3(pt.pblocks), dim3(256), 0, q, ctx->scene, pt.fr, pt.st, s);
-                for (int it = 0; it < 2 * segs; ++it) {
+                for (int it = 0; it < (segs > 0 ? segs + 1 : 0); ++it) {
                     if (have_mesh) {
                         pt.st.dbg = (dbg_env && it == dbg_it) ? static_cast<unsigned long long *>(dbgbuf.p) : nullptr;
                         const bool timed = j == 0 && s == fr.spp - 1;   // time part 0's traversal launches of the last sample
@@ -471,7 +473,7 @@ int rt_ctx_destroy(rt_ctx *ctx) {
     ctx->node_lo.release(); ctx->node_hi.release(); ctx->nodes2.release(); ctx->tri.release(); ctx->verts.release(); ctx->tidx.release();
     ctx->scratch_rgba.release(); ctx->scratch_rgb8.release(); ctx->work.release(); ctx->queue.release();
     ctx->wfR0.release(); ctx->wfR1.release(); ctx->wfM.release(); ctx->wfS0.release(); ctx->wfS1.release();
-    ctx->wfT.release(); ctx->wfF.release(); ctx->wfLS.release(); ctx->wfQ.release();
+    ctx->wfT.release(); ctx->wfF.release(); ctx->wfFL.release(); ctx->wfLS.release(); ctx->wfQ.release();
     for (hipEvent_t &e : ctx->ev_trav) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t &e : ctx->part_ev) if (e) (void)hipEventDestroy(e);
     for (hipStream_t &q : ctx->part_stream) if (q) (void)hipStreamDestroy(q);

@@ -16,7 +16,10 @@
 //              folds the finished path (cpu:642-644), accumulates the sample (cpu:711) and, after the last
 //              sample, stores the pixel as one float4 (cpu:713)
 //
-// run as  begin, (trav, advance) x 2*segments  per sample.  Path state lives in HBM as float4 SoA indexed
+// A shadow ray and the continuation (bounce / mirror / refraction) ray that leave the same hit point do not
+// depend on each other, so both are traced by the SAME wf_trav launch: per sample the sequence is
+//     begin, (trav, advance) x (segments + 1)
+// with launch j tracing the shadow rays of segment j-1 and the continuation rays of segment j.  Path state lives in HBM as float4 SoA indexed
 // by a TILE-ORDER path index (8x8 pixel tiles: a wave's 64 consecutive paths are one tile, and every state
 // access of wf_begin/wf_advance is a fully coalesced 1 KiB wave transaction).
 //
@@ -33,24 +36,29 @@
 
 namespace rtk {
 
-// path flags (int per path)
+// path flags (F.x, int per path)
 constexpr int WF_ALIVE = 1 << 8;      // path still being traced
-constexpr int WF_SHADOW = 1 << 9;     // the ray in flight is a shadow ray
-constexpr int WF_MESH = 1 << 20;      // the ray in flight passed the mesh's root box: traversal needed
-constexpr int WF_DEPTH = 0xff;        // segment index d
+constexpr int WF_HASX = 1 << 9;       // a shadow ray (X) of segment d-1's hit is in flight
+constexpr int WF_HASY = 1 << 21;      // a continuation ray (Y) of segment d is in flight
+constexpr int WF_DEPTH = 0xff;        // segment index d of the continuation ray (or of the next one)
+// ray flags (FL, int per ray: continuation rays at [0, n_paths), shadow rays at [n_paths, 2 n_paths))
+constexpr int WF_ACTIVE = 1 << 8;     // the ray slot holds a ray of the current launch
+constexpr int WF_MESH = 1 << 20;      // the ray passed the mesh's root box: traversal needed
+                                      // bits 10..19: nearest sphere before / after the mesh slot (object id + 1)
 constexpr unsigned long long WF_NOHIT = ~0ull;
 
 struct WfState {
-    float4 *R0, *R1;      // ray: (O.xyz, u.x) (u.yz, tA, tB): tA/tB = nearest sphere before/after the mesh slot
-    unsigned long long *M;   // traversal result: bits(t) << 32 | triangle index (visit order); WF_NOHIT if none
+    float4 *R0, *R1;      // rays [2 n_paths]: (O.xyz, u.x) (u.yz, tA, tB): tA/tB = nearest sphere before/after the mesh slot
+    unsigned long long *M;   // [2 n_paths] traversal result: bits(t) << 32 | triangle index (visit order); WF_NOHIT if none
+    int *FL;              // [2 n_paths] ray flags
     float4 *S0, *S1;      // surface being shaded: (P.xyz, bits(object id)) (N.xyz, refraction index of the ray)
     float4 *T;            // (sum of sample colours .xyz, rays traced)
-    int4 *F;              // (flags, diffuse mask, object ids lo, object ids hi); wins packed in flags bits 10..19
+    int4 *F;              // (flags, diffuse mask, object ids lo, object ids hi)
     float *LS;            // l of every diffuse segment: LS[d * n_paths + i]
     int n_paths;          // tiles_x * tiles_y * 64
     int tiles_x;
     // traversal scheduling: ray-slot q in [0, slots) maps to path 4*g + (q & 3), g = ((q>>2) & (S-1)) * Q + ((q>>2) >> log2S)
-    int log2S, Q, n_groups;   // n_groups = n_paths / 4;  S * Q >= n_groups
+    int log2S, Q, n_groups;   // n_groups = 2 n_paths / 4 (ray groups);  S * Q >= n_groups
     int slots_per_block;      // multiple of 4: ray slots owned by one workgroup, handed to its waves on demand
     unsigned long long *dbg;  // optional per-wave debug record
 };
@@ -88,22 +96,39 @@ __device__ __forceinline__ SphereHit spheres_split(const Scene &sc, f3 O, f3 u) 
 }
 __device__ __forceinline__ int wf_pack_wins(const SphereHit &h) { return ((h.winA + 1) & 31) << 10 | ((h.winB + 1) & 31) << 15; }
 
-// Emit a ray: record, sphere tests, root-box test (cpu:279; wave-uniform node data from kernel arguments).
+// Emit ray slot `r`: record, sphere tests, root-box test (cpu:279; wave-uniform node data from kernel arguments).
 template <bool STATS>
-__device__ __forceinline__ int wf_emit_ray(const Scene &sc, const WfState &st, int i, f3 O, f3 u, Work &wk) {
+__device__ __forceinline__ void wf_emit_ray(const Scene &sc, const WfState &st, int r, f3 O, f3 u, Work &wk) {
     const SphereHit h = spheres_split(sc, O, u);
-    st.R0[i] = make_float4(O.x, O.y, O.z, u.x);
-    st.R1[i] = make_float4(u.y, u.z, h.tA, h.tB);
-    int f = wf_pack_wins(h);
+    st.R0[r] = make_float4(O.x, O.y, O.z, u.x);
+    st.R1[r] = make_float4(u.y, u.z, h.tA, h.tB);
+    int f = WF_ACTIVE | wf_pack_wins(h);
     if (sc.mesh_slot >= 0 && sc.n_nodes > 0) {
         if (STATS) wk.box++;
         if (slab_filtered(sc.root_lo, sc.root_hi, O, u, ray_inv(u))) {
             if (STATS) wk.nodes++;
             f |= WF_MESH;
-            st.M[i] = WF_NOHIT;
+            st.M[r] = WF_NOHIT;
         }
     }
-    return f;
+    st.FL[r] = f;
+}
+
+// Scene::intersect_all's running minimum for ray slot r, replayed in object order: spheres before the mesh,
+// mesh, spheres after (strict '<', cpu:554).  Returns t_min; win = object id or -1; tri_win = winning triangle.
+__device__ __forceinline__ float wf_close_query(const Scene &sc, const WfState &st, int r, float4 r1, int &win, int &tri_win) {
+    const int fl = st.FL[r];
+    float t_min = r1.z; win = ((fl >> 10) & 31) - 1;
+    tri_win = -1;
+    if (fl & WF_MESH) {
+        const unsigned long long m = st.M[r];
+        if (m != WF_NOHIT) {
+            const float tmesh = __uint_as_float((unsigned int)(m >> 32));
+            if (tmesh < t_min) { t_min = tmesh; win = sc.mesh_slot; tri_win = (int)(unsigned int)m; }
+        }
+    }
+    if (r1.w < t_min) { t_min = r1.w; win = ((fl >> 15) & 31) - 1; }
+    return t_min;
 }
 
 template <bool STATS>
@@ -127,6 +152,7 @@ __global__ __launch_bounds__(256) void wf_begin(const Scene sc, const Frame fr, 
         wf_decode(st, fr, i, px, lrow, valid);
         if (!valid || fr.segs <= 0) {
             st.F[i] = make_int4(0, 0, 0, 0);
+            st.FL[i] = 0; st.FL[st.n_paths + i] = 0;
             if (samp == 0) st.T[i] = make_float4(0, 0, 0, 0);
             if (valid && samp == fr.spp - 1) {   // segs == 0 (optimized.cu convention with num_bounce 0): black
                 const float4 t = samp == 0 ? make_float4(0, 0, 0, 0) : st.T[i];
@@ -149,8 +175,9 @@ __global__ __launch_bounds__(256) void wf_begin(const Scene sc, const Frame fr, 
             }
             const f3 u = normalize(uu);
             const f3 O = mk(sc.camx, sc.camy, sc.camz);
-            const int f = wf_emit_ray<STATS>(sc, st, i, O, u, wk);
-            st.F[i] = make_int4(WF_ALIVE | f, 0, 0, 0);
+            wf_emit_ray<STATS>(sc, st, i, O, u, wk);                   // continuation ray of segment 0
+            st.FL[st.n_paths + i] = 0;
+            st.F[i] = make_int4(WF_ALIVE | WF_HASY, 0, 0, 0);
             st.S1[i] = make_float4(0, 0, 0, 1.f);                  // Ray::refraction_index = 1 (cpu:100)
             float4 t = samp == 0 ? make_float4(0, 0, 0, 0) : st.T[i];
             t.w += 1.f;                                            // this ray
@@ -350,8 +377,8 @@ __global__ __launch_bounds__(LDSN ? kTravBlockLds : kTravBlock) void wf_trav(con
                         const int qo = base + __popcll(idle & lane_lt);
                         const int path = qo < blk_n ? wf_slot_to_path(st, blk_base + qo) : -1;
                         if (path >= 0) {
-                            const int f = st.F[path].x;
-                            if ((f & (WF_ALIVE | WF_MESH)) == (WF_ALIVE | WF_MESH)) {
+                            const int f = st.FL[path];
+                            if ((f & (WF_ACTIVE | WF_MESH)) == (WF_ACTIVE | WF_MESH)) {
                                 const float4 r0 = st.R0[path], r1 = st.R1[path];
                                 O = mk(r0.x, r0.y, r0.z); u = mk(r0.w, r1.x, r1.y);
                                 rb = ray_box(O, u);
@@ -465,7 +492,7 @@ finished:
     wf_flush_work<STATS>(fr, wk);
 }
 
-// ---- wf_advance: close the query, shade, emit the next ray ------------------------------------------------
+// ---- wf_advance: close the queries, shade, emit the next rays -----------------------------------------------
 template <bool STATS>
 __global__ __launch_bounds__(256) void wf_advance(const Scene sc, const Frame fr, const WfState st, int samp) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -475,45 +502,61 @@ __global__ __launch_bounds__(256) void wf_advance(const Scene sc, const Frame fr
         const float PI_F = (float)3.14159265358979323846;
         const double PI_D = 3.14159265358979323846;
         const f3 L = mk(sc.Lx, sc.Ly, sc.Lz);
-        const float4 r0 = st.R0[i], r1 = st.R1[i];
-        f3 O = mk(r0.x, r0.y, r0.z), u = mk(r0.w, r1.x, r1.y);
-        int d = F.x & WF_DEPTH;
-        const bool shadow = (F.x & WF_SHADOW) != 0;
-        // Scene::intersect_all's running minimum, replayed in object order: spheres before the mesh, mesh, spheres after
-        float t_min = r1.z; int win = ((F.x >> 10) & 31) - 1;
-        int tri_win = -1;
-        if (F.x & WF_MESH) {
-            const unsigned long long m = st.M[i];
-            if (m != WF_NOHIT) {
-                const float tmesh = __uint_as_float((unsigned int)(m >> 32));
-                if (tmesh < t_min) { t_min = tmesh; win = sc.mesh_slot; tri_win = (int)(unsigned int)m; }
-            }
-        }
-        if (r1.w < t_min) { t_min = r1.w; win = ((F.x >> 15) & 31) - 1; }
-        float refr = st.S1[i].w;
-        bool path_done = false;
-        bool new_ray = false;
+        const int rx = st.n_paths + i;                                // shadow-ray slot of this path
+        int d = F.x & WF_DEPTH;                                       // segment of the continuation ray in flight
         int flags = WF_ALIVE;
+        float n_new = 0.f;
 
-        if (!shadow) {
-            if (win < 0) {
-                path_done = true;                                    // miss: black (cpu:571)
-            } else {
-                const f3 P = O + t_min * u;                          // cpu:560
+        // ---- (1) the shadow ray of segment d-1's hit came back: direct light (cpu:615-625) ----
+        if (F.x & WF_HASX) {
+            const float4 x0 = st.R0[rx], x1 = st.R1[rx];
+            const f3 Ox = mk(x0.x, x0.y, x0.z), ux = mk(x0.w, x1.x, x1.y);
+            int win, tri_win;
+            const float t_min = wf_close_query(sc, st, rx, x1, win, tri_win);
+            const float4 s0 = st.S0[i], s1 = st.S1[i];
+            const f3 Ps = mk(s0.x, s0.y, s0.z), Ns = mk(s1.x, s1.y, s1.z);
+            const int sid = __float_as_int(s0.w);
+            const int ds = d - 1;                                     // the shaded segment (d counts the continuation ray)
+            const f3 Pp = Ox + t_min * ux;                            // cpu:560 (Ox is P_adjusted)
+            float l = 0.f;
+            if (!(norm2(Pp - Ox) <= norm2(L - Ox))) {                 // cpu:615
+                const f3 wl = normalize(L - Ps);
+                const float dn = dot(Ns, wl);
+                const float mx = (dn < 0.f) ? 0.f : dn;
+                l = (float)((double)sc.intensity / (4 * PI_D * (double)norm2(L - Ps)) * (double)mx);   // cpu:623
+            }
+            st.LS[(size_t)ds * st.n_paths + i] = l;
+            const uint64_t ids = ((uint64_t)(uint32_t)F.w << 32 | (uint32_t)F.z) | (uint64_t)(sid & 15) << (4 * ds);
+            F.z = (int)(uint32_t)ids; F.w = (int)(uint32_t)(ids >> 32);
+            F.y |= 1 << ds;
+            st.FL[rx] = 0;
+        }
+
+        // ---- (2) the continuation ray of segment d came back: Scene::getColor's branch for its hit (cpu:570-614) ----
+        if (F.x & WF_HASY) {
+            const float4 r0 = st.R0[i], r1 = st.R1[i];
+            f3 O = mk(r0.x, r0.y, r0.z), u = mk(r0.w, r1.x, r1.y);
+            int win, tri_win;
+            const float t_min = wf_close_query(sc, st, i, r1, win, tri_win);
+            st.FL[i] = 0;
+            float refr = st.S1[i].w;
+            if (win >= 0) {                                           // a miss is black (cpu:571): nothing to emit
+                const f3 P = O + t_min * u;                           // cpu:560
                 f3 N;
                 if (win == sc.mesh_slot) {
                     const float4 q2 = sc.tri[3 * tri_win + 2];
-                    N = normalize(mk(q2.y, q2.z, q2.w));             // cpu:308
+                    N = normalize(mk(q2.y, q2.z, q2.w));              // cpu:308
                 } else {
-                    const Sphere &s = sc.sph[(sc.mesh_slot >= 0 && win > sc.mesh_slot) ? win - 1 : win];
-                    N = normalize(P - mk(s.cx, s.cy, s.cz));         // cpu:524-525
+                    const Sphere &sp = sc.sph[(sc.mesh_slot >= 0 && win > sc.mesh_slot) ? win - 1 : win];
+                    N = normalize(P - mk(sp.cx, sp.cy, sp.cz));       // cpu:524-525
                 }
                 const Material m = material_of(sc, win);
-                if (m.mirror) {                                      // cpu:573-579
+                bool cont = false;                                    // a continuation ray of segment d+1 was built in (O,u)
+                if (m.mirror) {                                       // cpu:573-579
                     O = P + fr.eps * N;
                     u = u - (2 * dot(u, N)) * N;
-                    d = d + 1; new_ray = d < fr.segs; path_done = !new_ray;
-                } else if (m.n_in != m.n_out) {                      // cpu:580-604
+                    cont = true;
+                } else if (m.n_in != m.n_out) {                       // cpu:580-604
                     float ratio;
                     const bool out2in = refr == m.n_out;
                     if (out2in) ratio = m.n_out / m.n_in;
@@ -529,69 +572,55 @@ __global__ __launch_bounds__(256) void wf_advance(const Scene sc, const Frame fr
                         u = Nc + Tc;
                         refr = out2in ? m.n_in : m.n_out;
                     }
-                    d = d + 1; new_ray = d < fr.segs; path_done = !new_ray;
-                } else {                                             // cpu:605-614: shadow ray
+                    cont = true;
+                } else {                                              // cpu:605-642: diffuse
                     st.S0[i] = make_float4(P.x, P.y, P.z, __int_as_float(win));
                     const f3 Pa = P + fr.eps * N;
                     const f3 toL = L - Pa;
-                    u = toL / rt_sqrtf(norm2(toL));                  // NORMED_VEC
-                    O = Pa;
+                    const f3 us = toL / rt_sqrtf(norm2(toL));         // NORMED_VEC, cpu:614
+                    wf_emit_ray<STATS>(sc, st, rx, Pa, us, wk);       // shadow ray of segment d
+                    flags |= WF_HASX;
+                    n_new += 1.f;
+                    if (d + 1 < fr.segs) {                            // the bounce ray (cpu:627-642): needs r1, r2 and N only
+                        int px, lrow; bool valid;
+                        wf_decode(st, fr, i, px, lrow, valid);
+                        const int row = fr.row0 + (lrow / fr.tile_rows) * fr.tile_rows * fr.tile_step + (lrow % fr.tile_rows);
+                        const uint32_t hp = mix32(((uint32_t)row * (uint32_t)fr.W + (uint32_t)px) ^ mix32(fr.seed));
+                        const uint32_t hs = mix32(hp ^ ((uint32_t)samp * 0x9E3779B1U));
+                        const float r1u = uniform01(hs, (uint32_t)d, 0);
+                        const float r2u = uniform01(hs, (uint32_t)d, 1);
+                        double sn, cs;
+                        sincos(2 * PI_D * (double)r1u, &sn, &cs);
+                        const float s1f = rt_sqrtf(1 - r2u);
+                        const float x = (float)(cs * (double)s1f);
+                        const float y = (float)(sn * (double)s1f);
+                        const float zz = rt_sqrtf(r2u);
+                        f3 T1;
+                        if (N.y != 0 && N.x != 0) T1 = mk(-N.y, N.x, 0);
+                        else T1 = mk(-N.z, 0, N.x);
+                        T1 = normalize(T1);
+                        const f3 T2 = cross(N, T1);
+                        u = x * T1 + y * T2 + zz * N;
+                        O = Pa;
+                        refr = 1.f;                                   // Ray(P_adjusted, random_direction): index 1
+                        cont = true;
+                    }
                     st.S1[i] = make_float4(N.x, N.y, N.z, refr);
-                    flags |= WF_SHADOW;
-                    new_ray = true;
                 }
-                if (!(flags & WF_SHADOW)) st.S1[i].w = refr;
+                if (cont && d + 1 < fr.segs) {
+                    wf_emit_ray<STATS>(sc, st, i, O, u, wk);          // continuation ray of segment d+1
+                    flags |= WF_HASY;
+                    n_new += 1.f;
+                    if (!(flags & WF_HASX)) st.S1[i].w = refr;
+                }
             }
-        } else {
-            const float4 s0 = st.S0[i], s1 = st.S1[i];
-            const f3 Ps = mk(s0.x, s0.y, s0.z), Ns = mk(s1.x, s1.y, s1.z);
-            const int sid = __float_as_int(s0.w);
-            const f3 Pp = O + t_min * u;                             // cpu:560 (O is P_adjusted)
-            float l = 0.f;
-            if (!(norm2(Pp - O) <= norm2(L - O))) {                  // cpu:615
-                const f3 wl = normalize(L - Ps);
-                const float dn = dot(Ns, wl);
-                const float mx = (dn < 0.f) ? 0.f : dn;
-                l = (float)((double)sc.intensity / (4 * PI_D * (double)norm2(L - Ps)) * (double)mx);   // cpu:623
-            }
-            st.LS[(size_t)d * st.n_paths + i] = l;
-            const uint64_t ids = ((uint64_t)(uint32_t)F.w << 32 | (uint32_t)F.z) | (uint64_t)(sid & 15) << (4 * d);
-            F.z = (int)(uint32_t)ids; F.w = (int)(uint32_t)(ids >> 32);
-            F.y |= 1 << d;
-            if (d + 1 < fr.segs) {                                   // the bounce ray (cpu:627-642)
-                int px, lrow; bool valid;
-                wf_decode(st, fr, i, px, lrow, valid);
-                const int row = fr.row0 + (lrow / fr.tile_rows) * fr.tile_rows * fr.tile_step + (lrow % fr.tile_rows);
-                const uint32_t hp = mix32(((uint32_t)row * (uint32_t)fr.W + (uint32_t)px) ^ mix32(fr.seed));
-                const uint32_t hs = mix32(hp ^ ((uint32_t)samp * 0x9E3779B1U));
-                const float r1u = uniform01(hs, (uint32_t)d, 0);
-                const float r2u = uniform01(hs, (uint32_t)d, 1);
-                double sn, cs;
-                sincos(2 * PI_D * (double)r1u, &sn, &cs);
-                const float s1f = rt_sqrtf(1 - r2u);
-                const float x = (float)(cs * (double)s1f);
-                const float y = (float)(sn * (double)s1f);
-                const float zz = rt_sqrtf(r2u);
-                f3 T1;
-                if (Ns.y != 0 && Ns.x != 0) T1 = mk(-Ns.y, Ns.x, 0);
-                else T1 = mk(-Ns.z, 0, Ns.x);
-                T1 = normalize(T1);
-                const f3 T2 = cross(Ns, T1);
-                u = x * T1 + y * T2 + zz * Ns;                       // O stays P_adjusted
-                st.S1[i].w = 1.f;                                    // Ray(P_adjusted, random_direction): index 1
-                d = d + 1;
-                new_ray = true;
-            } else {
-                d = d + 1;
-                path_done = true;
-            }
+            d = d + 1;
         }
 
-        if (new_ray) {
-            const int f = wf_emit_ray<STATS>(sc, st, i, O, u, wk);
-            st.F[i] = make_int4(flags | d | f, F.y, F.z, F.w);
-            st.T[i].w += 1.f;
-        } else if (path_done) {   // fold the path back to front (cpu:642-644), accumulate the sample (cpu:711)
+        if (flags & (WF_HASX | WF_HASY)) {
+            st.F[i] = make_int4(flags | d, F.y, F.z, F.w);
+            st.T[i].w += n_new;
+        } else {   // nothing in flight: fold the path back to front (cpu:642-644), accumulate the sample (cpu:711)
             f3 ans = mk(0, 0, 0);
             const int nseg = d < fr.segs ? d : fr.segs;
             const uint64_t ids = (uint64_t)(uint32_t)F.w << 32 | (uint32_t)F.z;
