@@ -196,7 +196,10 @@ __global__ __launch_bounds__(256) void wf_begin(const Scene sc, const Frame fr, 
 // lanes refill from the wave's scrambled share of the rays or take a split from a busy lane.
 constexpr int kTravBlock = 512;             // nodes from HBM/L2: 512-thread blocks (8 waves share one slot pool), 3 per CU
 constexpr int kTravBlockLds = 1024;         // nodes staged in LDS: ONE 1024-thread block per CU shares the copy
-constexpr int kBoxMin = 44;                 // service when fewer lanes than this can take a BOX step
+#ifndef RT_BOXMIN
+#define RT_BOXMIN 36
+#endif
+constexpr int kBoxMin = RT_BOXMIN;                 // service when fewer lanes than this can take a BOX step
 
 // per-wave LDS carve: ray0[64] ray1[64] (float4) | best[64] (u64) | ring[QCAP] (u32) | leaf[LEAFCAP][64] (u32)
 template <int QCAP, int LEAFCAP> struct TravCarve {
