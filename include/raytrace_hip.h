@@ -57,9 +57,12 @@ typedef enum rt_variant {
     RT_VARIANT_WAVEFRONT = 6,  /* uniform per-pixel shade/generate kernels alternating with a lean
                                   persistent traversal kernel; path state as float4 SoA in HBM;
                                   BVH nodes and triangles read from HBM through L2/L1               */
-    RT_VARIANT_WAVEFRONT_LDS = 7 /* the same with every BVH node staged in LDS (one 1024-thread
+    RT_VARIANT_WAVEFRONT_LDS = 7, /* the same with every BVH node staged in LDS (one 1024-thread
                                   workgroup per CU shares the copy); RT_ERR_UNSUPPORTED when the
                                   nodes do not fit the 160 KB                                       */
+    RT_VARIANT_WAVEFRONT_QUEUE = 8 /* wavefront pipeline whose traversal kernel keeps a per-wave LDS
+                                  work stack of (ray, node) pairs: every lane tests one box or one
+                                  triangle per step, no per-lane walk (rt_travq.hip.h)              */
 } rt_variant;
 
 typedef struct rt_ctx rt_ctx;

@@ -5,6 +5,7 @@
 #include "rt_kernels.hip.h"
 #include "rt_persistent.hip.h"
 #include "rt_wavefront.hip.h"
+#include "rt_travq.hip.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -31,10 +32,11 @@ struct rt_ctx {
     hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
     bool have_scene = false, have_kernel_time = false, have_tonemap_time = false;
     rtk::Scene scene{};
-    DevBuf node_lo, node_hi, nodes2, tri, verts, tidx, scratch_rgba, scratch_rgb8, work, queue;
+    DevBuf node_lo, node_hi, nodes2, nodesq, tri, verts, tidx, scratch_rgba, scratch_rgb8, work, queue;
     int n_cus = 0;
     DevBuf wfR0, wfR1, wfM, wfFL, wfS0, wfS1, wfT, wfF, wfLS, wfQ;   // wavefront path state (HBM)
     int trav_blocks_per_cu[4] = {0, 0, 0, 0};
+    int travq_blocks_per_cu[4] = {0, 0, 0, 0};   // [STATS + 2 * (R == 32)]
     static constexpr int kMaxParts = 8;
     hipStream_t part_stream[kMaxParts] = {};
     hipEvent_t part_ev[kMaxParts] = {};
@@ -92,9 +94,11 @@ inline h3 hcross(h3 a, h3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * 
 // Converts the reference's bvhTreeToArray layout (optimized.cu:512-534) into traversal order.
 // The reference pops the right child first (cpu:291-292 push left then right), so the
 // pre-order here descends right before left.
-int build_threaded(rt_ctx *ctx, const rt_mesh *m, std::vector<float4> &lo, std::vector<float4> &hi, std::vector<int> &perm) {
+int build_threaded(rt_ctx *ctx, const rt_mesh *m, std::vector<float4> &lo, std::vector<float4> &hi, std::vector<int> &perm,
+                   std::vector<int> &left_of) {
     const int n = m->n_nodes;
     perm.clear();
+    left_of.assign(n, -1);                                        // internal nodes: traversal-order index of the LEFT child
     lo.assign(n, make_float4(0, 0, 0, 0));
     hi.assign(n, make_float4(0, 0, 0, 0));
     if (n == 0) return RT_OK;
@@ -138,6 +142,7 @@ int build_threaded(rt_ctx *ctx, const rt_mesh *m, std::vector<float4> &lo, std::
         } else if (it.stage == 1) {
             it.stage = 2;
             const int left = (int)a[0];
+            left_of[it.out] = emitted;                               // the left subtree starts right behind the right one
             st.push_back({left, -1, 0});
         } else {
             lo[it.out].w = __builtin_bit_cast(float, emitted);   // next node on a box miss: past the subtree
@@ -159,7 +164,7 @@ int check_params(rt_ctx *ctx, const rt_params *p, int &segs) {
         return fail(ctx, RT_ERR_INVALID, "depth_convention must be 0 (cpu_launcher) or 1 (optimized.cu)");
     segs = p->depth_convention == 0 ? p->num_bounce + 1 : p->num_bounce;
     if (segs > RT_MAX_SEGMENTS) return fail(ctx, RT_ERR_INVALID, "more than %d ray segments", RT_MAX_SEGMENTS);
-    if (p->variant < RT_VARIANT_AUTO || p->variant > RT_VARIANT_WAVEFRONT_LDS) return fail(ctx, RT_ERR_INVALID, "unknown variant %d", p->variant);
+    if (p->variant < RT_VARIANT_AUTO || p->variant > RT_VARIANT_WAVEFRONT_QUEUE) return fail(ctx, RT_ERR_INVALID, "unknown variant %d", p->variant);
     return RT_OK;
 }
 
@@ -189,7 +194,9 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
         if (ctx->scene.n_nodes == 0) variant = RT_VARIANT_WAVEFRONT;      // no mesh: nothing to stage
         else return fail(ctx, RT_ERR_UNSUPPORTED, "%d BVH nodes need %zu bytes of LDS (> 160 KiB)", ctx->scene.n_nodes, lds_nodes_bytes);
     }
-    if (variant != RT_VARIANT_GLOBAL && variant != RT_VARIANT_LOCKSTEP && variant != RT_VARIANT_WAVEFRONT && variant != RT_VARIANT_WAVEFRONT_LDS)
+    if (variant == RT_VARIANT_WAVEFRONT_QUEUE && ctx->scene.n_nodes >= (1 << rtk::kQNodeBits)) variant = RT_VARIANT_WAVEFRONT;   // entry = slot << 26 | node
+    if (variant != RT_VARIANT_GLOBAL && variant != RT_VARIANT_LOCKSTEP && variant != RT_VARIANT_WAVEFRONT && variant != RT_VARIANT_WAVEFRONT_LDS &&
+        variant != RT_VARIANT_WAVEFRONT_QUEUE)
         return fail(ctx, RT_ERR_UNSUPPORTED, "variant %d is not available in this build", variant);
 
     RT_HIP(ctx, hipSetDevice(ctx->device));
@@ -210,8 +217,13 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
     if (rows->n_rows == 0) { ctx->stats.grid_blocks = 0; ctx->have_kernel_time = false; return RT_OK; }
     const int nseg = segs > 0 ? segs : 1;
     ctx->n_trav_events = 0;
-    if (variant == RT_VARIANT_WAVEFRONT || variant == RT_VARIANT_WAVEFRONT_LDS) {
+    if (variant == RT_VARIANT_WAVEFRONT || variant == RT_VARIANT_WAVEFRONT_LDS || variant == RT_VARIANT_WAVEFRONT_QUEUE) {
         const bool ldsn = variant == RT_VARIANT_WAVEFRONT_LDS;
+        const bool queue = variant == RT_VARIANT_WAVEFRONT_QUEUE;
+        int qR = 64;                                                  // ray slots per wave of the work-stack kernel
+        if (const char *e = getenv("RT_TRAVQ_R")) { if (atoi(e) == 32) qR = 32; }
+        int qcap = qR == 64 ? rtk::QStackCap<64>::value : rtk::QStackCap<32>::value;
+        if (const char *e = getenv("RT_TRAVQ_CAP")) { const int v = atoi(e); if (v >= 256 && v < qcap) qcap = v; }   // tests: force the serial drain
         // begin, (trav, advance) x 2*segments per sample; path state SoA in HBM, tile-order path index.
         // The rows are cut into `parts` independent sub-frames (interleaved tiles), each running its own kernel
         // sequence on its own stream: the traversal kernel ends in a latency-bound tail (a few long rays), and
@@ -225,16 +237,17 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
         if (R % 8 != 0 || work_dev || getenv("RT_DEBUG_TRAV")) parts = 1;
         if (parts > T) parts = T > 0 ? T : 1;
         const int tiles_x = (p->width + 7) / 8;
-        const int tb = ldsn ? rtk::kTravBlockLds : rtk::kTravBlock;
+        const int tb = queue ? rtk::kQBlock : ldsn ? rtk::kTravBlockLds : rtk::kTravBlock;
         const int wpb = tb / 64;
-        const size_t trav_lds = ldsn ? lds_nodes_bytes : (size_t)(rtk::kTravBlock / 64) * rtk::TravCarve<512, 8>::kBytes + 16;
+        const size_t q_lds = (size_t)wpb * (qR == 64 ? rtk::QCarve<64, rtk::QStackCap<64>::value, 128>::kBytes : rtk::QCarve<32, rtk::QStackCap<32>::value, 128>::kBytes) + 16;
+        const size_t trav_lds = queue ? q_lds : ldsn ? lds_nodes_bytes : (size_t)(rtk::kTravBlock / 64) * rtk::TravCarve<512, 8>::kBytes + 16;
         if (!ctx->trav_attr_set) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(rtk::wf_trav<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(rtk::wf_trav<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             ctx->trav_attr_set = true;
         }
         const int si = (work_dev ? 1 : 0) + (ldsn ? 2 : 0);
-        if (ctx->trav_blocks_per_cu[si] == 0) {
+        if (!queue && ctx->trav_blocks_per_cu[si] == 0) {
             int nb = 0;
             if (ldsn) nb = 1;
             else if (work_dev) RT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtk::wf_trav<true, false>, rtk::kTravBlock, trav_lds));
@@ -242,6 +255,21 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
             ctx->trav_blocks_per_cu[si] = nb > 0 ? nb : 1;
         }
         int bpc = ctx->trav_blocks_per_cu[si];                       // blocks per CU
+        if (queue) {
+            const int qi = (work_dev ? 1 : 0) + (qR == 32 ? 2 : 0);
+            if (ctx->travq_blocks_per_cu[qi] == 0) {
+                int nb = 0;
+                if (qR == 64) {
+                    if (work_dev) RT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtk::wf_travq<true, 64>, rtk::kQBlock, trav_lds));
+                    else RT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtk::wf_travq<false, 64>, rtk::kQBlock, trav_lds));
+                } else {
+                    if (work_dev) RT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtk::wf_travq<true, 32>, rtk::kQBlock, trav_lds));
+                    else RT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtk::wf_travq<false, 32>, rtk::kQBlock, trav_lds));
+                }
+                ctx->travq_blocks_per_cu[qi] = nb > 0 ? nb : 1;
+            }
+            bpc = ctx->travq_blocks_per_cu[qi];
+        }
         if (const char *e = getenv("RT_TRAV_WAVES")) { const int v = atoi(e); if (!ldsn && v >= 1 && v <= bpc) bpc = v; }
         const bool have_mesh = ctx->scene.mesh_slot >= 0 && ctx->scene.n_nodes > 0;
         static DevBuf dbgbuf;
@@ -328,7 +356,15 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
                         const bool timed = j == 0 && s == fr.spp - 1;   // time part 0's traversal launches of the last sample
                         if (timed) RT_HIP(ctx, hipEventRecord(ctx->ev_trav[2 * it], q));
                         const dim3 tg((unsigned)pt.tblocks), tbd(tb);
-                        if (ldsn) {
+                        if (queue) {
+                            if (qR == 64) {
+                                if (work_dev) hipLaunchKernelGGL((rtk::wf_travq<true, 64>), tg, tbd, trav_lds, q, ctx->scene, pt.fr, pt.st, qcap);
+                                else hipLaunchKernelGGL((rtk::wf_travq<false, 64>), tg, tbd, trav_lds, q, ctx->scene, pt.fr, pt.st, qcap);
+                            } else {
+                                if (work_dev) hipLaunchKernelGGL((rtk::wf_travq<true, 32>), tg, tbd, trav_lds, q, ctx->scene, pt.fr, pt.st, qcap);
+                                else hipLaunchKernelGGL((rtk::wf_travq<false, 32>), tg, tbd, trav_lds, q, ctx->scene, pt.fr, pt.st, qcap);
+                            }
+                        } else if (ldsn) {
                             if (work_dev) hipLaunchKernelGGL((rtk::wf_trav<true, true>), tg, tbd, trav_lds, q, ctx->scene, pt.fr, pt.st);
                             else hipLaunchKernelGGL((rtk::wf_trav<false, true>), tg, tbd, trav_lds, q, ctx->scene, pt.fr, pt.st);
                         } else {
@@ -470,7 +506,7 @@ int rt_ctx_destroy(rt_ctx *ctx) {
     if (!ctx) return RT_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    ctx->node_lo.release(); ctx->node_hi.release(); ctx->nodes2.release(); ctx->tri.release(); ctx->verts.release(); ctx->tidx.release();
+    ctx->node_lo.release(); ctx->node_hi.release(); ctx->nodes2.release(); ctx->nodesq.release(); ctx->tri.release(); ctx->verts.release(); ctx->tidx.release();
     ctx->scratch_rgba.release(); ctx->scratch_rgb8.release(); ctx->work.release(); ctx->queue.release();
     ctx->wfR0.release(); ctx->wfR1.release(); ctx->wfM.release(); ctx->wfS0.release(); ctx->wfS1.release();
     ctx->wfT.release(); ctx->wfF.release(); ctx->wfFL.release(); ctx->wfLS.release(); ctx->wfQ.release();
@@ -520,6 +556,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_sphere *spheres, int n_spheres, const 
     ctx->have_scene = false;
     std::vector<float4> lo, hi, tri, verts;
     std::vector<int4> tidx;
+    std::vector<int> left_of;
     if (mesh) {
         if (mesh->object_slot < 0 || mesh->object_slot > n_spheres)
             return fail(ctx, RT_ERR_INVALID, "mesh object_slot %d outside [0,%d]", mesh->object_slot, n_spheres);
@@ -531,7 +568,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_sphere *spheres, int n_spheres, const 
         sc.mesh_slot = mesh->object_slot;
         sc.mar = mesh->albedo[0]; sc.mag = mesh->albedo[1]; sc.mab = mesh->albedo[2];
         std::vector<int> perm;
-        int rc = build_threaded(ctx, mesh, lo, hi, perm);
+        int rc = build_threaded(ctx, mesh, lo, hi, perm, left_of);
         if (rc != RT_OK) return rc;
         if (perm.size() >= ((size_t)1 << 31)) return fail(ctx, RT_ERR_INVALID, "too many leaf triangles");
         for (int t = 0; t < mesh->n_triangles; ++t) {
@@ -570,12 +607,18 @@ int rt_scene_upload(rt_ctx *ctx, const rt_sphere *spheres, int n_spheres, const 
     std::vector<float4> inter(lo.size() * 2);
     for (size_t k = 0; k < lo.size(); ++k) { inter[2 * k] = lo[k]; inter[2 * k + 1] = hi[k]; }
     if ((rc = upload(ctx, ctx->nodes2, inter.data(), inter.size() * sizeof(float4))) != RT_OK) return rc;
+    sc.root_left = 0;
+    for (size_t k = 0; k < lo.size(); ++k)                            // work-stack layout: an internal node names its other child
+        if (left_of[k] >= 0) inter[2 * k].w = __builtin_bit_cast(float, left_of[k]);
+    if (!lo.empty() && left_of[0] >= 0) sc.root_left = left_of[0];
+    if ((rc = upload(ctx, ctx->nodesq, inter.data(), inter.size() * sizeof(float4))) != RT_OK) return rc;
     if ((rc = upload(ctx, ctx->tri, tri.data(), tri.size() * sizeof(float4))) != RT_OK) return rc;
     if ((rc = upload(ctx, ctx->verts, verts.data(), verts.size() * sizeof(float4))) != RT_OK) return rc;
     if ((rc = upload(ctx, ctx->tidx, tidx.data(), tidx.size() * sizeof(int4))) != RT_OK) return rc;
     sc.node_lo = static_cast<const float4 *>(ctx->node_lo.p);
     sc.node_hi = static_cast<const float4 *>(ctx->node_hi.p);
     sc.nodes = static_cast<const float4 *>(ctx->nodes2.p);
+    sc.nodesq = static_cast<const float4 *>(ctx->nodesq.p);
     sc.tri = static_cast<const float4 *>(ctx->tri.p);
     sc.verts = static_cast<const float4 *>(ctx->verts.p);
     sc.tidx = static_cast<const int4 *>(ctx->tidx.p);

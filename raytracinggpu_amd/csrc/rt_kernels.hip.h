@@ -47,6 +47,8 @@ struct Scene {
     float camx, camy, camz, fov;
     const float4 *node_lo, *node_hi;
     const float4 *nodes;      // the same nodes interleaved: nodes[2i] = lo, nodes[2i+1] = hi (one address per visit)
+    const float4 *nodesq;     // interleaved, for the work-stack traversal: lo.w of an internal node = its OTHER child (the first one is i+1)
+    int root_left;            // nodesq[0].lo.w
     const float4 *tri;
     const float4 *verts;
     const int4 *tidx;

@@ -1,0 +1,325 @@
+// rt_travq.hip.h -- wf_travq: BVH traversal as a wave-level work stack of (ray, node) pairs.
+//
+// Replaces the walk of TriangleMesh::intersect (cpu_launcher.cpp:277-311; optimized.cu:245-285) inside the
+// wavefront pipeline of rt_wavefront.hip.h (same path state, same wf_begin / wf_advance kernels).
+//
+// The reference pushes EVERY child whose box is hit (no distance pruning), so the set of nodes and
+// triangles a ray visits does not depend on the order they are visited in, and the nearest hit is the minimum
+// over the visited triangles of (t, visit rank) -- the strict '<' of cpu:301 keeps the earliest of equal t, and
+// triangles are stored in visit order, so rank == triangle index.  Hence a ray's traversal is not a walk but a
+// bag of independent box tests: a wave keeps R rays resident in LDS and one LIFO stack of 32-bit entries
+// (ray slot << 26 | node).  A BOX step pops 64 entries, every lane tests ONE box (BoundingBox::intersect,
+// cpu:146-157, through the error-bounded filter of rt_kernels.hip.h) and pushes the two children of a hit
+// internal node or appends a hit leaf's (first, count) to the wave's leaf queue.  A TRI step takes leaf entries
+// worth 64 triangles, hands every lane one triangle (prefix sum + mark/ballot expansion) and merges accepted hits
+// with a 64-bit LDS min on bits(t) << 32 | index (moller_trumbore, cpu:226-236).  Per-slot counters of
+// outstanding entries tell when a ray is finished; finished slots are refilled from the workgroup's share of the
+// ray slots.  Lanes carry no per-ray state, so there are no dependent node-to-node load chains, no stragglers
+// (a long ray is spread over the lanes), and lane occupancy is that of the stack, not of the slowest ray.
+//
+// LDS is bounded for any tree: when the stack cannot take the 128 pushes of a full BOX step, the wave drains 64
+// entries by walking their subtrees serially with the stackless (skip-pointer) node array instead.
+#pragma once
+#include "rt_wavefront.hip.h"
+
+namespace rtk {
+
+constexpr int kQBlock = 256;                 // 4 waves per workgroup share one ray-slot cursor
+constexpr int kQNodeBits = 26;               // entry = slot << 26 | node
+constexpr unsigned kQNodeMask = (1u << kQNodeBits) - 1u;
+
+// stack capacity: sized so that four waves' carves (+ the cursor) fill 40 KiB (R = 64: 4 workgroups per CU) or less
+template <int R> struct QStackCap { static constexpr int value = R == 64 ? 1016 : 504; };
+
+template <int R, int SCAP, int LCAP> struct QCarve {
+    static constexpr int kTabA = 0;                       // float4[R]: (1/u.xyz by v_rcp_f32, c0 | +inf if the filter must not decide)
+    static constexpr int kTabB = kTabA + 16 * R;          // float4[R]: (O.xyz * 1/u.xyz, -)
+    static constexpr int kTabC = kTabB + 16 * R;          // float4[R]: (O.xyz, u.x)
+    static constexpr int kTabD = kTabC + 16 * R;          // float4[R]: (u.y, u.z, -, -)
+    static constexpr int kBest = kTabD + 16 * R;          // u64[R]: nearest accepted hit
+    static constexpr int kPend = kBest + 8 * R;           // int[R]: outstanding stack + leaf-queue entries
+    static constexpr int kMarks = kPend + 4 * R;          // u32[64]: TRI-step expansion marks (all zero between steps)
+    static constexpr int kStack = kMarks + 256;           // u32[SCAP]
+    static constexpr int kLeaf = kStack + 4 * SCAP;       // uint2[LCAP]: (first triangle, slot | count << 8)
+    static constexpr int kBytes = kLeaf + 8 * LCAP;
+};
+
+// wave64 inclusive prefix sum by DPP (row_shr 1,2,4,8 inside the 16-lane rows, then row_bcast:15 / row_bcast:31).
+// Must be called with all 64 lanes active.
+__device__ __forceinline__ unsigned int wave_incl_scan(unsigned int x) {
+    x += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);
+    x += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);
+    x += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);
+    x += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);
+    x += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
+    x += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
+    return x;
+}
+__device__ __forceinline__ int lanes_below(unsigned long long m) {   // set bits of m below this lane
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+}
+
+// BoundingBox::intersect (cpu:146-157) through the fused filter (see RayBox in rt_wavefront.hip.h): returns whether
+// the filter decided; `hit` is then the reference's result.  A = (r.xyz, c0), B = (O*r).xyz; c0 = +inf for rays the
+// filter must not decide (0 / denormal / inf / NaN components), which makes every comparison below false.
+__device__ __forceinline__ bool qbox_filter(const float4 lo, const float4 hi, const float4 A, const float4 B, bool &hit) {
+    const float ax = fmaf(lo.x, A.x, -B.x), bx = fmaf(hi.x, A.x, -B.x);
+    const float ay = fmaf(lo.y, A.y, -B.y), by = fmaf(hi.y, A.y, -B.y);
+    const float az = fmaf(lo.z, A.z, -B.z), bz = fmaf(hi.z, A.z, -B.z);
+    const float tn = vmax3(vmin(ax, bx), vmin(ay, by), vmin(az, bz));
+    const float tf = vmin3(vmax(ax, bx), vmax(ay, by), vmax(az, bz));
+    const float M = vmax(vmax3abs(ax, bx, ay), vmax3abs(by, az, bz));
+    const float d = tf - tn;
+    const float band = fmaf(M, 2.f * kRel, A.w);
+    hit = d > band;
+    return M < kBig && (hit || d < -band);
+}
+
+// moller_trumbore (cpu:226-236) + the acceptance test of the leaf loop (cpu:301): beta/gamma through the filter,
+// undecided lanes by the literal divisions, t always by the exact division.
+__device__ __forceinline__ bool qtri_test(const float4 q0, const float4 q1, const float4 q2, const f3 Oo, const f3 uo,
+                                          const float tri_tmin, float &t_out) {
+    const f3 A = mk(q0.x, q0.y, q0.z), e1 = mk(q0.w, q1.x, q1.y), e2 = mk(q1.z, q1.w, q2.x);
+    const f3 N = mk(q2.y, q2.z, q2.w);
+    const float det = dot(uo, N);
+    const f3 AO = A - Oo;
+    const f3 c = cross(AO, uo);
+    const float bn = dot(e2, c);
+    const float gn = -dot(e1, c);
+    const float rd = __builtin_amdgcn_rcpf(det);
+    const float b = bn * rd, g = gn * rd;
+    const float eb = fmaf(fabsf(b), kRel, kAbs), eg = fmaf(fabsf(g), kRel, kAbs);
+    const float sum = b + g;
+    const float es = fmaf(fabsf(sum), 0x1p-22f, eb + eg);
+    const bool trust = fabsf(det) > kTiny;      // also false for det == 0 and NaN
+    const bool reject = trust && (b < -eb || b > 1.f + eb || g < -eg || g > 1.f + eg || sum > 1.f + es);
+    bool ok = trust && b >= eb && b <= 1.f - eb && g >= eg && g <= 1.f - eg && sum <= 1.f - es;
+    if (!reject && !ok && det != 0) {           // undecided: the literal tests (rare)
+        const float beta = bn / det;
+        const float gamma = gn / det;
+        ok = (0 <= beta && beta <= 1) && (0 <= gamma && gamma <= 1) && (beta + gamma <= 1);
+    }
+    if (!ok) return false;
+    const float t = dot(AO, N) / det;
+    t_out = t;
+    return t > 0 && t > tri_tmin && t < 1e9f;   // cpu:235, cpu:301; 1e9f = INF narrowed (cpu:283)
+}
+
+template <bool STATS, int R>
+__global__ __launch_bounds__(kQBlock) void wf_travq(const Scene sc, const Frame fr, const WfState st, const int cap) {
+    constexpr int SCAP = QStackCap<R>::value, LCAP = 128;
+    constexpr int kLow = 128;                     // refill while the stack holds fewer entries than this
+    constexpr int kMinFree = R / 4;               // ... and at least this many slots are free (or the stack is short)
+    using Carve = QCarve<R, SCAP, LCAP>;
+    static_assert(R <= 64 && (R & (R - 1)) == 0, "ray slots are owned by lanes");
+    extern __shared__ __attribute__((aligned(16))) unsigned char travq_smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wib = tid >> 6;
+    unsigned char *const wl = travq_smem + wib * Carve::kBytes;
+    int *const blk_cur = reinterpret_cast<int *>(travq_smem + (kQBlock / 64) * Carve::kBytes);
+    float4 *const tabA = reinterpret_cast<float4 *>(wl + Carve::kTabA);
+    float4 *const tabB = reinterpret_cast<float4 *>(wl + Carve::kTabB);
+    float4 *const tabC = reinterpret_cast<float4 *>(wl + Carve::kTabC);
+    float4 *const tabD = reinterpret_cast<float4 *>(wl + Carve::kTabD);
+    unsigned long long *const best = reinterpret_cast<unsigned long long *>(wl + Carve::kBest);
+    int *const pend = reinterpret_cast<int *>(wl + Carve::kPend);
+    unsigned int *const marks = reinterpret_cast<unsigned int *>(wl + Carve::kMarks);
+    unsigned int *const stack = reinterpret_cast<unsigned int *>(wl + Carve::kStack);
+    uint2 *const leafq = reinterpret_cast<uint2 *>(wl + Carve::kLeaf);
+    if (tid == 0) *blk_cur = 0;
+    marks[lane] = 0u;
+    if (lane < R) pend[lane] = 0;
+    __syncthreads();
+
+    const float4 *const nodes = sc.nodesq;        // lo.w = other child (internal) | first triangle (leaf); hi.w = -1 | end
+    const int blk_base = blockIdx.x * st.slots_per_block;
+    const int blk_n = st.slots_per_block;
+    const int root_hiw = __float_as_int(sc.root_hi.w);
+    int path = -1;                                // lane r < R owns ray slot r: the path index of the ray in it
+    int top = 0;                                  // wave-uniform: entries on the stack
+    unsigned int lhead = 0, ltail = 0;            // wave-uniform: leaf-queue cursors (monotonic)
+    bool drained = false;
+    Work wk;
+
+    for (;;) {
+        // wave-uniform by construction; say so (the loop-carried values then live in SGPRs and the branches are scalar)
+        top = __builtin_amdgcn_readfirstlane(top);
+        lhead = (unsigned int)__builtin_amdgcn_readfirstlane((int)lhead);
+        ltail = (unsigned int)__builtin_amdgcn_readfirstlane((int)ltail);
+        drained = __builtin_amdgcn_readfirstlane((int)drained) != 0;
+        // =============================== retire + refill ===============================
+        if (top < kLow) {
+            if (lane < R && path >= 0) {
+                if (pend[lane] == 0) {
+                    const unsigned long long key = best[lane];
+                    if (key != WF_NOHIT) st.M[path] = key;
+                    path = -1;
+                }
+            }
+            for (int round = 0; round < 4 && !drained && top < kLow; ++round) {
+                const unsigned long long freem = __ballot(lane < R && path < 0);
+                const int n_free = __popcll(freem);
+                if (n_free == 0 || (n_free < kMinFree && top >= 64)) break;
+                int base = 0;
+                if (lane == 0) base = atomicAdd(blk_cur, n_free);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base + n_free >= blk_n) drained = true;
+                bool got = false;
+                if (lane < R && path < 0) {
+                    const int qo = base + lanes_below(freem);
+                    const int p = qo < blk_n ? wf_slot_to_path(st, blk_base + qo) : -1;
+                    if (p >= 0) {
+                        const int f = st.FL[p];
+                        if ((f & (WF_ACTIVE | WF_MESH)) == (WF_ACTIVE | WF_MESH)) {
+                            const float4 r0 = st.R0[p], r1 = st.R1[p];
+                            const f3 O = mk(r0.x, r0.y, r0.z), u = mk(r0.w, r1.x, r1.y);
+                            const RayBox rb = ray_box(O, u);
+                            tabA[lane] = make_float4(rb.rx, rb.ry, rb.rz, rb.safe ? rb.c0 : __builtin_inff());
+                            tabB[lane] = make_float4(rb.ox, rb.oy, rb.oz, 0.f);
+                            tabC[lane] = r0;
+                            tabD[lane] = make_float4(r1.x, r1.y, 0.f, 0.f);
+                            best[lane] = WF_NOHIT;
+                            path = p;
+                            got = true;
+                        }
+                    }
+                }
+                // the root box was tested when the ray was emitted (wf_emit_ray): start with what is below it
+                const unsigned long long gm = __ballot(got);
+                if (root_hiw < 0) {
+                    if (got) {
+                        const int pos = top + 2 * lanes_below(gm);
+                        stack[pos] = (unsigned int)lane << kQNodeBits | (unsigned int)sc.root_left;
+                        stack[pos + 1] = (unsigned int)lane << kQNodeBits | 1u;
+                        pend[lane] = 2;
+                    }
+                    top += 2 * __popcll(gm);
+                } else {                           // the root is a leaf
+                    const int first = __float_as_int(sc.root_lo.w), cnt = root_hiw - first;
+                    if (cnt > 0) {
+                        if (got) {
+                            leafq[(ltail + (unsigned int)lanes_below(gm)) & (LCAP - 1)] = make_uint2((unsigned int)first, (unsigned int)lane | (unsigned int)cnt << 8);
+                            pend[lane] = 1;
+                            if (STATS) wk.tris += (uint32_t)cnt;
+                        }
+                        ltail += (unsigned int)__popcll(gm);
+                    } else if (got) {
+                        pend[lane] = 0;
+                    }
+                    break;                         // at most R leaf entries per pass: the TRI steps below drain them
+                }
+            }
+        }
+        // =============================== TRI step ===============================
+        const unsigned int lcount = ltail - lhead;
+        if (lcount >= 64u || (top == 0 && lcount > 0u)) {
+            const unsigned int m = lcount < 64u ? lcount : 64u;
+            uint2 E = make_uint2(0u, 0u);
+            if ((unsigned int)lane < m) E = leafq[(lhead + (unsigned int)lane) & (LCAP - 1)];
+            const unsigned int c = E.y >> 8;                         // >= 1 for queued entries, 0 beyond them
+            const unsigned int incl = wave_incl_scan(c);
+            const unsigned int P = incl - c;                         // first lane of this entry's triangles
+            const bool part = c > 0u && P < 64u;
+            const unsigned int all = (unsigned int)__builtin_amdgcn_readlane((int)incl, 63);
+            const unsigned int total = all < 64u ? all : 64u;
+            if (part) marks[P] = 1u;
+            __builtin_amdgcn_wave_barrier();
+            const unsigned int mk_ = marks[lane];
+            const unsigned long long B = __ballot(mk_ != 0u);
+            __builtin_amdgcn_wave_barrier();
+            if (part) marks[P] = 0u;
+            const int j = lanes_below(B) + (int)((B >> lane) & 1ull) - 1;   // entry whose range covers this lane
+            const unsigned int first_j = (unsigned int)__shfl((int)E.x, j, 64);
+            const unsigned int y_j = (unsigned int)__shfl((int)E.y, j, 64);
+            const unsigned int P_j = (unsigned int)__shfl((int)P, j, 64);
+            if ((unsigned int)lane < total) {
+                const int o = (int)(y_j & 0xffu);
+                const int i = (int)(first_j + ((unsigned int)lane - P_j));
+                const float4 *tp = sc.tri + 3 * (size_t)i;
+                const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+                const float4 C = tabC[o], D = tabD[o];
+                float t;
+                if (qtri_test(q0, q1, q2, mk(C.x, C.y, C.z), mk(C.w, D.x, D.y), fr.tri_tmin, t))
+                    atomicMin(&best[o], (unsigned long long)__float_as_uint(t) << 32 | (unsigned int)i);
+            }
+            const bool full = part && P + c <= 64u;
+            if (part && !full) {                                     // at most one entry straddles lane 63: keep its rest
+                const unsigned int took = 64u - P;
+                leafq[(lhead + (unsigned int)lane) & (LCAP - 1)] = make_uint2(E.x + took, (E.y & 0xffu) | (c - took) << 8);
+            }
+            lhead += (unsigned int)__popcll(__ballot(full));
+            if (full) atomicAdd(&pend[E.y & 0xffu], -1);            // after the mins above (LDS operations stay in order)
+            continue;
+        }
+        if (top == 0) {
+            if (drained && __ballot(path >= 0) == 0ull) break;       // every wave gets here: each step consumes entries
+            continue;
+        }
+        const int n = top < 64 ? top : 64;
+        const bool act = lane < n;
+        const unsigned int e = act ? stack[top - 1 - lane] : 0u;
+        top -= n;
+        const int o = (int)(e >> kQNodeBits);
+        const int node = (int)(e & kQNodeMask);
+        if (cap - (top + n) < 64) {
+            // =============================== serial drain (stack nearly full) ===============================
+            if (act) {
+                const float4 A = tabA[o], B = tabB[o], C = tabC[o], D = tabD[o];
+                const f3 O = mk(C.x, C.y, C.z), u = mk(C.w, D.x, D.y);
+                const float4 h0 = sc.nodes[2 * node + 1];
+                const int end = __float_as_int(h0.w) >= 0 ? node + 1 : __float_as_int(sc.nodes[2 * node].w);
+                for (int x = node; x < end;) {
+                    const float4 lo = sc.nodes[2 * x], hi = sc.nodes[2 * x + 1];
+                    const int hiw = __float_as_int(hi.w), low = __float_as_int(lo.w);
+                    bool hit;
+                    if (!qbox_filter(lo, hi, A, B, hit)) hit = slab(lo, hi, O, u);
+                    if (STATS) { wk.box++; if (hit) wk.nodes++; }
+                    if (hit && hiw >= 0) {
+                        if (STATS) wk.tris += (uint32_t)(hiw - low);
+                        for (int i = low; i < hiw; ++i) {
+                            const float4 *tp = sc.tri + 3 * (size_t)i;
+                            float t;
+                            if (qtri_test(tp[0], tp[1], tp[2], O, u, fr.tri_tmin, t))
+                                atomicMin(&best[o], (unsigned long long)__float_as_uint(t) << 32 | (unsigned int)i);
+                        }
+                    }
+                    x = (hit || hiw >= 0) ? x + 1 : low;
+                }
+                atomicAdd(&pend[o], -1);
+            }
+            continue;
+        }
+        // =============================== BOX step ===============================
+        const float4 A = tabA[o], B = tabB[o];
+        const float4 lo = nodes[2 * node], hi = nodes[2 * node + 1];
+        bool hit;
+        const bool decided = qbox_filter(lo, hi, A, B, hit);
+        // literal arithmetic for undecided lanes behind a wave-uniform branch (six IEEE divisions, almost never needed)
+        if (__builtin_expect(__ballot(act && !decided) != 0ull, 0)) {
+            if (act && !decided) {
+                const float4 C = tabC[o], D = tabD[o];
+                hit = slab(lo, hi, mk(C.x, C.y, C.z), mk(C.w, D.x, D.y));
+            }
+        }
+        const int hiw = __float_as_int(hi.w), low = __float_as_int(lo.w);
+        const int cnt = hiw - low;
+        hit = hit && act;
+        const bool hitI = hit && hiw < 0;
+        const bool hitL = hit && hiw >= 0 && cnt > 0;
+        if (STATS) { wk.box += act ? 1u : 0u; wk.nodes += hit ? 1u : 0u; wk.tris += (hit && hiw >= 0) ? (uint32_t)cnt : 0u; }
+        const unsigned long long mI = __ballot(hitI), mL = __ballot(hitL);
+        if (hitI) {
+            const int pos = top + 2 * lanes_below(mI);
+            stack[pos] = (e & ~kQNodeMask) | (unsigned int)low;      // the other child
+            stack[pos + 1] = e + 1u;                                 // the child stored right behind its parent
+        }
+        top += 2 * __popcll(mI);
+        if (hitL) leafq[(ltail + (unsigned int)lanes_below(mL)) & (LCAP - 1)] = make_uint2((unsigned int)low, (unsigned int)o | (unsigned int)cnt << 8);
+        ltail += (unsigned int)__popcll(mL);
+        if (act && !hitL) atomicAdd(&pend[o], hitI ? 1 : -1);        // internal hit: -1 + 2; leaf hit: -1 + 1; miss: -1
+    }
+    wf_flush_work<STATS>(fr, wk);
+}
+
+}  // namespace rtk

@@ -38,7 +38,7 @@ def values_equal(a, b):
     return (a == b) | (np.isnan(a) & np.isnan(b))
 
 
-VARIANTS = ["wavefront_lds", "wavefront", "global", "lockstep"]
+VARIANTS = ["wavefront_queue", "wavefront_lds", "wavefront", "global", "lockstep"]
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -209,3 +209,18 @@ def test_variants_are_bitwise_identical_at_full_size(ctx, cat_golden):
         else:
             np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
     assert int(ref[..., 3].sum()) == 16588799
+
+
+@pytest.mark.parametrize("env", [{"RT_TRAVQ_CAP": "256"}, {"RT_TRAVQ_R": "32"}, {"RT_TRAVQ_R": "32", "RT_TRAVQ_CAP": "256"}])
+def test_work_stack_traversal_bounded_stack_and_slot_counts(ctx, cat_golden, monkeypatch, env):
+    """wf_travq with a 256-entry stack (forces the serial-drain path that keeps LDS bounded for any tree) and with
+    32 ray slots per wave: same bits and same work counters as the default configuration."""
+    upload(ctx, "cpu", cat_golden)
+    p = rt.make_params(640, 360, 2, 3, variant="wavefront_queue", **rt.scenes.CPU_LAUNCHER)
+    ref = ctx.render(rt.make_params(640, 360, 2, 3, variant="wavefront", **rt.scenes.CPU_LAUNCHER))
+    work = ctx.count_work(rt.make_params(640, 360, 2, 3, variant="wavefront", **rt.scenes.CPU_LAUNCHER))
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    got = ctx.render(p)
+    np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
+    assert ctx.count_work(p) == work
