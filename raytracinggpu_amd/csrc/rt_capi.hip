@@ -35,6 +35,8 @@ struct rt_ctx {
     DevBuf node_lo, node_hi, nodes2, nodesq, tri, verts, tidx, scratch_rgba, scratch_rgb8, work, queue;
     int n_cus = 0;
     DevBuf wfR0, wfR1, wfM, wfFL, wfS0, wfS1, wfT, wfF, wfLS, wfQ;   // wavefront path state (HBM)
+    DevBuf wfQA, wfQB, wfQF;                                        // traversal queue in slot order (work-stack variant)
+    uint64_t qf_sig = 0;                                            // layout the queue flags were last zeroed for
     int trav_blocks_per_cu[4] = {0, 0, 0, 0};
     int travq_blocks_per_cu[4] = {0, 0, 0, 0};   // [STATS + 2 * (R == 32)]
     static constexpr int kMaxParts = 8;
@@ -279,7 +281,7 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
         if (dbg_env) { rc2 = ensure(ctx, dbgbuf, 10 * 8 * 65536); if (rc2 != RT_OK) return rc2; }
 
         // per-part geometry
-        struct Part { rtk::Frame fr; rtk::WfState st; int64_t tblocks; unsigned pblocks; size_t base; };
+        struct Part { rtk::Frame fr; rtk::WfState st; int64_t tblocks; unsigned pblocks; size_t base; size_t qbase; };
         std::vector<Part> pv(parts);
         size_t np_total = 0;
         for (int j = 0; j < parts; ++j) {
@@ -327,8 +329,30 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
             (rc2 = ensure(ctx, ctx->wfS1, np * 16)) != RT_OK || (rc2 = ensure(ctx, ctx->wfT, np * 16)) != RT_OK ||
             (rc2 = ensure(ctx, ctx->wfF, np * 16)) != RT_OK || (rc2 = ensure(ctx, ctx->wfLS, np * 4 * (size_t)nseg)) != RT_OK)
             return rc2;
+        size_t q_slots = 0;                                           // traversal-queue slots of all parts (padding included)
+        uint64_t q_sig = 0xcbf29ce484222325ull;
+        if (queue) {
+            for (Part &pt : pv) {
+                pt.qbase = q_slots;
+                q_slots += (size_t)pt.st.slots_per_block * (size_t)pt.tblocks;
+                for (uint64_t v : {(uint64_t)pt.st.n_paths, (uint64_t)pt.st.log2S, (uint64_t)pt.st.Q, (uint64_t)pt.st.slots_per_block, (uint64_t)pt.tblocks})
+                    q_sig = (q_sig ^ v) * 0x100000001b3ull;
+            }
+            const size_t had = ctx->wfQF.bytes;
+            if ((rc2 = ensure(ctx, ctx->wfQA, q_slots * 16)) != RT_OK || (rc2 = ensure(ctx, ctx->wfQB, q_slots * 8)) != RT_OK ||
+                (rc2 = ensure(ctx, ctx->wfQF, q_slots * 4)) != RT_OK)
+                return rc2;
+            if (ctx->wfQF.bytes != had || ctx->qf_sig != q_sig) {         // padding slots are never written by the kernels: zero once per layout
+                RT_HIP(ctx, hipMemsetAsync(ctx->wfQF.p, 0, ctx->wfQF.bytes, stream));
+                ctx->qf_sig = q_sig;
+            }
+        }
         for (Part &pt : pv) {
             rtk::WfState &st = pt.st;
+            if (queue) {
+                st.QA = static_cast<float4 *>(ctx->wfQA.p) + pt.qbase; st.QB = static_cast<float2 *>(ctx->wfQB.p) + pt.qbase;
+                st.QF = static_cast<int *>(ctx->wfQF.p) + pt.qbase;
+            }
             st.R0 = static_cast<float4 *>(ctx->wfR0.p) + 2 * pt.base; st.R1 = static_cast<float4 *>(ctx->wfR1.p) + 2 * pt.base;
             st.M = static_cast<unsigned long long *>(ctx->wfM.p) + 2 * pt.base; st.FL = static_cast<int *>(ctx->wfFL.p) + 2 * pt.base;
             st.S0 = static_cast<float4 *>(ctx->wfS0.p) + pt.base;
@@ -510,6 +534,7 @@ int rt_ctx_destroy(rt_ctx *ctx) {
     ctx->scratch_rgba.release(); ctx->scratch_rgb8.release(); ctx->work.release(); ctx->queue.release();
     ctx->wfR0.release(); ctx->wfR1.release(); ctx->wfM.release(); ctx->wfS0.release(); ctx->wfS1.release();
     ctx->wfT.release(); ctx->wfF.release(); ctx->wfFL.release(); ctx->wfLS.release(); ctx->wfQ.release();
+    ctx->wfQA.release(); ctx->wfQB.release(); ctx->wfQF.release();
     for (hipEvent_t &e : ctx->ev_trav) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t &e : ctx->part_ev) if (e) (void)hipEventDestroy(e);
     for (hipStream_t &q : ctx->part_stream) if (q) (void)hipStreamDestroy(q);

@@ -28,8 +28,9 @@ constexpr int kQBlock = 256;                 // 4 waves per workgroup share one 
 constexpr int kQNodeBits = 26;               // entry = slot << 26 | node
 constexpr unsigned kQNodeMask = (1u << kQNodeBits) - 1u;
 
-// stack capacity: sized so that four waves' carves (+ the cursor) fill 40 KiB (R = 64: 4 workgroups per CU) or less
-template <int R> struct QStackCap { static constexpr int value = R == 64 ? 1016 : 504; };
+// stack capacity: sized so that four waves' carves (+ the cursor) fill 40 KiB (R = 64: 4 workgroups per CU) or less;
+// a fuller stack is drained serially (see below), which the cat never needs (its stack stays below ~300 entries)
+template <int R> struct QStackCap { static constexpr int value = 504; };
 
 template <int R, int SCAP, int LCAP> struct QCarve {
     static constexpr int kTabA = 0;                       // float4[R]: (1/u.xyz by v_rcp_f32, c0 | +inf if the filter must not decide)
@@ -41,7 +42,8 @@ template <int R, int SCAP, int LCAP> struct QCarve {
     static constexpr int kMarks = kPend + 4 * R;          // u32[64]: TRI-step expansion marks (all zero between steps)
     static constexpr int kStack = kMarks + 256;           // u32[SCAP]
     static constexpr int kLeaf = kStack + 4 * SCAP;       // uint2[LCAP]: (first triangle, slot | count << 8)
-    static constexpr int kBytes = kLeaf + 8 * LCAP;
+    static constexpr int kStage = kLeaf + 8 * LCAP;       // float4[64] x2: ray records fetched from the queue, not yet in a slot
+    static constexpr int kBytes = kStage + 2048;
 };
 
 // wave64 inclusive prefix sum by DPP (row_shr 1,2,4,8 inside the 16-lane rows, then row_bcast:15 / row_bcast:31).
@@ -127,20 +129,29 @@ __global__ __launch_bounds__(kQBlock) void wf_travq(const Scene sc, const Frame 
     unsigned int *const marks = reinterpret_cast<unsigned int *>(wl + Carve::kMarks);
     unsigned int *const stack = reinterpret_cast<unsigned int *>(wl + Carve::kStack);
     uint2 *const leafq = reinterpret_cast<uint2 *>(wl + Carve::kLeaf);
+    float4 *const stA = reinterpret_cast<float4 *>(wl + Carve::kStage);
+    float4 *const stB = stA + 64;
     if (tid == 0) *blk_cur = 0;
     marks[lane] = 0u;
     if (lane < R) pend[lane] = 0;
     __syncthreads();
 
     const float4 *const nodes = sc.nodesq;        // lo.w = other child (internal) | first triangle (leaf); hi.w = -1 | end
-    const int blk_base = blockIdx.x * st.slots_per_block;
+    const size_t blk_base = (size_t)blockIdx.x * (size_t)st.slots_per_block;
     const int blk_n = st.slots_per_block;
+    int stage_n = 0, stage_used = 0;              // wave-uniform: staged records and how many of them have been given a slot
     const int root_hiw = __float_as_int(sc.root_hi.w);
     int path = -1;                                // lane r < R owns ray slot r: the path index of the ray in it
     int top = 0;                                  // wave-uniform: entries on the stack
     unsigned int lhead = 0, ltail = 0;            // wave-uniform: leaf-queue cursors (monotonic)
     bool drained = false;
     Work wk;
+    // optional per-wave record (RT_DEBUG_TRAV): st.dbg[16 * wave + k]
+    const bool dbg_on = st.dbg != nullptr;
+    const unsigned long long dbg_t0 = dbg_on ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    unsigned long long dbg_tdrain = 0ull, cy_srv = 0, cy_tri = 0, cy_box = 0, stamp = dbg_on ? __builtin_amdgcn_s_memtime() : 0ull;
+    unsigned int d_box = 0, d_boxl = 0, d_tri = 0, d_tril = 0, d_rounds = 0, d_rays = 0, d_serial = 0, d_idle = 0, d_fetch = 0, d_maxtop = 0;
+#define WQ_STAMP(acc) do { if (dbg_on) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - stamp; stamp = t_; } } while (0)
 
     for (;;) {
         // wave-uniform by construction; say so (the loop-carried values then live in SGPRs and the branches are scalar)
@@ -148,6 +159,8 @@ __global__ __launch_bounds__(kQBlock) void wf_travq(const Scene sc, const Frame 
         lhead = (unsigned int)__builtin_amdgcn_readfirstlane((int)lhead);
         ltail = (unsigned int)__builtin_amdgcn_readfirstlane((int)ltail);
         drained = __builtin_amdgcn_readfirstlane((int)drained) != 0;
+        stage_n = __builtin_amdgcn_readfirstlane(stage_n);
+        stage_used = __builtin_amdgcn_readfirstlane(stage_used);
         // =============================== retire + refill ===============================
         if (top < kLow) {
             if (lane < R && path >= 0) {
@@ -157,36 +170,50 @@ __global__ __launch_bounds__(kQBlock) void wf_travq(const Scene sc, const Frame 
                     path = -1;
                 }
             }
-            for (int round = 0; round < 4 && !drained && top < kLow; ++round) {
+            // refill free slots.  The workgroup owns a spatially scrambled, contiguous share of the traversal queue; its
+            // waves take 64 slots at a time through an LDS cursor, flag and record in ONE round trip, and park the rays that
+            // need traversal in the LDS staging area, from where free slots are filled.
+            for (int round = 0; round < 6 && top < kLow; ++round) {
                 const unsigned long long freem = __ballot(lane < R && path < 0);
                 const int n_free = __popcll(freem);
                 if (n_free == 0 || (n_free < kMinFree && top >= 64)) break;
-                int base = 0;
-                if (lane == 0) base = atomicAdd(blk_cur, n_free);
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (base + n_free >= blk_n) drained = true;
-                bool got = false;
-                if (lane < R && path < 0) {
-                    const int qo = base + lanes_below(freem);
-                    const int p = qo < blk_n ? wf_slot_to_path(st, blk_base + qo) : -1;
-                    if (p >= 0) {
-                        const int f = st.FL[p];
-                        if ((f & (WF_ACTIVE | WF_MESH)) == (WF_ACTIVE | WF_MESH)) {
-                            const float4 r0 = st.R0[p], r1 = st.R1[p];
-                            const f3 O = mk(r0.x, r0.y, r0.z), u = mk(r0.w, r1.x, r1.y);
-                            const RayBox rb = ray_box(O, u);
-                            tabA[lane] = make_float4(rb.rx, rb.ry, rb.rz, rb.safe ? rb.c0 : __builtin_inff());
-                            tabB[lane] = make_float4(rb.ox, rb.oy, rb.oz, 0.f);
-                            tabC[lane] = r0;
-                            tabD[lane] = make_float4(r1.x, r1.y, 0.f, 0.f);
-                            best[lane] = WF_NOHIT;
-                            path = p;
-                            got = true;
-                        }
+                if (stage_used >= stage_n) {
+                    if (drained) break;
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(blk_cur, 64);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base + 64 >= blk_n) { drained = true; if (dbg_on && !dbg_tdrain) dbg_tdrain = __builtin_amdgcn_s_memrealtime(); }
+                    int f = 0;
+                    float4 r0 = make_float4(0, 0, 0, 0); float2 r1 = make_float2(0, 0);
+                    if (base + lane < blk_n) {
+                        const size_t q = (size_t)blk_base + (size_t)(base + lane);
+                        f = st.QF[q]; r0 = st.QA[q]; r1 = st.QB[q];
                     }
+                    const unsigned long long am = __ballot(f != 0);
+                    if (f != 0) { const int k = lanes_below(am); stA[k] = r0; stB[k] = make_float4(r1.x, r1.y, __int_as_float(f - 1), 0.f); }
+                    stage_n = __popcll(am);
+                    stage_used = 0;
+                    if (dbg_on) d_fetch++;
+                    if (stage_n == 0) continue;
                 }
+                const int take = n_free < stage_n - stage_used ? n_free : stage_n - stage_used;
+                const int rank = lanes_below(freem);
+                const bool got = lane < R && path < 0 && rank < take;
+                if (got) {
+                    const float4 r0 = stA[stage_used + rank], r1 = stB[stage_used + rank];
+                    const f3 O = mk(r0.x, r0.y, r0.z), u = mk(r0.w, r1.x, r1.y);
+                    const RayBox rb = ray_box(O, u);
+                    tabA[lane] = make_float4(rb.rx, rb.ry, rb.rz, rb.safe ? rb.c0 : __builtin_inff());
+                    tabB[lane] = make_float4(rb.ox, rb.oy, rb.oz, 0.f);
+                    tabC[lane] = r0;
+                    tabD[lane] = make_float4(r1.x, r1.y, 0.f, 0.f);
+                    best[lane] = WF_NOHIT;
+                    path = __float_as_int(r1.z);
+                }
+                stage_used += take;
                 // the root box was tested when the ray was emitted (wf_emit_ray): start with what is below it
                 const unsigned long long gm = __ballot(got);
+                if (dbg_on) { d_rounds++; d_rays += (unsigned int)__popcll(gm); }
                 if (root_hiw < 0) {
                     if (got) {
                         const int pos = top + 2 * lanes_below(gm);
@@ -211,6 +238,7 @@ __global__ __launch_bounds__(kQBlock) void wf_travq(const Scene sc, const Frame 
                 }
             }
         }
+        WQ_STAMP(cy_srv);
         // =============================== TRI step ===============================
         const unsigned int lcount = ltail - lhead;
         if (lcount >= 64u || (top == 0 && lcount > 0u)) {
@@ -250,10 +278,13 @@ __global__ __launch_bounds__(kQBlock) void wf_travq(const Scene sc, const Frame 
             }
             lhead += (unsigned int)__popcll(__ballot(full));
             if (full) atomicAdd(&pend[E.y & 0xffu], -1);            // after the mins above (LDS operations stay in order)
+            if (dbg_on) { d_tri++; d_tril += total; }
+            WQ_STAMP(cy_tri);
             continue;
         }
         if (top == 0) {
             if (drained && __ballot(path >= 0) == 0ull) break;       // every wave gets here: each step consumes entries
+            d_idle++;
             continue;
         }
         const int n = top < 64 ? top : 64;
@@ -288,6 +319,8 @@ __global__ __launch_bounds__(kQBlock) void wf_travq(const Scene sc, const Frame 
                 }
                 atomicAdd(&pend[o], -1);
             }
+            d_serial++;
+            WQ_STAMP(cy_box);
             continue;
         }
         // =============================== BOX step ===============================
@@ -318,6 +351,14 @@ __global__ __launch_bounds__(kQBlock) void wf_travq(const Scene sc, const Frame 
         if (hitL) leafq[(ltail + (unsigned int)lanes_below(mL)) & (LCAP - 1)] = make_uint2((unsigned int)low, (unsigned int)o | (unsigned int)cnt << 8);
         ltail += (unsigned int)__popcll(mL);
         if (act && !hitL) atomicAdd(&pend[o], hitI ? 1 : -1);        // internal hit: -1 + 2; leaf hit: -1 + 1; miss: -1
+        if (dbg_on) { d_box++; d_boxl += (unsigned int)n; if ((unsigned int)top > d_maxtop) d_maxtop = (unsigned int)top; }
+        WQ_STAMP(cy_box);
+    }
+#undef WQ_STAMP
+    if (dbg_on && lane == 0) {
+        unsigned long long *d = st.dbg + 16 * (size_t)((blockIdx.x * blockDim.x + tid) >> 6);
+        d[0] = dbg_t0; d[1] = __builtin_amdgcn_s_memrealtime(); d[2] = d_box; d[3] = d_boxl; d[4] = d_tri; d[5] = d_tril;
+        d[6] = d_rounds; d[7] = d_rays; d[8] = d_serial; d[9] = cy_srv; d[10] = cy_tri; d[11] = cy_box; d[12] = dbg_tdrain; d[13] = d_idle; d[14] = d_fetch; d[15] = d_maxtop;
     }
     wf_flush_work<STATS>(fr, wk);
 }

@@ -61,6 +61,11 @@ struct WfState {
     int log2S, Q, n_groups;   // n_groups = 2 n_paths / 4 (ray groups);  S * Q >= n_groups
     int slots_per_block;      // multiple of 4: ray slots owned by one workgroup, handed to its waves on demand
     unsigned long long *dbg;  // optional per-wave debug record
+    // traversal queue (work-stack variant only; QA == nullptr otherwise): the rays in TRAVERSAL-SLOT order, so that the
+    // slots a traversal workgroup owns are contiguous and one round trip brings flag and record
+    int *QF;                  // [slots] ray slot + 1 if the ray needs traversal (active and inside the root box), else 0
+    float4 *QA;               // [slots] (O.xyz, u.x)
+    float2 *QB;               // [slots] (u.y, u.z)
 };
 
 __device__ __forceinline__ void wf_decode(const WfState &st, const Frame &fr, int i, int &px, int &lrow, bool &valid) {
@@ -98,7 +103,7 @@ __device__ __forceinline__ int wf_pack_wins(const SphereHit &h) { return ((h.win
 
 // Emit ray slot `r`: record, sphere tests, root-box test (cpu:279; wave-uniform node data from kernel arguments).
 template <bool STATS>
-__device__ __forceinline__ void wf_emit_ray(const Scene &sc, const WfState &st, int r, f3 O, f3 u, Work &wk) {
+__device__ __forceinline__ bool wf_emit_ray(const Scene &sc, const WfState &st, int r, f3 O, f3 u, Work &wk) {
     const SphereHit h = spheres_split(sc, O, u);
     st.R0[r] = make_float4(O.x, O.y, O.z, u.x);
     st.R1[r] = make_float4(u.y, u.z, h.tA, h.tB);
@@ -112,6 +117,21 @@ __device__ __forceinline__ void wf_emit_ray(const Scene &sc, const WfState &st, 
         }
     }
     st.FL[r] = f;
+    return (f & WF_MESH) != 0;
+}
+
+// inverse of wf_slot_to_path: the traversal slot of ray r
+__device__ __forceinline__ int wf_ray_to_slot(const WfState &st, int r) {
+    const int g = r >> 2;
+    const int a = g / st.Q, col = g - a * st.Q;
+    return ((col << st.log2S | a) << 2) | (r & 3);
+}
+// Traversal queue entry of ray r (work-stack variant): written for every ray slot of a live lane, needed or not.
+__device__ __forceinline__ void wf_queue_ray(const WfState &st, int r, bool need, f3 O, f3 u) {
+    if (st.QA == nullptr) return;
+    const int q = wf_ray_to_slot(st, r);
+    st.QF[q] = need ? r + 1 : 0;
+    if (need) { st.QA[q] = make_float4(O.x, O.y, O.z, u.x); st.QB[q] = make_float2(u.y, u.z); }
 }
 
 // Scene::intersect_all's running minimum for ray slot r, replayed in object order: spheres before the mesh,
@@ -147,6 +167,7 @@ template <bool STATS>
 __global__ __launch_bounds__(256) void wf_begin(const Scene sc, const Frame fr, const WfState st, int samp) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     Work wk;
+    bool qy = false; f3 qO = mk(0, 0, 0), qu = mk(0, 0, 0);
     if (i < st.n_paths) {
         int px, lrow; bool valid;
         wf_decode(st, fr, i, px, lrow, valid);
@@ -175,7 +196,8 @@ __global__ __launch_bounds__(256) void wf_begin(const Scene sc, const Frame fr, 
             }
             const f3 u = normalize(uu);
             const f3 O = mk(sc.camx, sc.camy, sc.camz);
-            wf_emit_ray<STATS>(sc, st, i, O, u, wk);                   // continuation ray of segment 0
+            qy = wf_emit_ray<STATS>(sc, st, i, O, u, wk);              // continuation ray of segment 0
+            qO = O; qu = u;
             st.FL[st.n_paths + i] = 0;
             st.F[i] = make_int4(WF_ALIVE | WF_HASY, 0, 0, 0);
             st.S1[i] = make_float4(0, 0, 0, 1.f);                  // Ray::refraction_index = 1 (cpu:100)
@@ -184,6 +206,7 @@ __global__ __launch_bounds__(256) void wf_begin(const Scene sc, const Frame fr, 
             st.T[i] = t;
         }
     }
+    if (i < st.n_paths) { wf_queue_ray(st, i, qy, qO, qu); wf_queue_ray(st, st.n_paths + i, false, qO, qu); }
     wf_flush_work<STATS>(fr, wk);
 }
 
@@ -501,6 +524,7 @@ __global__ __launch_bounds__(256) void wf_advance(const Scene sc, const Frame fr
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     Work wk;
     int4 F = i < st.n_paths ? st.F[i] : make_int4(0, 0, 0, 0);
+    bool qx = false, qy = false; f3 qOx = mk(0, 0, 0), qux = mk(0, 0, 0), qOy = mk(0, 0, 0), quy = mk(0, 0, 0);
     if (F.x & WF_ALIVE) {
         const float PI_F = (float)3.14159265358979323846;
         const double PI_D = 3.14159265358979323846;
@@ -581,7 +605,8 @@ __global__ __launch_bounds__(256) void wf_advance(const Scene sc, const Frame fr
                     const f3 Pa = P + fr.eps * N;
                     const f3 toL = L - Pa;
                     const f3 us = toL / rt_sqrtf(norm2(toL));         // NORMED_VEC, cpu:614
-                    wf_emit_ray<STATS>(sc, st, rx, Pa, us, wk);       // shadow ray of segment d
+                    qx = wf_emit_ray<STATS>(sc, st, rx, Pa, us, wk);  // shadow ray of segment d
+                    qOx = Pa; qux = us;
                     flags |= WF_HASX;
                     n_new += 1.f;
                     if (d + 1 < fr.segs) {                            // the bounce ray (cpu:627-642): needs r1, r2 and N only
@@ -611,7 +636,8 @@ __global__ __launch_bounds__(256) void wf_advance(const Scene sc, const Frame fr
                     st.S1[i] = make_float4(N.x, N.y, N.z, refr);
                 }
                 if (cont && d + 1 < fr.segs) {
-                    wf_emit_ray<STATS>(sc, st, i, O, u, wk);          // continuation ray of segment d+1
+                    qy = wf_emit_ray<STATS>(sc, st, i, O, u, wk);     // continuation ray of segment d+1
+                    qOy = O; quy = u;
                     flags |= WF_HASY;
                     n_new += 1.f;
                     if (!(flags & WF_HASX)) st.S1[i].w = refr;
@@ -648,6 +674,7 @@ __global__ __launch_bounds__(256) void wf_advance(const Scene sc, const Frame fr
             }
         }
     }
+    if (i < st.n_paths) { wf_queue_ray(st, i, qy, qOy, quy); wf_queue_ray(st, st.n_paths + i, qx, qOx, qux); }
     wf_flush_work<STATS>(fr, wk);
 }
 
