@@ -32,7 +32,7 @@ struct rt_ctx {
     hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
     bool have_scene = false, have_kernel_time = false, have_tonemap_time = false;
     rtk::Scene scene{};
-    DevBuf node_lo, node_hi, nodes2, nodesq, tri, verts, tidx, scratch_rgba, scratch_rgb8, work, queue;
+    DevBuf node_lo, node_hi, nodes2, nodesq, q2thr, tri, verts, tidx, scratch_rgba, scratch_rgb8, work, queue;
     int n_cus = 0;
     DevBuf wfR0, wfR1, wfM, wfFL, wfS0, wfS1, wfT, wfF, wfLS, wfQ;   // wavefront path state (HBM)
     DevBuf wfQA, wfQB, wfQF;                                        // traversal queue in slot order (work-stack variant)
@@ -170,6 +170,18 @@ int check_params(rt_ctx *ctx, const rt_params *p, int &segs) {
     return RT_OK;
 }
 
+// wf_travq instantiations: [STATS][R == 32][LDSN]
+using TravqFn = void (*)(const rtk::Scene, const rtk::Frame, const rtk::WfState, const int, const int);
+TravqFn travq_fn(bool stats, int R, bool ldsn) {
+    static const TravqFn tab[2][2][2] = {
+        {{rtk::wf_travq<false, 64, false>, rtk::wf_travq<false, 64, true>}, {rtk::wf_travq<false, 32, false>, rtk::wf_travq<false, 32, true>}},
+        {{rtk::wf_travq<true, 64, false>, rtk::wf_travq<true, 64, true>}, {rtk::wf_travq<true, 32, false>, rtk::wf_travq<true, 32, true>}}};
+    return tab[stats ? 1 : 0][R == 32 ? 1 : 0][ldsn ? 1 : 0];
+}
+size_t travq_carve_bytes(int R) {
+    return R == 64 ? (size_t)rtk::QCarve<64, rtk::QStackCap<64>::value, 256>::kBytes : (size_t)rtk::QCarve<32, rtk::QStackCap<32>::value, 256>::kBytes;
+}
+
 int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *out_dev, hipStream_t stream,
                   unsigned long long *work_dev = nullptr) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
@@ -226,6 +238,16 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
         if (const char *e = getenv("RT_TRAVQ_R")) { if (atoi(e) == 32) qR = 32; }
         int qcap = qR == 64 ? rtk::QStackCap<64>::value : rtk::QStackCap<32>::value;
         if (const char *e = getenv("RT_TRAVQ_CAP")) { const int v = atoi(e); if (v >= 256 && v < qcap) qcap = v; }   // tests: force the serial drain
+        // BVH nodes staged in LDS (breadth-first prefix) by ONE workgroup of qW waves per CU; 0 = nodes through L1/L2
+        int qW = 0;
+        if (const char *e = getenv("RT_TRAVQ_LDS")) { const int v = atoi(e); if (v >= 1 && v <= 16) qW = v; }
+        int q_nlds = 0;
+        if (queue && qW > 0) {
+            const int64_t room = 160 * 1024 - 16 - (int64_t)qW * (int64_t)travq_carve_bytes(qR);
+            q_nlds = room > 0 ? (int)std::min<int64_t>(room / 32, ctx->scene.n_nodes) : 0;
+            if (q_nlds <= 0) { qW = 0; q_nlds = 0; }
+        }
+        const bool qlds = queue && qW > 0;
         // begin, (trav, advance) x 2*segments per sample; path state SoA in HBM, tile-order path index.
         // The rows are cut into `parts` independent sub-frames (interleaved tiles), each running its own kernel
         // sequence on its own stream: the traversal kernel ends in a latency-bound tail (a few long rays), and
@@ -239,9 +261,9 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
         if (R % 8 != 0 || work_dev || getenv("RT_DEBUG_TRAV")) parts = 1;
         if (parts > T) parts = T > 0 ? T : 1;
         const int tiles_x = (p->width + 7) / 8;
-        const int tb = queue ? rtk::kQBlock : ldsn ? rtk::kTravBlockLds : rtk::kTravBlock;
+        const int tb = qlds ? 64 * qW : queue ? rtk::kQBlock : ldsn ? rtk::kTravBlockLds : rtk::kTravBlock;
         const int wpb = tb / 64;
-        const size_t q_lds = (size_t)wpb * (qR == 64 ? rtk::QCarve<64, rtk::QStackCap<64>::value, 128>::kBytes : rtk::QCarve<32, rtk::QStackCap<32>::value, 128>::kBytes) + 16;
+        const size_t q_lds = (size_t)wpb * travq_carve_bytes(qR) + 16 + (size_t)q_nlds * 32;
         const size_t trav_lds = queue ? q_lds : ldsn ? lds_nodes_bytes : (size_t)(rtk::kTravBlock / 64) * rtk::TravCarve<512, 8>::kBytes + 16;
         if (!ctx->trav_attr_set) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(rtk::wf_trav<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -259,18 +281,17 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
         int bpc = ctx->trav_blocks_per_cu[si];                       // blocks per CU
         if (queue) {
             const int qi = (work_dev ? 1 : 0) + (qR == 32 ? 2 : 0);
-            if (ctx->travq_blocks_per_cu[qi] == 0) {
-                int nb = 0;
-                if (qR == 64) {
-                    if (work_dev) RT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtk::wf_travq<true, 64>, rtk::kQBlock, trav_lds));
-                    else RT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtk::wf_travq<false, 64>, rtk::kQBlock, trav_lds));
-                } else {
-                    if (work_dev) RT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtk::wf_travq<true, 32>, rtk::kQBlock, trav_lds));
-                    else RT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtk::wf_travq<false, 32>, rtk::kQBlock, trav_lds));
+            if (qlds) {
+                bpc = 1;
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(travq_fn(work_dev != nullptr, qR, true)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            } else {
+                if (ctx->travq_blocks_per_cu[qi] == 0) {
+                    int nb = 0;
+                    RT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, travq_fn(work_dev != nullptr, qR, false), rtk::kQBlock, trav_lds));
+                    ctx->travq_blocks_per_cu[qi] = nb > 0 ? nb : 1;
                 }
-                ctx->travq_blocks_per_cu[qi] = nb > 0 ? nb : 1;
+                bpc = ctx->travq_blocks_per_cu[qi];
             }
-            bpc = ctx->travq_blocks_per_cu[qi];
         }
         if (const char *e = getenv("RT_TRAV_WAVES")) { const int v = atoi(e); if (!ldsn && v >= 1 && v <= bpc) bpc = v; }
         const bool have_mesh = ctx->scene.mesh_slot >= 0 && ctx->scene.n_nodes > 0;
@@ -381,13 +402,7 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
                         if (timed) RT_HIP(ctx, hipEventRecord(ctx->ev_trav[2 * it], q));
                         const dim3 tg((unsigned)pt.tblocks), tbd(tb);
                         if (queue) {
-                            if (qR == 64) {
-                                if (work_dev) hipLaunchKernelGGL((rtk::wf_travq<true, 64>), tg, tbd, trav_lds, q, ctx->scene, pt.fr, pt.st, qcap);
-                                else hipLaunchKernelGGL((rtk::wf_travq<false, 64>), tg, tbd, trav_lds, q, ctx->scene, pt.fr, pt.st, qcap);
-                            } else {
-                                if (work_dev) hipLaunchKernelGGL((rtk::wf_travq<true, 32>), tg, tbd, trav_lds, q, ctx->scene, pt.fr, pt.st, qcap);
-                                else hipLaunchKernelGGL((rtk::wf_travq<false, 32>), tg, tbd, trav_lds, q, ctx->scene, pt.fr, pt.st, qcap);
-                            }
+                            hipLaunchKernelGGL(travq_fn(work_dev != nullptr, qR, qlds), tg, tbd, trav_lds, q, ctx->scene, pt.fr, pt.st, qcap, q_nlds);
                         } else if (ldsn) {
                             if (work_dev) hipLaunchKernelGGL((rtk::wf_trav<true, true>), tg, tbd, trav_lds, q, ctx->scene, pt.fr, pt.st);
                             else hipLaunchKernelGGL((rtk::wf_trav<false, true>), tg, tbd, trav_lds, q, ctx->scene, pt.fr, pt.st);
@@ -530,7 +545,7 @@ int rt_ctx_destroy(rt_ctx *ctx) {
     if (!ctx) return RT_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    ctx->node_lo.release(); ctx->node_hi.release(); ctx->nodes2.release(); ctx->nodesq.release(); ctx->tri.release(); ctx->verts.release(); ctx->tidx.release();
+    ctx->node_lo.release(); ctx->node_hi.release(); ctx->nodes2.release(); ctx->nodesq.release(); ctx->q2thr.release(); ctx->tri.release(); ctx->verts.release(); ctx->tidx.release();
     ctx->scratch_rgba.release(); ctx->scratch_rgb8.release(); ctx->work.release(); ctx->queue.release();
     ctx->wfR0.release(); ctx->wfR1.release(); ctx->wfM.release(); ctx->wfS0.release(); ctx->wfS1.release();
     ctx->wfT.release(); ctx->wfF.release(); ctx->wfFL.release(); ctx->wfLS.release(); ctx->wfQ.release();
@@ -632,11 +647,28 @@ int rt_scene_upload(rt_ctx *ctx, const rt_sphere *spheres, int n_spheres, const 
     std::vector<float4> inter(lo.size() * 2);
     for (size_t k = 0; k < lo.size(); ++k) { inter[2 * k] = lo[k]; inter[2 * k + 1] = hi[k]; }
     if ((rc = upload(ctx, ctx->nodes2, inter.data(), inter.size() * sizeof(float4))) != RT_OK) return rc;
-    sc.root_left = 0;
-    for (size_t k = 0; k < lo.size(); ++k)                            // work-stack layout: an internal node names its other child
-        if (left_of[k] >= 0) inter[2 * k].w = __builtin_bit_cast(float, left_of[k]);
-    if (!lo.empty() && left_of[0] >= 0) sc.root_left = left_of[0];
-    if ((rc = upload(ctx, ctx->nodesq, inter.data(), inter.size() * sizeof(float4))) != RT_OK) return rc;
+    {   // work-stack layout: breadth-first order (the top of the tree is a prefix: LDS staging), children adjacent
+        const size_t n = lo.size();
+        std::vector<int> order;                                      // order[k] = traversal-order index of breadth-first node k
+        std::vector<int> bfs_of(n, -1);
+        order.reserve(n);
+        if (n) { order.push_back(0); bfs_of[0] = 0; }
+        for (size_t k = 0; k < order.size(); ++k) {
+            const int x = order[k];
+            if (left_of[x] >= 0) {                                    // internal: right child x + 1, left child left_of[x]
+                bfs_of[x + 1] = (int)order.size(); order.push_back(x + 1);
+                bfs_of[left_of[x]] = (int)order.size(); order.push_back(left_of[x]);
+            }
+        }
+        std::vector<float4> q(2 * order.size());
+        for (size_t k = 0; k < order.size(); ++k) {
+            const int x = order[k];
+            q[2 * k] = lo[x]; q[2 * k + 1] = hi[x];
+            if (left_of[x] >= 0) q[2 * k].w = __builtin_bit_cast(float, bfs_of[x + 1]);
+        }
+        if ((rc = upload(ctx, ctx->nodesq, q.data(), q.size() * sizeof(float4))) != RT_OK) return rc;
+        if ((rc = upload(ctx, ctx->q2thr, order.data(), order.size() * sizeof(int))) != RT_OK) return rc;
+    }
     if ((rc = upload(ctx, ctx->tri, tri.data(), tri.size() * sizeof(float4))) != RT_OK) return rc;
     if ((rc = upload(ctx, ctx->verts, verts.data(), verts.size() * sizeof(float4))) != RT_OK) return rc;
     if ((rc = upload(ctx, ctx->tidx, tidx.data(), tidx.size() * sizeof(int4))) != RT_OK) return rc;
@@ -644,6 +676,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_sphere *spheres, int n_spheres, const 
     sc.node_hi = static_cast<const float4 *>(ctx->node_hi.p);
     sc.nodes = static_cast<const float4 *>(ctx->nodes2.p);
     sc.nodesq = static_cast<const float4 *>(ctx->nodesq.p);
+    sc.q2thr = static_cast<const int *>(ctx->q2thr.p);
     sc.tri = static_cast<const float4 *>(ctx->tri.p);
     sc.verts = static_cast<const float4 *>(ctx->verts.p);
     sc.tidx = static_cast<const int4 *>(ctx->tidx.p);

@@ -47,8 +47,9 @@ struct Scene {
     float camx, camy, camz, fov;
     const float4 *node_lo, *node_hi;
     const float4 *nodes;      // the same nodes interleaved: nodes[2i] = lo, nodes[2i+1] = hi (one address per visit)
-    const float4 *nodesq;     // interleaved, for the work-stack traversal: lo.w of an internal node = its OTHER child (the first one is i+1)
-    int root_left;            // nodesq[0].lo.w
+    const float4 *nodesq;     // interleaved, for the work-stack traversal, in BREADTH-FIRST order: lo.w of an internal node = its first
+                              // child, the second one is stored next to it (the root's children are nodes 1 and 2)
+    const int *q2thr;         // nodesq index -> index of the same node in `nodes`
     const float4 *tri;
     const float4 *verts;
     const int4 *tidx;

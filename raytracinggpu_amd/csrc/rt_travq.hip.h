@@ -8,16 +8,18 @@
 // over the visited triangles of (t, visit rank) -- the strict '<' of cpu:301 keeps the earliest of equal t, and
 // triangles are stored in visit order, so rank == triangle index.  Hence a ray's traversal is not a walk but a
 // bag of independent box tests: a wave keeps R rays resident in LDS and one LIFO stack of 32-bit entries
-// (ray slot << 26 | node).  A BOX step pops 64 entries, every lane tests ONE box (BoundingBox::intersect,
-// cpu:146-157, through the error-bounded filter of rt_kernels.hip.h) and pushes the two children of a hit
-// internal node or appends a hit leaf's (first, count) to the wave's leaf queue.  A TRI step takes leaf entries
-// worth 64 triangles, hands every lane one triangle (prefix sum + mark/ballot expansion) and merges accepted hits
-// with a 64-bit LDS min on bits(t) << 32 | index (moller_trumbore, cpu:226-236).  Per-slot counters of
-// outstanding entries tell when a ray is finished; finished slots are refilled from the workgroup's share of the
-// ray slots.  Lanes carry no per-ray state, so there are no dependent node-to-node load chains, no stragglers
-// (a long ray is spread over the lanes), and lane occupancy is that of the stack, not of the slowest ray.
+// (ray slot << 26 | node).  A BOX step pops up to 128 entries, every lane tests TWO boxes (BoundingBox::intersect,
+// cpu:146-157, through the error-bounded filter of rt_kernels.hip.h; the two tests are independent, so their loads
+// are in flight together) and pushes the two children of a hit internal node or appends a hit leaf's (first, count)
+// to the wave's leaf queue.  A TRI step takes leaf entries worth up to 128 triangles, hands every lane two of them
+// (prefix sum + mark/ballot expansion) and merges accepted hits with a 64-bit LDS min on bits(t) << 32 | index
+// (moller_trumbore, cpu:226-236).  Per-slot counters of outstanding entries tell when a ray is finished; finished
+// slots are refilled from the workgroup's share of the traversal queue (slot order: flag and record arrive in one
+// round trip, 64 slots at a time, and wait in an LDS staging area).  Lanes carry no per-ray state, so there are no
+// dependent node-to-node load chains, no stragglers (a long ray is spread over the lanes), and lane occupancy is
+// that of the stack, not of the slowest ray.
 //
-// LDS is bounded for any tree: when the stack cannot take the 128 pushes of a full BOX step, the wave drains 64
+// LDS is bounded for any tree: when the stack cannot take the pushes of a full BOX step, the wave drains the popped
 // entries by walking their subtrees serially with the stackless (skip-pointer) node array instead.
 #pragma once
 #include "rt_wavefront.hip.h"
@@ -29,18 +31,17 @@ constexpr int kQNodeBits = 26;               // entry = slot << 26 | node
 constexpr unsigned kQNodeMask = (1u << kQNodeBits) - 1u;
 
 // stack capacity: sized so that four waves' carves (+ the cursor) fill 40 KiB (R = 64: 4 workgroups per CU) or less;
-// a fuller stack is drained serially (see below), which the cat never needs (its stack stays below ~300 entries)
-template <int R> struct QStackCap { static constexpr int value = 504; };
+// a fuller stack is drained serially (see above), which the cat never needs
+template <int R> struct QStackCap { static constexpr int value = 664; };
 
 template <int R, int SCAP, int LCAP> struct QCarve {
     static constexpr int kTabA = 0;                       // float4[R]: (1/u.xyz by v_rcp_f32, c0 | +inf if the filter must not decide)
-    static constexpr int kTabB = kTabA + 16 * R;          // float4[R]: (O.xyz * 1/u.xyz, -)
-    static constexpr int kTabC = kTabB + 16 * R;          // float4[R]: (O.xyz, u.x)
-    static constexpr int kTabD = kTabC + 16 * R;          // float4[R]: (u.y, u.z, -, -)
-    static constexpr int kBest = kTabD + 16 * R;          // u64[R]: nearest accepted hit
+    static constexpr int kTabC = kTabA + 16 * R;          // float4[R]: (O.xyz, u.x)
+    static constexpr int kTabD = kTabC + 16 * R;          // float2[R]: (u.y, u.z)
+    static constexpr int kBest = kTabD + 8 * R;           // u64[R]: nearest accepted hit
     static constexpr int kPend = kBest + 8 * R;           // int[R]: outstanding stack + leaf-queue entries
-    static constexpr int kMarks = kPend + 4 * R;          // u32[64]: TRI-step expansion marks (all zero between steps)
-    static constexpr int kStack = kMarks + 256;           // u32[SCAP]
+    static constexpr int kMarks = kPend + 4 * R;          // u8[128]: TRI-step expansion marks (all zero between steps)
+    static constexpr int kStack = kMarks + 128;           // u32[SCAP]
     static constexpr int kLeaf = kStack + 4 * SCAP;       // uint2[LCAP]: (first triangle, slot | count << 8)
     static constexpr int kStage = kLeaf + 8 * LCAP;       // float4[64] x2: ray records fetched from the queue, not yet in a slot
     static constexpr int kBytes = kStage + 2048;
@@ -62,12 +63,14 @@ __device__ __forceinline__ int lanes_below(unsigned long long m) {   // set bits
 }
 
 // BoundingBox::intersect (cpu:146-157) through the fused filter (see RayBox in rt_wavefront.hip.h): returns whether
-// the filter decided; `hit` is then the reference's result.  A = (r.xyz, c0), B = (O*r).xyz; c0 = +inf for rays the
-// filter must not decide (0 / denormal / inf / NaN components), which makes every comparison below false.
-__device__ __forceinline__ bool qbox_filter(const float4 lo, const float4 hi, const float4 A, const float4 B, bool &hit) {
-    const float ax = fmaf(lo.x, A.x, -B.x), bx = fmaf(hi.x, A.x, -B.x);
-    const float ay = fmaf(lo.y, A.y, -B.y), by = fmaf(hi.y, A.y, -B.y);
-    const float az = fmaf(lo.z, A.z, -B.z), bz = fmaf(hi.z, A.z, -B.z);
+// the filter decided; `hit` is then the reference's result.  A = (r.xyz, c0) with r = v_rcp_f32(u), C = (O.xyz, -);
+// c0 = +inf for rays the filter must not decide (0 / denormal / inf / NaN components), which makes every comparison
+// below false.
+__device__ __forceinline__ bool qbox_filter(const float4 lo, const float4 hi, const float4 A, const float4 C, bool &hit) {
+    const float ox = C.x * A.x, oy = C.y * A.y, oz = C.z * A.z;       // RayBox::ox.. (single roundings, as in ray_box)
+    const float ax = fmaf(lo.x, A.x, -ox), bx = fmaf(hi.x, A.x, -ox);
+    const float ay = fmaf(lo.y, A.y, -oy), by = fmaf(hi.y, A.y, -oy);
+    const float az = fmaf(lo.z, A.z, -oz), bz = fmaf(hi.z, A.z, -oz);
     const float tn = vmax3(vmin(ax, bx), vmin(ay, by), vmin(az, bz));
     const float tf = vmin3(vmax(ax, bx), vmax(ay, by), vmax(az, bz));
     const float M = vmax(vmax3abs(ax, bx, ay), vmax3abs(by, az, bz));
@@ -107,10 +110,12 @@ __device__ __forceinline__ bool qtri_test(const float4 q0, const float4 q1, cons
     return t > 0 && t > tri_tmin && t < 1e9f;   // cpu:235, cpu:301; 1e9f = INF narrowed (cpu:283)
 }
 
-template <bool STATS, int R>
-__global__ __launch_bounds__(kQBlock) void wf_travq(const Scene sc, const Frame fr, const WfState st, const int cap) {
-    constexpr int SCAP = QStackCap<R>::value, LCAP = 128;
-    constexpr int kLow = 128;                     // refill while the stack holds fewer entries than this
+// LDSN: the first n_lds nodes (breadth-first order: the top of the tree) are staged in LDS behind the waves' carves and
+// read from there; the launch then uses ONE workgroup per CU (blockDim.x = 64 x waves, up to 1024).
+template <bool STATS, int R, bool LDSN>
+__global__ __launch_bounds__(LDSN ? 1024 : kQBlock, 4) void wf_travq(const Scene sc, const Frame fr, const WfState st, const int cap, const int n_lds) {
+    constexpr int SCAP = QStackCap<R>::value, LCAP = 256;
+    constexpr int kLow = 192;                     // refill while the stack holds fewer entries than this
     constexpr int kMinFree = R / 4;               // ... and at least this many slots are free (or the stack is short)
     using Carve = QCarve<R, SCAP, LCAP>;
     static_assert(R <= 64 && (R & (R - 1)) == 0, "ray slots are owned by lanes");
@@ -118,25 +123,27 @@ __global__ __launch_bounds__(kQBlock) void wf_travq(const Scene sc, const Frame 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wib = tid >> 6;
+    const int wpb = LDSN ? (int)(blockDim.x >> 6) : kQBlock / 64;
     unsigned char *const wl = travq_smem + wib * Carve::kBytes;
-    int *const blk_cur = reinterpret_cast<int *>(travq_smem + (kQBlock / 64) * Carve::kBytes);
+    int *const blk_cur = reinterpret_cast<int *>(travq_smem + wpb * Carve::kBytes);
+    float4 *const lnodes = reinterpret_cast<float4 *>(travq_smem + wpb * Carve::kBytes + 16);
     float4 *const tabA = reinterpret_cast<float4 *>(wl + Carve::kTabA);
-    float4 *const tabB = reinterpret_cast<float4 *>(wl + Carve::kTabB);
     float4 *const tabC = reinterpret_cast<float4 *>(wl + Carve::kTabC);
-    float4 *const tabD = reinterpret_cast<float4 *>(wl + Carve::kTabD);
+    float2 *const tabD = reinterpret_cast<float2 *>(wl + Carve::kTabD);
     unsigned long long *const best = reinterpret_cast<unsigned long long *>(wl + Carve::kBest);
     int *const pend = reinterpret_cast<int *>(wl + Carve::kPend);
-    unsigned int *const marks = reinterpret_cast<unsigned int *>(wl + Carve::kMarks);
+    unsigned char *const marks = wl + Carve::kMarks;
     unsigned int *const stack = reinterpret_cast<unsigned int *>(wl + Carve::kStack);
     uint2 *const leafq = reinterpret_cast<uint2 *>(wl + Carve::kLeaf);
     float4 *const stA = reinterpret_cast<float4 *>(wl + Carve::kStage);
     float4 *const stB = stA + 64;
     if (tid == 0) *blk_cur = 0;
-    marks[lane] = 0u;
+    marks[lane] = 0; marks[lane + 64] = 0;
     if (lane < R) pend[lane] = 0;
+    if (LDSN) for (int k = tid; k < 2 * n_lds; k += (int)blockDim.x) lnodes[k] = sc.nodesq[k];
     __syncthreads();
 
-    const float4 *const nodes = sc.nodesq;        // lo.w = other child (internal) | first triangle (leaf); hi.w = -1 | end
+    const float4 *const nodes = sc.nodesq;        // breadth-first order; lo.w = first child, the other is next to it (internal) | first triangle (leaf); hi.w = -1 | end
     const size_t blk_base = (size_t)blockIdx.x * (size_t)st.slots_per_block;
     const int blk_n = st.slots_per_block;
     int stage_n = 0, stage_used = 0;              // wave-uniform: staged records and how many of them have been given a slot
@@ -152,6 +159,44 @@ __global__ __launch_bounds__(kQBlock) void wf_travq(const Scene sc, const Frame 
     unsigned long long dbg_tdrain = 0ull, cy_srv = 0, cy_tri = 0, cy_box = 0, stamp = dbg_on ? __builtin_amdgcn_s_memtime() : 0ull;
     unsigned int d_box = 0, d_boxl = 0, d_tri = 0, d_tril = 0, d_rounds = 0, d_rays = 0, d_serial = 0, d_idle = 0, d_fetch = 0, d_maxtop = 0;
 #define WQ_STAMP(acc) do { if (dbg_on) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - stamp; stamp = t_; } } while (0)
+
+    // node of a stack entry: LDS for the staged top of the tree, L1/L2 otherwise
+    auto load_node = [&](int node, float4 &lo, float4 &hi) {
+        if (LDSN) {
+            const bool inl = node < n_lds;
+            if (inl) { lo = lnodes[2 * node]; hi = lnodes[2 * node + 1]; }
+            if (__ballot(!inl) != 0ull) { if (!inl) { lo = nodes[2 * node]; hi = nodes[2 * node + 1]; } }
+        } else {
+            lo = nodes[2 * node]; hi = nodes[2 * node + 1];
+        }
+    };
+    // stack nearly full: walk the subtree of one popped entry serially with the stackless (skip-pointer) node array
+    auto drain_serial = [&](int o, int node) {
+        const float4 A = tabA[o], C = tabC[o];
+        const float2 D = tabD[o];
+        const f3 O = mk(C.x, C.y, C.z), u = mk(C.w, D.x, D.y);
+        const int xt = sc.q2thr[node];                                // the same node in the stackless array
+        const float4 h0 = sc.nodes[2 * xt + 1];
+        const int end = __float_as_int(h0.w) >= 0 ? xt + 1 : __float_as_int(sc.nodes[2 * xt].w);
+        for (int x = xt; x < end;) {
+            const float4 lo = sc.nodes[2 * x], hi = sc.nodes[2 * x + 1];
+            const int hiw = __float_as_int(hi.w), low = __float_as_int(lo.w);
+            bool hit;
+            if (!qbox_filter(lo, hi, A, C, hit)) hit = slab(lo, hi, O, u);
+            if (STATS) { wk.box++; if (hit) wk.nodes++; }
+            if (hit && hiw >= 0) {
+                if (STATS) wk.tris += (uint32_t)(hiw - low);
+                for (int i = low; i < hiw; ++i) {
+                    const float4 *tp = sc.tri + 3 * (size_t)i;
+                    float t;
+                    if (qtri_test(tp[0], tp[1], tp[2], O, u, fr.tri_tmin, t))
+                        atomicMin(&best[o], (unsigned long long)__float_as_uint(t) << 32 | (unsigned int)i);
+                }
+            }
+            x = (hit || hiw >= 0) ? x + 1 : low;
+        }
+        atomicAdd(&pend[o], -1);
+    };
 
     for (;;) {
         // wave-uniform by construction; say so (the loop-carried values then live in SGPRs and the branches are scalar)
@@ -204,9 +249,8 @@ __global__ __launch_bounds__(kQBlock) void wf_travq(const Scene sc, const Frame 
                     const f3 O = mk(r0.x, r0.y, r0.z), u = mk(r0.w, r1.x, r1.y);
                     const RayBox rb = ray_box(O, u);
                     tabA[lane] = make_float4(rb.rx, rb.ry, rb.rz, rb.safe ? rb.c0 : __builtin_inff());
-                    tabB[lane] = make_float4(rb.ox, rb.oy, rb.oz, 0.f);
                     tabC[lane] = r0;
-                    tabD[lane] = make_float4(r1.x, r1.y, 0.f, 0.f);
+                    tabD[lane] = make_float2(r1.x, r1.y);
                     best[lane] = WF_NOHIT;
                     path = __float_as_int(r1.z);
                 }
@@ -217,7 +261,7 @@ __global__ __launch_bounds__(kQBlock) void wf_travq(const Scene sc, const Frame 
                 if (root_hiw < 0) {
                     if (got) {
                         const int pos = top + 2 * lanes_below(gm);
-                        stack[pos] = (unsigned int)lane << kQNodeBits | (unsigned int)sc.root_left;
+                        stack[pos] = (unsigned int)lane << kQNodeBits | 2u;      // breadth-first order: the root's children are 1, 2
                         stack[pos + 1] = (unsigned int)lane << kQNodeBits | 1u;
                         pend[lane] = 2;
                     }
@@ -239,7 +283,7 @@ __global__ __launch_bounds__(kQBlock) void wf_travq(const Scene sc, const Frame 
             }
         }
         WQ_STAMP(cy_srv);
-        // =============================== TRI step ===============================
+        // =============================== TRI step: two triangles per lane ===============================
         const unsigned int lcount = ltail - lhead;
         if (lcount >= 64u || (top == 0 && lcount > 0u)) {
             const unsigned int m = lcount < 64u ? lcount : 64u;
@@ -247,33 +291,37 @@ __global__ __launch_bounds__(kQBlock) void wf_travq(const Scene sc, const Frame 
             if ((unsigned int)lane < m) E = leafq[(lhead + (unsigned int)lane) & (LCAP - 1)];
             const unsigned int c = E.y >> 8;                         // >= 1 for queued entries, 0 beyond them
             const unsigned int incl = wave_incl_scan(c);
-            const unsigned int P = incl - c;                         // first lane of this entry's triangles
-            const bool part = c > 0u && P < 64u;
+            const unsigned int P = incl - c;                         // position of this entry's first triangle
+            const bool part = c > 0u && P < 128u;
             const unsigned int all = (unsigned int)__builtin_amdgcn_readlane((int)incl, 63);
-            const unsigned int total = all < 64u ? all : 64u;
-            if (part) marks[P] = 1u;
+            const unsigned int total = all < 128u ? all : 128u;
+            if (part) marks[P] = 1;
             __builtin_amdgcn_wave_barrier();
-            const unsigned int mk_ = marks[lane];
-            const unsigned long long B = __ballot(mk_ != 0u);
+            const unsigned int mk0 = marks[lane], mk1 = marks[lane + 64];
+            const unsigned long long B0 = __ballot(mk0 != 0u), B1 = __ballot(mk1 != 0u);
             __builtin_amdgcn_wave_barrier();
-            if (part) marks[P] = 0u;
-            const int j = lanes_below(B) + (int)((B >> lane) & 1ull) - 1;   // entry whose range covers this lane
-            const unsigned int first_j = (unsigned int)__shfl((int)E.x, j, 64);
-            const unsigned int y_j = (unsigned int)__shfl((int)E.y, j, 64);
-            const unsigned int P_j = (unsigned int)__shfl((int)P, j, 64);
-            if ((unsigned int)lane < total) {
-                const int o = (int)(y_j & 0xffu);
-                const int i = (int)(first_j + ((unsigned int)lane - P_j));
-                const float4 *tp = sc.tri + 3 * (size_t)i;
-                const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
-                const float4 C = tabC[o], D = tabD[o];
-                float t;
-                if (qtri_test(q0, q1, q2, mk(C.x, C.y, C.z), mk(C.w, D.x, D.y), fr.tri_tmin, t))
-                    atomicMin(&best[o], (unsigned long long)__float_as_uint(t) << 32 | (unsigned int)i);
-            }
-            const bool full = part && P + c <= 64u;
-            if (part && !full) {                                     // at most one entry straddles lane 63: keep its rest
-                const unsigned int took = 64u - P;
+            if (part) marks[P] = 0;
+            // entry whose triangle range covers position lane (j0) and position lane + 64 (j1)
+            const int j0 = lanes_below(B0) + (int)((B0 >> lane) & 1ull) - 1;
+            const int j1 = __popcll(B0) + lanes_below(B1) + (int)((B1 >> lane) & 1ull) - 1;
+            const unsigned int f0 = (unsigned int)__shfl((int)E.x, j0, 64), y0 = (unsigned int)__shfl((int)E.y, j0, 64), P0 = (unsigned int)__shfl((int)P, j0, 64);
+            const unsigned int f1 = (unsigned int)__shfl((int)E.x, j1, 64), y1 = (unsigned int)__shfl((int)E.y, j1, 64), P1 = (unsigned int)__shfl((int)P, j1, 64);
+            const bool t0 = (unsigned int)lane < total, t1 = (unsigned int)lane + 64u < total;
+            const int o0 = t0 ? (int)(y0 & 0xffu) : 0, o1 = t1 ? (int)(y1 & 0xffu) : 0;
+            const int i0 = t0 ? (int)(f0 + ((unsigned int)lane - P0)) : 0, i1 = t1 ? (int)(f1 + ((unsigned int)lane + 64u - P1)) : 0;
+            const float4 *tp0 = sc.tri + 3 * (size_t)i0, *tp1 = sc.tri + 3 * (size_t)i1;
+            const float4 a0 = tp0[0], a1 = tp0[1], a2 = tp0[2];
+            const float4 b0 = tp1[0], b1 = tp1[1], b2 = tp1[2];
+            const float4 C0 = tabC[o0], C1 = tabC[o1];
+            const float2 D0 = tabD[o0], D1 = tabD[o1];
+            float ta, tb;
+            const bool ok0 = qtri_test(a0, a1, a2, mk(C0.x, C0.y, C0.z), mk(C0.w, D0.x, D0.y), fr.tri_tmin, ta) && t0;
+            const bool ok1 = qtri_test(b0, b1, b2, mk(C1.x, C1.y, C1.z), mk(C1.w, D1.x, D1.y), fr.tri_tmin, tb) && t1;
+            if (ok0) atomicMin(&best[o0], (unsigned long long)__float_as_uint(ta) << 32 | (unsigned int)i0);
+            if (ok1) atomicMin(&best[o1], (unsigned long long)__float_as_uint(tb) << 32 | (unsigned int)i1);
+            const bool full = part && P + c <= 128u;
+            if (part && !full) {                                     // at most one entry straddles position 127: keep its rest
+                const unsigned int took = 128u - P;
                 leafq[(lhead + (unsigned int)lane) & (LCAP - 1)] = make_uint2(E.x + took, (E.y & 0xffu) | (c - took) << 8);
             }
             lhead += (unsigned int)__popcll(__ballot(full));
@@ -283,74 +331,66 @@ __global__ __launch_bounds__(kQBlock) void wf_travq(const Scene sc, const Frame 
             continue;
         }
         if (top == 0) {
-            if (drained && __ballot(path >= 0) == 0ull) break;       // every wave gets here: each step consumes entries
+            if (drained && stage_used >= stage_n && __ballot(path >= 0) == 0ull) break;   // every wave gets here: each step consumes entries
             d_idle++;
             continue;
         }
-        const int n = top < 64 ? top : 64;
-        const bool act = lane < n;
-        const unsigned int e = act ? stack[top - 1 - lane] : 0u;
-        top -= n;
-        const int o = (int)(e >> kQNodeBits);
-        const int node = (int)(e & kQNodeMask);
-        if (cap - (top + n) < 64) {
-            // =============================== serial drain (stack nearly full) ===============================
-            if (act) {
-                const float4 A = tabA[o], B = tabB[o], C = tabC[o], D = tabD[o];
-                const f3 O = mk(C.x, C.y, C.z), u = mk(C.w, D.x, D.y);
-                const float4 h0 = sc.nodes[2 * node + 1];
-                const int end = __float_as_int(h0.w) >= 0 ? node + 1 : __float_as_int(sc.nodes[2 * node].w);
-                for (int x = node; x < end;) {
-                    const float4 lo = sc.nodes[2 * x], hi = sc.nodes[2 * x + 1];
-                    const int hiw = __float_as_int(hi.w), low = __float_as_int(lo.w);
-                    bool hit;
-                    if (!qbox_filter(lo, hi, A, B, hit)) hit = slab(lo, hi, O, u);
-                    if (STATS) { wk.box++; if (hit) wk.nodes++; }
-                    if (hit && hiw >= 0) {
-                        if (STATS) wk.tris += (uint32_t)(hiw - low);
-                        for (int i = low; i < hiw; ++i) {
-                            const float4 *tp = sc.tri + 3 * (size_t)i;
-                            float t;
-                            if (qtri_test(tp[0], tp[1], tp[2], O, u, fr.tri_tmin, t))
-                                atomicMin(&best[o], (unsigned long long)__float_as_uint(t) << 32 | (unsigned int)i);
-                        }
-                    }
-                    x = (hit || hiw >= 0) ? x + 1 : low;
-                }
-                atomicAdd(&pend[o], -1);
-            }
+        // =============================== BOX step: two entries per lane ===============================
+        const int n = top < 128 ? top : 128;
+        const bool act0 = lane < n, act1 = lane + 64 < n;
+        const unsigned int e0 = act0 ? stack[top - 1 - lane] : 0u;
+        const unsigned int e1 = act1 ? stack[top - 65 - lane] : 0u;
+        const int o0 = (int)(e0 >> kQNodeBits), o1 = (int)(e1 >> kQNodeBits);
+        const int nd0 = (int)(e0 & kQNodeMask), nd1 = (int)(e1 & kQNodeMask);
+        if (cap - top < 128) {                                        // no room for up to 256 pushes: serial drain
+            top -= n;
+            if (act0) drain_serial(o0, nd0);
+            if (act1) drain_serial(o1, nd1);
             d_serial++;
             WQ_STAMP(cy_box);
             continue;
         }
-        // =============================== BOX step ===============================
-        const float4 A = tabA[o], B = tabB[o];
-        const float4 lo = nodes[2 * node], hi = nodes[2 * node + 1];
-        bool hit;
-        const bool decided = qbox_filter(lo, hi, A, B, hit);
+        top -= n;
+        const float4 A0 = tabA[o0], C0 = tabC[o0], A1 = tabA[o1], C1 = tabC[o1];
+        float4 lo0, hi0, lo1, hi1;
+        load_node(nd0, lo0, hi0);
+        load_node(nd1, lo1, hi1);
+        bool hit0, hit1;
+        const bool dec0 = qbox_filter(lo0, hi0, A0, C0, hit0);
+        const bool dec1 = qbox_filter(lo1, hi1, A1, C1, hit1);
         // literal arithmetic for undecided lanes behind a wave-uniform branch (six IEEE divisions, almost never needed)
-        if (__builtin_expect(__ballot(act && !decided) != 0ull, 0)) {
-            if (act && !decided) {
-                const float4 C = tabC[o], D = tabD[o];
-                hit = slab(lo, hi, mk(C.x, C.y, C.z), mk(C.w, D.x, D.y));
-            }
+        if (__builtin_expect(__ballot((act0 && !dec0) || (act1 && !dec1)) != 0ull, 0)) {
+            if (act0 && !dec0) { const float2 D = tabD[o0]; hit0 = slab(lo0, hi0, mk(C0.x, C0.y, C0.z), mk(C0.w, D.x, D.y)); }
+            if (act1 && !dec1) { const float2 D = tabD[o1]; hit1 = slab(lo1, hi1, mk(C1.x, C1.y, C1.z), mk(C1.w, D.x, D.y)); }
         }
-        const int hiw = __float_as_int(hi.w), low = __float_as_int(lo.w);
-        const int cnt = hiw - low;
-        hit = hit && act;
-        const bool hitI = hit && hiw < 0;
-        const bool hitL = hit && hiw >= 0 && cnt > 0;
-        if (STATS) { wk.box += act ? 1u : 0u; wk.nodes += hit ? 1u : 0u; wk.tris += (hit && hiw >= 0) ? (uint32_t)cnt : 0u; }
-        const unsigned long long mI = __ballot(hitI), mL = __ballot(hitL);
-        if (hitI) {
-            const int pos = top + 2 * lanes_below(mI);
-            stack[pos] = (e & ~kQNodeMask) | (unsigned int)low;      // the other child
-            stack[pos + 1] = e + 1u;                                 // the child stored right behind its parent
+        const int hiw0 = __float_as_int(hi0.w), low0 = __float_as_int(lo0.w), cnt0 = hiw0 - low0;
+        const int hiw1 = __float_as_int(hi1.w), low1 = __float_as_int(lo1.w), cnt1 = hiw1 - low1;
+        hit0 = hit0 && act0; hit1 = hit1 && act1;
+        const bool hI0 = hit0 && hiw0 < 0, hI1 = hit1 && hiw1 < 0;
+        const bool hL0 = hit0 && hiw0 >= 0 && cnt0 > 0, hL1 = hit1 && hiw1 >= 0 && cnt1 > 0;
+        if (STATS) {
+            wk.box += (act0 ? 1u : 0u) + (act1 ? 1u : 0u); wk.nodes += (hit0 ? 1u : 0u) + (hit1 ? 1u : 0u);
+            wk.tris += ((hit0 && hiw0 >= 0) ? (uint32_t)cnt0 : 0u) + ((hit1 && hiw1 >= 0) ? (uint32_t)cnt1 : 0u);
         }
-        top += 2 * __popcll(mI);
-        if (hitL) leafq[(ltail + (unsigned int)lanes_below(mL)) & (LCAP - 1)] = make_uint2((unsigned int)low, (unsigned int)o | (unsigned int)cnt << 8);
-        ltail += (unsigned int)__popcll(mL);
-        if (act && !hitL) atomicAdd(&pend[o], hitI ? 1 : -1);        // internal hit: -1 + 2; leaf hit: -1 + 1; miss: -1
+        const unsigned long long mI0 = __ballot(hI0), mI1 = __ballot(hI1), mL0 = __ballot(hL0), mL1 = __ballot(hL1);
+        const int nI0 = __popcll(mI0), nL0 = __popcll(mL0);
+        if (hI0) {
+            const int pos = top + 2 * lanes_below(mI0);
+            const unsigned int c = (e0 & ~kQNodeMask) | (unsigned int)low0;
+            stack[pos] = c + 1u; stack[pos + 1] = c;                 // the two children are neighbours
+        }
+        if (hI1) {
+            const int pos = top + 2 * (nI0 + lanes_below(mI1));
+            const unsigned int c = (e1 & ~kQNodeMask) | (unsigned int)low1;
+            stack[pos] = c + 1u; stack[pos + 1] = c;
+        }
+        top += 2 * (nI0 + __popcll(mI1));
+        if (hL0) leafq[(ltail + (unsigned int)lanes_below(mL0)) & (LCAP - 1)] = make_uint2((unsigned int)low0, (unsigned int)o0 | (unsigned int)cnt0 << 8);
+        if (hL1) leafq[(ltail + (unsigned int)(nL0 + lanes_below(mL1))) & (LCAP - 1)] = make_uint2((unsigned int)low1, (unsigned int)o1 | (unsigned int)cnt1 << 8);
+        ltail += (unsigned int)(nL0 + __popcll(mL1));
+        // outstanding entries: internal hit -1 + 2, leaf hit -1 + 1, miss -1 (inactive lanes add 0 to slot 0)
+        atomicAdd(&pend[o0], hI0 ? 1 : (act0 && !hL0) ? -1 : 0);
+        atomicAdd(&pend[o1], hI1 ? 1 : (act1 && !hL1) ? -1 : 0);
         if (dbg_on) { d_box++; d_boxl += (unsigned int)n; if ((unsigned int)top > d_maxtop) d_maxtop = (unsigned int)top; }
         WQ_STAMP(cy_box);
     }
@@ -358,7 +398,8 @@ __global__ __launch_bounds__(kQBlock) void wf_travq(const Scene sc, const Frame 
     if (dbg_on && lane == 0) {
         unsigned long long *d = st.dbg + 16 * (size_t)((blockIdx.x * blockDim.x + tid) >> 6);
         d[0] = dbg_t0; d[1] = __builtin_amdgcn_s_memrealtime(); d[2] = d_box; d[3] = d_boxl; d[4] = d_tri; d[5] = d_tril;
-        d[6] = d_rounds; d[7] = d_rays; d[8] = d_serial; d[9] = cy_srv; d[10] = cy_tri; d[11] = cy_box; d[12] = dbg_tdrain; d[13] = d_idle; d[14] = d_fetch; d[15] = d_maxtop;
+        d[6] = d_rounds; d[7] = d_rays; d[8] = d_serial; d[9] = cy_srv; d[10] = cy_tri; d[11] = cy_box; d[12] = dbg_tdrain; d[13] = d_idle;
+        d[14] = d_fetch; d[15] = d_maxtop;
     }
     wf_flush_work<STATS>(fr, wk);
 }

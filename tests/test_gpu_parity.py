@@ -211,10 +211,13 @@ def test_variants_are_bitwise_identical_at_full_size(ctx, cat_golden):
     assert int(ref[..., 3].sum()) == 16588799
 
 
-@pytest.mark.parametrize("env", [{"RT_TRAVQ_CAP": "256"}, {"RT_TRAVQ_R": "32"}, {"RT_TRAVQ_R": "32", "RT_TRAVQ_CAP": "256"}])
+@pytest.mark.parametrize("env", [{"RT_TRAVQ_CAP": "256"}, {"RT_TRAVQ_R": "32"}, {"RT_TRAVQ_R": "32", "RT_TRAVQ_CAP": "256"},
+                                 {"RT_TRAVQ_LDS": "12"}, {"RT_TRAVQ_LDS": "12", "RT_TRAVQ_R": "32"}, {"RT_TRAVQ_LDS": "16"},
+                                 {"RT_TRAVQ_LDS": "8", "RT_TRAVQ_CAP": "256"}])
 def test_work_stack_traversal_bounded_stack_and_slot_counts(ctx, cat_golden, monkeypatch, env):
-    """wf_travq with a 256-entry stack (forces the serial-drain path that keeps LDS bounded for any tree) and with
-    32 ray slots per wave: same bits and same work counters as the default configuration."""
+    """wf_travq with a 256-entry stack (forces the serial-drain path that keeps LDS bounded for any tree), with
+    32 ray slots per wave, and with all / the top 15 BVH nodes staged in LDS (RT_TRAVQ_LDS = waves per CU): same bits
+    and same work counters as the stackless-walk kernel."""
     upload(ctx, "cpu", cat_golden)
     p = rt.make_params(640, 360, 2, 3, variant="wavefront_queue", **rt.scenes.CPU_LAUNCHER)
     ref = ctx.render(rt.make_params(640, 360, 2, 3, variant="wavefront", **rt.scenes.CPU_LAUNCHER))

@@ -23,8 +23,9 @@ print("wave duration us: mean %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f ; start o
 print("end time us: p10 %.1f p50 %.1f p90 %.1f max %.1f" % tuple(np.percentile((t1 - base) / 100.0, [10, 50, 90, 100])))
 box, boxl, tri, tril = (a[:, k].astype(float) for k in (2, 3, 4, 5))
 print("fetches %.1f max stack %d" % (a[:, 14].mean(), a[:, 15].max()))
+print("fetches %.1f max stack %d" % (a[:, 14].mean(), a[:, 15].max()))
 print("per wave: BOX steps %.0f (occupancy %.3f)  TRI steps %.0f (occupancy %.3f)  refill rounds %.0f rays %.0f  serial %.1f idle loops %.1f" %
-      (box.mean(), boxl.sum() / 64 / max(box.sum(), 1), tri.mean(), tril.sum() / 64 / max(tri.sum(), 1), a[:, 6].mean(), a[:, 7].mean(), a[:, 8].mean(), a[:, 13].mean()))
+      (box.mean(), boxl.sum() / 128 / max(box.sum(), 1), tri.mean(), tril.sum() / 128 / max(tri.sum(), 1), a[:, 6].mean(), a[:, 7].mean(), a[:, 8].mean(), a[:, 13].mean()))
 cy = a[:, 9:12].astype(float)
 tot = cy.sum()
 print("cycle shares: service %.3f tri %.3f box %.3f ; cycles per wave %.0f ; per BOX step %.0f per TRI step %.0f per refill round %.0f" %
