@@ -198,14 +198,14 @@ def main():
             if st["trav_launches"] > 0:
                 # wavefront variant: the dominant kernel is the traversal kernel; its launches of the last timed
                 # frame are bracketed by HIP events inside the library, on the stream they run on
-                kname = "rtk::wf_trav<false>"
+                kname = {6: "rtk::wf_trav<false, false>", 7: "rtk::wf_trav<false, true>"}.get(st["variant"], "rtk::wf_travq<false, 64, false>")
                 launches = st["trav_launches"]
                 k_ms = st["trav_ms"] / launches
-                # `parts` sub-frames run concurrently on separate streams; the timed launches are part 0's.  While one of
-                # them runs, the matching launches of the other parts run beside it, so the chip moves the whole step's
-                # bytes (all parts) in that window: achieved = step bytes / launch duration.
+                # `parts` sub-frames run concurrently on separate streams (one traversal launch per part and step); the
+                # timed launches are part 0's.  achieved = ONE launch's algorithmic bytes / its own duration, although the
+                # twin launch of the other part shares the chip during that time (conservative).
                 parts = max(st.get("parts", 1), 1)
-                alg_launch = trav_bytes / world / launches
+                alg_launch = trav_bytes / world / (launches * parts)
             else:
                 kname = "rtk::render_persistent<false>" if st["variant"] == 1 else "rtk::render_kernel<false>"
                 launches, k_ms, alg_launch = 1, kernel_ms_max, (trav_bytes + fb_bytes) / world
@@ -213,7 +213,7 @@ def main():
             res["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                                "kernel": kname, "kernel_ms": round(k_ms, 4), "launches_per_frame": launches * max(st.get("parts", 1), 1), "concurrent_launches": max(st.get("parts", 1), 1),
-                               "algorithmic_bytes_per_launch": int(alg_launch / max(st.get("parts", 1), 1)), "algorithmic_bytes_per_launch_window": int(alg_launch),
+                               "algorithmic_bytes_per_launch": int(alg_launch),
                                "frame_algorithmic_bytes": int(trav_bytes + fb_bytes), "frame_kernels_ms": round(kernel_ms_max, 4),
                                "per_ray": {k: round(counts[k] / counts["rays"], 3) for k in ("box_tests", "nodes", "tri_tests")},
                                "note": "algorithmic bytes (SURVEY 8d: 24 B/box test + 16 B/node + 48 B/triangle test); "

@@ -201,9 +201,9 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
     const size_t lds_nodes_bytes = (size_t)ctx->scene.n_nodes * 32 + (rtk::kTravBlockLds / 64) * (size_t)rtk::TravCarve<256, 4>::kBytes + 16;
     const bool lds_fits = ctx->scene.n_nodes > 0 && lds_nodes_bytes <= 160 * 1024;
     int variant = p->variant;
-    // measured on MI355X (cat, 1080p): nodes through L2/L1 at 6 waves/SIMD beat LDS-staged nodes at 4 waves/SIMD
-    // (the traversal is latency-bound; occupancy wins), so AUTO is the HBM/L2 variant
-    if (variant == RT_VARIANT_AUTO) variant = RT_VARIANT_WAVEFRONT;
+    // measured on MI355X (cat, 1080p): the work-stack traversal (1.67 ms/frame) beats the per-lane stackless walk
+    // (2.48 ms/frame; with LDS-staged nodes 2.65), so AUTO is the work-stack variant
+    if (variant == RT_VARIANT_AUTO) variant = RT_VARIANT_WAVEFRONT_QUEUE;
     if (variant == RT_VARIANT_WAVEFRONT_LDS && !lds_fits) {
         if (ctx->scene.n_nodes == 0) variant = RT_VARIANT_WAVEFRONT;      // no mesh: nothing to stage
         else return fail(ctx, RT_ERR_UNSUPPORTED, "%d BVH nodes need %zu bytes of LDS (> 160 KiB)", ctx->scene.n_nodes, lds_nodes_bytes);
@@ -290,7 +290,7 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
                     RT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, travq_fn(work_dev != nullptr, qR, false), rtk::kQBlock, trav_lds));
                     ctx->travq_blocks_per_cu[qi] = nb > 0 ? nb : 1;
                 }
-                bpc = ctx->travq_blocks_per_cu[qi];
+                bpc = std::min(ctx->travq_blocks_per_cu[qi], 4);    // a fifth workgroup per CU fits but does not pay (measured)
             }
         }
         if (const char *e = getenv("RT_TRAV_WAVES")) { const int v = atoi(e); if (!ldsn && v >= 1 && v <= bpc) bpc = v; }
@@ -324,6 +324,11 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
             rtk::WfState &st = pt.st;
             st.n_groups = 2 * st.n_paths / 4;                         // two ray slots per path (continuation + shadow)
             int64_t tblocks = std::max<int64_t>(1, (int64_t)ctx->n_cus * bpc / parts);   // all parts co-resident
+            // work-stack kernel: more workgroups than fit at once; the dispatcher hands a finished workgroup's CU share to
+            // the next one, which evens out the cost differences between the workgroups' shares of the rays
+            int oversub = 2;                                           // measured: 1.85 -> 1.67 ms/frame (cat, 1080p)
+            if (const char *e = getenv("RT_TRAVQ_OVERSUB")) { const int v = atoi(e); if (v >= 1 && v <= 16) oversub = v; }
+            if (queue && !qlds) tblocks *= oversub;
             int min_groups = 16 * wpb;                                // >= 64 ray slots per wave on average
             if (const char *e = getenv("RT_TRAV_MIN_GROUPS")) { const int v = atoi(e); if (v >= 4) min_groups = v * wpb; }
             int64_t groups_per_block = (st.n_groups + tblocks - 1) / tblocks;

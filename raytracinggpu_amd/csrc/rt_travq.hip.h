@@ -30,9 +30,9 @@ constexpr int kQBlock = 256;                 // 4 waves per workgroup share one 
 constexpr int kQNodeBits = 26;               // entry = slot << 26 | node
 constexpr unsigned kQNodeMask = (1u << kQNodeBits) - 1u;
 
-// stack capacity: sized so that four waves' carves (+ the cursor) fill 40 KiB (R = 64: 4 workgroups per CU) or less;
+// stack capacity: sized so that four waves' carves (+ the cursor) fill 32 KiB (R = 64: 5 workgroups per CU) or less;
 // a fuller stack is drained serially (see above), which the cat never needs
-template <int R> struct QStackCap { static constexpr int value = 664; };
+template <int R> struct QStackCap { static constexpr int value = 652; };
 
 template <int R, int SCAP, int LCAP> struct QCarve {
     static constexpr int kTabA = 0;                       // float4[R]: (1/u.xyz by v_rcp_f32, c0 | +inf if the filter must not decide)
@@ -43,8 +43,9 @@ template <int R, int SCAP, int LCAP> struct QCarve {
     static constexpr int kMarks = kPend + 4 * R;          // u8[128]: TRI-step expansion marks (all zero between steps)
     static constexpr int kStack = kMarks + 128;           // u32[SCAP]
     static constexpr int kLeaf = kStack + 4 * SCAP;       // uint2[LCAP]: (first triangle, slot | count << 8)
-    static constexpr int kStage = kLeaf + 8 * LCAP;       // float4[64] x2: ray records fetched from the queue, not yet in a slot
-    static constexpr int kBytes = kStage + 2048;
+    static constexpr int kStage = kLeaf + 8 * LCAP;       // u8[64]: lanes whose registers hold a fetched ray record that has no slot yet
+    static constexpr int kBytes = kStage + 64;
+    static_assert(kBytes % 16 == 0 && kLeaf % 8 == 0 && kStack % 4 == 0, "the next wave's float4 tables start at kBytes");
 };
 
 // wave64 inclusive prefix sum by DPP (row_shr 1,2,4,8 inside the 16-lane rows, then row_bcast:15 / row_bcast:31).
@@ -113,7 +114,7 @@ __device__ __forceinline__ bool qtri_test(const float4 q0, const float4 q1, cons
 // LDSN: the first n_lds nodes (breadth-first order: the top of the tree) are staged in LDS behind the waves' carves and
 // read from there; the launch then uses ONE workgroup per CU (blockDim.x = 64 x waves, up to 1024).
 template <bool STATS, int R, bool LDSN>
-__global__ __launch_bounds__(LDSN ? 1024 : kQBlock, 4) void wf_travq(const Scene sc, const Frame fr, const WfState st, const int cap, const int n_lds) {
+__global__ __launch_bounds__(LDSN ? 1024 : kQBlock, LDSN ? 4 : 5) void wf_travq(const Scene sc, const Frame fr, const WfState st, const int cap, const int n_lds) {
     constexpr int SCAP = QStackCap<R>::value, LCAP = 256;
     constexpr int kLow = 192;                     // refill while the stack holds fewer entries than this
     constexpr int kMinFree = R / 4;               // ... and at least this many slots are free (or the stack is short)
@@ -135,8 +136,7 @@ __global__ __launch_bounds__(LDSN ? 1024 : kQBlock, 4) void wf_travq(const Scene
     unsigned char *const marks = wl + Carve::kMarks;
     unsigned int *const stack = reinterpret_cast<unsigned int *>(wl + Carve::kStack);
     uint2 *const leafq = reinterpret_cast<uint2 *>(wl + Carve::kLeaf);
-    float4 *const stA = reinterpret_cast<float4 *>(wl + Carve::kStage);
-    float4 *const stB = stA + 64;
+    unsigned char *const sidx = wl + Carve::kStage;
     if (tid == 0) *blk_cur = 0;
     marks[lane] = 0; marks[lane + 64] = 0;
     if (lane < R) pend[lane] = 0;
@@ -147,6 +147,9 @@ __global__ __launch_bounds__(LDSN ? 1024 : kQBlock, 4) void wf_travq(const Scene
     const size_t blk_base = (size_t)blockIdx.x * (size_t)st.slots_per_block;
     const int blk_n = st.slots_per_block;
     int stage_n = 0, stage_used = 0;              // wave-uniform: staged records and how many of them have been given a slot
+    float4 sp0 = make_float4(0, 0, 0, 0);         // staged record of this lane (registers; sidx[k] = lane of the k-th staged record)
+    float2 sp1 = make_float2(0, 0);
+    int spf = 0;
     const int root_hiw = __float_as_int(sc.root_hi.w);
     int path = -1;                                // lane r < R owns ray slot r: the path index of the ray in it
     int top = 0;                                  // wave-uniform: entries on the stack
@@ -228,14 +231,14 @@ __global__ __launch_bounds__(LDSN ? 1024 : kQBlock, 4) void wf_travq(const Scene
                     if (lane == 0) base = atomicAdd(blk_cur, 64);
                     base = __builtin_amdgcn_readfirstlane(base);
                     if (base + 64 >= blk_n) { drained = true; if (dbg_on && !dbg_tdrain) dbg_tdrain = __builtin_amdgcn_s_memrealtime(); }
-                    int f = 0;
-                    float4 r0 = make_float4(0, 0, 0, 0); float2 r1 = make_float2(0, 0);
+                    spf = 0;
                     if (base + lane < blk_n) {
                         const size_t q = (size_t)blk_base + (size_t)(base + lane);
-                        f = st.QF[q]; r0 = st.QA[q]; r1 = st.QB[q];
+                        spf = st.QF[q]; sp0 = st.QA[q]; sp1 = st.QB[q];
                     }
-                    const unsigned long long am = __ballot(f != 0);
-                    if (f != 0) { const int k = lanes_below(am); stA[k] = r0; stB[k] = make_float4(r1.x, r1.y, __int_as_float(f - 1), 0.f); }
+                    const unsigned long long am = __ballot(spf != 0);
+                    if (spf != 0) sidx[lanes_below(am)] = (unsigned char)lane;
+                    __builtin_amdgcn_wave_barrier();
                     stage_n = __popcll(am);
                     stage_used = 0;
                     if (dbg_on) d_fetch++;
@@ -244,15 +247,18 @@ __global__ __launch_bounds__(LDSN ? 1024 : kQBlock, 4) void wf_travq(const Scene
                 const int take = n_free < stage_n - stage_used ? n_free : stage_n - stage_used;
                 const int rank = lanes_below(freem);
                 const bool got = lane < R && path < 0 && rank < take;
+                const int src = got ? (int)sidx[stage_used + rank] : lane;   // the staged record lives in that lane's registers
+                const float4 r0 = make_float4(__shfl(sp0.x, src, 64), __shfl(sp0.y, src, 64), __shfl(sp0.z, src, 64), __shfl(sp0.w, src, 64));
+                const float2 r1 = make_float2(__shfl(sp1.x, src, 64), __shfl(sp1.y, src, 64));
+                const int rf = __shfl(spf, src, 64);
                 if (got) {
-                    const float4 r0 = stA[stage_used + rank], r1 = stB[stage_used + rank];
                     const f3 O = mk(r0.x, r0.y, r0.z), u = mk(r0.w, r1.x, r1.y);
                     const RayBox rb = ray_box(O, u);
                     tabA[lane] = make_float4(rb.rx, rb.ry, rb.rz, rb.safe ? rb.c0 : __builtin_inff());
                     tabC[lane] = r0;
-                    tabD[lane] = make_float2(r1.x, r1.y);
+                    tabD[lane] = r1;
                     best[lane] = WF_NOHIT;
-                    path = __float_as_int(r1.z);
+                    path = rf - 1;
                 }
                 stage_used += take;
                 // the root box was tested when the ray was emitted (wf_emit_ray): start with what is below it
