@@ -180,6 +180,33 @@ int rt_count_work(rt_ctx *ctx, const rt_params *p, int row_begin, int row_end, r
 int rt_synchronize(rt_ctx *ctx);
 int rt_get_stats(rt_ctx *ctx, rt_stats *stats);        /* waits for the last render to finish */
 
+/* --- one host process, several devices (SURVEY 8b rt_render_multi; the reference uses the implicit device 0,
+ *     optimized.cu:828-856).  The frame is cut into RT_MULTI_TILE_ROWS-row tiles, tile k -> device k mod n
+ *     (interleaved); the scene is replicated; every device renders its tiles; each peer pushes them over
+ *     xGMI into the root device (device_ids[0]); one kernel on the root restores row order.  The result is bitwise
+ *     the single-device frame.  Device ids may repeat (several contexts on one device).  The one-process-per-GPU
+ *     path (rt_render_device + an RCCL gather) is the other way to use several GPUs. ------------- */
+#define RT_MAX_DEVICES 16
+#define RT_MULTI_TILE_ROWS 8
+typedef struct rt_multi rt_multi;
+typedef struct rt_multi_stats {
+    int32_t  n_devices;
+    int32_t  device_id[RT_MAX_DEVICES];
+    float    kernel_ms[RT_MAX_DEVICES];   /* HIP-event time of each device's render kernels                  */
+    float    gather_ms;                   /* root: end of its own render -> frame assembled (waits for peers) */
+    float    frame_ms;                    /* host wall clock of the whole call                                */
+    uint64_t rays;                        /* rays traced for the frame (sum of the .w channel)                */
+} rt_multi_stats;
+int rt_multi_create(rt_multi **m, const int *device_ids, int n_devices);
+int rt_multi_destroy(rt_multi *m);
+const char *rt_multi_last_error(const rt_multi *m);   /* m may be NULL: last global error */
+int rt_multi_scene_upload(rt_multi *m, const rt_sphere *spheres, int n_spheres, const rt_mesh *mesh,
+                          const rt_light *light, const rt_camera *camera);
+/* full frame, height*width float4, to host memory / to memory of the root device */
+int rt_render_multi(rt_multi *m, const rt_params *p, float *out_rgba_host);
+int rt_render_multi_device(rt_multi *m, const rt_params *p, void *out_rgba_dev_on_root);
+int rt_multi_get_stats(rt_multi *m, rt_multi_stats *stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,7 +19,10 @@ VARIANTS = {"auto": 0, "global": 1, "lds_verts": 2, "lds_top": 3, "lds_all": 4, 
 # every symbol include/raytrace_hip.h declares (tests check the .so exports each)
 EXPORTS = ["rt_abi_version", "rt_device_count", "rt_ctx_create", "rt_ctx_destroy", "rt_last_error",
            "rt_device_name", "rt_scene_upload", "rt_render", "rt_render_device", "rt_tonemap_device",
-           "rt_render_rgb8", "rt_synchronize", "rt_get_stats", "rt_count_work"]
+           "rt_render_rgb8", "rt_synchronize", "rt_get_stats", "rt_count_work",
+           "rt_multi_create", "rt_multi_destroy", "rt_multi_last_error", "rt_multi_scene_upload", "rt_render_multi",
+           "rt_render_multi_device", "rt_multi_get_stats"]
+MAX_DEVICES = 16
 
 
 class RtError(RuntimeError):
@@ -68,6 +71,11 @@ class Stats(C.Structure):
                 ("trav_ms", C.c_float), ("trav_launches", C.c_int32), ("parts", C.c_int32), ("reserved", C.c_int32)]
 
 
+class MultiStats(C.Structure):
+    _fields_ = [("n_devices", C.c_int32), ("device_id", C.c_int32 * MAX_DEVICES), ("kernel_ms", C.c_float * MAX_DEVICES),
+                ("gather_ms", C.c_float), ("frame_ms", C.c_float), ("rays", C.c_uint64)]
+
+
 _lib = None
 
 
@@ -105,6 +113,14 @@ def load():
     L.rt_count_work.argtypes = [vp, C.POINTER(Params), C.c_int, C.c_int, C.POINTER(Work)]
     L.rt_synchronize.argtypes = [vp]
     L.rt_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.rt_multi_create.argtypes = [C.POINTER(vp), C.POINTER(C.c_int), C.c_int]
+    L.rt_multi_destroy.argtypes = [vp]
+    L.rt_multi_last_error.argtypes = [vp]
+    L.rt_multi_last_error.restype = C.c_char_p
+    L.rt_multi_scene_upload.argtypes = [vp, C.POINTER(Sphere), C.c_int, C.POINTER(Mesh), C.POINTER(Light), C.POINTER(Camera)]
+    L.rt_render_multi.argtypes = [vp, C.POINTER(Params), C.POINTER(C.c_float)]
+    L.rt_render_multi_device.argtypes = [vp, C.POINTER(Params), vp]
+    L.rt_multi_get_stats.argtypes = [vp, C.POINTER(MultiStats)]
     _lib = L
     return L
 
@@ -132,6 +148,38 @@ def interleaved_rows(height, tile_rows, rank, world):
         else np.zeros(0, np.int64)
     r = Rows(rank * tile_rows, len(idx), tile_rows, world)
     return r, idx
+
+
+def _marshal_scene(spheres, mesh, light, camera):
+    """C structs of a scene description (shared by Context and MultiContext)."""
+    arr = (Sphere * max(len(spheres), 1))()
+    for i, s in enumerate(spheres):
+        c, r, a = s[0], s[1], s[2]
+        arr[i].center[:] = c
+        arr[i].radius = r
+        arr[i].albedo[:] = a
+        arr[i].mirror = int(s[3]) if len(s) > 3 else 0
+        arr[i].in_refraction_index = s[4] if len(s) > 4 else 1.0
+        arr[i].out_refraction_index = s[5] if len(s) > 5 else 1.0
+    m, keep = None, None
+    if mesh is not None:
+        v = np.ascontiguousarray(mesh["vertices"], np.float32).reshape(-1, 3)
+        ix = np.ascontiguousarray(mesh["indices"], np.int32)
+        stride = ix.shape[1] if ix.ndim == 2 else 3
+        bv = np.ascontiguousarray(mesh["bvh_arr10"], np.float32).reshape(-1, 10)
+        m = Mesh()
+        m.vertices = v.ctypes.data_as(C.POINTER(C.c_float)); m.n_vertices = len(v)
+        m.indices = ix.ctypes.data_as(C.POINTER(C.c_int32)); m.index_stride = stride
+        m.n_triangles = ix.size // stride
+        m.bvh_arr10 = bv.ctypes.data_as(C.POINTER(C.c_float)); m.n_nodes = len(bv)
+        m.albedo[:] = mesh.get("albedo", (0.25, 0.25, 0.25))
+        m.object_slot = mesh.get("object_slot", len(spheres))
+        keep = (v, ix, bv)
+    lt = Light(); lt.position[:] = light[0]; lt.intensity = light[1]
+    cam = Camera(); cam.position[:] = camera[0]
+    # float alpha = PI/3 (cpu:666)
+    cam.fov = np.float32(np.pi / 3) if camera[1] is None else np.float32(camera[1])
+    return arr, len(spheres), m, lt, cam, keep
 
 
 class Context:
@@ -165,35 +213,8 @@ class Context:
     def scene_upload(self, spheres, mesh=None, light=((-10.0, 20.0, 40.0), 3e10), camera=((0.0, 0.0, 55.0), None)):
         """spheres: iterable of (center, radius, albedo[, mirror, n_in, n_out]);
         mesh: dict(vertices, indices, bvh_arr10, albedo, object_slot) with the reference's array layouts."""
-        arr = (Sphere * max(len(spheres), 1))()
-        for i, s in enumerate(spheres):
-            c, r, a = s[0], s[1], s[2]
-            arr[i].center[:] = c
-            arr[i].radius = r
-            arr[i].albedo[:] = a
-            arr[i].mirror = int(s[3]) if len(s) > 3 else 0
-            arr[i].in_refraction_index = s[4] if len(s) > 4 else 1.0
-            arr[i].out_refraction_index = s[5] if len(s) > 5 else 1.0
-        m = None
-        if mesh is not None:
-            v = np.ascontiguousarray(mesh["vertices"], np.float32).reshape(-1, 3)
-            ix = np.ascontiguousarray(mesh["indices"], np.int32)
-            stride = ix.shape[1] if ix.ndim == 2 else 3
-            bv = np.ascontiguousarray(mesh["bvh_arr10"], np.float32).reshape(-1, 10)
-            m = Mesh()
-            m.vertices = v.ctypes.data_as(C.POINTER(C.c_float)); m.n_vertices = len(v)
-            m.indices = ix.ctypes.data_as(C.POINTER(C.c_int32)); m.index_stride = stride
-            m.n_triangles = ix.size // stride
-            m.bvh_arr10 = bv.ctypes.data_as(C.POINTER(C.c_float)); m.n_nodes = len(bv)
-            m.albedo[:] = mesh.get("albedo", (0.25, 0.25, 0.25))
-            m.object_slot = mesh.get("object_slot", len(spheres))
-            self._keep = (v, ix, bv)
-        lt = Light(); lt.position[:] = light[0]; lt.intensity = light[1]
-        cam = Camera(); cam.position[:] = camera[0]
-        # float alpha = PI/3 (cpu:666)
-        cam.fov = np.float32(np.pi / 3) if camera[1] is None else np.float32(camera[1])
-        self._check(self._L.rt_scene_upload(self._h, arr, len(spheres), C.byref(m) if m is not None else None,
-                                            C.byref(lt), C.byref(cam)))
+        arr, n, m, lt, cam, self._keep = _marshal_scene(spheres, mesh, light, camera)
+        self._check(self._L.rt_scene_upload(self._h, arr, n, C.byref(m) if m is not None else None, C.byref(lt), C.byref(cam)))
 
     def render(self, params, row_begin=0, row_end=None):
         row_end = params.height if row_end is None else row_end
@@ -230,3 +251,46 @@ class Context:
         s = Stats()
         self._check(self._L.rt_get_stats(self._h, C.byref(s)))
         return {k: getattr(s, k) for k, _ in Stats._fields_}
+
+
+class MultiContext:
+    """One host process, several devices (rt_multi_*): interleaved 8-row tiles, peer copies to device_ids[0]."""
+
+    def __init__(self, device_ids):
+        self._L = load()
+        self._h = C.c_void_p()
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        rc = self._L.rt_multi_create(C.byref(self._h), ids, len(device_ids))
+        if rc != RT_OK:
+            raise RtError(rc, self._L.rt_multi_last_error(None).decode())
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.rt_multi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc != RT_OK:
+            raise RtError(rc, self._L.rt_multi_last_error(self._h).decode())
+
+    def scene_upload(self, spheres, mesh=None, light=((-10.0, 20.0, 40.0), 3e10), camera=((0.0, 0.0, 55.0), None)):
+        arr, n, m, lt, cam, self._keep = _marshal_scene(spheres, mesh, light, camera)
+        self._check(self._L.rt_multi_scene_upload(self._h, arr, n, C.byref(m) if m is not None else None, C.byref(lt), C.byref(cam)))
+
+    def render(self, params):
+        out = np.empty((params.height, params.width, 4), np.float32)
+        self._check(self._L.rt_render_multi(self._h, C.byref(params), out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def render_device(self, params, out_ptr):
+        self._check(self._L.rt_render_multi_device(self._h, C.byref(params), C.c_void_p(out_ptr)))
+
+    def stats(self):
+        s = MultiStats()
+        self._check(self._L.rt_multi_get_stats(self._h, C.byref(s)))
+        n = s.n_devices
+        return {"n_devices": n, "device_id": list(s.device_id)[:n], "kernel_ms": list(s.kernel_ms)[:n],
+                "gather_ms": s.gather_ms, "frame_ms": s.frame_ms, "rays": int(s.rays)}

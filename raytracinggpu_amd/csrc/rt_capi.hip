@@ -10,7 +10,9 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -792,3 +794,5 @@ int rt_get_stats(rt_ctx *ctx, rt_stats *stats) {
 }
 
 }  // extern "C"
+
+#include "rt_multi.hip.h"

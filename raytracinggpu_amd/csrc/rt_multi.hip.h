@@ -1,0 +1,213 @@
+// rt_multi.hip.h -- one host process driving several devices (rt_render_multi).
+// Included at the end of rt_capi.hip (same translation unit: it launches through launch_render).
+//
+// The reference renders on the implicit CUDA device 0 (optimized.cu:828-856).  Here the frame is cut into 8-row
+// tiles, tile k -> device k mod n (interleaved: the cat sits in the middle rows), the scene is replicated,
+// every device renders its tiles into a dense local buffer on its own stream, each peer pushes that buffer over xGMI
+// into the root device's staging area (hipMemcpyPeerAsync, one link per peer, no ring), and one kernel on the root
+// restores row order.  The one-process-per-GPU path (bench.py, torch.distributed) does the same exchange with one
+// RCCL gather instead; results are bitwise the single-device frame either way.
+
+namespace rtk {
+
+struct MultiSrc { const float4 *base[RT_MAX_DEVICES]; };
+
+// frame[row][x] <- the dense buffer of the device that rendered `row`
+__global__ __launch_bounds__(256) void deinterleave_kernel(const MultiSrc src, int n_dev, int W, int H, int tile_rows, float4 *__restrict__ frame,
+                                                           unsigned long long *__restrict__ rays) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float w = 0.f;
+    if (i < (int64_t)W * H) {
+        const int row = (int)(i / W), x = (int)(i - (int64_t)row * W);
+        const int tile = row / tile_rows, k = tile % n_dev;
+        const int lrow = (tile / n_dev) * tile_rows + row % tile_rows;
+        const float4 v = src.base[k][(size_t)lrow * W + x];
+        frame[i] = v;
+        w = v.w;
+    }
+    // rays traced = sum of .w (small exact integers): wave sums, one atomic per wave
+    const uint32_t s = wave_sum((uint32_t)w);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(rays, (unsigned long long)s);
+}
+
+}  // namespace rtk
+
+struct rt_multi {
+    int n = 0;
+    rt_ctx *ctx[RT_MAX_DEVICES] = {};
+    DevBuf local[RT_MAX_DEVICES];           // dense tiles of device k (on device k)
+    DevBuf stage, frame, rays;              // on the root device (device of ctx[0])
+    hipEvent_t done[RT_MAX_DEVICES] = {};   // device k's tiles have arrived on the root
+    hipEvent_t g0 = nullptr, g1 = nullptr;
+    rt_multi_stats stats{};
+    std::string err;
+};
+
+namespace {
+
+int mfail(rt_multi *m, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    if (m) m->err = buf;
+    return code;
+}
+#define RT_MHIP(m, call)                                                                       \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) return mfail(m, RT_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+int multi_render(rt_multi *m, const rt_params *p, void *out_dev_on_root, float *out_host) {
+    if (!m) return mfail(nullptr, RT_ERR_INVALID, "multi context is NULL");
+    if (!p) return mfail(m, RT_ERR_INVALID, "params is NULL");
+    if (p->width <= 0 || p->height <= 0) return mfail(m, RT_ERR_INVALID, "width/height must be positive");
+    const auto t_begin = std::chrono::steady_clock::now();
+    const int n = m->n, W = p->width, H = p->height, R = RT_MULTI_TILE_ROWS;
+    const int n_tiles = (H + R - 1) / R;
+    rt_ctx *root = m->ctx[0];
+    size_t off[RT_MAX_DEVICES + 1] = {0};
+    int nrows[RT_MAX_DEVICES] = {0};
+    for (int k = 0; k < n; ++k) {
+        for (int t = k; t < n_tiles; t += n) nrows[k] += std::min(R, H - t * R);
+        off[k + 1] = off[k] + (k == 0 ? 0 : (size_t)nrows[k] * W);          // device 0's tiles are read in place
+    }
+    int rc;
+    RT_MHIP(m, hipSetDevice(root->device));
+    const size_t frame_bytes = (size_t)W * H * sizeof(float4);
+    if ((rc = ensure(root, m->stage, off[n] * sizeof(float4))) != RT_OK || (rc = ensure(root, m->rays, 8)) != RT_OK ||
+        (!out_dev_on_root && (rc = ensure(root, m->frame, frame_bytes)) != RT_OK)) { m->err = root->err; return rc; }
+    RT_MHIP(m, hipMemsetAsync(m->rays.p, 0, 8, root->stream));
+    // 1. every device renders its tiles; peers push them to the root as soon as they are done
+    for (int k = 0; k < n; ++k) {
+        rt_ctx *c = m->ctx[k];
+        RT_MHIP(m, hipSetDevice(c->device));
+        if ((rc = ensure(c, m->local[k], std::max<size_t>((size_t)nrows[k] * W, 1) * sizeof(float4))) != RT_OK) { m->err = c->err; return rc; }
+        rt_rows rows{k * R, nrows[k], R, n};
+        if ((rc = launch_render(c, p, &rows, m->local[k].p, c->stream)) != RT_OK) { m->err = c->err; return rc; }
+        if (k > 0) {
+            if (nrows[k] > 0)
+                RT_MHIP(m, hipMemcpyPeerAsync(static_cast<float4 *>(m->stage.p) + off[k], root->device, m->local[k].p, c->device,
+                                              (size_t)nrows[k] * W * sizeof(float4), c->stream));
+            RT_MHIP(m, hipEventRecord(m->done[k], c->stream));
+        }
+    }
+    // 2. root: wait for the peers, restore row order
+    RT_MHIP(m, hipSetDevice(root->device));
+    RT_MHIP(m, hipEventRecord(m->g0, root->stream));
+    for (int k = 1; k < n; ++k) RT_MHIP(m, hipStreamWaitEvent(root->stream, m->done[k], 0));
+    rtk::MultiSrc src{};
+    src.base[0] = static_cast<const float4 *>(m->local[0].p);
+    for (int k = 1; k < n; ++k) src.base[k] = static_cast<const float4 *>(m->stage.p) + off[k];
+    float4 *frame = static_cast<float4 *>(out_dev_on_root ? out_dev_on_root : m->frame.p);
+    const int64_t npix = (int64_t)W * H;
+    hipLaunchKernelGGL(rtk::deinterleave_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, root->stream, src, n, W, H, R, frame,
+                       static_cast<unsigned long long *>(m->rays.p));
+    RT_MHIP(m, hipGetLastError());
+    RT_MHIP(m, hipEventRecord(m->g1, root->stream));
+    unsigned long long rays = 0;
+    RT_MHIP(m, hipMemcpyAsync(&rays, m->rays.p, 8, hipMemcpyDeviceToHost, root->stream));
+    if (out_host) RT_MHIP(m, hipMemcpyAsync(out_host, frame, frame_bytes, hipMemcpyDeviceToHost, root->stream));
+    RT_MHIP(m, hipStreamSynchronize(root->stream));
+    // 3. statistics
+    m->stats.n_devices = n;
+    m->stats.rays = rays;
+    RT_MHIP(m, hipEventElapsedTime(&m->stats.gather_ms, m->g0, m->g1));
+    for (int k = 0; k < n; ++k) {
+        rt_stats s{};
+        if ((rc = rt_get_stats(m->ctx[k], &s)) != RT_OK) { m->err = m->ctx[k]->err; return rc; }
+        m->stats.kernel_ms[k] = s.kernel_ms;
+        m->stats.device_id[k] = m->ctx[k]->device;
+    }
+    m->stats.frame_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_multi_create(rt_multi **out, const int *device_ids, int n_devices) {
+    if (!out) return mfail(nullptr, RT_ERR_INVALID, "multi out-pointer is NULL");
+    *out = nullptr;
+    if (!device_ids || n_devices < 1 || n_devices > RT_MAX_DEVICES)
+        return mfail(nullptr, RT_ERR_INVALID, "need 1..%d device ids", RT_MAX_DEVICES);
+    rt_multi *m = new (std::nothrow) rt_multi();
+    if (!m) return mfail(nullptr, RT_ERR_INVALID, "out of host memory");
+    m->n = n_devices;
+    for (int k = 0; k < n_devices; ++k) {
+        const int rc = rt_ctx_create(&m->ctx[k], device_ids[k]);
+        if (rc != RT_OK) { rt_multi_destroy(m); return rc; }
+    }
+    hipError_t e = hipSetDevice(m->ctx[0]->device);
+    if (e == hipSuccess) e = hipEventCreate(&m->g0);
+    if (e == hipSuccess) e = hipEventCreate(&m->g1);
+    for (int k = 1; k < n_devices && e == hipSuccess; ++k) {
+        e = hipSetDevice(m->ctx[k]->device);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&m->done[k], hipEventDisableTiming);
+        if (e == hipSuccess && m->ctx[k]->device != m->ctx[0]->device) {
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, m->ctx[k]->device, m->ctx[0]->device) == hipSuccess && can) {
+                const hipError_t pe = hipDeviceEnablePeerAccess(m->ctx[0]->device, 0);   // direct xGMI writes into the root's staging area
+                if (pe != hipSuccess) (void)hipGetLastError();                             // already enabled: fine
+            }
+        }
+    }
+    if (e != hipSuccess) { const int code = mfail(nullptr, RT_ERR_HIP, "multi context: %s", hipGetErrorString(e)); rt_multi_destroy(m); return code; }
+    *out = m;
+    return RT_OK;
+}
+
+int rt_multi_destroy(rt_multi *m) {
+    if (!m) return RT_OK;
+    if (m->ctx[0]) {
+        (void)hipSetDevice(m->ctx[0]->device);
+        if (m->ctx[0]->stream) (void)hipStreamSynchronize(m->ctx[0]->stream);
+        m->stage.release(); m->frame.release(); m->rays.release();
+        if (m->g0) (void)hipEventDestroy(m->g0);
+        if (m->g1) (void)hipEventDestroy(m->g1);
+    }
+    for (int k = 0; k < m->n; ++k) {
+        if (!m->ctx[k]) continue;
+        (void)hipSetDevice(m->ctx[k]->device);
+        if (m->ctx[k]->stream) (void)hipStreamSynchronize(m->ctx[k]->stream);
+        m->local[k].release();
+        if (m->done[k]) (void)hipEventDestroy(m->done[k]);
+        rt_ctx_destroy(m->ctx[k]);
+    }
+    delete m;
+    return RT_OK;
+}
+
+const char *rt_multi_last_error(const rt_multi *m) { return m ? m->err.c_str() : g_last_error.c_str(); }
+
+int rt_multi_scene_upload(rt_multi *m, const rt_sphere *spheres, int n_spheres, const rt_mesh *mesh,
+                          const rt_light *light, const rt_camera *camera) {
+    if (!m) return mfail(nullptr, RT_ERR_INVALID, "multi context is NULL");
+    for (int k = 0; k < m->n; ++k) {
+        const int rc = rt_scene_upload(m->ctx[k], spheres, n_spheres, mesh, light, camera);
+        if (rc != RT_OK) { m->err = m->ctx[k]->err; return rc; }
+    }
+    return RT_OK;
+}
+
+int rt_render_multi(rt_multi *m, const rt_params *p, float *out_rgba_host) {
+    if (m && !out_rgba_host) return mfail(m, RT_ERR_INVALID, "output pointer is NULL");
+    return multi_render(m, p, nullptr, out_rgba_host);
+}
+
+int rt_render_multi_device(rt_multi *m, const rt_params *p, void *out_rgba_dev_on_root) {
+    if (m && !out_rgba_dev_on_root) return mfail(m, RT_ERR_INVALID, "output pointer is NULL");
+    return multi_render(m, p, out_rgba_dev_on_root, nullptr);
+}
+
+int rt_multi_get_stats(rt_multi *m, rt_multi_stats *stats) {
+    if (!m || !stats) return mfail(m, RT_ERR_INVALID, "bad arguments");
+    *stats = m->stats;
+    return RT_OK;
+}
+
+}  // extern "C"

@@ -35,6 +35,7 @@ def test_struct_sizes_match_header():
     assert ctypes.sizeof(_capi.Rows) == 16
     assert ctypes.sizeof(_capi.Light) == 16 and ctypes.sizeof(_capi.Camera) == 16
     assert ctypes.sizeof(_capi.Stats) == 48 and ctypes.sizeof(_capi.Work) == 32
+    assert ctypes.sizeof(_capi.MultiStats) == 4 + 64 + 64 + 4 + 4 + 4 + 8     # incl. 4 bytes of padding before `rays`
 
 
 def test_no_cpu_fallback_without_a_gpu():
@@ -43,6 +44,15 @@ def test_no_cpu_fallback_without_a_gpu():
     with pytest.raises(rt.RtError) as e:
         rt.Context(0)
     assert e.value.code in (-2, -3)
+
+
+def test_multi_device_entry_fails_loudly_without_a_gpu():
+    if rt.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(rt.RtError):
+        rt.MultiContext([0, 0])
+    with pytest.raises(rt.RtError):
+        rt.MultiContext([])
 
 
 def test_interleaved_rows_partition_the_image():

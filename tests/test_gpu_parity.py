@@ -227,3 +227,80 @@ def test_work_stack_traversal_bounded_stack_and_slot_counts(ctx, cat_golden, mon
     got = ctx.render(p)
     np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
     assert ctx.count_work(p) == work
+
+
+def test_jitter_sigma_0p2_matches_oracle(ctx, oracle, oracle_cat, cat_golden):
+    """anti-aliasing jitter sigma = 0.2 (optimized.cu:753; cpu:705-707 with its sigma line enabled),
+    Box-Muller from the counter RNG's dims 2,3: same estimator as the oracle, within the stated tolerance."""
+    upload(ctx, "cpu", cat_golden)
+    kw = dict(rt.scenes.CPU_LAUNCHER, sigma=0.2)
+    got = ctx.render(rt.make_params(320, 200, 4, 2, **kw))
+    exp, _, _ = oracle.Scene.preset("cpu", oracle_cat).render(320, 200, 4, 2, sigma=0.2, want_rgb8=False)
+    same = values_equal(got[..., :3], exp[..., :3]).mean()
+    print(f"sigma=0.2: bit-identical channels {same:.6f}, Linf(gamma) {linf(oracle, got, exp):.3g}")
+    assert linf(oracle, got, exp) <= TOL
+    assert same > 0.99
+    np.testing.assert_array_equal(got[..., 3], exp[..., 3])
+    # jitter really moves the samples: the image differs from the sigma = 0 one along edges
+    plain = ctx.render(rt.make_params(320, 200, 4, 2, **rt.scenes.CPU_LAUNCHER))
+    assert (plain[..., :3] != got[..., :3]).any()
+
+
+def test_config4_3840x2160_lds_staged_variants_and_oracle_bands(ctx, oracle, oracle_cat, cat_golden, monkeypatch):
+    """BASELINE config 4 (cat, 3840x2160, LDS-staged variant): the default kernel, the work-stack kernel with the top
+    of the BVH staged in LDS and the stackless kernel with every node staged in LDS write the same bits; row bands of
+    the deterministic (num_bounce = 0) frame equal the oracle bit for bit."""
+    upload(ctx, "cpu", cat_golden)
+    W, H = 3840, 2160
+    p3 = rt.make_params(W, H, 1, 3, **rt.scenes.CPU_LAUNCHER)
+    ref = ctx.render(p3)
+    assert np.isfinite(ref).all()
+    lds_all = ctx.render(rt.make_params(W, H, 1, 3, variant="wavefront_lds", **rt.scenes.CPU_LAUNCHER))
+    np.testing.assert_array_equal(lds_all.view(np.uint32), ref.view(np.uint32))
+    del lds_all
+    monkeypatch.setenv("RT_TRAVQ_LDS", "16")
+    lds_top = ctx.render(p3)
+    monkeypatch.delenv("RT_TRAVQ_LDS")
+    np.testing.assert_array_equal(lds_top.view(np.uint32), ref.view(np.uint32))
+    del lds_top
+    direct = ctx.render(rt.make_params(W, H, 1, 0, **rt.scenes.CPU_LAUNCHER))
+    sc = oracle.Scene.preset("cpu", oracle_cat)
+    for a, b in ((0, 4), (1076, 1092), (1600, 1604), (2156, 2160)):
+        exp, _, _ = sc.render(W, H, 1, 0, rows=(a, b), want_rgb8=False)
+        np.testing.assert_array_equal(direct[a:b].view(np.uint32), exp.view(np.uint32))
+    exp, _, _ = sc.render(W, H, 1, 3, rows=(1080, 1084), want_rgb8=False)
+    assert linf(oracle, ref[1080:1084], exp) <= TOL
+    np.testing.assert_array_equal(ref[1080:1084, :, 3], exp[..., 3])
+
+
+def test_config5_7680x4320_eight_way_tiles_are_bitwise_the_full_frame(ctx, oracle, oracle_cat, cat_golden):
+    """BASELINE config 5 (cat, 7680x4320, row-tiled over 8 GPUs): the eight ranks' interleaved 8-row tiles, rendered
+    one after the other on the one GPU of the test box, are bitwise the single-device frame (the RNG and the camera
+    are keyed by the global pixel); row bands equal the oracle; rt_render_multi with eight contexts gives the same
+    frame (size-independent properties at the full BASELINE size)."""
+    import torch
+    upload(ctx, "cpu", cat_golden)
+    W, H = 7680, 4320
+    p = rt.make_params(W, H, 1, 1, **rt.scenes.CPU_LAUNCHER)
+    full = ctx.render(p)
+    assert int(full[..., 3].astype(np.float64).sum()) > W * H
+    for rank in range(8):
+        rows, idx = rt.interleaved_rows(H, 8, rank, 8)
+        buf = torch.empty((rows.n_rows, W, 4), dtype=torch.float32, device="cuda:0")
+        ctx.render_device(p, rows, buf.data_ptr())
+        ctx.synchronize()
+        np.testing.assert_array_equal(buf.cpu().numpy().view(np.uint32), full[idx].view(np.uint32))
+        del buf
+    sc = oracle.Scene.preset("cpu", oracle_cat)
+    for a, b in ((2158, 2162), (4316, 4320)):
+        exp, _, _ = sc.render(W, H, 1, 1, rows=(a, b), want_rgb8=False)
+        assert linf(oracle, full[a:b], exp) <= TOL
+        np.testing.assert_array_equal(full[a:b, :, 3], exp[..., 3])
+    mesh = dict(vertices=cat_golden["vertices"], indices=cat_golden["tri_bvh_order"], bvh_arr10=cat_golden["bvh_arr10"],
+                albedo=rt.scenes.CAT_ALBEDO, object_slot=6)
+    m = rt.MultiContext([0] * 8)
+    m.scene_upload(rt.scenes.spheres("cpu"), mesh)
+    got = m.render(p)
+    np.testing.assert_array_equal(got.view(np.uint32), full.view(np.uint32))
+    assert m.stats()["rays"] == int(full[..., 3].astype(np.float64).sum())
+    m.close()

@@ -99,3 +99,34 @@ def test_gathered_gpu_tiles_equal_single_gpu_frame(tmp_path):
     ctx.scene_upload(rt.scenes.spheres("cpu"), hostlib.build_mesh(g["vertices"], g["tri_obj_order"], object_slot=6))
     full = ctx.render(rt.make_params(W, H, spp, b, **rt.scenes.CPU_LAUNCHER))
     np.testing.assert_array_equal(got.view(np.uint32), full.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_single_process_multi_device_frame_is_bitwise_the_single_device_frame():
+    """rt_render_multi (one host process, several device contexts, peer copies + one de-interleave kernel on the
+    root): three contexts on the one GPU of the test box == the single-context frame, bit for bit; ray count and
+    per-device statistics are reported."""
+    import raytracinggpu_amd as rt
+    from .conftest import load_golden
+    g = load_golden("cat_mesh.npz")
+    mesh = dict(vertices=g["vertices"], indices=g["tri_bvh_order"], bvh_arr10=g["bvh_arr10"], albedo=rt.scenes.CAT_ALBEDO, object_slot=6)
+    one = rt.Context(0)
+    one.scene_upload(rt.scenes.spheres("cpu"), mesh)
+    for ids, (W, H) in (([0, 0, 0], (400, 250)), ([0], (333, 77)), ([0, 0, 0, 0, 0, 0, 0, 0], (640, 360))):
+        p = rt.make_params(W, H, 2, 2, **rt.scenes.CPU_LAUNCHER)
+        ref = one.render(p)
+        m = rt.MultiContext(ids)
+        m.scene_upload(rt.scenes.spheres("cpu"), mesh)
+        got = m.render(p)
+        np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
+        st = m.stats()
+        assert st["n_devices"] == len(ids) and st["rays"] == int(ref[..., 3].sum())
+        assert all(k > 0 for k in st["kernel_ms"]) and st["gather_ms"] >= 0 and st["frame_ms"] > 0
+        import torch
+        dev = torch.empty((H, W, 4), dtype=torch.float32, device="cuda:0")
+        m.render_device(p, dev.data_ptr())
+        np.testing.assert_array_equal(dev.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+        m.close()
+    with pytest.raises(rt.RtError):
+        rt.MultiContext([0, 99])
+    one.close()
