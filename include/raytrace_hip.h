@@ -180,6 +180,23 @@ int rt_count_work(rt_ctx *ctx, const rt_params *p, int row_begin, int row_end, r
 int rt_synchronize(rt_ctx *ctx);
 int rt_get_stats(rt_ctx *ctx, rt_stats *stats);        /* waits for the last render to finish */
 
+/* --- posed camera + progressive accumulation: the headless form of realtime_render.cu.  Camera
+ *     {C, yaw, pitch} with Camera::rotate() (realtime_render.cu:803-861); ray generation and per-sample averaging of its
+ *     KernelLaunch (:1100-1134: u_center = C + bz*z + bx*X + by*Y, outcolor += color * (1./num_rays)); accumulation and
+ *     display of :1136-1147 (accumbuffer += frame; display = accumbuffer / framenumber; powf(c, 1/2.2f)); the frame's RNG
+ *     seed is WangHash(framenumber) (:1190-1197, :1268).  Wavefront variants only.  Parity: checked against the oracle's
+ *     restatement; the reference program itself (CUDA + GL, cuRAND) cannot be run, so this row is unpinned. ----------- */
+typedef struct rt_camera_pose { float position[3]; float yaw; float pitch; float fov; } rt_camera_pose;
+int rt_camera_basis(const rt_camera_pose *pose, float bx[3], float by[3], float bz[3]);   /* Camera::rotate(), host */
+/* one frame with the posed camera (no accumulation): full frame to host / rows to device memory */
+int rt_render_pose(rt_ctx *ctx, const rt_params *p, const rt_camera_pose *pose, float *out_rgba_host);
+int rt_render_pose_device(rt_ctx *ctx, const rt_params *p, const rt_camera_pose *pose, const rt_rows *rows, void *out_rgba_dev, void *stream);
+/* disp(): buffer_reset / frames++ / KernelLaunch / display.  Outputs may be NULL.  display: height*width float4
+ * (.xyz = accumulated colour / frames, .w = rays traced so far); rgb8: interleaved RGB8 */
+int rt_progressive_reset(rt_ctx *ctx);
+int rt_progressive_frame(rt_ctx *ctx, const rt_params *p, const rt_camera_pose *pose, float *display_rgba_host, uint8_t *rgb8_host);
+int rt_progressive_frames(const rt_ctx *ctx, int *frames);
+
 /* --- one host process, several devices (SURVEY 8b rt_render_multi; the reference uses the implicit device 0,
  *     optimized.cu:828-856).  The frame is cut into RT_MULTI_TILE_ROWS-row tiles, tile k -> device k mod n
  *     (interleaved); the scene is replicated; every device renders its tiles; each peer pushes them over

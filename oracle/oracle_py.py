@@ -26,7 +26,8 @@ class Params(C.Structure):
                 ("row_begin", C.c_int32), ("row_end", C.c_int32),
                 ("sigma", C.c_float), ("eps", C.c_float), ("tri_tmin", C.c_float), ("fov", C.c_float),
                 ("cam", C.c_float * 3), ("seed", C.c_uint32), ("threads", C.c_int32),
-                ("rng_mode", C.c_int32), ("stride", C.c_int32), ("tile_rows", C.c_int32), ("tile_step", C.c_int32)]
+                ("rng_mode", C.c_int32), ("stride", C.c_int32), ("tile_rows", C.c_int32), ("tile_step", C.c_int32),
+                ("cam_mode", C.c_int32), ("yaw", C.c_float), ("pitch", C.c_float)]
 
 
 def build(force=False):
@@ -76,6 +77,10 @@ def lib():
     L.or_render.argtypes = [vp, C.POINTER(Params), fp, C.POINTER(C.c_uint8), C.POINTER(Counters)]
     L.or_tonemap.argtypes = [fp, C.c_int, C.POINTER(C.c_uint8)]
     L.or_max_threads.restype = C.c_int
+    L.or_camera_basis.argtypes = [C.c_float, C.c_float, fp, fp, fp]
+    L.or_wang_hash.argtypes = [C.c_uint32]
+    L.or_wang_hash.restype = C.c_uint32
+    L.or_progressive_accumulate.argtypes = [fp, fp, C.c_int, C.c_int, fp, C.POINTER(C.c_uint8)]
     _lib = L
     return L
 
@@ -212,8 +217,11 @@ class Scene:
 
     def render(self, W, H, num_rays=1, num_bounce=0, rows=None, sigma=0.0, eps=1e-3, tri_tmin=1e-4,
                fov=None, cam=(0, 0, 55), seed=123456, threads=0, rng_mode=0, stride=1, want_rgb8=True,
-               tile_rows=0, tile_step=0):
+               tile_rows=0, tile_step=0, pose=None):
+        """pose = (yaw, pitch): realtime_render.cu's camera and per-sample averaging."""
         p = Params()
+        if pose is not None:
+            p.cam_mode, p.yaw, p.pitch = 1, pose[0], pose[1]
         p.W, p.H, p.num_rays, p.num_bounce = W, H, num_rays, num_bounce
         p.row_begin, p.row_end = rows if rows else (0, H)
         p.sigma, p.eps, p.tri_tmin = sigma, eps, tri_tmin
@@ -236,6 +244,29 @@ class Scene:
         if rc != 0:
             raise ValueError("or_render: bad parameters")
         return rgba, rgb8, cnt.as_dict()
+
+
+def camera_basis(yaw, pitch):
+    """Camera::rotate() of realtime_render.cu:823-846 -> (bx, by, bz)."""
+    out = [np.zeros(3, np.float32) for _ in range(3)]
+    lib().or_camera_basis(yaw, pitch, *[o.ctypes.data_as(C.POINTER(C.c_float)) for o in out])
+    return out
+
+
+def wang_hash(a):
+    return int(lib().or_wang_hash(a & 0xffffffff))
+
+
+def progressive_accumulate(accum, frame, framenumber):
+    """accum (H,W,4 float32, updated in place) += frame; returns (display float32, rgb8) per realtime:1136-1147."""
+    assert accum.dtype == np.float32 and accum.flags.c_contiguous
+    frame = np.ascontiguousarray(frame, np.float32)
+    disp = np.zeros_like(accum)
+    rgb8 = np.zeros(accum.shape[:-1] + (3,), np.uint8)
+    fpt = C.POINTER(C.c_float)
+    lib().or_progressive_accumulate(accum.ctypes.data_as(fpt), frame.ctypes.data_as(fpt), accum.size // 4, framenumber,
+                                    disp.ctypes.data_as(fpt), rgb8.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return disp, rgb8
 
 
 def tonemap(rgba):

@@ -672,6 +672,48 @@ int or_max_threads(void) {
 #endif
 }
 
+/* Camera::rotate(), realtime_render.cu:823-846 (host code: float cos/sin/sqrt overloads) */
+void or_camera_basis(float yaw, float pitch, float obx[3], float oby[3], float obz[3]) {
+    vec bx = V(1, 0, 0), by = V(0, 1, 0), bz = V(0, 0, -1);
+    const float cy = cosf(yaw), sy = sinf(yaw);
+    bx = vadd(vmuls(bx, cy), vmuls(bz, sy));
+    bz = cross(by, bx);
+    const float cp = cosf(pitch), sp = sinf(pitch);
+    by = vsub(vmuls(by, cp), vmuls(bz, sp));
+    bz = cross(bx, by);
+    bx = normalize(bx); by = normalize(by); bz = normalize(bz);
+    for (int k = 0; k < 3; k++) { obx[k] = bx.d[k]; oby[k] = by.d[k]; obz[k] = bz.d[k]; }
+}
+
+/* WangHash, realtime_render.cu:1190-1197 */
+uint32_t or_wang_hash(uint32_t a) {
+    a = (a ^ 61u) ^ (a >> 16);
+    a = a + (a << 3);
+    a = a ^ (a >> 4);
+    a = a * 0x27d4eb2du;
+    a = a ^ (a >> 15);
+    return a;
+}
+
+/* realtime_render.cu:1136-1147 */
+void or_progressive_accumulate(float *accum, const float *frame, int npix, int framenumber, float *display, uint8_t *out_rgb8) {
+    const float inv = 1.0f / (float)framenumber;                      /* cutil_math operator/(float3, float) */
+    for (int p = 0; p < npix; p++) {
+        for (int k = 0; k < 3; k++) {
+            accum[4 * p + k] += frame[4 * p + k];
+            const float c = accum[4 * p + k] * inv;
+            if (display) display[4 * p + k] = c;
+            if (out_rgb8) {
+                double v = (double)powf(c, 1 / 2.2f);
+                if (!(v < 255.)) v = 255.;
+                out_rgb8[3 * p + k] = (uint8_t)v;
+            }
+        }
+        accum[4 * p + 3] += frame[4 * p + 3];                         /* rays traced so far */
+        if (display) display[4 * p + 3] = accum[4 * p + 3];
+    }
+}
+
 /* main's pixel loop, cpu:693-718 */
 int or_render(const or_scene *s, const or_params *p, float *out_rgba, uint8_t *out_rgb8, or_counters *cnt) {
     const int W = p->W, H = p->H;
@@ -692,6 +734,9 @@ int or_render(const or_scene *s, const or_params *p, float *out_rgba, uint8_t *o
      * the folded value (pinned by tests/golden/ref_render.npz; DESIGN.md hazard H12). */
     const float z = -W / (2 * (float)tan((double)(alpha / 2)));
     const vec Cc = V(p->cam[0], p->cam[1], p->cam[2]);
+    float cbx[3] = {1, 0, 0}, cby[3] = {0, 1, 0}, cbz[3] = {0, 0, -1};
+    if (p->cam_mode == 1) or_camera_basis(p->yaw, p->pitch, cbx, cby, cbz);
+    const vec Bx = V(cbx[0], cbx[1], cbx[2]), By = V(cby[0], cby[1], cby[2]), Bz = V(cbz[0], cbz[1], cbz[2]);
     or_counters total = {0, 0, 0, 0, 0};
     int nthreads = 1;
 #ifdef _OPENMP
@@ -711,6 +756,9 @@ int or_render(const or_scene *s, const or_params *p, float *out_rgba, uint8_t *o
                 /* cpu:699: the +0.5 / -0.5 are double literals, narrowed by Vector(float,...) */
                 vec u_center = V((float)((double)((float)j - (float)W / 2) + 0.5),
                                  (float)((double)((float)H / 2 - (float)i) - 0.5), z);
+                if (p->cam_mode == 1)   /* realtime:1115: cam.C + cam.bz * z + cam.bx * (x - W/2 + 0.5) + cam.by * (H/2 - y - 0.5) */
+                    u_center = vadd(vadd(vadd(Cc, vmuls(Bz, z)), vmuls(Bx, u_center.d[0])), vmuls(By, u_center.d[1]));
+                const float inv_n = (float)(1. / p->num_rays);           /* realtime:1131 color * (1./num_rays) */
                 vec color_total = V(0, 0, 0);
                 uint64_t rays_before = local.rays;
                 uint32_t pixel = (uint32_t)i * (uint32_t)W + (uint32_t)j;
@@ -725,9 +773,9 @@ int or_render(const or_scene *s, const or_params *p, float *out_rgba, uint8_t *o
                                 (float)((double)bm * sin(2 * OR_PI * (double)r2)), 0);
                     vec u = normalize(vadd(u_center, jit));
                     vec color = get_color(s, R(Cc, u, 1.f), p->num_bounce, 0, &c);
-                    color_total = vadd(color_total, color);
+                    color_total = vadd(color_total, p->cam_mode == 1 ? vmuls(color, inv_n) : color);
                 }
-                vec color_avg = vdivs(color_total, (float)p->num_rays);           /* cpu:713 */
+                vec color_avg = p->cam_mode == 1 ? color_total : vdivs(color_total, (float)p->num_rays);   /* cpu:713 */
                 size_t o = (size_t)ii * ncols + jj;
                 if (out_rgba) {
                     out_rgba[4 * o + 0] = color_avg.d[0]; out_rgba[4 * o + 1] = color_avg.d[1];

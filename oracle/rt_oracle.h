@@ -55,6 +55,11 @@ typedef struct or_params {
     int32_t tile_rows;       /* with tile_step > 1: only rows of every tile_step-th tile of      */
     int32_t tile_step;       /* tile_rows rows (counted from row_begin) are rendered, densely
                                 packed in the output (the interleaved tiling of SURVEY 8e)     */
+    int32_t cam_mode;        /* 0: cpu_launcher's fixed camera (cpu:694-699)
+                                1: realtime_render.cu's posed camera and per-sample averaging
+                                   (KernelLaunch realtime:1100-1134, Camera realtime:803-861);
+                                   parity UNPINNED: that program cannot be built here (CUDA + GL)  */
+    float   yaw, pitch;      /* cam_mode 1: Camera::yaw / Camera::pitch                          */
 } or_params;
 
 /* ---- mesh (TriangleMesh, cpu:167-502) ---- */
@@ -121,6 +126,15 @@ int or_render(const or_scene *s, const or_params *p, float *out_rgba, uint8_t *o
 void or_tonemap(const float *rgba, int npix, uint8_t *out_rgb8);
 
 int or_max_threads(void);
+
+/* ---- realtime_render.cu pieces (parity unpinned, see cam_mode) ---- */
+/* Camera::rotate() (realtime:823-846): orthonormal basis from yaw and pitch */
+void or_camera_basis(float yaw, float pitch, float bx[3], float by[3], float bz[3]);
+/* WangHash (realtime:1190-1197): the per-frame RNG seed */
+uint32_t or_wang_hash(uint32_t a);
+/* accumbuffer += frame; display = accumbuffer / framenumber (cutil_math: a * (1.0f / s)); 8-bit image =
+ * (unsigned char)min(powf(c, 1 / 2.2f), 255.) (realtime:1136-1147).  accum/frame/display: npix * 4 floats */
+void or_progressive_accumulate(float *accum, const float *frame, int npix, int framenumber, float *display, uint8_t *out_rgb8);
 
 #ifdef __cplusplus
 }

@@ -20,6 +20,8 @@ VARIANTS = {"auto": 0, "global": 1, "lds_verts": 2, "lds_top": 3, "lds_all": 4, 
 EXPORTS = ["rt_abi_version", "rt_device_count", "rt_ctx_create", "rt_ctx_destroy", "rt_last_error",
            "rt_device_name", "rt_scene_upload", "rt_render", "rt_render_device", "rt_tonemap_device",
            "rt_render_rgb8", "rt_synchronize", "rt_get_stats", "rt_count_work",
+           "rt_camera_basis", "rt_render_pose", "rt_render_pose_device", "rt_progressive_reset", "rt_progressive_frame",
+           "rt_progressive_frames",
            "rt_multi_create", "rt_multi_destroy", "rt_multi_last_error", "rt_multi_scene_upload", "rt_render_multi",
            "rt_render_multi_device", "rt_multi_get_stats"]
 MAX_DEVICES = 16
@@ -71,6 +73,19 @@ class Stats(C.Structure):
                 ("trav_ms", C.c_float), ("trav_launches", C.c_int32), ("parts", C.c_int32), ("reserved", C.c_int32)]
 
 
+class CameraPose(C.Structure):
+    _fields_ = [("position", C.c_float * 3), ("yaw", C.c_float), ("pitch", C.c_float), ("fov", C.c_float)]
+
+
+def make_pose(position=(0.0, 0.0, 55.0), yaw=0.0, pitch=0.3, fov=None):
+    """Camera() of realtime_render.cu:805-810 (C = (0,0,55), yaw 0, pitch 0.3); Scene::pov = PI / 2 (realtime:1021)."""
+    q = CameraPose()
+    q.position[:] = position
+    q.yaw, q.pitch = yaw, pitch
+    q.fov = np.float32(np.pi / 2) if fov is None else np.float32(fov)
+    return q
+
+
 class MultiStats(C.Structure):
     _fields_ = [("n_devices", C.c_int32), ("device_id", C.c_int32 * MAX_DEVICES), ("kernel_ms", C.c_float * MAX_DEVICES),
                 ("gather_ms", C.c_float), ("frame_ms", C.c_float), ("rays", C.c_uint64)]
@@ -113,6 +128,13 @@ def load():
     L.rt_count_work.argtypes = [vp, C.POINTER(Params), C.c_int, C.c_int, C.POINTER(Work)]
     L.rt_synchronize.argtypes = [vp]
     L.rt_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    fp3 = C.POINTER(C.c_float)
+    L.rt_camera_basis.argtypes = [C.POINTER(CameraPose), fp3, fp3, fp3]
+    L.rt_render_pose.argtypes = [vp, C.POINTER(Params), C.POINTER(CameraPose), fp3]
+    L.rt_render_pose_device.argtypes = [vp, C.POINTER(Params), C.POINTER(CameraPose), C.POINTER(Rows), vp, vp]
+    L.rt_progressive_reset.argtypes = [vp]
+    L.rt_progressive_frame.argtypes = [vp, C.POINTER(Params), C.POINTER(CameraPose), fp3, C.POINTER(C.c_uint8)]
+    L.rt_progressive_frames.argtypes = [vp, C.POINTER(C.c_int)]
     L.rt_multi_create.argtypes = [C.POINTER(vp), C.POINTER(C.c_int), C.c_int]
     L.rt_multi_destroy.argtypes = [vp]
     L.rt_multi_last_error.argtypes = [vp]
@@ -123,6 +145,15 @@ def load():
     L.rt_multi_get_stats.argtypes = [vp, C.POINTER(MultiStats)]
     _lib = L
     return L
+
+
+def camera_basis(pose):
+    """Camera::rotate() (realtime_render.cu:823-846) as the library computes it -> (bx, by, bz)."""
+    out = [np.zeros(3, np.float32) for _ in range(3)]
+    rc = load().rt_camera_basis(C.byref(pose), *[o.ctypes.data_as(C.POINTER(C.c_float)) for o in out])
+    if rc != RT_OK:
+        raise RtError(rc, "rt_camera_basis")
+    return out
 
 
 def device_count():
@@ -243,6 +274,28 @@ class Context:
         w = Work()
         self._check(self._L.rt_count_work(self._h, C.byref(params), row_begin, row_end, C.byref(w)))
         return {k: int(getattr(w, k)) for k, _ in Work._fields_}
+
+    def render_pose(self, params, pose):
+        """One frame with realtime_render.cu's posed camera and per-sample averaging (no accumulation)."""
+        out = np.empty((params.height, params.width, 4), np.float32)
+        self._check(self._L.rt_render_pose(self._h, C.byref(params), C.byref(pose), out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def progressive_reset(self):
+        self._check(self._L.rt_progressive_reset(self._h))
+
+    def progressive_frame(self, params, pose):
+        """frames++, render with seed WangHash(frames), accumulate; returns (display float4, rgb8)."""
+        disp = np.empty((params.height, params.width, 4), np.float32)
+        rgb8 = np.empty((params.height, params.width, 3), np.uint8)
+        self._check(self._L.rt_progressive_frame(self._h, C.byref(params), C.byref(pose), disp.ctypes.data_as(C.POINTER(C.c_float)),
+                                                 rgb8.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return disp, rgb8
+
+    def progressive_frames(self):
+        n = C.c_int(0)
+        self._check(self._L.rt_progressive_frames(self._h, C.byref(n)))
+        return n.value
 
     def synchronize(self):
         self._check(self._L.rt_synchronize(self._h))

@@ -38,6 +38,8 @@ struct rt_ctx {
     int n_cus = 0;
     DevBuf wfR0, wfR1, wfM, wfFL, wfS0, wfS1, wfT, wfF, wfLS, wfQ;   // wavefront path state (HBM)
     DevBuf wfQA, wfQB, wfQF;                                        // traversal queue in slot order (work-stack variant)
+    DevBuf accum;                                                   // progressive mode: sum of the frames so far (float4 per pixel)
+    int prog_frames = 0, prog_w = 0, prog_h = 0;
     uint64_t qf_sig = 0;                                            // layout the queue flags were last zeroed for
     int trav_blocks_per_cu[4] = {0, 0, 0, 0};
     int travq_blocks_per_cu[4] = {0, 0, 0, 0};   // [STATS + 2 * (R == 32)]
@@ -184,8 +186,22 @@ size_t travq_carve_bytes(int R) {
     return R == 64 ? (size_t)rtk::QCarve<64, rtk::QStackCap<64>::value, 256>::kBytes : (size_t)rtk::QCarve<32, rtk::QStackCap<32>::value, 256>::kBytes;
 }
 
+// Camera::rotate(), realtime_render.cu:823-846 (host code there too: float cos/sin/sqrt)
+void camera_basis(float yaw, float pitch, float bx[3], float by[3], float bz[3]) {
+    h3 x{1, 0, 0}, y{0, 1, 0}, z{0, 0, -1};
+    const float cy = cosf(yaw), sy = sinf(yaw);
+    x = h3{x.x * cy + z.x * sy, x.y * cy + z.y * sy, x.z * cy + z.z * sy};
+    z = hcross(y, x);
+    const float cp = cosf(pitch), sp = sinf(pitch);
+    y = h3{y.x * cp - z.x * sp, y.y * cp - z.y * sp, y.z * cp - z.z * sp};
+    z = hcross(x, y);
+    auto norm = [](h3 v) { const float n = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); return h3{v.x / n, v.y / n, v.z / n}; };
+    x = norm(x); y = norm(y); z = norm(z);
+    bx[0] = x.x; bx[1] = x.y; bx[2] = x.z; by[0] = y.x; by[1] = y.y; by[2] = y.z; bz[0] = z.x; bz[1] = z.y; bz[2] = z.z;
+}
+
 int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *out_dev, hipStream_t stream,
-                  unsigned long long *work_dev = nullptr) {
+                  unsigned long long *work_dev = nullptr, const rt_camera_pose *pose = nullptr) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
     if (!ctx->have_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_scene_upload has not been called");
     int segs = 0;
@@ -227,6 +243,17 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
     fr.out = static_cast<float4 *>(out_dev);
     fr.work = work_dev;
     fr.out_tile0 = 0; fr.out_tile_step = 1;
+    rtk::Scene scn = ctx->scene;                                      // per-launch copy: a pose moves the camera
+    fr.cam_mode = 0; fr.inv_n = 1.f;
+    if (pose) {                                                       // realtime_render.cu's camera
+        if (variant != RT_VARIANT_WAVEFRONT && variant != RT_VARIANT_WAVEFRONT_LDS && variant != RT_VARIANT_WAVEFRONT_QUEUE)
+            return fail(ctx, RT_ERR_UNSUPPORTED, "a camera pose needs a wavefront variant");
+        fr.cam_mode = 1;
+        camera_basis(pose->yaw, pose->pitch, fr.bx, fr.by, fr.bz);
+        scn.camx = pose->position[0]; scn.camy = pose->position[1]; scn.camz = pose->position[2];
+        fr.z = -(float)p->width / (2 * (float)std::tan((double)(pose->fov / 2)));   // realtime:1112, evaluated as cpu:694 is here
+        fr.inv_n = (float)(1. / p->num_rays);                         // realtime:1131
+    }
 
     ctx->stats.pixels = (uint64_t)rows->n_rows * p->width;
     ctx->stats.variant = variant;
@@ -400,8 +427,8 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
             if (j > 0) RT_HIP(ctx, hipStreamWaitEvent(q, ctx->fork_ev, 0));
             if (pt.st.n_paths == 0) continue;
             for (int s = 0; s < fr.spp; ++s) {
-                if (work_dev) hipLaunchKernelGGL(rtk::wf_begin<true>, dim3(pt.pblocks), dim3(256), 0, q, ctx->scene, pt.fr, pt.st, s);
-                else hipLaunchKernelGGL(rtk::wf_begin<false>, dim3(pt.pblocks), dim3(256), 0, q, ctx->scene, pt.fr, pt.st, s);
+                if (work_dev) hipLaunchKernelGGL(rtk::wf_begin<true>, dim3(pt.pblocks), dim3(256), 0, q, scn, pt.fr, pt.st, s);
+                else hipLaunchKernelGGL(rtk::wf_begin<false>, dim3(pt.pblocks), dim3(256), 0, q, scn, pt.fr, pt.st, s);
                 for (int it = 0; it < (segs > 0 ? segs + 1 : 0); ++it) {
                     if (have_mesh) {
                         pt.st.dbg = (dbg_env && it == dbg_it) ? static_cast<unsigned long long *>(dbgbuf.p) : nullptr;
@@ -409,19 +436,19 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
                         if (timed) RT_HIP(ctx, hipEventRecord(ctx->ev_trav[2 * it], q));
                         const dim3 tg((unsigned)pt.tblocks), tbd(tb);
                         if (queue) {
-                            hipLaunchKernelGGL(travq_fn(work_dev != nullptr, qR, qlds), tg, tbd, trav_lds, q, ctx->scene, pt.fr, pt.st, qcap, q_nlds);
+                            hipLaunchKernelGGL(travq_fn(work_dev != nullptr, qR, qlds), tg, tbd, trav_lds, q, scn, pt.fr, pt.st, qcap, q_nlds);
                         } else if (ldsn) {
-                            if (work_dev) hipLaunchKernelGGL((rtk::wf_trav<true, true>), tg, tbd, trav_lds, q, ctx->scene, pt.fr, pt.st);
-                            else hipLaunchKernelGGL((rtk::wf_trav<false, true>), tg, tbd, trav_lds, q, ctx->scene, pt.fr, pt.st);
+                            if (work_dev) hipLaunchKernelGGL((rtk::wf_trav<true, true>), tg, tbd, trav_lds, q, scn, pt.fr, pt.st);
+                            else hipLaunchKernelGGL((rtk::wf_trav<false, true>), tg, tbd, trav_lds, q, scn, pt.fr, pt.st);
                         } else {
-                            if (work_dev) hipLaunchKernelGGL((rtk::wf_trav<true, false>), tg, tbd, trav_lds, q, ctx->scene, pt.fr, pt.st);
-                            else hipLaunchKernelGGL((rtk::wf_trav<false, false>), tg, tbd, trav_lds, q, ctx->scene, pt.fr, pt.st);
+                            if (work_dev) hipLaunchKernelGGL((rtk::wf_trav<true, false>), tg, tbd, trav_lds, q, scn, pt.fr, pt.st);
+                            else hipLaunchKernelGGL((rtk::wf_trav<false, false>), tg, tbd, trav_lds, q, scn, pt.fr, pt.st);
                         }
                         if (timed) { RT_HIP(ctx, hipEventRecord(ctx->ev_trav[2 * it + 1], q)); ctx->n_trav_events = it + 1; }
                         pt.st.dbg = nullptr;
                     }
-                    if (work_dev) hipLaunchKernelGGL(rtk::wf_advance<true>, dim3(pt.pblocks), dim3(256), 0, q, ctx->scene, pt.fr, pt.st, s);
-                    else hipLaunchKernelGGL(rtk::wf_advance<false>, dim3(pt.pblocks), dim3(256), 0, q, ctx->scene, pt.fr, pt.st, s);
+                    if (work_dev) hipLaunchKernelGGL(rtk::wf_advance<true>, dim3(pt.pblocks), dim3(256), 0, q, scn, pt.fr, pt.st, s);
+                    else hipLaunchKernelGGL(rtk::wf_advance<false>, dim3(pt.pblocks), dim3(256), 0, q, scn, pt.fr, pt.st, s);
                 }
             }
             if (j > 0) { RT_HIP(ctx, hipEventRecord(ctx->part_ev[j], q)); }
@@ -441,8 +468,8 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
         ctx->stats.block_threads = rtk::kBlockThreads;
         ctx->stats.grid_blocks = (int)(grid.x * grid.y);
         RT_HIP(ctx, hipEventRecord(ctx->ev_k0, stream));
-        if (work_dev) hipLaunchKernelGGL(rtk::render_kernel<true>, grid, dim3(rtk::kBlockThreads), lds, stream, ctx->scene, fr);
-        else hipLaunchKernelGGL(rtk::render_kernel<false>, grid, dim3(rtk::kBlockThreads), lds, stream, ctx->scene, fr);
+        if (work_dev) hipLaunchKernelGGL(rtk::render_kernel<true>, grid, dim3(rtk::kBlockThreads), lds, stream, scn, fr);
+        else hipLaunchKernelGGL(rtk::render_kernel<false>, grid, dim3(rtk::kBlockThreads), lds, stream, scn, fr);
     } else {
         // persistent lanes: as many workgroups as are co-resident, pixels drawn from a global queue
         rtk::PFrame pf{};
@@ -470,8 +497,8 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
         ctx->stats.grid_blocks = (int)blocks;
         RT_HIP(ctx, hipMemsetAsync(pf.queue, 0, sizeof(unsigned int), stream));
         RT_HIP(ctx, hipEventRecord(ctx->ev_k0, stream));
-        if (work_dev) hipLaunchKernelGGL(rtk::render_persistent<true>, dim3((unsigned)blocks), dim3(rtk::kPBlock), lds, stream, ctx->scene, pf);
-        else hipLaunchKernelGGL(rtk::render_persistent<false>, dim3((unsigned)blocks), dim3(rtk::kPBlock), lds, stream, ctx->scene, pf);
+        if (work_dev) hipLaunchKernelGGL(rtk::render_persistent<true>, dim3((unsigned)blocks), dim3(rtk::kPBlock), lds, stream, scn, pf);
+        else hipLaunchKernelGGL(rtk::render_persistent<false>, dim3((unsigned)blocks), dim3(rtk::kPBlock), lds, stream, scn, pf);
     }
     RT_HIP(ctx, hipGetLastError());
     RT_HIP(ctx, hipEventRecord(ctx->ev_k1, stream));
@@ -556,7 +583,7 @@ int rt_ctx_destroy(rt_ctx *ctx) {
     ctx->scratch_rgba.release(); ctx->scratch_rgb8.release(); ctx->work.release(); ctx->queue.release();
     ctx->wfR0.release(); ctx->wfR1.release(); ctx->wfM.release(); ctx->wfS0.release(); ctx->wfS1.release();
     ctx->wfT.release(); ctx->wfF.release(); ctx->wfFL.release(); ctx->wfLS.release(); ctx->wfQ.release();
-    ctx->wfQA.release(); ctx->wfQB.release(); ctx->wfQF.release();
+    ctx->wfQA.release(); ctx->wfQB.release(); ctx->wfQF.release(); ctx->accum.release();
     for (hipEvent_t &e : ctx->ev_trav) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t &e : ctx->part_ev) if (e) (void)hipEventDestroy(e);
     for (hipStream_t &q : ctx->part_stream) if (q) (void)hipStreamDestroy(q);
@@ -758,6 +785,76 @@ int rt_count_work(rt_ctx *ctx, const rt_params *p, int row_begin, int row_end, r
     double rays = 0;                                  // .w of every pixel = rays traced for it (exact in binary32)
     for (size_t k = 3; k < fb.size(); k += 4) rays += fb[k];
     out->rays = (uint64_t)rays; out->box_tests = h[1]; out->nodes = h[2]; out->tri_tests = h[3];
+    return RT_OK;
+}
+
+int rt_camera_basis(const rt_camera_pose *pose, float bx[3], float by[3], float bz[3]) {
+    if (!pose || !bx || !by || !bz) return fail(nullptr, RT_ERR_INVALID, "bad arguments");
+    camera_basis(pose->yaw, pose->pitch, bx, by, bz);
+    return RT_OK;
+}
+
+int rt_render_pose(rt_ctx *ctx, const rt_params *p, const rt_camera_pose *pose, float *out_rgba_host) {
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    if (!p || !pose || !out_rgba_host) return fail(ctx, RT_ERR_INVALID, "params/pose/out is NULL");
+    const size_t bytes = (size_t)(p->height > 0 ? p->height : 0) * (p->width > 0 ? p->width : 0) * sizeof(float4);
+    int rc = ensure(ctx, ctx->scratch_rgba, bytes);
+    if (rc != RT_OK) return rc;
+    rt_rows rows{0, p->height, p->height > 0 ? p->height : 1, 1};
+    if ((rc = launch_render(ctx, p, &rows, ctx->scratch_rgba.p, ctx->stream, nullptr, pose)) != RT_OK) return rc;
+    RT_HIP(ctx, hipMemcpyAsync(out_rgba_host, ctx->scratch_rgba.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_render_pose_device(rt_ctx *ctx, const rt_params *p, const rt_camera_pose *pose, const rt_rows *rows, void *out_rgba_dev, void *stream) {
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    if (!pose) return fail(ctx, RT_ERR_INVALID, "pose is NULL");
+    return launch_render(ctx, p, rows, out_rgba_dev, stream ? static_cast<hipStream_t>(stream) : ctx->stream, nullptr, pose);
+}
+
+int rt_progressive_reset(rt_ctx *ctx) {
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    ctx->prog_frames = 0;                                             // buffer_reset, realtime:1246-1251
+    return RT_OK;
+}
+
+int rt_progressive_frames(const rt_ctx *ctx, int *frames) {
+    if (!ctx || !frames) return fail(nullptr, RT_ERR_INVALID, "bad arguments");
+    *frames = ctx->prog_frames;
+    return RT_OK;
+}
+
+int rt_progressive_frame(rt_ctx *ctx, const rt_params *p, const rt_camera_pose *pose, float *display_rgba_host, uint8_t *rgb8_host) {
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    if (!p || !pose) return fail(ctx, RT_ERR_INVALID, "params/pose is NULL");
+    if (p->width <= 0 || p->height <= 0) return fail(ctx, RT_ERR_INVALID, "width/height must be positive");
+    const int64_t npix = (int64_t)p->width * p->height;
+    const size_t bytes = (size_t)npix * sizeof(float4);
+    int rc;
+    if ((rc = ensure(ctx, ctx->scratch_rgba, bytes)) != RT_OK || (rc = ensure(ctx, ctx->accum, 2 * bytes)) != RT_OK ||
+        (rc = ensure(ctx, ctx->scratch_rgb8, (size_t)npix * 3 + 16)) != RT_OK)
+        return rc;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->prog_frames == 0 || ctx->prog_w != p->width || ctx->prog_h != p->height) {   // realtime:1246-1251 (a new size also resets)
+        RT_HIP(ctx, hipMemsetAsync(ctx->accum.p, 0, bytes, ctx->stream));
+        ctx->prog_frames = 0; ctx->prog_w = p->width; ctx->prog_h = p->height;
+    }
+    const int frame_no = ctx->prog_frames + 1;                        // frames++, realtime:1253
+    rt_params q = *p;
+    uint32_t a = (uint32_t)frame_no;                                  // WangHash(frames), realtime:1190-1197, seeds the frame's RNG
+    a = (a ^ 61u) ^ (a >> 16); a = a + (a << 3); a = a ^ (a >> 4); a = a * 0x27d4eb2du; a = a ^ (a >> 15);
+    q.seed = a;
+    rt_rows rows{0, p->height, p->height, 1};
+    if ((rc = launch_render(ctx, &q, &rows, ctx->scratch_rgba.p, ctx->stream, nullptr, pose)) != RT_OK) return rc;
+    float4 *accum = static_cast<float4 *>(ctx->accum.p), *display = accum + npix;
+    hipLaunchKernelGGL(rtk::accumulate_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, ctx->stream,
+                       static_cast<const float4 *>(ctx->scratch_rgba.p), accum, display, static_cast<uint8_t *>(ctx->scratch_rgb8.p), npix, frame_no);
+    RT_HIP(ctx, hipGetLastError());
+    ctx->prog_frames = frame_no;
+    if (display_rgba_host) RT_HIP(ctx, hipMemcpyAsync(display_rgba_host, display, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (rgb8_host) RT_HIP(ctx, hipMemcpyAsync(rgb8_host, ctx->scratch_rgb8.p, (size_t)npix * 3, hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return RT_OK;
 }
 

@@ -65,6 +65,11 @@ struct Frame {
     float4 *out;
     unsigned long long *work;   // STATS kernels only: {rays, box_tests, nodes, tri_tests}
     int out_tile0, out_tile_step;   // local row r is stored at output row ((r / tile_rows) * out_tile_step + out_tile0) * tile_rows + r % tile_rows
+    // cam_mode 1 = realtime_render.cu's camera and sample averaging (KernelLaunch realtime:1100-1134; wavefront variants only):
+    // u_center = C + bz * z + bx * X + by * Y, every sample weighted by inv_n = (float)(1. / num_rays) as it is added
+    int cam_mode;
+    float bx[3], by[3], bz[3];
+    float inv_n;
 };
 __device__ __forceinline__ size_t out_index(const Frame &fr, int lrow, int px) {
     const int orow = ((lrow / fr.tile_rows) * fr.out_tile_step + fr.out_tile0) * fr.tile_rows + lrow % fr.tile_rows;
@@ -443,6 +448,27 @@ __global__ __launch_bounds__(256) void tonemap_kernel(const float4 *__restrict__
     } else {
         for (int64_t k = 0; p0 + k < npix; ++k)
             for (int ch = 0; ch < 3; ++ch) out[3 * (p0 + k) + ch] = (uint8_t)b[3 * k + ch];
+    }
+}
+
+// Progressive accumulation, realtime_render.cu:1136-1147: accumbuffer += frame; display = accumbuffer / framenumber
+// (cutil_math: a * (1.0f / s)); 8-bit image = (unsigned char)min(powf(c, 1 / 2.2f), 255.).  .w carries the ray counts.
+__global__ __launch_bounds__(256) void accumulate_kernel(const float4 *__restrict__ frame, float4 *__restrict__ accum, float4 *__restrict__ display,
+                                                         uint8_t *__restrict__ rgb8, int64_t npix, int framenumber) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const float4 f = frame[i];
+    float4 a = accum[i];
+    a.x += f.x; a.y += f.y; a.z += f.z; a.w += f.w;
+    accum[i] = a;
+    const float inv = 1.0f / (float)framenumber;
+    const float4 d = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w);
+    display[i] = d;
+    const float c[3] = {d.x, d.y, d.z};
+    for (int k = 0; k < 3; ++k) {
+        double v = (double)powf(c[k], 1 / 2.2f);
+        if (!(v < 255.)) v = 255.;
+        rgb8[3 * i + k] = (uint8_t)v;
     }
 }
 

@@ -184,7 +184,14 @@ __global__ __launch_bounds__(256) void wf_begin(const Scene sc, const Frame fr, 
             // cpu:699: +0.5/-0.5 are double literals, narrowed by the Vector constructor
             const f3 uc = mk((float)((double)((float)px - (float)fr.W / 2) + 0.5),
                              (float)((double)((float)fr.H / 2 - (float)row) - 0.5), fr.z);
-            f3 uu = uc;
+            f3 ucm = uc;
+            if (fr.cam_mode == 1) {   // realtime:1115: cam.C + cam.bz * z + cam.bx * X + cam.by * Y (the position is part of the direction there)
+                const f3 Cc = mk(sc.camx, sc.camy, sc.camz), Bx = mk(fr.bx[0], fr.bx[1], fr.bx[2]), By = mk(fr.by[0], fr.by[1], fr.by[2]), Bz = mk(fr.bz[0], fr.bz[1], fr.bz[2]);
+                const f3 a = Cc + mk(Bz.x * fr.z, Bz.y * fr.z, Bz.z * fr.z);
+                const f3 b = a + mk(Bx.x * uc.x, Bx.y * uc.x, Bx.z * uc.x);
+                ucm = b + mk(By.x * uc.y, By.y * uc.y, By.z * uc.y);
+            }
+            f3 uu = ucm;
             if (fr.sigma != 0.f) {   // cpu:705-707; with sigma == 0 the jitter is exactly +-0
                 const uint32_t hp = mix32(((uint32_t)row * (uint32_t)fr.W + (uint32_t)px) ^ mix32(fr.seed));
                 const uint32_t hs = mix32(hp ^ ((uint32_t)samp * 0x9E3779B1U));
@@ -192,7 +199,7 @@ __global__ __launch_bounds__(256) void wf_begin(const Scene sc, const Frame fr, 
                 const float bm = fr.sigma * rt_sqrtf(-2 * logf(r1));
                 double sn, cs;
                 sincos(2 * 3.14159265358979323846 * (double)r2, &sn, &cs);
-                uu = uc + mk((float)((double)bm * cs), (float)((double)bm * sn), 0.f);
+                uu = ucm + mk((float)((double)bm * cs), (float)((double)bm * sn), 0.f);
             }
             const f3 u = normalize(uu);
             const f3 O = mk(sc.camx, sc.camy, sc.camz);
@@ -662,12 +669,13 @@ __global__ __launch_bounds__(256) void wf_advance(const Scene sc, const Frame fr
                 }
             }
             float4 t = st.T[i];
-            t.x += ans.x; t.y += ans.y; t.z += ans.z;
+            if (fr.cam_mode == 1) { t.x += ans.x * fr.inv_n; t.y += ans.y * fr.inv_n; t.z += ans.z * fr.inv_n; }   // realtime:1131
+            else { t.x += ans.x; t.y += ans.y; t.z += ans.z; }
             st.F[i] = make_int4(0, 0, 0, 0);
             if (samp == fr.spp - 1) {                                // cpu:713 + the framebuffer store
                 int px, lrow; bool valid;
                 wf_decode(st, fr, i, px, lrow, valid);
-                const float n = (float)fr.spp;
+                const float n = fr.cam_mode == 1 ? 1.f : (float)fr.spp;
                 fr.out[out_index(fr, lrow, px)] = make_float4(t.x / n, t.y / n, t.z / n, t.w);
             } else {
                 st.T[i] = t;

@@ -34,7 +34,7 @@ def test_struct_sizes_match_header():
     assert ctypes.sizeof(_capi.Params) == 40
     assert ctypes.sizeof(_capi.Rows) == 16
     assert ctypes.sizeof(_capi.Light) == 16 and ctypes.sizeof(_capi.Camera) == 16
-    assert ctypes.sizeof(_capi.Stats) == 48 and ctypes.sizeof(_capi.Work) == 32
+    assert ctypes.sizeof(_capi.Stats) == 48 and ctypes.sizeof(_capi.Work) == 32 and ctypes.sizeof(_capi.CameraPose) == 24
     assert ctypes.sizeof(_capi.MultiStats) == 4 + 64 + 64 + 4 + 4 + 4 + 8     # incl. 4 bytes of padding before `rays`
 
 
@@ -44,6 +44,17 @@ def test_no_cpu_fallback_without_a_gpu():
     with pytest.raises(rt.RtError) as e:
         rt.Context(0)
     assert e.value.code in (-2, -3)
+
+
+def test_camera_basis_matches_oracle_restatement(oracle):
+    """rt_camera_basis is host code (Camera::rotate(), realtime_render.cu:823-846): identical to the oracle's."""
+    for yaw, pitch in ((0.0, 0.3), (0.7, -0.2), (-2.5, 1.1), (3.0, 0.0)):
+        got = rt.camera_basis(rt.make_pose(yaw=yaw, pitch=pitch))
+        exp = oracle.camera_basis(yaw, pitch)
+        for a, b in zip(got, exp):
+            np.testing.assert_array_equal(a, b)
+        m = np.stack(got).astype(np.float64)
+        np.testing.assert_allclose(m @ m.T, np.eye(3), atol=1e-6)   # orthonormal
 
 
 def test_multi_device_entry_fails_loudly_without_a_gpu():

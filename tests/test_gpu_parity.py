@@ -304,3 +304,37 @@ def test_config5_7680x4320_eight_way_tiles_are_bitwise_the_full_frame(ctx, oracl
     np.testing.assert_array_equal(got.view(np.uint32), full.view(np.uint32))
     assert m.stats()["rays"] == int(full[..., 3].astype(np.float64).sum())
     m.close()
+
+
+def test_posed_camera_and_progressive_accumulation(ctx, oracle, oracle_cat, cat_golden):
+    """SURVEY 8f2 (headless realtime_render.cu): posed camera {C, yaw, pitch} with the reference's ray generation and
+    per-sample averaging, frame seeds WangHash(frame), accumbuffer / framenumber display.  Checked against the oracle's
+    restatement (the CUDA + GL program itself cannot run here: this row's parity is unpinned)."""
+    upload(ctx, "cpu", cat_golden)
+    W, H, spp, b = 256, 160, 2, 2
+    kw = dict(rt.scenes.CPU_LAUNCHER, sigma=0.2)
+    sc = oracle.Scene.preset("cpu", oracle_cat)
+    for pos, yaw, pitch in (((0.0, 0.0, 55.0), 0.0, 0.3), ((-6.0, 4.0, 49.0), 0.35, 0.1)):
+        pose = rt.make_pose(pos, yaw, pitch)
+        ctx.progressive_reset()
+        accum = np.zeros((H, W, 4), np.float32)
+        for frame in (1, 2, 3):
+            seed = oracle.wang_hash(frame)
+            got = ctx.render_pose(rt.make_params(W, H, spp, b, **dict(kw, seed=seed)), pose)
+            exp, _, _ = sc.render(W, H, spp, b, sigma=0.2, seed=seed, fov=np.float32(np.pi / 2), cam=pos, pose=(yaw, pitch), want_rgb8=False)
+            assert linf(oracle, got, exp) <= TOL
+            assert values_equal(got[..., :3], exp[..., :3]).mean() > 0.99
+            np.testing.assert_array_equal(got[..., 3], exp[..., 3])
+            # the library's own accumulation of the SAME frames, replayed by the oracle's accumulate: bit-exact floats
+            disp, rgb8 = ctx.progressive_frame(rt.make_params(W, H, spp, b, **kw), pose)
+            assert ctx.progressive_frames() == frame
+            edisp, ergb8 = oracle.progressive_accumulate(accum, got, frame)
+            np.testing.assert_array_equal(disp.view(np.uint32), edisp.view(np.uint32))
+            assert np.abs(rgb8.astype(int) - ergb8.astype(int)).max() <= 1      # device powf vs glibc powf at a truncation boundary
+            assert (rgb8 != ergb8).mean() < 1e-3
+    # the pose really is used: yawing the camera changes the image; variants without the pose path refuse
+    a = ctx.render_pose(rt.make_params(W, H, 1, 0, **rt.scenes.CPU_LAUNCHER), rt.make_pose(yaw=0.0))
+    b2 = ctx.render_pose(rt.make_params(W, H, 1, 0, **rt.scenes.CPU_LAUNCHER), rt.make_pose(yaw=0.5))
+    assert (a != b2).any()
+    with pytest.raises(rt.RtError):
+        ctx.render_pose(rt.make_params(W, H, 1, 0, variant="lockstep", **rt.scenes.CPU_LAUNCHER), rt.make_pose())
