@@ -338,3 +338,81 @@ def test_posed_camera_and_progressive_accumulation(ctx, oracle, oracle_cat, cat_
     assert (a != b2).any()
     with pytest.raises(rt.RtError):
         ctx.render_pose(rt.make_params(W, H, 1, 0, variant="lockstep", **rt.scenes.CPU_LAUNCHER), rt.make_pose())
+
+
+def _synthetic_mesh(kind, rng):
+    """Meshes that reach the corners of the traversal code the cat does not."""
+    if kind == "three_triangles":          # fewer than 5 triangles: the BVH is a single leaf (root-is-a-leaf path)
+        v = rng.uniform(-12, 12, (9, 3)).astype(np.float32)
+        t = np.arange(9, dtype=np.int32).reshape(3, 3)
+    elif kind == "axis_aligned_quads":     # flat, axis-aligned geometry: zero-thickness boxes, the strict '>' of cpu:156 (SURVEY H7)
+        vs, ts = [], []
+        for k in range(40):
+            c = rng.uniform(-15, 15, 3)
+            ax = k % 3
+            a, b = [(1, 2), (0, 2), (0, 1)][ax]
+            e = np.zeros((4, 3)); s = rng.uniform(1, 6, 2)
+            e[1, a] = s[0]; e[2, a] = s[0]; e[2, b] = s[1]; e[3, b] = s[1]
+            base = len(vs)
+            vs += list(np.round(c) + e)     # integer coordinates: rays through corners and edges do occur
+            ts += [[base, base + 1, base + 2], [base, base + 2, base + 3]]
+        v = np.array(vs, np.float32); t = np.array(ts, np.int32)
+    elif kind == "soup":                   # random triangle soup with duplicates and degenerate (zero-area) triangles
+        v = rng.uniform(-20, 20, (300, 3)).astype(np.float32)
+        t = rng.integers(0, 300, (400, 3)).astype(np.int32)
+        t[::50, 1] = t[::50, 0]             # zero-area
+        t = np.concatenate([t, t[:20]])     # duplicates: exact t ties, the earliest must win
+    elif kind == "deep_strip":             # a long spiral strip: 6000 triangles, deep unbalanced BVH, many big leaves
+        n = 3001
+        s = np.linspace(0, 1, n)
+        ang = 40 * s
+        r = 3 + 14 * s
+        p0 = np.stack([r * np.cos(ang), -8 + 20 * s, r * np.sin(ang)], 1)
+        p1 = p0 + np.array([0, 1.5, 0])
+        v = np.empty((2 * n, 3), np.float32); v[0::2] = p0; v[1::2] = p1
+        i = np.arange(n - 1) * 2
+        t = np.concatenate([np.stack([i, i + 1, i + 2], 1), np.stack([i + 1, i + 3, i + 2], 1)]).astype(np.int32)
+    elif kind == "geometric_chain":        # triangles at x = 24 * 0.7^k, each 0.7 the size of the previous: every midpoint split
+        k = np.arange(100)                 # peels off two triangles => a BVH far deeper than optimized.cu's s[30] (SURVEY H9)
+        x = 24.0 * 0.7 ** k
+        c = np.stack([x - 10, np.full(100, -6.0), np.zeros(100)], 1)
+        d = rng.uniform(-0.1, 0.1, (100, 3, 3)) * x[:, None, None]
+        v = (c[:, None, :] + d).reshape(-1, 3).astype(np.float32)
+        t = np.arange(300, dtype=np.int32).reshape(100, 3)
+    else:
+        raise ValueError(kind)
+    return v, t
+
+
+@pytest.mark.parametrize("kind", ["three_triangles", "axis_aligned_quads", "soup", "deep_strip", "geometric_chain"])
+def test_synthetic_meshes_bit_exact(ctx, oracle, kind, monkeypatch):
+    """Random / degenerate / deep meshes through the product's own BVH builder: direct lighting bit-exact against the
+    oracle (which builds its own BVH from the same arrays), bounces within tolerance, all traversal kernels and the
+    bounded-stack / LDS-staged configurations of the work-stack kernel writing the same bits and counting the same work."""
+    from raytracinggpu_amd import hostlib
+    rng = np.random.default_rng({"three_triangles": 1, "axis_aligned_quads": 2, "soup": 3, "deep_strip": 4, "geometric_chain": 5}[kind])
+    v, t = _synthetic_mesh(kind, rng)
+    om = oracle.Mesh.from_arrays(v, t).build_bvh()
+    osc = oracle.Scene.preset("cpu", om)
+    ctx.scene_upload(rt.scenes.spheres("cpu"), hostlib.build_mesh(v, t, albedo=rt.scenes.CAT_ALBEDO, object_slot=6))
+    W, H = 320, 200
+    exp0, _, cnt0 = osc.render(W, H, 1, 0, want_rgb8=False)
+    exp2, _, _ = osc.render(W, H, 2, 2, want_rgb8=False)
+    ref0 = None
+    for variant in ("wavefront_queue", "wavefront", "lockstep"):
+        got = ctx.render(rt.make_params(W, H, 1, 0, variant=variant, **rt.scenes.CPU_LAUNCHER))
+        assert values_equal(got[..., :3], exp0[..., :3]).all(), variant
+        np.testing.assert_array_equal(got[..., 3], exp0[..., 3])
+        got_work = ctx.count_work(rt.make_params(W, H, 1, 0, variant=variant, **rt.scenes.CPU_LAUNCHER))
+        assert got_work == {k: cnt0[k] for k in ("rays", "box_tests", "nodes", "tri_tests")}, variant
+        ref0 = got if ref0 is None else ref0
+    got2 = ctx.render(rt.make_params(W, H, 2, 2, **rt.scenes.CPU_LAUNCHER))
+    assert linf(oracle, got2, exp2) <= TOL
+    np.testing.assert_array_equal(got2[..., 3], exp2[..., 3])
+    for env in ({"RT_TRAVQ_CAP": "256"}, {"RT_TRAVQ_LDS": "16"}, {"RT_TRAVQ_LDS": "8", "RT_TRAVQ_R": "32"}):
+        for k, val in env.items():
+            monkeypatch.setenv(k, val)
+        alt = ctx.render(rt.make_params(W, H, 2, 2, variant="wavefront_queue", **rt.scenes.CPU_LAUNCHER))
+        np.testing.assert_array_equal(alt.view(np.uint32), got2.view(np.uint32))
+        for k in env:
+            monkeypatch.delenv(k)
