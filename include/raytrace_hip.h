@@ -180,6 +180,13 @@ int rt_count_work(rt_ctx *ctx, const rt_params *p, int row_begin, int row_end, r
 int rt_synchronize(rt_ctx *ctx);
 int rt_get_stats(rt_ctx *ctx, rt_stats *stats);        /* waits for the last render to finish */
 
+/* --- device-side mesh transform: the `transform` kernel of global_launcher.cu:340-365 / transformMesh
+ *     (realtime_render.cu:1151-1166) applied to the uploaded vertices -- v' = R v (row-major 3x3), then += translation --
+ *     followed, on the device, by the triangle precompute and a REFIT of the BVH: same tree, same triangle order, every
+ *     node's box recomputed as compute_bbox (cpu_launcher.cpp:180-188) of its range.  (The reference never refits: to get
+ *     the tree buildBVH would build for the moved mesh, rebuild on the host and call rt_scene_upload.) ------------------ */
+int rt_mesh_transform(rt_ctx *ctx, const float rotation[9], const float translation[3]);
+
 /* --- posed camera + progressive accumulation: the headless form of realtime_render.cu.  Camera
  *     {C, yaw, pitch} with Camera::rotate() (realtime_render.cu:803-861); ray generation and per-sample averaging of its
  *     KernelLaunch (:1100-1134: u_center = C + bz*z + bx*X + by*Y, outcolor += color * (1./num_rays)); accumulation and

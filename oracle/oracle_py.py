@@ -54,6 +54,8 @@ def lib():
     L.or_mesh_set_arrays.argtypes = [vp, fp, C.c_int, C.POINTER(C.c_int32), C.c_int]
     L.or_mesh_rescale.argtypes = [vp, C.c_float, fp]
     L.or_mesh_build_bvh.argtypes = [vp]
+    L.or_mesh_transform.argtypes = [vp, fp, fp]
+    L.or_mesh_refit.argtypes = [vp]
     for n in ("or_mesh_num_vertices", "or_mesh_num_triangles", "or_mesh_num_nodes", "or_mesh_max_depth"):
         getattr(L, n).argtypes = [vp]
     L.or_mesh_get_vertices.argtypes = [vp, fp]
@@ -129,6 +131,16 @@ class Mesh:
 
     def build_bvh(self):
         lib().or_mesh_build_bvh(self.h)
+        return self
+
+    def transform(self, rotation, translation):
+        """global_launcher.cu's `transform` kernel on the vertices (row-major 3x3, then translation)."""
+        r, rp = _f(np.asarray(rotation, np.float32).reshape(9)); t, tp = _f(translation)
+        lib().or_mesh_transform(self.h, rp, tp)
+        return self
+
+    def refit(self):
+        lib().or_mesh_refit(self.h)
         return self
 
     @property

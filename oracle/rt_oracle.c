@@ -265,6 +265,26 @@ static bbox compute_bbox(const or_mesh *m, int ts, int te) {
 }
 
 /* cpu:190-224 */
+/* rotate + transform kernels, global_launcher.cu:340-365 (realtime_render.cu:1151-1166 launches the same):
+ * v' = (R[0]*v0 + R[1]*v1 + R[2]*v2, ...) then += translation.  Vertices only (this restatement carries no normals). */
+void or_mesh_transform(or_mesh *m, const float R[9], const float t[3]) {
+    for (int i = 0; i < m->nv; i++) {
+        const vec v = m->vertices[i];
+        vec r = V(R[0] * v.d[0] + R[1] * v.d[1] + R[2] * v.d[2],
+                  R[3] * v.d[0] + R[4] * v.d[1] + R[5] * v.d[2],
+                  R[6] * v.d[0] + R[7] * v.d[1] + R[8] * v.d[2]);
+        r.d[0] += t[0]; r.d[1] += t[1]; r.d[2] += t[2];
+        m->vertices[i] = r;
+    }
+}
+/* keep the tree, recompute every node's box from its triangle range exactly as buildBVH does (cpu:193 compute_bbox) */
+static void refit_node(or_mesh *m, bvh_node *n) {
+    if (!n) return;
+    n->bb = compute_bbox(m, n->triangle_start, n->triangle_end);
+    refit_node(m, n->left); refit_node(m, n->right);
+}
+void or_mesh_refit(or_mesh *m) { refit_node(m, m->bvh); }
+
 static void build_bvh(or_mesh *m, bvh_node *cur, int ts, int te, int depth) {
     m->n_nodes++;
     if (depth > m->max_depth) m->max_depth = depth;

@@ -73,6 +73,10 @@ int      or_mesh_read_obj(or_mesh *m, const char *path, float scale, const float
 void     or_mesh_set_arrays(or_mesh *m, const float *verts_xyz, int nv, const int32_t *tri_vidx, int nt);
 /* TriangleMeshHost::rescale (optimized.cu:297-301) */
 void     or_mesh_rescale(or_mesh *m, float scale, const float offset[3]);
+/* the `transform` kernel of global_launcher.cu:340-365 on the vertices (rotation matrix row-major, then translation) */
+void     or_mesh_transform(or_mesh *m, const float rotation[9], const float translation[3]);
+/* keep the BVH's topology and triangle order, recompute every node's box (compute_bbox, cpu:180-188) */
+void     or_mesh_refit(or_mesh *m);
 /* buildBVH(&bvh, 0, indices.size()) (cpu:190-224) */
 void     or_mesh_build_bvh(or_mesh *m);
 int      or_mesh_num_vertices(const or_mesh *m);

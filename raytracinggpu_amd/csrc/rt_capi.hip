@@ -6,6 +6,7 @@
 #include "rt_persistent.hip.h"
 #include "rt_wavefront.hip.h"
 #include "rt_travq.hip.h"
+#include "rt_meshops.hip.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -34,6 +35,8 @@ struct rt_ctx {
     hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
     bool have_scene = false, have_kernel_time = false, have_tonemap_time = false;
     rtk::Scene scene{};
+    DevBuf left_dev, lvl_nodes, lvl_off;                             // tree topology for the device-side refit
+    int n_levels = 0;
     DevBuf node_lo, node_hi, nodes2, nodesq, q2thr, tri, verts, tidx, scratch_rgba, scratch_rgb8, work, queue;
     int n_cus = 0;
     DevBuf wfR0, wfR1, wfM, wfFL, wfS0, wfS1, wfT, wfF, wfLS, wfQ;   // wavefront path state (HBM)
@@ -579,7 +582,7 @@ int rt_ctx_destroy(rt_ctx *ctx) {
     if (!ctx) return RT_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    ctx->node_lo.release(); ctx->node_hi.release(); ctx->nodes2.release(); ctx->nodesq.release(); ctx->q2thr.release(); ctx->tri.release(); ctx->verts.release(); ctx->tidx.release();
+    ctx->node_lo.release(); ctx->node_hi.release(); ctx->nodes2.release(); ctx->nodesq.release(); ctx->q2thr.release(); ctx->left_dev.release(); ctx->lvl_nodes.release(); ctx->lvl_off.release(); ctx->tri.release(); ctx->verts.release(); ctx->tidx.release();
     ctx->scratch_rgba.release(); ctx->scratch_rgb8.release(); ctx->work.release(); ctx->queue.release();
     ctx->wfR0.release(); ctx->wfR1.release(); ctx->wfM.release(); ctx->wfS0.release(); ctx->wfS1.release();
     ctx->wfT.release(); ctx->wfF.release(); ctx->wfFL.release(); ctx->wfLS.release(); ctx->wfQ.release();
@@ -702,6 +705,20 @@ int rt_scene_upload(rt_ctx *ctx, const rt_sphere *spheres, int n_spheres, const 
         }
         if ((rc = upload(ctx, ctx->nodesq, q.data(), q.size() * sizeof(float4))) != RT_OK) return rc;
         if ((rc = upload(ctx, ctx->q2thr, order.data(), order.size() * sizeof(int))) != RT_OK) return rc;
+        // levels of the tree (pre-order indices sorted by depth) for the device-side refit (rt_mesh_transform)
+        std::vector<int> depth(n, 0), lvl_off, lvl_nodes(n);
+        int maxd = 0;
+        for (size_t x = 0; x < n; ++x)
+            if (left_of[x] >= 0) { depth[x + 1] = depth[left_of[x]] = depth[x] + 1; maxd = std::max(maxd, depth[x] + 1); }
+        lvl_off.assign(maxd + 2, 0);
+        for (size_t x = 0; x < n; ++x) lvl_off[depth[x] + 1]++;
+        for (int d = 0; d <= maxd; ++d) lvl_off[d + 1] += lvl_off[d];
+        std::vector<int> fill(lvl_off.begin(), lvl_off.end() - 1);
+        for (size_t x = 0; x < n; ++x) lvl_nodes[fill[depth[x]]++] = (int)x;
+        ctx->n_levels = n ? maxd + 1 : 0;
+        if ((rc = upload(ctx, ctx->left_dev, left_of.data(), left_of.size() * sizeof(int))) != RT_OK) return rc;
+        if ((rc = upload(ctx, ctx->lvl_nodes, lvl_nodes.data(), lvl_nodes.size() * sizeof(int))) != RT_OK) return rc;
+        if ((rc = upload(ctx, ctx->lvl_off, lvl_off.data(), lvl_off.size() * sizeof(int))) != RT_OK) return rc;
     }
     if ((rc = upload(ctx, ctx->tri, tri.data(), tri.size() * sizeof(float4))) != RT_OK) return rc;
     if ((rc = upload(ctx, ctx->verts, verts.data(), verts.size() * sizeof(float4))) != RT_OK) return rc;
@@ -785,6 +802,38 @@ int rt_count_work(rt_ctx *ctx, const rt_params *p, int row_begin, int row_end, r
     double rays = 0;                                  // .w of every pixel = rays traced for it (exact in binary32)
     for (size_t k = 3; k < fb.size(); k += 4) rays += fb[k];
     out->rays = (uint64_t)rays; out->box_tests = h[1]; out->nodes = h[2]; out->tri_tests = h[3];
+    return RT_OK;
+}
+
+int rt_mesh_transform(rt_ctx *ctx, const float rotation[9], const float translation[3]) {
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    if (!rotation || !translation) return fail(ctx, RT_ERR_INVALID, "rotation/translation is NULL");
+    if (!ctx->have_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_scene_upload has not been called");
+    rtk::Scene &sc = ctx->scene;
+    if (sc.mesh_slot < 0 || sc.n_nodes <= 0 || sc.n_verts <= 0) return RT_OK;     // no mesh: nothing to move
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    rtk::Mat3 m;
+    for (int k = 0; k < 9; ++k) m.r[k] = rotation[k];
+    for (int k = 0; k < 3; ++k) m.t[k] = translation[k];
+    hipLaunchKernelGGL(rtk::transform_kernel, dim3((unsigned)((sc.n_verts + 255) / 256)), dim3(256), 0, ctx->stream,
+                       static_cast<float4 *>(ctx->verts.p), sc.n_verts, m);
+    hipLaunchKernelGGL(rtk::retri_kernel, dim3((unsigned)((sc.n_tris + 255) / 256)), dim3(256), 0, ctx->stream,
+                       static_cast<const int4 *>(ctx->tidx.p), static_cast<const float4 *>(ctx->verts.p), static_cast<float4 *>(ctx->tri.p), sc.n_tris);
+    rtk::RefitArgs a{};
+    a.node_lo = static_cast<float4 *>(ctx->node_lo.p); a.node_hi = static_cast<float4 *>(ctx->node_hi.p);
+    a.nodes2 = static_cast<float4 *>(ctx->nodes2.p); a.nodesq = static_cast<float4 *>(ctx->nodesq.p);
+    a.q2thr = static_cast<const int *>(ctx->q2thr.p); a.left_of = static_cast<const int *>(ctx->left_dev.p);
+    a.lvl_nodes = static_cast<const int *>(ctx->lvl_nodes.p); a.lvl_off = static_cast<const int *>(ctx->lvl_off.p);
+    a.tidx = static_cast<const int4 *>(ctx->tidx.p); a.verts = static_cast<const float4 *>(ctx->verts.p);
+    a.n_nodes = sc.n_nodes; a.n_levels = ctx->n_levels;
+    hipLaunchKernelGGL(rtk::refit_kernel, dim3(1), dim3(1024), 0, ctx->stream, a);
+    RT_HIP(ctx, hipGetLastError());
+    // the root box travels as a kernel argument (uniform root-box pre-test): fetch the refitted one
+    float4 root[2];
+    RT_HIP(ctx, hipMemcpyAsync(&root[0], ctx->node_lo.p, sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipMemcpyAsync(&root[1], ctx->node_hi.p, sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    sc.root_lo = root[0]; sc.root_hi = root[1];
     return RT_OK;
 }
 

@@ -416,3 +416,39 @@ def test_synthetic_meshes_bit_exact(ctx, oracle, kind, monkeypatch):
         np.testing.assert_array_equal(alt.view(np.uint32), got2.view(np.uint32))
         for k in env:
             monkeypatch.delenv(k)
+
+
+def test_device_mesh_transform_and_refit(ctx, oracle, cat_golden):
+    """rt_mesh_transform = the reference's `transform` kernel (global_launcher.cu:340-365) on the uploaded
+    vertices + triangle precompute + BVH refit, all on the device.  Against the oracle doing the same on the host
+    (or_mesh_transform + or_mesh_refit: same tree, boxes by compute_bbox): bit-exact direct lighting and equal work
+    counters on every node layout (pre-order SoA / interleaved, breadth-first), also after a second transform."""
+    def rot(ax, a):
+        c, s = np.float32(np.cos(a)), np.float32(np.sin(a))
+        m = np.eye(3, dtype=np.float32)
+        i, j = [(1, 2), (0, 2), (0, 1)][ax]
+        m[i, i] = c; m[j, j] = c; m[i, j] = -s; m[j, i] = s
+        return m
+    om = oracle.Mesh.from_arrays(cat_golden["vertices"], cat_golden["tri_obj_order"]).build_bvh()
+    upload(ctx, "cpu", cat_golden)
+    W, H = 400, 250
+    for R, t in ((rot(1, 0.4) @ rot(0, 0.2), (1.5, -2.0, 0.5)), (rot(2, -0.3), (-3.0, 1.0, 2.0))):
+        om.transform(R, t).refit()
+        ctx.mesh_transform(R, t)
+        osc = oracle.Scene.preset("cpu", om)
+        exp, _, cnt = osc.render(W, H, 1, 0, want_rgb8=False)
+        for variant in ("wavefront_queue", "wavefront", "lockstep"):
+            p = rt.make_params(W, H, 1, 0, variant=variant, **rt.scenes.CPU_LAUNCHER)
+            got = ctx.render(p)
+            assert values_equal(got[..., :3], exp[..., :3]).all(), variant
+            np.testing.assert_array_equal(got[..., 3], exp[..., 3])
+            assert ctx.count_work(p) == {k: cnt[k] for k in ("rays", "box_tests", "nodes", "tri_tests")}, variant
+        exp2, _, _ = osc.render(W, H, 2, 2, want_rgb8=False)
+        got2 = ctx.render(rt.make_params(W, H, 2, 2, **rt.scenes.CPU_LAUNCHER))
+        assert linf(oracle, got2, exp2) <= TOL
+    # the moved cat is a different picture, and a scene without a mesh accepts the call
+    upload(ctx, "cpu", cat_golden)
+    still = ctx.render(rt.make_params(W, H, 1, 0, **rt.scenes.CPU_LAUNCHER))
+    assert (still[..., :3] != exp[..., :3]).any()
+    upload(ctx, "spheres", cat_golden)
+    ctx.mesh_transform(np.eye(3), (0, 0, 0))
