@@ -187,6 +187,14 @@ int rt_get_stats(rt_ctx *ctx, rt_stats *stats);        /* waits for the last ren
  *     the tree buildBVH would build for the moved mesh, rebuild on the host and call rt_scene_upload.) ------------------ */
 int rt_mesh_transform(rt_ctx *ctx, const float rotation[9], const float translation[3]);
 
+/* --- smooth (interpolated) normals: get_smooth_normal of realtime_render.cu:221-245 / global_launcher.cu:207-231
+ *     -- beta, gamma by the literal divisions, alpha = 1 - beta - gamma, N = normalize(alpha Na + beta Nb + gamma Nc) --
+ *     replaces the flat normal of the winning triangle.  normals_xyz: n_normals * 3; nidx: TriangleIndices::ni,nj,nk of
+ *     triangle t at nidx[t * index_stride .. +2], triangles in the order of rt_mesh.indices (for a TriangleIndices array
+ *     pass &indices[0].ni and stride 10).  Call after rt_scene_upload (a new upload drops them); NULL = flat again.
+ *     rt_mesh_transform then moves the normals the way the reference's kernel does.  Wavefront variants only. ---------- */
+int rt_mesh_set_normals(rt_ctx *ctx, const float *normals_xyz, int n_normals, const int32_t *nidx, int index_stride, int n_triangles);
+
 /* --- posed camera + progressive accumulation: the headless form of realtime_render.cu.  Camera
  *     {C, yaw, pitch} with Camera::rotate() (realtime_render.cu:803-861); ray generation and per-sample averaging of its
  *     KernelLaunch (:1100-1134: u_center = C + bz*z + bx*X + by*Y, outcolor += color * (1./num_rays)); accumulation and

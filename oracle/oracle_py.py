@@ -54,6 +54,7 @@ def lib():
     L.or_mesh_set_arrays.argtypes = [vp, fp, C.c_int, C.POINTER(C.c_int32), C.c_int]
     L.or_mesh_rescale.argtypes = [vp, C.c_float, fp]
     L.or_mesh_build_bvh.argtypes = [vp]
+    L.or_mesh_set_normals.argtypes = [vp, fp, C.c_int, C.POINTER(C.c_int32)]
     L.or_mesh_transform.argtypes = [vp, fp, fp]
     L.or_mesh_refit.argtypes = [vp]
     for n in ("or_mesh_num_vertices", "or_mesh_num_triangles", "or_mesh_num_nodes", "or_mesh_max_depth"):
@@ -131,6 +132,16 @@ class Mesh:
 
     def build_bvh(self):
         lib().or_mesh_build_bvh(self.h)
+        return self
+
+    def set_normals(self, normals, nidx):
+        """Vertex normals + per-triangle (ni, nj, nk) in the mesh's CURRENT triangle order: smooth shading (realtime:221-245)."""
+        if normals is None:
+            lib().or_mesh_set_normals(self.h, None, 0, None)
+            return self
+        n, np_ = _f(np.asarray(normals, np.float32).reshape(-1, 3))
+        ix = np.ascontiguousarray(nidx, np.int32).reshape(-1, 3)
+        lib().or_mesh_set_normals(self.h, np_, len(n), ix.ctypes.data_as(C.POINTER(C.c_int32)))
         return self
 
     def transform(self, rotation, translation):

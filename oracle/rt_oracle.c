@@ -112,7 +112,7 @@ typedef struct bvh_node {
 } bvh_node;
 
 /* cpu:121-129: only vtxi,vtxj,vtxk are read on the render path */
-typedef struct { int vtxi, vtxj, vtxk; } tri_idx;
+typedef struct { int vtxi, vtxj, vtxk; int ni, nj, nk; } tri_idx;   /* ni,nj,nk: smooth shading only (realtime_render.cu:221-245) */
 
 struct or_mesh {
     vec *vertices; int nv, cap_v;
@@ -121,6 +121,7 @@ struct or_mesh {
     bvh_node *bvh;                 /* root; NULL until built */
     int n_nodes, max_depth;
     vec albedo;
+    vec *normals; int n_shading_normals;   /* smooth shading; NULL = flat, as in cpu_launcher.cpp */
 };
 
 or_mesh *or_mesh_new(void) {
@@ -134,7 +135,7 @@ static void bvh_free(bvh_node *n) {
 }
 void or_mesh_free(or_mesh *m) {
     if (!m) return;
-    bvh_free(m->bvh); free(m->vertices); free(m->indices); free(m);
+    bvh_free(m->bvh); free(m->vertices); free(m->indices); free(m->normals); free(m);
 }
 static void push_vertex(or_mesh *m, vec v) {
     if (m->nv == m->cap_v) { m->cap_v = m->cap_v ? 2 * m->cap_v : 1024; m->vertices = (vec *)realloc(m->vertices, sizeof(vec) * m->cap_v); }
@@ -142,7 +143,7 @@ static void push_vertex(or_mesh *m, vec v) {
 }
 static void push_tri(or_mesh *m, int i, int j, int k) {
     if (m->nt == m->cap_t) { m->cap_t = m->cap_t ? 2 * m->cap_t : 1024; m->indices = (tri_idx *)realloc(m->indices, sizeof(tri_idx) * m->cap_t); }
-    tri_idx t = {i, j, k};
+    tri_idx t = {i, j, k, -1, -1, -1};
     m->indices[m->nt++] = t;
 }
 void or_mesh_set_albedo(or_mesh *m, float r, float g, float b) { m->albedo = V(r, g, b); }
@@ -248,6 +249,16 @@ void or_mesh_set_arrays(or_mesh *m, const float *verts_xyz, int nv, const int32_
     bvh_free(m->bvh); m->bvh = NULL; m->n_nodes = 0; m->max_depth = 0;
 }
 
+/* vertex normals + per-triangle normal indices (TriangleIndices::ni,nj,nk) in the CURRENT triangle order; NULL = flat */
+void or_mesh_set_normals(or_mesh *m, const float *normals_xyz, int n, const int32_t *nidx) {
+    free(m->normals); m->normals = NULL; m->n_shading_normals = 0;
+    if (!normals_xyz || !nidx) return;
+    m->normals = (vec *)malloc(sizeof(vec) * (size_t)(n > 0 ? n : 1));
+    for (int i = 0; i < n; i++) m->normals[i] = V(normals_xyz[3 * i], normals_xyz[3 * i + 1], normals_xyz[3 * i + 2]);
+    m->n_shading_normals = n;
+    for (int i = 0; i < m->nt; i++) { m->indices[i].ni = nidx[3 * i]; m->indices[i].nj = nidx[3 * i + 1]; m->indices[i].nk = nidx[3 * i + 2]; }
+}
+
 /* opt:297-301 */
 void or_mesh_rescale(or_mesh *m, float scale, const float offset[3]) {
     for (int i = 0; i < m->nv; i++) m->vertices[i] = vadd(vmuls(m->vertices[i], scale), V(offset[0], offset[1], offset[2]));
@@ -275,6 +286,14 @@ void or_mesh_transform(or_mesh *m, const float R[9], const float t[3]) {
                   R[6] * v.d[0] + R[7] * v.d[1] + R[8] * v.d[2]);
         r.d[0] += t[0]; r.d[1] += t[1]; r.d[2] += t[2];
         m->vertices[i] = r;
+    }
+    for (int i = 0; i < m->n_shading_normals; i++) {   /* the kernel also ADDS the translation to the normals (global_launcher.cu:357-363) */
+        const vec v = m->normals[i];
+        vec r = V(R[0] * v.d[0] + R[1] * v.d[1] + R[2] * v.d[2],
+                  R[3] * v.d[0] + R[4] * v.d[1] + R[5] * v.d[2],
+                  R[6] * v.d[0] + R[7] * v.d[1] + R[8] * v.d[2]);
+        r.d[0] += t[0]; r.d[1] += t[1]; r.d[2] += t[2];
+        m->normals[i] = r;
     }
 }
 /* keep the tree, recompute every node's box from its triangle range exactly as buildBVH does (cpu:193 compute_bbox) */
@@ -383,7 +402,7 @@ static int mesh_intersect(const or_mesh *m, const ray *r, float tri_tmin, float 
     stack[sp++] = m->bvh;
 
     float t_min = (float)OR_INF;                                    /* cpu:283 */
-    int any = 0;
+    int any = 0, idx_min = -1;
     vec Nbest = V(0, 0, 0);
     while (sp) {
         const bvh_node *cur = stack[--sp];
@@ -406,13 +425,24 @@ static int mesh_intersect(const or_mesh *m, const ray *r, float tri_tmin, float 
                 if (t_cur > tri_tmin && t_cur < t_min) {            /* cpu:301 */
                     t_min = t_cur;
                     Nbest = N_triangle;
-                    any = 1;
+                    any = 1; idx_min = i;
                 }
             }
         }
     }
     if (!any) return 0;
     *N = normalize(Nbest);                                          /* cpu:308 */
+    if (m->normals && idx_min >= 0) {                               /* get_smooth_normal, realtime_render.cu:221-245 */
+        const tri_idx tid = m->indices[idx_min];
+        const vec A = m->vertices[tid.vtxi], B = m->vertices[tid.vtxj], C = m->vertices[tid.vtxk];
+        const vec e1 = vsub(B, A), e2 = vsub(C, A);
+        const vec Nt = cross(e1, e2);
+        const float beta = dot(e2, cross(vsub(A, r->O), r->u)) / dot(r->u, Nt);
+        const float gamma = -dot(e1, cross(vsub(A, r->O), r->u)) / dot(r->u, Nt);
+        const float alpha = 1 - beta - gamma;
+        const vec Na = m->normals[tid.ni], Nb = m->normals[tid.nj], Nc = m->normals[tid.nk];
+        *N = normalize(vadd(vadd(smul(alpha, Na), smul(beta, Nb)), smul(gamma, Nc)));
+    }
     *t = t_min;
     return 1;
 }

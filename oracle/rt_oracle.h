@@ -71,6 +71,9 @@ void     or_mesh_free(or_mesh *m);
 int      or_mesh_read_obj(or_mesh *m, const char *path, float scale, const float offset[3]);
 /* replace geometry by explicit arrays (already transformed vertices, OBJ order) */
 void     or_mesh_set_arrays(or_mesh *m, const float *verts_xyz, int nv, const int32_t *tri_vidx, int nt);
+/* smooth shading (parity unpinned: realtime_render.cu:221-245 get_smooth_normal): vertex normals and the
+ * triangles' ni,nj,nk (3 per triangle, in the mesh's current triangle order); NULL switches back to flat shading */
+void     or_mesh_set_normals(or_mesh *m, const float *normals_xyz, int n_normals, const int32_t *nidx);
 /* TriangleMeshHost::rescale (optimized.cu:297-301) */
 void     or_mesh_rescale(or_mesh *m, float scale, const float offset[3]);
 /* the `transform` kernel of global_launcher.cu:340-365 on the vertices (rotation matrix row-major, then translation) */

@@ -20,7 +20,7 @@ VARIANTS = {"auto": 0, "global": 1, "lds_verts": 2, "lds_top": 3, "lds_all": 4, 
 EXPORTS = ["rt_abi_version", "rt_device_count", "rt_ctx_create", "rt_ctx_destroy", "rt_last_error",
            "rt_device_name", "rt_scene_upload", "rt_render", "rt_render_device", "rt_tonemap_device",
            "rt_render_rgb8", "rt_synchronize", "rt_get_stats", "rt_count_work",
-           "rt_mesh_transform", "rt_camera_basis", "rt_render_pose", "rt_render_pose_device", "rt_progressive_reset", "rt_progressive_frame",
+           "rt_mesh_transform", "rt_mesh_set_normals", "rt_camera_basis", "rt_render_pose", "rt_render_pose_device", "rt_progressive_reset", "rt_progressive_frame",
            "rt_progressive_frames",
            "rt_multi_create", "rt_multi_destroy", "rt_multi_last_error", "rt_multi_scene_upload", "rt_render_multi",
            "rt_render_multi_device", "rt_multi_get_stats"]
@@ -130,6 +130,7 @@ def load():
     L.rt_get_stats.argtypes = [vp, C.POINTER(Stats)]
     fp3 = C.POINTER(C.c_float)
     L.rt_mesh_transform.argtypes = [vp, fp3, fp3]
+    L.rt_mesh_set_normals.argtypes = [vp, fp3, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_int]
     L.rt_camera_basis.argtypes = [C.POINTER(CameraPose), fp3, fp3, fp3]
     L.rt_render_pose.argtypes = [vp, C.POINTER(Params), C.POINTER(CameraPose), fp3]
     L.rt_render_pose_device.argtypes = [vp, C.POINTER(Params), C.POINTER(CameraPose), C.POINTER(Rows), vp, vp]
@@ -281,6 +282,16 @@ class Context:
         r = np.ascontiguousarray(rotation, np.float32).reshape(9)
         t = np.ascontiguousarray(translation, np.float32).reshape(3)
         self._check(self._L.rt_mesh_transform(self._h, r.ctypes.data_as(C.POINTER(C.c_float)), t.ctypes.data_as(C.POINTER(C.c_float))))
+
+    def mesh_set_normals(self, normals, nidx):
+        """Smooth shading: vertex normals + per-triangle (ni, nj, nk) rows in the order of the uploaded indices; None = flat."""
+        if normals is None:
+            self._check(self._L.rt_mesh_set_normals(self._h, None, 0, None, 3, 0))
+            return
+        n = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+        ix = np.ascontiguousarray(nidx, np.int32).reshape(-1, 3)
+        self._check(self._L.rt_mesh_set_normals(self._h, n.ctypes.data_as(C.POINTER(C.c_float)), len(n),
+                                                ix.ctypes.data_as(C.POINTER(C.c_int32)), 3, len(ix)))
 
     def render_pose(self, params, pose):
         """One frame with realtime_render.cu's posed camera and per-sample averaging (no accumulation)."""

@@ -35,6 +35,8 @@ struct rt_ctx {
     hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
     bool have_scene = false, have_kernel_time = false, have_tonemap_time = false;
     rtk::Scene scene{};
+    DevBuf nrm;                                                     // smooth shading: 3 normals per triangle, visit order
+    std::vector<int> tri_perm;                                       // visit order -> triangle index in the uploaded (BVH-order) arrays
     DevBuf left_dev, lvl_nodes, lvl_off;                             // tree topology for the device-side refit
     int n_levels = 0;
     DevBuf node_lo, node_hi, nodes2, nodesq, q2thr, tri, verts, tidx, scratch_rgba, scratch_rgb8, work, queue;
@@ -248,6 +250,8 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
     fr.out_tile0 = 0; fr.out_tile_step = 1;
     rtk::Scene scn = ctx->scene;                                      // per-launch copy: a pose moves the camera
     fr.cam_mode = 0; fr.inv_n = 1.f;
+    if (scn.nrm != nullptr && variant != RT_VARIANT_WAVEFRONT && variant != RT_VARIANT_WAVEFRONT_LDS && variant != RT_VARIANT_WAVEFRONT_QUEUE)
+        return fail(ctx, RT_ERR_UNSUPPORTED, "smooth normals need a wavefront variant");
     if (pose) {                                                       // realtime_render.cu's camera
         if (variant != RT_VARIANT_WAVEFRONT && variant != RT_VARIANT_WAVEFRONT_LDS && variant != RT_VARIANT_WAVEFRONT_QUEUE)
             return fail(ctx, RT_ERR_UNSUPPORTED, "a camera pose needs a wavefront variant");
@@ -582,7 +586,7 @@ int rt_ctx_destroy(rt_ctx *ctx) {
     if (!ctx) return RT_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    ctx->node_lo.release(); ctx->node_hi.release(); ctx->nodes2.release(); ctx->nodesq.release(); ctx->q2thr.release(); ctx->left_dev.release(); ctx->lvl_nodes.release(); ctx->lvl_off.release(); ctx->tri.release(); ctx->verts.release(); ctx->tidx.release();
+    ctx->node_lo.release(); ctx->node_hi.release(); ctx->nodes2.release(); ctx->nodesq.release(); ctx->q2thr.release(); ctx->left_dev.release(); ctx->lvl_nodes.release(); ctx->lvl_off.release(); ctx->nrm.release(); ctx->tri.release(); ctx->verts.release(); ctx->tidx.release();
     ctx->scratch_rgba.release(); ctx->scratch_rgb8.release(); ctx->work.release(); ctx->queue.release();
     ctx->wfR0.release(); ctx->wfR1.release(); ctx->wfM.release(); ctx->wfS0.release(); ctx->wfS1.release();
     ctx->wfT.release(); ctx->wfF.release(); ctx->wfFL.release(); ctx->wfLS.release(); ctx->wfQ.release();
@@ -631,6 +635,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_sphere *spheres, int n_spheres, const 
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->have_scene = false;
+    ctx->tri_perm.clear();
     std::vector<float4> lo, hi, tri, verts;
     std::vector<int4> tidx;
     std::vector<int> left_of;
@@ -655,6 +660,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_sphere *spheres, int n_spheres, const 
                     return fail(ctx, RT_ERR_INVALID, "triangle %d references vertex %d outside [0,%d)", t, ix[k], mesh->n_vertices);
         }
         const int n_int = (int)perm.size();
+        ctx->tri_perm = perm;
         tri.resize((size_t)n_int * 3);
         tidx.resize(n_int);
         for (int t = 0; t < n_int; ++t) {
@@ -805,6 +811,30 @@ int rt_count_work(rt_ctx *ctx, const rt_params *p, int row_begin, int row_end, r
     return RT_OK;
 }
 
+int rt_mesh_set_normals(rt_ctx *ctx, const float *normals_xyz, int n_normals, const int32_t *nidx, int index_stride, int n_triangles) {
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    if (!ctx->have_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_scene_upload has not been called");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!normals_xyz || !nidx) { ctx->scene.nrm = nullptr; return RT_OK; }          // back to flat shading
+    if (ctx->scene.mesh_slot < 0) return fail(ctx, RT_ERR_INVALID, "the scene has no mesh");
+    if (n_normals <= 0 || index_stride < 3) return fail(ctx, RT_ERR_INVALID, "bad normal array sizes");
+    std::vector<float4> nr(ctx->tri_perm.size() * 3);
+    for (size_t t = 0; t < ctx->tri_perm.size(); ++t) {
+        const int src = ctx->tri_perm[t];
+        if (src < 0 || src >= n_triangles) return fail(ctx, RT_ERR_INVALID, "n_triangles %d does not cover the uploaded mesh", n_triangles);
+        for (int k = 0; k < 3; ++k) {
+            const int ni = nidx[(size_t)src * index_stride + k];
+            if (ni < 0 || ni >= n_normals) return fail(ctx, RT_ERR_INVALID, "triangle %d references normal %d outside [0,%d)", src, ni, n_normals);
+            nr[3 * t + k] = make_float4(normals_xyz[3 * (size_t)ni], normals_xyz[3 * (size_t)ni + 1], normals_xyz[3 * (size_t)ni + 2], 0.f);
+        }
+    }
+    int rc = upload(ctx, ctx->nrm, nr.data(), nr.size() * sizeof(float4));
+    if (rc != RT_OK) return rc;
+    ctx->scene.nrm = static_cast<const float4 *>(ctx->nrm.p);
+    return RT_OK;
+}
+
 int rt_mesh_transform(rt_ctx *ctx, const float rotation[9], const float translation[3]) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
     if (!rotation || !translation) return fail(ctx, RT_ERR_INVALID, "rotation/translation is NULL");
@@ -817,6 +847,9 @@ int rt_mesh_transform(rt_ctx *ctx, const float rotation[9], const float translat
     for (int k = 0; k < 3; ++k) m.t[k] = translation[k];
     hipLaunchKernelGGL(rtk::transform_kernel, dim3((unsigned)((sc.n_verts + 255) / 256)), dim3(256), 0, ctx->stream,
                        static_cast<float4 *>(ctx->verts.p), sc.n_verts, m);
+    if (sc.nrm != nullptr)      // the reference's kernel rotates the normals and ADDS the translation to them as well (global_launcher.cu:357-363)
+        hipLaunchKernelGGL(rtk::transform_kernel, dim3((unsigned)((3 * sc.n_tris + 255) / 256)), dim3(256), 0, ctx->stream,
+                           static_cast<float4 *>(ctx->nrm.p), 3 * sc.n_tris, m);
     hipLaunchKernelGGL(rtk::retri_kernel, dim3((unsigned)((sc.n_tris + 255) / 256)), dim3(256), 0, ctx->stream,
                        static_cast<const int4 *>(ctx->tidx.p), static_cast<const float4 *>(ctx->verts.p), static_cast<float4 *>(ctx->tri.p), sc.n_tris);
     rtk::RefitArgs a{};

@@ -50,6 +50,7 @@ struct Scene {
     const float4 *nodesq;     // interleaved, for the work-stack traversal, in BREADTH-FIRST order: lo.w of an internal node = its first
                               // child, the second one is stored next to it (the root's children are nodes 1 and 2)
     const int *q2thr;         // nodesq index -> index of the same node in `nodes`
+    const float4 *nrm;        // smooth shading (wavefront variants): 3 vertex normals per triangle, visit order; nullptr = flat
     const float4 *tri;
     const float4 *verts;
     const int4 *tidx;

@@ -577,7 +577,15 @@ __global__ __launch_bounds__(256) void wf_advance(const Scene sc, const Frame fr
             if (win >= 0) {                                           // a miss is black (cpu:571): nothing to emit
                 const f3 P = O + t_min * u;                           // cpu:560
                 f3 N;
-                if (win == sc.mesh_slot) {
+                if (win == sc.mesh_slot && sc.nrm != nullptr) {       // get_smooth_normal, realtime_render.cu:221-245
+                    const float4 q0 = sc.tri[3 * tri_win], q1 = sc.tri[3 * tri_win + 1], q2 = sc.tri[3 * tri_win + 2];
+                    const f3 A = mk(q0.x, q0.y, q0.z), e1 = mk(q0.w, q1.x, q1.y), e2 = mk(q1.z, q1.w, q2.x), Nt = mk(q2.y, q2.z, q2.w);
+                    const float beta = dot(e2, cross(A - O, u)) / dot(u, Nt);
+                    const float gamma = -dot(e1, cross(A - O, u)) / dot(u, Nt);
+                    const float alpha = 1 - beta - gamma;
+                    const float4 na = sc.nrm[3 * tri_win], nb = sc.nrm[3 * tri_win + 1], nc = sc.nrm[3 * tri_win + 2];
+                    N = normalize((alpha * mk(na.x, na.y, na.z) + beta * mk(nb.x, nb.y, nb.z)) + gamma * mk(nc.x, nc.y, nc.z));
+                } else if (win == sc.mesh_slot) {
                     const float4 q2 = sc.tri[3 * tri_win + 2];
                     N = normalize(mk(q2.y, q2.z, q2.w));              // cpu:308
                 } else {

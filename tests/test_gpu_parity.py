@@ -452,3 +452,45 @@ def test_device_mesh_transform_and_refit(ctx, oracle, cat_golden):
     assert (still[..., :3] != exp[..., :3]).any()
     upload(ctx, "spheres", cat_golden)
     ctx.mesh_transform(np.eye(3), (0, 0, 0))
+
+
+def test_smooth_normals(ctx, oracle, cat_golden):
+    """interpolated vertex normals (get_smooth_normal, realtime_render.cu:221-245) replace the flat normal of
+    the winning triangle.  Against the oracle's restatement (parity unpinned: the reference programs that do this are
+    CUDA-only): bit-exact direct lighting, bounces within tolerance, also after a device-side transform (which moves the
+    normals the way the reference's kernel does, translation included)."""
+    v = cat_golden["vertices"].astype(np.float64)
+    t_obj, t_bvh = cat_golden["tri_obj_order"], cat_golden["tri_bvh_order"]
+    fn = np.cross(v[t_obj[:, 1]] - v[t_obj[:, 0]], v[t_obj[:, 2]] - v[t_obj[:, 0]])
+    vn = np.zeros_like(v)
+    for k in range(3):
+        np.add.at(vn, t_obj[:, k], fn)
+    vn = (vn / np.maximum(np.linalg.norm(vn, axis=1, keepdims=True), 1e-20)).astype(np.float32)
+    om = oracle.Mesh.from_arrays(cat_golden["vertices"], t_obj).set_normals(vn, t_obj).build_bvh()
+    osc = oracle.Scene.preset("cpu", om)
+    upload(ctx, "cpu", cat_golden)
+    W, H = 400, 250
+    flat = ctx.render(rt.make_params(W, H, 1, 0, **rt.scenes.CPU_LAUNCHER))
+    ctx.mesh_set_normals(vn, t_bvh)
+    for variant in ("wavefront_queue", "wavefront"):
+        got = ctx.render(rt.make_params(W, H, 1, 0, variant=variant, **rt.scenes.CPU_LAUNCHER))
+        exp, _, _ = osc.render(W, H, 1, 0, want_rgb8=False)
+        assert values_equal(got[..., :3], exp[..., :3]).all(), variant
+        np.testing.assert_array_equal(got[..., 3], exp[..., 3])
+    assert (got[..., :3] != flat[..., :3]).any()
+    got2 = ctx.render(rt.make_params(W, H, 2, 2, **rt.scenes.CPU_LAUNCHER))
+    exp2, _, _ = osc.render(W, H, 2, 2, want_rgb8=False)
+    assert linf(oracle, got2, exp2) <= TOL
+    np.testing.assert_array_equal(got2[..., 3], exp2[..., 3])
+    with pytest.raises(rt.RtError):
+        ctx.render(rt.make_params(W, H, 1, 0, variant="lockstep", **rt.scenes.CPU_LAUNCHER))
+    R = np.array([[0.9553365, 0, 0.29552022], [0, 1, 0], [-0.29552022, 0, 0.9553365]], np.float32)
+    om.transform(R, (0.5, 0.25, -0.5)).refit()
+    ctx.mesh_transform(R, (0.5, 0.25, -0.5))
+    got3 = ctx.render(rt.make_params(W, H, 1, 0, **rt.scenes.CPU_LAUNCHER))
+    exp3, _, _ = oracle.Scene.preset("cpu", om).render(W, H, 1, 0, want_rgb8=False)
+    assert values_equal(got3[..., :3], exp3[..., :3]).all()
+    ctx.mesh_set_normals(None, None)
+    upload(ctx, "cpu", cat_golden)
+    again = ctx.render(rt.make_params(W, H, 1, 0, **rt.scenes.CPU_LAUNCHER))
+    np.testing.assert_array_equal(again.view(np.uint32), flat.view(np.uint32))
