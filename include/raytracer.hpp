@@ -384,6 +384,31 @@ public:
     rt_stats stats() { rt_stats st{}; check(rt_get_stats(ctx_, &st), "rt_get_stats"); return st; }
     rt_ctx *handle() { return ctx_; }
 
+    // --- the pieces of realtime_render.cu / global_launcher.cu behind the same boundary ---
+    // transformMesh (global_launcher.cu:932-946) on the uploaded mesh, then triangle precompute + BVH refit on the device
+    void transform_mesh(const float rotation[9], const Vector &translation) {
+        const float t[3] = {translation[0], translation[1], translation[2]};
+        check(rt_mesh_transform(ctx_, rotation, t), "rt_mesh_transform");
+    }
+    // get_smooth_normal (realtime_render.cu:221-245): the mesh's `normals` and its TriangleIndices::ni,nj,nk (all >= 0)
+    void use_smooth_normals(const TriangleMesh &mesh) {
+        std::vector<float> n(mesh.normals.size() * 3);
+        for (size_t i = 0; i < mesh.normals.size(); ++i)
+            for (int k = 0; k < 3; ++k) n[3 * i + k] = mesh.normals[i][k];
+        check(rt_mesh_set_normals(ctx_, n.data(), (int)mesh.normals.size(), mesh.indices.empty() ? nullptr : &mesh.indices[0].ni,
+                                  (int)(sizeof(TriangleIndices) / sizeof(int32_t)), (int)mesh.indices.size()), "rt_mesh_set_normals");
+    }
+    void use_flat_normals() { check(rt_mesh_set_normals(ctx_, nullptr, 0, nullptr, 3, 0), "rt_mesh_set_normals"); }
+    // Camera{C, yaw, pitch} (realtime_render.cu:803-861) and disp() (:1243-1290) without the window: one accumulated frame
+    std::vector<unsigned char> progressive_frame(const RenderSettings &s, const rt_camera_pose &pose, std::vector<float> *display = nullptr) {
+        rt_params p = params(s);
+        std::vector<unsigned char> image((size_t)s.W * s.H * 3);
+        if (display) display->resize((size_t)s.W * s.H * 4);
+        check(rt_progressive_frame(ctx_, &p, &pose, display ? display->data() : nullptr, image.data()), "rt_progressive_frame");
+        return image;
+    }
+    void progressive_reset() { check(rt_progressive_reset(ctx_), "rt_progressive_reset"); }   // buffer_reset
+
 private:
     static rt_params params(const RenderSettings &s) {
         rt_params p{};
