@@ -180,7 +180,7 @@ int check_params(rt_ctx *ctx, const rt_params *p, int &segs) {
 }
 
 // wf_travq instantiations: [STATS][R == 32][LDSN]
-using TravqFn = void (*)(const rtk::Scene, const rtk::Frame, const rtk::WfState, const int, const int);
+using TravqFn = void (*)(const rtk::Scene, const rtk::Frame, const rtk::WfState, const int, const int, const int, const int);
 TravqFn travq_fn(bool stats, int R, bool ldsn) {
     static const TravqFn tab[2][2][2] = {
         {{rtk::wf_travq<false, 64, false>, rtk::wf_travq<false, 64, true>}, {rtk::wf_travq<false, 32, false>, rtk::wf_travq<false, 32, true>}},
@@ -284,6 +284,9 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
             if (q_nlds <= 0) { qW = 0; q_nlds = 0; }
         }
         const bool qlds = queue && qW > 0;
+        int q_low = 192, q_minfree = qR / 4;                        // refill thresholds of the work-stack kernel (tuning knobs)
+        if (const char *e = getenv("RT_TRAVQ_LOW")) { const int v = atoi(e); if (v >= 64 && v <= 320) q_low = v; }
+        if (const char *e = getenv("RT_TRAVQ_MINFREE")) { const int v = atoi(e); if (v >= 1 && v <= qR) q_minfree = v; }
         // begin, (trav, advance) x 2*segments per sample; path state SoA in HBM, tile-order path index.
         // The rows are cut into `parts` independent sub-frames (interleaved tiles), each running its own kernel
         // sequence on its own stream: the traversal kernel ends in a latency-bound tail (a few long rays), and
@@ -443,7 +446,7 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
                         if (timed) RT_HIP(ctx, hipEventRecord(ctx->ev_trav[2 * it], q));
                         const dim3 tg((unsigned)pt.tblocks), tbd(tb);
                         if (queue) {
-                            hipLaunchKernelGGL(travq_fn(work_dev != nullptr, qR, qlds), tg, tbd, trav_lds, q, scn, pt.fr, pt.st, qcap, q_nlds);
+                            hipLaunchKernelGGL(travq_fn(work_dev != nullptr, qR, qlds), tg, tbd, trav_lds, q, scn, pt.fr, pt.st, qcap, q_nlds, q_low, q_minfree);
                         } else if (ldsn) {
                             if (work_dev) hipLaunchKernelGGL((rtk::wf_trav<true, true>), tg, tbd, trav_lds, q, scn, pt.fr, pt.st);
                             else hipLaunchKernelGGL((rtk::wf_trav<false, true>), tg, tbd, trav_lds, q, scn, pt.fr, pt.st);

@@ -114,10 +114,10 @@ __device__ __forceinline__ bool qtri_test(const float4 q0, const float4 q1, cons
 // LDSN: the first n_lds nodes (breadth-first order: the top of the tree) are staged in LDS behind the waves' carves and
 // read from there; the launch then uses ONE workgroup per CU (blockDim.x = 64 x waves, up to 1024).
 template <bool STATS, int R, bool LDSN>
-__global__ __launch_bounds__(LDSN ? 1024 : kQBlock, LDSN ? 4 : 5) void wf_travq(const Scene sc, const Frame fr, const WfState st, const int cap, const int n_lds) {
+__global__ __launch_bounds__(LDSN ? 1024 : kQBlock, LDSN ? 4 : 5) void wf_travq(const Scene sc, const Frame fr, const WfState st, const int cap, const int n_lds, const int kLow, const int kMinFree) {
+    // kLow: refill while the stack holds fewer entries than this (default 192); kMinFree: ... and at least this many slots
+    // are free, or the stack is short (default R / 4)
     constexpr int SCAP = QStackCap<R>::value, LCAP = 256;
-    constexpr int kLow = 192;                     // refill while the stack holds fewer entries than this
-    constexpr int kMinFree = R / 4;               // ... and at least this many slots are free (or the stack is short)
     using Carve = QCarve<R, SCAP, LCAP>;
     static_assert(R <= 64 && (R & (R - 1)) == 0, "ray slots are owned by lanes");
     extern __shared__ __attribute__((aligned(16))) unsigned char travq_smem[];
