@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libraytrace_hip.so")
+LIB_PATH = os.environ.get("RT_LIB") or os.path.join(HERE, "libraytrace_hip.so")   # RT_LIB: an experimental build (tools/)
 
 RT_OK = 0
 VARIANT_AUTO, VARIANT_GLOBAL, VARIANT_LDS_VERTS, VARIANT_LDS_TOP, VARIANT_LDS_ALL, VARIANT_LOCKSTEP, VARIANT_WAVEFRONT, VARIANT_WAVEFRONT_LDS, VARIANT_WAVEFRONT_QUEUE = range(9)

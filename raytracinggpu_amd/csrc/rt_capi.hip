@@ -231,7 +231,7 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
         if (ctx->scene.n_nodes == 0) variant = RT_VARIANT_WAVEFRONT;      // no mesh: nothing to stage
         else return fail(ctx, RT_ERR_UNSUPPORTED, "%d BVH nodes need %zu bytes of LDS (> 160 KiB)", ctx->scene.n_nodes, lds_nodes_bytes);
     }
-    if (variant == RT_VARIANT_WAVEFRONT_QUEUE && ctx->scene.n_nodes >= (1 << rtk::kQNodeBits)) variant = RT_VARIANT_WAVEFRONT;   // entry = slot << 26 | node
+    if (variant == RT_VARIANT_WAVEFRONT_QUEUE && ctx->scene.n_nodes + 2 >= (1 << rtk::kQNodeBits)) variant = RT_VARIANT_WAVEFRONT;   // entry = slot << 26 | node
     if (variant != RT_VARIANT_GLOBAL && variant != RT_VARIANT_LOCKSTEP && variant != RT_VARIANT_WAVEFRONT && variant != RT_VARIANT_WAVEFRONT_LDS &&
         variant != RT_VARIANT_WAVEFRONT_QUEUE)
         return fail(ctx, RT_ERR_UNSUPPORTED, "variant %d is not available in this build", variant);
@@ -273,19 +273,19 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
         int qR = 64;                                                  // ray slots per wave of the work-stack kernel
         if (const char *e = getenv("RT_TRAVQ_R")) { if (atoi(e) == 32) qR = 32; }
         int qcap = qR == 64 ? rtk::QStackCap<64>::value : rtk::QStackCap<32>::value;
-        if (const char *e = getenv("RT_TRAVQ_CAP")) { const int v = atoi(e); if (v >= 256 && v < qcap) qcap = v; }   // tests: force the serial drain
+        if (const char *e = getenv("RT_TRAVQ_CAP")) { const int v = atoi(e); if (v >= 128 && v < qcap) qcap = v; }   // tests: force the serial drain
         // BVH nodes staged in LDS (breadth-first prefix) by ONE workgroup of qW waves per CU; 0 = nodes through L1/L2
         int qW = 0;
         if (const char *e = getenv("RT_TRAVQ_LDS")) { const int v = atoi(e); if (v >= 1 && v <= 16) qW = v; }
         int q_nlds = 0;
         if (queue && qW > 0) {
             const int64_t room = 160 * 1024 - 16 - (int64_t)qW * (int64_t)travq_carve_bytes(qR);
-            q_nlds = room > 0 ? (int)std::min<int64_t>(room / 32, ctx->scene.n_nodes) : 0;
+            q_nlds = room > 0 ? (int)(std::min<int64_t>(room / 32, ctx->scene.n_nodes + 1) & ~(int64_t)1) : 0;   // even: sibling pairs stay together
             if (q_nlds <= 0) { qW = 0; q_nlds = 0; }
         }
         const bool qlds = queue && qW > 0;
-        int q_low = 192, q_minfree = qR / 4;                        // refill thresholds of the work-stack kernel (tuning knobs)
-        if (const char *e = getenv("RT_TRAVQ_LOW")) { const int v = atoi(e); if (v >= 64 && v <= 320) q_low = v; }
+        int q_low = 96, q_minfree = qR / 4;                         // refill thresholds of the work-stack kernel (tuning knobs; stack entries are sibling pairs)
+        if (const char *e = getenv("RT_TRAVQ_LOW")) { const int v = atoi(e); if (v >= 32 && v <= 320) q_low = v; }
         if (const char *e = getenv("RT_TRAVQ_MINFREE")) { const int v = atoi(e); if (v >= 1 && v <= qR) q_minfree = v; }
         // begin, (trav, advance) x 2*segments per sample; path state SoA in HBM, tile-order path index.
         // The rows are cut into `parts` independent sub-frames (interleaved tiles), each running its own kernel
@@ -329,7 +329,7 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
                     RT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, travq_fn(work_dev != nullptr, qR, false), rtk::kQBlock, trav_lds));
                     ctx->travq_blocks_per_cu[qi] = nb > 0 ? nb : 1;
                 }
-                bpc = std::min(ctx->travq_blocks_per_cu[qi], 4);    // a fifth workgroup per CU fits but does not pay (measured)
+                bpc = std::min(ctx->travq_blocks_per_cu[qi], getenv("RT_TRAVQ_BPC5") ? 5 : 4);    // a fifth workgroup per CU fits but does not pay (measured)
             }
         }
         if (const char *e = getenv("RT_TRAV_WAVES")) { const int v = atoi(e); if (!ldsn && v >= 1 && v <= bpc) bpc = v; }
@@ -706,14 +706,17 @@ int rt_scene_upload(rt_ctx *ctx, const rt_sphere *spheres, int n_spheres, const 
                 bfs_of[left_of[x]] = (int)order.size(); order.push_back(left_of[x]);
             }
         }
-        std::vector<float4> q(2 * order.size());
+        // index 0 is padding, the root is node 1, so that every sibling pair (2m, 2m + 1) is one aligned 64-byte line
+        std::vector<float4> q(2 * (order.size() + 1), make_float4(0, 0, 0, 0));
+        std::vector<int> q2t(order.size() + 1, 0);
         for (size_t k = 0; k < order.size(); ++k) {
             const int x = order[k];
-            q[2 * k] = lo[x]; q[2 * k + 1] = hi[x];
-            if (left_of[x] >= 0) q[2 * k].w = __builtin_bit_cast(float, bfs_of[x + 1]);
+            q[2 * (k + 1)] = lo[x]; q[2 * (k + 1) + 1] = hi[x];
+            if (left_of[x] >= 0) q[2 * (k + 1)].w = __builtin_bit_cast(float, bfs_of[x + 1] + 1);
+            q2t[k + 1] = x;
         }
         if ((rc = upload(ctx, ctx->nodesq, q.data(), q.size() * sizeof(float4))) != RT_OK) return rc;
-        if ((rc = upload(ctx, ctx->q2thr, order.data(), order.size() * sizeof(int))) != RT_OK) return rc;
+        if ((rc = upload(ctx, ctx->q2thr, q2t.data(), q2t.size() * sizeof(int))) != RT_OK) return rc;
         // levels of the tree (pre-order indices sorted by depth) for the device-side refit (rt_mesh_transform)
         std::vector<int> depth(n, 0), lvl_off, lvl_nodes(n);
         int maxd = 0;

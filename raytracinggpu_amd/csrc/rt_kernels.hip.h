@@ -47,8 +47,9 @@ struct Scene {
     float camx, camy, camz, fov;
     const float4 *node_lo, *node_hi;
     const float4 *nodes;      // the same nodes interleaved: nodes[2i] = lo, nodes[2i+1] = hi (one address per visit)
-    const float4 *nodesq;     // interleaved, for the work-stack traversal, in BREADTH-FIRST order: lo.w of an internal node = its first
-                              // child, the second one is stored next to it (the root's children are nodes 1 and 2)
+    const float4 *nodesq;     // interleaved, for the work-stack traversal, in BREADTH-FIRST order from index 1 (index 0 is padding, so
+                              // sibling pairs are aligned 64-byte lines): lo.w of an internal node = its first child (even), the second
+                              // one is stored next to it (the root is node 1, its children 2 and 3)
     const int *q2thr;         // nodesq index -> index of the same node in `nodes`
     const float4 *nrm;        // smooth shading (wavefront variants): 3 vertex normals per triangle, visit order; nullptr = flat
     const float4 *tri;

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(1024) void refit_kernel(const RefitArgs a) {
         l2.x = lo.x; l2.y = lo.y; l2.z = lo.z; h2.x = hi.x; h2.y = hi.y; h2.z = hi.z;
         a.nodes2[2 * x] = l2; a.nodes2[2 * x + 1] = h2;
     }
-    for (int k = (int)threadIdx.x; k < a.n_nodes; k += (int)blockDim.x) {
+    for (int k = 1 + (int)threadIdx.x; k <= a.n_nodes; k += (int)blockDim.x) {   // breadth-first array: node k lives at index k (0 is padding)
         const int x = a.q2thr[k];
         const float4 lo = a.node_lo[x], hi = a.node_hi[x];
         float4 lq = a.nodesq[2 * k], hq = a.nodesq[2 * k + 1];

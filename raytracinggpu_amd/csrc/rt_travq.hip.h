@@ -8,10 +8,11 @@
 // over the visited triangles of (t, visit rank) -- the strict '<' of cpu:301 keeps the earliest of equal t, and
 // triangles are stored in visit order, so rank == triangle index.  Hence a ray's traversal is not a walk but a
 // bag of independent box tests: a wave keeps R rays resident in LDS and one LIFO stack of 32-bit entries
-// (ray slot << 26 | node).  A BOX step pops up to 128 entries, every lane tests TWO boxes (BoundingBox::intersect,
-// cpu:146-157, through the error-bounded filter of rt_kernels.hip.h; the two tests are independent, so their loads
-// are in flight together) and pushes the two children of a hit internal node or appends a hit leaf's (first, count)
-// to the wave's leaf queue.  A TRI step takes leaf entries worth up to 128 triangles, hands every lane two of them
+// (ray slot << 26 | c), each standing for the SIBLING PAIR of nodes c, c + 1 (the reference tests both children of a hit
+// node, cpu:288-289; in the breadth-first node array they share one 64-byte line).  A BOX step pops up to 64 entries,
+// every lane tests the two boxes of its pair (BoundingBox::intersect, cpu:146-157, through the error-bounded filter of
+// rt_kernels.hip.h: one table read, four loads in flight together, one counter update) and pushes one entry per hit
+// internal child or appends a hit leaf's (first, count) to the wave's leaf queue.  A TRI step takes leaf entries worth up to 128 triangles, hands every lane two of them
 // (prefix sum + mark/ballot expansion) and merges accepted hits with a 64-bit LDS min on bits(t) << 32 | index
 // (moller_trumbore, cpu:226-236).  Per-slot counters of outstanding entries tell when a ray is finished; finished
 // slots are refilled from the workgroup's share of the traversal queue (slot order: flag and record arrive in one
@@ -20,7 +21,7 @@
 // that of the stack, not of the slowest ray.
 //
 // LDS is bounded for any tree: when the stack cannot take the pushes of a full BOX step, the wave drains the popped
-// entries by walking their subtrees serially with the stackless (skip-pointer) node array instead.
+// pairs by walking their subtrees serially with the stackless (skip-pointer) node array instead.
 #pragma once
 #include "rt_wavefront.hip.h"
 
@@ -115,8 +116,8 @@ __device__ __forceinline__ bool qtri_test(const float4 q0, const float4 q1, cons
 // read from there; the launch then uses ONE workgroup per CU (blockDim.x = 64 x waves, up to 1024).
 template <bool STATS, int R, bool LDSN>
 __global__ __launch_bounds__(LDSN ? 1024 : kQBlock, LDSN ? 4 : 5) void wf_travq(const Scene sc, const Frame fr, const WfState st, const int cap, const int n_lds, const int kLow, const int kMinFree) {
-    // kLow: refill while the stack holds fewer entries than this (default 192); kMinFree: ... and at least this many slots
-    // are free, or the stack is short (default R / 4)
+    // kLow: refill while the stack holds fewer entries (sibling pairs) than this (default 96); kMinFree: ... and at least this
+    // many slots are free, or the stack is short (default R / 4)
     constexpr int SCAP = QStackCap<R>::value, LCAP = 256;
     using Carve = QCarve<R, SCAP, LCAP>;
     static_assert(R <= 64 && (R & (R - 1)) == 0, "ray slots are owned by lanes");
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(LDSN ? 1024 : kQBlock, LDSN ? 4 : 5) void wf_travq(
     if (LDSN) for (int k = tid; k < 2 * n_lds; k += (int)blockDim.x) lnodes[k] = sc.nodesq[k];
     __syncthreads();
 
-    const float4 *const nodes = sc.nodesq;        // breadth-first order; lo.w = first child, the other is next to it (internal) | first triangle (leaf); hi.w = -1 | end
+    const float4 *const nodes = sc.nodesq;        // breadth-first order from index 1 (0 is padding): lo.w = first child (even; the other one is next to it) | first triangle (leaf); hi.w = -1 | end
     const size_t blk_base = (size_t)blockIdx.x * (size_t)st.slots_per_block;
     const int blk_n = st.slots_per_block;
     int stage_n = 0, stage_used = 0;              // wave-uniform: staged records and how many of them have been given a slot
@@ -163,14 +164,15 @@ __global__ __launch_bounds__(LDSN ? 1024 : kQBlock, LDSN ? 4 : 5) void wf_travq(
     unsigned int d_box = 0, d_boxl = 0, d_tri = 0, d_tril = 0, d_rounds = 0, d_rays = 0, d_serial = 0, d_idle = 0, d_fetch = 0, d_maxtop = 0;
 #define WQ_STAMP(acc) do { if (dbg_on) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - stamp; stamp = t_; } } while (0)
 
-    // node of a stack entry: LDS for the staged top of the tree, L1/L2 otherwise
-    auto load_node = [&](int node, float4 &lo, float4 &hi) {
+    // the sibling nodes c, c + 1 of a stack entry (c is even: the pair is one 64-byte line): LDS for the staged top of the
+    // tree (n_lds is even), L1/L2 otherwise
+    auto load_pair = [&](int c, float4 &lo0, float4 &hi0, float4 &lo1, float4 &hi1) {
         if (LDSN) {
-            const bool inl = node < n_lds;
-            if (inl) { lo = lnodes[2 * node]; hi = lnodes[2 * node + 1]; }
-            if (__ballot(!inl) != 0ull) { if (!inl) { lo = nodes[2 * node]; hi = nodes[2 * node + 1]; } }
+            const bool inl = c < n_lds;
+            if (inl) { lo0 = lnodes[2 * c]; hi0 = lnodes[2 * c + 1]; lo1 = lnodes[2 * c + 2]; hi1 = lnodes[2 * c + 3]; }
+            if (__ballot(!inl) != 0ull) { if (!inl) { lo0 = nodes[2 * c]; hi0 = nodes[2 * c + 1]; lo1 = nodes[2 * c + 2]; hi1 = nodes[2 * c + 3]; } }
         } else {
-            lo = nodes[2 * node]; hi = nodes[2 * node + 1];
+            lo0 = nodes[2 * c]; hi0 = nodes[2 * c + 1]; lo1 = nodes[2 * c + 2]; hi1 = nodes[2 * c + 3];
         }
     };
     // stack nearly full: walk the subtree of one popped entry serially with the stackless (skip-pointer) node array
@@ -198,7 +200,6 @@ __global__ __launch_bounds__(LDSN ? 1024 : kQBlock, LDSN ? 4 : 5) void wf_travq(
             }
             x = (hit || hiw >= 0) ? x + 1 : low;
         }
-        atomicAdd(&pend[o], -1);
     };
 
     for (;;) {
@@ -266,12 +267,10 @@ __global__ __launch_bounds__(LDSN ? 1024 : kQBlock, LDSN ? 4 : 5) void wf_travq(
                 if (dbg_on) { d_rounds++; d_rays += (unsigned int)__popcll(gm); }
                 if (root_hiw < 0) {
                     if (got) {
-                        const int pos = top + 2 * lanes_below(gm);
-                        stack[pos] = (unsigned int)lane << kQNodeBits | 2u;      // breadth-first order: the root's children are 1, 2
-                        stack[pos + 1] = (unsigned int)lane << kQNodeBits | 1u;
-                        pend[lane] = 2;
+                        stack[top + lanes_below(gm)] = (unsigned int)lane << kQNodeBits | 2u;   // the root (node 1) has the children 2, 3
+                        pend[lane] = 1;
                     }
-                    top += 2 * __popcll(gm);
+                    top += __popcll(gm);
                 } else {                           // the root is a leaf
                     const int first = __float_as_int(sc.root_lo.w), cnt = root_hiw - first;
                     if (cnt > 0) {
@@ -341,63 +340,80 @@ __global__ __launch_bounds__(LDSN ? 1024 : kQBlock, LDSN ? 4 : 5) void wf_travq(
             d_idle++;
             continue;
         }
-        // =============================== BOX step: two entries per lane ===============================
-        const int n = top < 128 ? top : 128;
-        const bool act0 = lane < n, act1 = lane + 64 < n;
-        const unsigned int e0 = act0 ? stack[top - 1 - lane] : 0u;
-        const unsigned int e1 = act1 ? stack[top - 65 - lane] : 0u;
-        const int o0 = (int)(e0 >> kQNodeBits), o1 = (int)(e1 >> kQNodeBits);
-        const int nd0 = (int)(e0 & kQNodeMask), nd1 = (int)(e1 & kQNodeMask);
-        if (cap - top < 128) {                                        // no room for up to 256 pushes: serial drain
+        // =============================== BOX step: one sibling pair (two boxes) per lane ===============================
+#if defined(RT_PAD_SALU)     // sensitivity experiment (tools/pad_experiment.sh): extra scalar / vector issue slots per BOX step
+        asm volatile("s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n"
+                     "s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0");
+#endif
+#if defined(RT_PAD_VALU)
+        { int pad_ = lane; asm volatile("v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n"
+                     "v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n"
+                     "v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n"
+                     "v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1" : "+v"(pad_)); }
+#endif
+#if defined(RT_PAD_LDS)
+        { unsigned int pl_ = marks[lane]; pl_ += marks[lane + 64]; pl_ += marks[lane]; pl_ += marks[lane + 64]; asm volatile("" :: "v"(pl_)); }
+#endif
+        const int n = top < 64 ? top : 64;
+        const bool act = lane < n;
+        const unsigned int e = act ? stack[top - 1 - lane] : 0u;        // slot << 26 | c: the sibling nodes c, c + 1 (one 64-byte line)
+        const int o = (int)(e >> kQNodeBits);
+        const int c = (int)(e & kQNodeMask);
+        if (cap - top < 64) {                                         // no room for up to 128 pushes: serial drain
             top -= n;
-            if (act0) drain_serial(o0, nd0);
-            if (act1) drain_serial(o1, nd1);
+            if (act) { drain_serial(o, c); drain_serial(o, c + 1); atomicAdd(&pend[o], -1); }
             d_serial++;
             WQ_STAMP(cy_box);
             continue;
         }
         top -= n;
-        const float4 A0 = tabA[o0], C0 = tabC[o0], A1 = tabA[o1], C1 = tabC[o1];
+        const float4 A = tabA[o], C = tabC[o];                        // siblings belong to one ray: one table read for both
         float4 lo0, hi0, lo1, hi1;
-        load_node(nd0, lo0, hi0);
-        load_node(nd1, lo1, hi1);
+        load_pair(c, lo0, hi0, lo1, hi1);
+#if defined(RT_PAD_VMEM)     // sensitivity experiment: the same four 16-byte loads once more (L1 hits: address / tag pipeline only)
+        {
+            const float4 *pp = nodes + 2 * c;
+            typedef float pad_v4f __attribute__((ext_vector_type(4)));
+            pad_v4f x0, x1, x2, x3;
+            asm volatile("global_load_dwordx4 %0, %4, off\n global_load_dwordx4 %1, %4, off offset:16\n global_load_dwordx4 %2, %4, off offset:32\n"
+                         "global_load_dwordx4 %3, %4, off offset:48\n s_waitcnt vmcnt(0)" : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3) : "v"(pp) : "memory");
+            asm volatile("" :: "v"(x0), "v"(x1), "v"(x2), "v"(x3));
+        }
+#endif
         bool hit0, hit1;
-        const bool dec0 = qbox_filter(lo0, hi0, A0, C0, hit0);
-        const bool dec1 = qbox_filter(lo1, hi1, A1, C1, hit1);
+        const bool dec0 = qbox_filter(lo0, hi0, A, C, hit0);
+        const bool dec1 = qbox_filter(lo1, hi1, A, C, hit1);
         // literal arithmetic for undecided lanes behind a wave-uniform branch (six IEEE divisions, almost never needed)
-        if (__builtin_expect(__ballot((act0 && !dec0) || (act1 && !dec1)) != 0ull, 0)) {
-            if (act0 && !dec0) { const float2 D = tabD[o0]; hit0 = slab(lo0, hi0, mk(C0.x, C0.y, C0.z), mk(C0.w, D.x, D.y)); }
-            if (act1 && !dec1) { const float2 D = tabD[o1]; hit1 = slab(lo1, hi1, mk(C1.x, C1.y, C1.z), mk(C1.w, D.x, D.y)); }
+        if (__builtin_expect(__ballot(act && !(dec0 && dec1)) != 0ull, 0)) {
+            if (act && !(dec0 && dec1)) {
+                const float2 D = tabD[o];
+                const f3 O = mk(C.x, C.y, C.z), u = mk(C.w, D.x, D.y);
+                if (!dec0) hit0 = slab(lo0, hi0, O, u);
+                if (!dec1) hit1 = slab(lo1, hi1, O, u);
+            }
         }
         const int hiw0 = __float_as_int(hi0.w), low0 = __float_as_int(lo0.w), cnt0 = hiw0 - low0;
         const int hiw1 = __float_as_int(hi1.w), low1 = __float_as_int(lo1.w), cnt1 = hiw1 - low1;
-        hit0 = hit0 && act0; hit1 = hit1 && act1;
+        hit0 = hit0 && act; hit1 = hit1 && act;
         const bool hI0 = hit0 && hiw0 < 0, hI1 = hit1 && hiw1 < 0;
         const bool hL0 = hit0 && hiw0 >= 0 && cnt0 > 0, hL1 = hit1 && hiw1 >= 0 && cnt1 > 0;
         if (STATS) {
-            wk.box += (act0 ? 1u : 0u) + (act1 ? 1u : 0u); wk.nodes += (hit0 ? 1u : 0u) + (hit1 ? 1u : 0u);
+            wk.box += act ? 2u : 0u; wk.nodes += (hit0 ? 1u : 0u) + (hit1 ? 1u : 0u);
             wk.tris += ((hit0 && hiw0 >= 0) ? (uint32_t)cnt0 : 0u) + ((hit1 && hiw1 >= 0) ? (uint32_t)cnt1 : 0u);
         }
         const unsigned long long mI0 = __ballot(hI0), mI1 = __ballot(hI1), mL0 = __ballot(hL0), mL1 = __ballot(hL1);
         const int nI0 = __popcll(mI0), nL0 = __popcll(mL0);
-        if (hI0) {
-            const int pos = top + 2 * lanes_below(mI0);
-            const unsigned int c = (e0 & ~kQNodeMask) | (unsigned int)low0;
-            stack[pos] = c + 1u; stack[pos + 1] = c;                 // the two children are neighbours
-        }
-        if (hI1) {
-            const int pos = top + 2 * (nI0 + lanes_below(mI1));
-            const unsigned int c = (e1 & ~kQNodeMask) | (unsigned int)low1;
-            stack[pos] = c + 1u; stack[pos + 1] = c;
-        }
-        top += 2 * (nI0 + __popcll(mI1));
-        if (hL0) leafq[(ltail + (unsigned int)lanes_below(mL0)) & (LCAP - 1)] = make_uint2((unsigned int)low0, (unsigned int)o0 | (unsigned int)cnt0 << 8);
-        if (hL1) leafq[(ltail + (unsigned int)(nL0 + lanes_below(mL1))) & (LCAP - 1)] = make_uint2((unsigned int)low1, (unsigned int)o1 | (unsigned int)cnt1 << 8);
+        const unsigned int sbits = e & ~kQNodeMask;
+        if (hI0) stack[top + lanes_below(mI0)] = sbits | (unsigned int)low0;            // a hit internal node pushes ITS pair of children
+        if (hI1) stack[top + nI0 + lanes_below(mI1)] = sbits | (unsigned int)low1;
+        top += nI0 + __popcll(mI1);
+        if (hL0) leafq[(ltail + (unsigned int)lanes_below(mL0)) & (LCAP - 1)] = make_uint2((unsigned int)low0, (unsigned int)o | (unsigned int)cnt0 << 8);
+        if (hL1) leafq[(ltail + (unsigned int)(nL0 + lanes_below(mL1))) & (LCAP - 1)] = make_uint2((unsigned int)low1, (unsigned int)o | (unsigned int)cnt1 << 8);
         ltail += (unsigned int)(nL0 + __popcll(mL1));
-        // outstanding entries: internal hit -1 + 2, leaf hit -1 + 1, miss -1 (inactive lanes add 0 to slot 0)
-        atomicAdd(&pend[o0], hI0 ? 1 : (act0 && !hL0) ? -1 : 0);
-        atomicAdd(&pend[o1], hI1 ? 1 : (act1 && !hL1) ? -1 : 0);
-        if (dbg_on) { d_box++; d_boxl += (unsigned int)n; if ((unsigned int)top > d_maxtop) d_maxtop = (unsigned int)top; }
+        // outstanding entries of the ray: this pair is gone (-1), every pushed pair and leaf entry counts +1: one LDS add per lane
+        const int delta = (hI0 ? 1 : 0) + (hI1 ? 1 : 0) + (hL0 ? 1 : 0) + (hL1 ? 1 : 0) - (act ? 1 : 0);
+        if (delta != 0) atomicAdd(&pend[o], delta);
+        if (dbg_on) { d_box++; d_boxl += 2u * (unsigned int)n; if ((unsigned int)top > d_maxtop) d_maxtop = (unsigned int)top; }
         WQ_STAMP(cy_box);
     }
 #undef WQ_STAMP

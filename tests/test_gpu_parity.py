@@ -211,9 +211,9 @@ def test_variants_are_bitwise_identical_at_full_size(ctx, cat_golden):
     assert int(ref[..., 3].sum()) == 16588799
 
 
-@pytest.mark.parametrize("env", [{"RT_TRAVQ_CAP": "256"}, {"RT_TRAVQ_R": "32"}, {"RT_TRAVQ_R": "32", "RT_TRAVQ_CAP": "256"},
+@pytest.mark.parametrize("env", [{"RT_TRAVQ_CAP": "128"}, {"RT_TRAVQ_R": "32"}, {"RT_TRAVQ_R": "32", "RT_TRAVQ_CAP": "128"},
                                  {"RT_TRAVQ_LDS": "12"}, {"RT_TRAVQ_LDS": "12", "RT_TRAVQ_R": "32"}, {"RT_TRAVQ_LDS": "16"},
-                                 {"RT_TRAVQ_LDS": "8", "RT_TRAVQ_CAP": "256"}])
+                                 {"RT_TRAVQ_LDS": "8", "RT_TRAVQ_CAP": "128"}])
 def test_work_stack_traversal_bounded_stack_and_slot_counts(ctx, cat_golden, monkeypatch, env):
     """wf_travq with a 256-entry stack (forces the serial-drain path that keeps LDS bounded for any tree), with
     32 ray slots per wave, and with all / the top 15 BVH nodes staged in LDS (RT_TRAVQ_LDS = waves per CU): same bits
@@ -409,7 +409,7 @@ def test_synthetic_meshes_bit_exact(ctx, oracle, kind, monkeypatch):
     got2 = ctx.render(rt.make_params(W, H, 2, 2, **rt.scenes.CPU_LAUNCHER))
     assert linf(oracle, got2, exp2) <= TOL
     np.testing.assert_array_equal(got2[..., 3], exp2[..., 3])
-    for env in ({"RT_TRAVQ_CAP": "256"}, {"RT_TRAVQ_LDS": "16"}, {"RT_TRAVQ_LDS": "8", "RT_TRAVQ_R": "32"}):
+    for env in ({"RT_TRAVQ_CAP": "128"}, {"RT_TRAVQ_LDS": "16"}, {"RT_TRAVQ_LDS": "8", "RT_TRAVQ_R": "32"}):
         for k, val in env.items():
             monkeypatch.setenv(k, val)
         alt = ctx.render(rt.make_params(W, H, 2, 2, variant="wavefront_queue", **rt.scenes.CPU_LAUNCHER))
