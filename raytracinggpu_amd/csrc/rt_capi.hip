@@ -367,7 +367,14 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
             // the next one, which evens out the cost differences between the workgroups' shares of the rays
             int oversub = 2;                                           // measured: 1.85 -> 1.67 ms/frame (cat, 1080p)
             if (const char *e = getenv("RT_TRAVQ_OVERSUB")) { const int v = atoi(e); if (v >= 1 && v <= 16) oversub = v; }
-            if (queue && !qlds) tblocks *= oversub;
+            if (queue && !qlds && oversub > 1) {
+                // (measured down to one GPU's share of a 1080p frame split over 8: oversubscribing pays at every size;
+                // RT_TRAVQ_OVERSUB_MIN = ray slots per wave below which a launch is not oversubscribed, for experiments)
+                int min_slots = 0;
+                if (const char *e = getenv("RT_TRAVQ_OVERSUB_MIN")) { const int v = atoi(e); if (v >= 0) min_slots = v; }
+                const int64_t slots_per_wave = (int64_t)st.n_groups * 4 / (tblocks * oversub * wpb);
+                if (slots_per_wave >= min_slots) tblocks *= oversub;
+            }
             int min_groups = 16 * wpb;                                // >= 64 ray slots per wave on average
             if (const char *e = getenv("RT_TRAV_MIN_GROUPS")) { const int v = atoi(e); if (v >= 4) min_groups = v * wpb; }
             int64_t groups_per_block = (st.n_groups + tblocks - 1) / tblocks;
