@@ -112,6 +112,12 @@ def load():
         except ImportError:
             pass
     L = C.CDLL(LIB_PATH)
+    if os.environ.get("RT_LIB"):      # an experimental / older build may lack the newest entry points: give them inert stand-ins
+        class _Missing:
+            argtypes = restype = None
+        for name in EXPORTS:
+            if not hasattr(L, name):
+                setattr(L, name, _Missing())
     vp = C.c_void_p
     L.rt_abi_version.restype = C.c_int
     L.rt_device_count.argtypes = [C.POINTER(C.c_int)]

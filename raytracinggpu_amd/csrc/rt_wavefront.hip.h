@@ -527,7 +527,7 @@ finished:
 
 // ---- wf_advance: close the queries, shade, emit the next rays -----------------------------------------------
 template <bool STATS>
-__global__ __launch_bounds__(256) void wf_advance(const Scene sc, const Frame fr, const WfState st, int samp) {
+__global__ __launch_bounds__(256, 8) void wf_advance(const Scene sc, const Frame fr, const WfState st, int samp) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     Work wk;
     int4 F = i < st.n_paths ? st.F[i] : make_int4(0, 0, 0, 0);
