@@ -127,7 +127,7 @@ def main():
     p = rt.make_params(W, H, args.spp, args.bounces, variant=args.variant, **rt.scenes.CPU_LAUNCHER)
     rows, idx = rt.interleaved_rows(H, TILE_ROWS, rank, world)
     local = tiling.local_buffer(H, W, world, dev)
-    gathered = [torch.empty_like(local) for _ in range(world)] if (world > 1 and rank == 0) else None
+    gathered = tiling.gather_buffer(local, world) if (world > 1 and rank == 0) else None
     frame = None
     # a non-default torch stream: its handle is non-NULL (NULL means "the context's own stream" in the C-ABI),
     # so the render kernel, torch's timing events and the RCCL gather are all ordered on ONE stream

@@ -29,14 +29,21 @@ def assemble(stacked, height, tile_rows=TILE_ROWS):
     return stacked.view(g, t, tile_rows, w, c).permute(1, 0, 2, 3, 4).reshape(-1, w, c)[:height]
 
 
-def gather_frame(local, height, world, rank, gather_list=None, tile_rows=TILE_ROWS):
+def gather_buffer(local, world):
+    """Rank 0's receive buffer [G, tiles_local * R, W, 4]: the ranks' tile buffers land in it side by side, so that
+    the reassembly is ONE permuted copy (no torch.stack of separately received tensors)."""
+    return torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+
+
+def gather_frame(local, height, world, rank, gathered=None, tile_rows=TILE_ROWS):
     """One gather of the float4 tiles to rank 0 (a grouped send/recv under RCCL: each peer uses its own xGMI
-    link to the root).  Returns the assembled [H, W, 4] frame on rank 0, None elsewhere."""
+    link to the root).  `gathered`: rank 0's gather_buffer (allocated here if None).  Returns the assembled
+    [H, W, 4] frame on rank 0, None elsewhere."""
     if world == 1:
         return local[:height]
-    if rank == 0 and gather_list is None:
-        gather_list = [torch.empty_like(local) for _ in range(world)]
-    dist.gather(local, gather_list if rank == 0 else None, dst=0)
+    if rank == 0 and gathered is None:
+        gathered = gather_buffer(local, world)
+    dist.gather(local, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
     if rank != 0:
         return None
-    return assemble(torch.stack(gather_list), height, tile_rows)
+    return assemble(gathered, height, tile_rows)
