@@ -188,7 +188,7 @@ TravqFn travq_fn(bool stats, int R, bool ldsn) {
     return tab[stats ? 1 : 0][R == 32 ? 1 : 0][ldsn ? 1 : 0];
 }
 size_t travq_carve_bytes(int R) {
-    return R == 64 ? (size_t)rtk::QCarve<64, rtk::QStackCap<64>::value, 256>::kBytes : (size_t)rtk::QCarve<32, rtk::QStackCap<32>::value, 256>::kBytes;
+    return R == 64 ? (size_t)rtk::QCarve<64, rtk::QStackCap<64>::value, rtk::kQLeafCap>::kBytes : (size_t)rtk::QCarve<32, rtk::QStackCap<32>::value, rtk::kQLeafCap>::kBytes;
 }
 
 // Camera::rotate(), realtime_render.cu:823-846 (host code there too: float cos/sin/sqrt)

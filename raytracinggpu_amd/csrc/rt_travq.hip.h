@@ -28,6 +28,10 @@
 namespace rtk {
 
 constexpr int kQBlock = 256;                 // 4 waves per workgroup share one ray-slot cursor
+#ifndef RT_TRAVQ_KP
+#define RT_TRAVQ_KP 1                        // sibling pairs per lane and BOX step
+#endif
+constexpr int kQLeafCap = 256 * RT_TRAVQ_KP;  // leaf-queue entries per wave: < 64 before a BOX step, which appends up to 128 per pair
 constexpr int kQNodeBits = 26;               // entry = slot << 26 | node
 constexpr unsigned kQNodeMask = (1u << kQNodeBits) - 1u;
 
@@ -115,10 +119,10 @@ __device__ __forceinline__ bool qtri_test(const float4 q0, const float4 q1, cons
 // LDSN: the first n_lds nodes (breadth-first order: the top of the tree) are staged in LDS behind the waves' carves and
 // read from there; the launch then uses ONE workgroup per CU (blockDim.x = 64 x waves, up to 1024).
 template <bool STATS, int R, bool LDSN>
-__global__ __launch_bounds__(LDSN ? 1024 : kQBlock, LDSN ? 4 : 5) void wf_travq(const Scene sc, const Frame fr, const WfState st, const int cap, const int n_lds, const int kLow, const int kMinFree) {
+__global__ __launch_bounds__(LDSN ? 1024 : kQBlock, (LDSN || RT_TRAVQ_KP > 1) ? 4 : 5) void wf_travq(const Scene sc, const Frame fr, const WfState st, const int cap, const int n_lds, const int kLow, const int kMinFree) {
     // kLow: refill while the stack holds fewer entries (sibling pairs) than this (default 96); kMinFree: ... and at least this
     // many slots are free, or the stack is short (default R / 4)
-    constexpr int SCAP = QStackCap<R>::value, LCAP = 256;
+    constexpr int SCAP = QStackCap<R>::value, LCAP = kQLeafCap;
     using Carve = QCarve<R, SCAP, LCAP>;
     static_assert(R <= 64 && (R & (R - 1)) == 0, "ray slots are owned by lanes");
     extern __shared__ __attribute__((aligned(16))) unsigned char travq_smem[];
@@ -340,39 +344,47 @@ __global__ __launch_bounds__(LDSN ? 1024 : kQBlock, LDSN ? 4 : 5) void wf_travq(
             d_idle++;
             continue;
         }
-        // =============================== BOX step: one sibling pair (two boxes) per lane ===============================
-#if defined(RT_PAD_SALU)     // sensitivity experiment (tools/pad_experiment.sh): extra scalar / vector issue slots per BOX step
+        // =============================== BOX step: KP sibling pairs (2 KP boxes) per lane ===============================
+        constexpr int KP = RT_TRAVQ_KP;
+#if defined(RT_PAD_SALU)     // sensitivity experiment (tools/pad_experiment.sh): 32 extra scalar / vector issue slots, 4 extra LDS reads per step
         asm volatile("s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n"
                      "s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0");
 #endif
 #if defined(RT_PAD_VALU)
-        { int pad_ = lane; asm volatile("v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n"
-                     "v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n"
-                     "v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n"
-                     "v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1" : "+v"(pad_)); }
+        { int pad_ = lane; for (int k_ = 0; k_ < 32; ++k_) asm volatile("v_add_u32 %0, %0, 1" : "+v"(pad_)); }
 #endif
 #if defined(RT_PAD_LDS)
         { unsigned int pl_ = marks[lane]; pl_ += marks[lane + 64]; pl_ += marks[lane]; pl_ += marks[lane + 64]; asm volatile("" :: "v"(pl_)); }
 #endif
-        const int n = top < 64 ? top : 64;
-        const bool act = lane < n;
-        const unsigned int e = act ? stack[top - 1 - lane] : 0u;        // slot << 26 | c: the sibling nodes c, c + 1 (one 64-byte line)
-        const int o = (int)(e >> kQNodeBits);
-        const int c = (int)(e & kQNodeMask);
-        if (cap - top < 64) {                                         // no room for up to 128 pushes: serial drain
-            top -= n;
-            if (act) { drain_serial(o, c); drain_serial(o, c + 1); atomicAdd(&pend[o], -1); }
+        const int n = top < 64 * KP ? top : 64 * KP;
+        if (cap - top < 64 * KP) {                                    // no room for up to 128 KP pushes: serial drain of 64 entries
+            const int nd = top < 64 ? top : 64;
+            const bool actd = lane < nd;
+            const unsigned int ed = actd ? stack[top - 1 - lane] : 0u;
+            top -= nd;
+            if (actd) { const int od = (int)(ed >> kQNodeBits), cd = (int)(ed & kQNodeMask); drain_serial(od, cd); drain_serial(od, cd + 1); atomicAdd(&pend[od], -1); }
             d_serial++;
             WQ_STAMP(cy_box);
             continue;
         }
+        bool act[KP]; unsigned int e[KP]; int o[KP], c[KP];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            act[k] = lane + 64 * k < n;
+            e[k] = act[k] ? stack[top - 1 - lane - 64 * k] : 0u;      // slot << 26 | c: the sibling nodes c, c + 1 (one 64-byte line)
+            o[k] = (int)(e[k] >> kQNodeBits);
+            c[k] = (int)(e[k] & kQNodeMask);
+        }
         top -= n;
-        const float4 A = tabA[o], C = tabC[o];                        // siblings belong to one ray: one table read for both
-        float4 lo0, hi0, lo1, hi1;
-        load_pair(c, lo0, hi0, lo1, hi1);
-#if defined(RT_PAD_VMEM)     // sensitivity experiment: the same four 16-byte loads once more (L1 hits: address / tag pipeline only)
+        float4 A[KP], C[KP], lo0[KP], hi0[KP], lo1[KP], hi1[KP];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {                                // all loads first: they are in flight together
+            A[k] = tabA[o[k]]; C[k] = tabC[o[k]];                      // siblings belong to one ray: one table read for both
+            load_pair(c[k], lo0[k], hi0[k], lo1[k], hi1[k]);
+        }
+#if defined(RT_PAD_VMEM)     // sensitivity experiment: the four 16-byte loads of the first pair once more (L1 hits: address / tag pipeline only)
         {
-            const float4 *pp = nodes + 2 * c;
+            const float4 *pp = nodes + 2 * c[0];
             typedef float pad_v4f __attribute__((ext_vector_type(4)));
             pad_v4f x0, x1, x2, x3;
             asm volatile("global_load_dwordx4 %0, %4, off\n global_load_dwordx4 %1, %4, off offset:16\n global_load_dwordx4 %2, %4, off offset:32\n"
@@ -380,39 +392,50 @@ __global__ __launch_bounds__(LDSN ? 1024 : kQBlock, LDSN ? 4 : 5) void wf_travq(
             asm volatile("" :: "v"(x0), "v"(x1), "v"(x2), "v"(x3));
         }
 #endif
-        bool hit0, hit1;
-        const bool dec0 = qbox_filter(lo0, hi0, A, C, hit0);
-        const bool dec1 = qbox_filter(lo1, hi1, A, C, hit1);
+        bool hit0[KP], hit1[KP], und = false;
+        bool dec0[KP], dec1[KP];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            dec0[k] = qbox_filter(lo0[k], hi0[k], A[k], C[k], hit0[k]);
+            dec1[k] = qbox_filter(lo1[k], hi1[k], A[k], C[k], hit1[k]);
+            und = und || (act[k] && !(dec0[k] && dec1[k]));
+        }
         // literal arithmetic for undecided lanes behind a wave-uniform branch (six IEEE divisions, almost never needed)
-        if (__builtin_expect(__ballot(act && !(dec0 && dec1)) != 0ull, 0)) {
-            if (act && !(dec0 && dec1)) {
-                const float2 D = tabD[o];
-                const f3 O = mk(C.x, C.y, C.z), u = mk(C.w, D.x, D.y);
-                if (!dec0) hit0 = slab(lo0, hi0, O, u);
-                if (!dec1) hit1 = slab(lo1, hi1, O, u);
+        if (__builtin_expect(__ballot(und) != 0ull, 0)) {
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                if (act[k] && !(dec0[k] && dec1[k])) {
+                    const float2 D = tabD[o[k]];
+                    const f3 O = mk(C[k].x, C[k].y, C[k].z), u = mk(C[k].w, D.x, D.y);
+                    if (!dec0[k]) hit0[k] = slab(lo0[k], hi0[k], O, u);
+                    if (!dec1[k]) hit1[k] = slab(lo1[k], hi1[k], O, u);
+                }
             }
         }
-        const int hiw0 = __float_as_int(hi0.w), low0 = __float_as_int(lo0.w), cnt0 = hiw0 - low0;
-        const int hiw1 = __float_as_int(hi1.w), low1 = __float_as_int(lo1.w), cnt1 = hiw1 - low1;
-        hit0 = hit0 && act; hit1 = hit1 && act;
-        const bool hI0 = hit0 && hiw0 < 0, hI1 = hit1 && hiw1 < 0;
-        const bool hL0 = hit0 && hiw0 >= 0 && cnt0 > 0, hL1 = hit1 && hiw1 >= 0 && cnt1 > 0;
-        if (STATS) {
-            wk.box += act ? 2u : 0u; wk.nodes += (hit0 ? 1u : 0u) + (hit1 ? 1u : 0u);
-            wk.tris += ((hit0 && hiw0 >= 0) ? (uint32_t)cnt0 : 0u) + ((hit1 && hiw1 >= 0) ? (uint32_t)cnt1 : 0u);
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const int hiw0 = __float_as_int(hi0[k].w), low0 = __float_as_int(lo0[k].w), cnt0 = hiw0 - low0;
+            const int hiw1 = __float_as_int(hi1[k].w), low1 = __float_as_int(lo1[k].w), cnt1 = hiw1 - low1;
+            const bool h0 = hit0[k] && act[k], h1 = hit1[k] && act[k];
+            const bool hI0 = h0 && hiw0 < 0, hI1 = h1 && hiw1 < 0;
+            const bool hL0 = h0 && hiw0 >= 0 && cnt0 > 0, hL1 = h1 && hiw1 >= 0 && cnt1 > 0;
+            if (STATS) {
+                wk.box += act[k] ? 2u : 0u; wk.nodes += (h0 ? 1u : 0u) + (h1 ? 1u : 0u);
+                wk.tris += ((h0 && hiw0 >= 0) ? (uint32_t)cnt0 : 0u) + ((h1 && hiw1 >= 0) ? (uint32_t)cnt1 : 0u);
+            }
+            const unsigned long long mI0 = __ballot(hI0), mI1 = __ballot(hI1), mL0 = __ballot(hL0), mL1 = __ballot(hL1);
+            const int nI0 = __popcll(mI0), nL0 = __popcll(mL0);
+            const unsigned int sbits = e[k] & ~kQNodeMask;
+            if (hI0) stack[top + lanes_below(mI0)] = sbits | (unsigned int)low0;        // a hit internal node pushes ITS pair of children
+            if (hI1) stack[top + nI0 + lanes_below(mI1)] = sbits | (unsigned int)low1;
+            top += nI0 + __popcll(mI1);
+            if (hL0) leafq[(ltail + (unsigned int)lanes_below(mL0)) & (LCAP - 1)] = make_uint2((unsigned int)low0, (unsigned int)o[k] | (unsigned int)cnt0 << 8);
+            if (hL1) leafq[(ltail + (unsigned int)(nL0 + lanes_below(mL1))) & (LCAP - 1)] = make_uint2((unsigned int)low1, (unsigned int)o[k] | (unsigned int)cnt1 << 8);
+            ltail += (unsigned int)(nL0 + __popcll(mL1));
+            // outstanding entries of the ray: this pair is gone (-1), every pushed pair and leaf entry counts +1: one LDS add per lane
+            const int delta = (hI0 ? 1 : 0) + (hI1 ? 1 : 0) + (hL0 ? 1 : 0) + (hL1 ? 1 : 0) - (act[k] ? 1 : 0);
+            if (delta != 0) atomicAdd(&pend[o[k]], delta);
         }
-        const unsigned long long mI0 = __ballot(hI0), mI1 = __ballot(hI1), mL0 = __ballot(hL0), mL1 = __ballot(hL1);
-        const int nI0 = __popcll(mI0), nL0 = __popcll(mL0);
-        const unsigned int sbits = e & ~kQNodeMask;
-        if (hI0) stack[top + lanes_below(mI0)] = sbits | (unsigned int)low0;            // a hit internal node pushes ITS pair of children
-        if (hI1) stack[top + nI0 + lanes_below(mI1)] = sbits | (unsigned int)low1;
-        top += nI0 + __popcll(mI1);
-        if (hL0) leafq[(ltail + (unsigned int)lanes_below(mL0)) & (LCAP - 1)] = make_uint2((unsigned int)low0, (unsigned int)o | (unsigned int)cnt0 << 8);
-        if (hL1) leafq[(ltail + (unsigned int)(nL0 + lanes_below(mL1))) & (LCAP - 1)] = make_uint2((unsigned int)low1, (unsigned int)o | (unsigned int)cnt1 << 8);
-        ltail += (unsigned int)(nL0 + __popcll(mL1));
-        // outstanding entries of the ray: this pair is gone (-1), every pushed pair and leaf entry counts +1: one LDS add per lane
-        const int delta = (hI0 ? 1 : 0) + (hI1 ? 1 : 0) + (hL0 ? 1 : 0) + (hL1 ? 1 : 0) - (act ? 1 : 0);
-        if (delta != 0) atomicAdd(&pend[o], delta);
         if (dbg_on) { d_box++; d_boxl += 2u * (unsigned int)n; if ((unsigned int)top > d_maxtop) d_maxtop = (unsigned int)top; }
         WQ_STAMP(cy_box);
     }
