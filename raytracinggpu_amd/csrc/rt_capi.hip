@@ -329,7 +329,7 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
                     RT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, travq_fn(work_dev != nullptr, qR, false), rtk::kQBlock, trav_lds));
                     ctx->travq_blocks_per_cu[qi] = nb > 0 ? nb : 1;
                 }
-                bpc = std::min(ctx->travq_blocks_per_cu[qi], getenv("RT_TRAVQ_BPC5") ? 5 : 4);    // a fifth workgroup per CU fits but does not pay (measured)
+                bpc = std::min(ctx->travq_blocks_per_cu[qi], (getenv("RT_TRAVQ_BPC5") ? 20 : 16) / (rtk::kQBlock / 64));    // a fifth workgroup per CU fits but does not pay (measured)
             }
         }
         if (const char *e = getenv("RT_TRAV_WAVES")) { const int v = atoi(e); if (!ldsn && v >= 1 && v <= bpc) bpc = v; }

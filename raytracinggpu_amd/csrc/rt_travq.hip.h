@@ -27,7 +27,10 @@
 
 namespace rtk {
 
-constexpr int kQBlock = 256;                 // 4 waves per workgroup share one ray-slot cursor
+#ifndef RT_TRAVQ_BLOCK
+#define RT_TRAVQ_BLOCK 256
+#endif
+constexpr int kQBlock = RT_TRAVQ_BLOCK;      // 4 waves per workgroup share one ray-slot cursor (128 / 512 measured: no better)
 #ifndef RT_TRAVQ_KP
 #define RT_TRAVQ_KP 1                        // sibling pairs per lane and BOX step
 #endif
@@ -119,7 +122,7 @@ __device__ __forceinline__ bool qtri_test(const float4 q0, const float4 q1, cons
 // LDSN: the first n_lds nodes (breadth-first order: the top of the tree) are staged in LDS behind the waves' carves and
 // read from there; the launch then uses ONE workgroup per CU (blockDim.x = 64 x waves, up to 1024).
 template <bool STATS, int R, bool LDSN>
-__global__ __launch_bounds__(LDSN ? 1024 : kQBlock, (LDSN || RT_TRAVQ_KP > 1) ? 4 : 5) void wf_travq(const Scene sc, const Frame fr, const WfState st, const int cap, const int n_lds, const int kLow, const int kMinFree) {
+__global__ __launch_bounds__(LDSN ? 1024 : kQBlock, (LDSN || RT_TRAVQ_KP > 1 || kQBlock != 256) ? 4 : 5) void wf_travq(const Scene sc, const Frame fr, const WfState st, const int cap, const int n_lds, const int kLow, const int kMinFree) {
     // kLow: refill while the stack holds fewer entries (sibling pairs) than this (default 96); kMinFree: ... and at least this
     // many slots are free, or the stack is short (default R / 4)
     constexpr int SCAP = QStackCap<R>::value, LCAP = kQLeafCap;
