@@ -387,6 +387,7 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
             // the stride pattern's period S is the largest power of two not above a workgroup's number of groups
             st.log2S = 0;
             while ((2 << st.log2S) <= groups_per_block && st.log2S < 16) ++st.log2S;
+            if (const char *e = getenv("RT_TRAV_LOG2S")) { const int v = atoi(e); if (v >= 0 && v < st.log2S) st.log2S = v; }   // experiment: less scrambling = more coherent rays per workgroup
             const int S = 1 << st.log2S;
             st.Q = (st.n_groups + S - 1) / S;
             const int64_t total_slots = (int64_t)S * st.Q * 4;
