@@ -97,9 +97,49 @@ def cpu_baseline(args, rays_per_frame):
         times.append(time.perf_counter() - t0)
     sec = statistics.median(times)
     what = f"full {W}x{H} frame" if step == 1 else f"every {step}th 8-row tile of the {W}x{H} frame"
-    return {"value": round(c["rays"] / sec / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"{what}, num_rays={args.spp}, num_bounce={args.bounces}, {c['rays']} rays, median of {reps} run(s), pixel loop only",
-            "seconds": round(sec, 4), "ms_per_frame_equiv": round(1e3 * rays_per_frame / (c["rays"] / sec), 2)}
+    out = {"value": round(c["rays"] / sec / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+           "sample": f"{what}, num_rays={args.spp}, num_bounce={args.bounces}, {c['rays']} rays, median of {reps} run(s), pixel loop only",
+           "seconds": round(sec, 4), "ms_per_frame_equiv": round(1e3 * rays_per_frame / (c["rays"] / sec), 2)}
+    if args.scene == "cpu":
+        try:
+            out["reference_check"] = reference_check(sc, threads)
+        except Exception as e:  # never lets the check take the baseline down
+            out["reference_check"] = {"skipped": str(e)}
+    return out
+
+
+def reference_check(sc, threads):
+    """The port is the timed baseline because the reference program is hard-wired to 512x512 and to an OBJ path.  Where
+    the build container compiled the reference itself (oracle/_ref/cpu, `make -C oracle ref`; it travels with the
+    snapshot), run THAT program at its own size next to the port: same host, same threads, `cpu 8 3` in a directory that
+    holds the cat as an OBJ rebuilt from the fixture (6-number vertex lines are not transformed by readOBJ, cpu:344-350)."""
+    import subprocess, tempfile
+    import raytracinggpu_amd as rt
+    exe = os.path.join(ROOT, "oracle", "_ref", "cpu")
+    if not os.path.exists(exe):
+        return {"skipped": "oracle/_ref/cpu not built"}
+    g = np.load(rt.scenes.CAT_FIXTURE, allow_pickle=False)
+    with tempfile.TemporaryDirectory() as d:
+        od = os.path.join(d, "cadnav.com_model", "Models_F0202A090")
+        os.makedirs(od)
+        with open(os.path.join(od, "cat.obj"), "w") as f:
+            for v in g["vertices"]:
+                f.write("v %.9g %.9g %.9g 1 1 1\r\n" % tuple(float(x) for x in v))
+            for t in g["tri_obj_order"]:
+                f.write("f %d/1/1 %d/1/1 %d/1/1\r\n" % tuple(int(x) + 1 for x in t))
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads))
+        ref_times = []
+        for _ in range(3):
+            r = subprocess.run([exe, "8", "3"], cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+            ref_times.append(float(r.stdout.split("Rendering time:")[1].split()[0]))
+    port_times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        sc.render(512, 512, 8, 3, threads=threads, want_rgb8=False)
+        port_times.append(time.perf_counter() - t0)
+    return {"config": "512x512, num_rays=8, num_bounce=3 (the reference program's own size)", "threads": threads,
+            "reference_program_s": round(statistics.median(ref_times), 4), "port_pixel_loop_s": round(statistics.median(port_times), 4),
+            "note": "the reference times its whole program (OBJ parse, BVH build, PNG) and draws from a clock()-seeded mt19937"}
 
 
 def main():
