@@ -311,20 +311,16 @@ public:
 
 // ---- Renderer: Scene -> libraytrace_hip.so.  Replaces the CUDA block of optimized.cu main()
 // (:794-857) and the pixel loop of cpu_launcher.cpp (:693-718). ---------------------------------
-class Renderer {
-public:
-    explicit Renderer(int device = 0) {
-        int rc = rt_ctx_create(&ctx_, device);
-        if (rc != RT_OK) throw Error(rc, std::string("rt_ctx_create: ") + rt_last_error(nullptr));
-    }
-    ~Renderer() { rt_ctx_destroy(ctx_); }
-    Renderer(const Renderer &) = delete;
-    Renderer &operator=(const Renderer &) = delete;
-
-    // Copies the scene to the GPU.  A TriangleMesh in the scene must have its BVH built
-    // (buildBVH / buildFlatBVH); at most one mesh (as in every reference program).
-    void upload(const Scene &scene, const Camera &cam = Camera()) {
-        std::vector<rt_sphere> sph;
+// The reference's Scene flattened into what rt_scene_upload / rt_multi_scene_upload take (the mesh as optimized.cu hands it
+// to its kernel: Vector[], TriangleIndices[] in BVH order, bvhTreeToArray's float[10] nodes).
+struct SceneArrays {
+    std::vector<rt_sphere> sph;
+    std::vector<float> arr, verts;
+    rt_mesh m{};
+    rt_light lt{};
+    rt_camera cm{};
+    bool has_mesh = false;
+    SceneArrays(const Scene &scene, const Camera &cam) {
         const TriangleMesh *mesh = nullptr;
         int slot = -1;
         for (size_t i = 0; i < scene.objects.size(); ++i) {
@@ -342,9 +338,6 @@ public:
             r.in_refraction_index = s->in_refraction_index; r.out_refraction_index = s->out_refraction_index;
             sph.push_back(r);
         }
-        rt_mesh m{};
-        std::vector<float> arr;
-        std::vector<float> verts;
         if (mesh) {
             size_t nodes = 0;
             count_nodes(&mesh->bvh, nodes);
@@ -361,10 +354,29 @@ public:
             m.bvh_arr10 = arr.data(); m.n_nodes = (int)nodes;
             for (int k = 0; k < 3; ++k) m.albedo[k] = mesh->albedo[k];
             m.object_slot = slot;
+            has_mesh = true;
         }
-        rt_light lt{{scene.L[0], scene.L[1], scene.L[2]}, scene.intensity};
-        rt_camera cm{{cam.C[0], cam.C[1], cam.C[2]}, cam.alpha};
-        check(rt_scene_upload(ctx_, sph.data(), (int)sph.size(), mesh ? &m : nullptr, &lt, &cm), "rt_scene_upload");
+        lt = rt_light{{scene.L[0], scene.L[1], scene.L[2]}, scene.intensity};
+        cm = rt_camera{{cam.C[0], cam.C[1], cam.C[2]}, cam.alpha};
+    }
+    static void count_nodes(const BVH *b, size_t &n) { ++n; if (b->left) count_nodes(b->left, n); if (b->right) count_nodes(b->right, n); }
+};
+
+class Renderer {
+public:
+    explicit Renderer(int device = 0) {
+        int rc = rt_ctx_create(&ctx_, device);
+        if (rc != RT_OK) throw Error(rc, std::string("rt_ctx_create: ") + rt_last_error(nullptr));
+    }
+    ~Renderer() { rt_ctx_destroy(ctx_); }
+    Renderer(const Renderer &) = delete;
+    Renderer &operator=(const Renderer &) = delete;
+
+    // Copies the scene to the GPU.  A TriangleMesh in the scene must have its BVH built
+    // (buildBVH / buildFlatBVH); at most one mesh (as in every reference program).
+    void upload(const Scene &scene, const Camera &cam = Camera()) {
+        SceneArrays a(scene, cam);
+        check(rt_scene_upload(ctx_, a.sph.data(), (int)a.sph.size(), a.has_mesh ? &a.m : nullptr, &a.lt, &a.cm), "rt_scene_upload");
     }
 
     // 8-bit interleaved RGB image, W*H*3 bytes, exactly what cpu:714-716 stores
@@ -409,7 +421,6 @@ public:
     }
     void progressive_reset() { check(rt_progressive_reset(ctx_), "rt_progressive_reset"); }   // buffer_reset
 
-private:
     static rt_params params(const RenderSettings &s) {
         rt_params p{};
         p.width = s.W; p.height = s.H; p.num_rays = s.num_rays; p.num_bounce = s.num_bounce;
@@ -417,9 +428,37 @@ private:
         p.seed = s.seed; p.variant = s.variant;
         return p;
     }
-    static void count_nodes(const BVH *b, size_t &n) { ++n; if (b->left) count_nodes(b->left, n); if (b->right) count_nodes(b->right, n); }
+
+private:
     void check(int rc, const char *what) { if (rc != RT_OK) throw Error(rc, std::string(what) + ": " + rt_last_error(ctx_)); }
     rt_ctx *ctx_ = nullptr;
+};
+
+// Several GPUs from ONE host process (rt_multi_*): interleaved 8-row tiles, tile k -> devices[k mod n], the frame assembled
+// on devices[0].  Same bits as Renderer.
+class MultiRenderer {
+public:
+    explicit MultiRenderer(const std::vector<int> &devices) {
+        int rc = rt_multi_create(&m_, devices.data(), (int)devices.size());
+        if (rc != RT_OK) throw Error(rc, std::string("rt_multi_create: ") + rt_multi_last_error(nullptr));
+    }
+    ~MultiRenderer() { rt_multi_destroy(m_); }
+    MultiRenderer(const MultiRenderer &) = delete;
+    MultiRenderer &operator=(const MultiRenderer &) = delete;
+    void upload(const Scene &scene, const Camera &cam = Camera()) {
+        SceneArrays a(scene, cam);
+        check(rt_multi_scene_upload(m_, a.sph.data(), (int)a.sph.size(), a.has_mesh ? &a.m : nullptr, &a.lt, &a.cm), "rt_multi_scene_upload");
+    }
+    std::vector<float> render_float(const RenderSettings &s) {
+        rt_params p = Renderer::params(s);
+        std::vector<float> fb((size_t)s.W * s.H * 4);
+        check(rt_render_multi(m_, &p, fb.data()), "rt_render_multi");
+        return fb;
+    }
+    rt_multi_stats stats() { rt_multi_stats st{}; check(rt_multi_get_stats(m_, &st), "rt_multi_get_stats"); return st; }
+private:
+    void check(int rc, const char *what) { if (rc != RT_OK) throw Error(rc, std::string(what) + ": " + rt_multi_last_error(m_)); }
+    rt_multi *m_ = nullptr;
 };
 
 // ---- PNG output: 8-bit RGB, what stbi_write_png(name, W, H, 3, data, 0) produces for the

@@ -5,8 +5,12 @@
 // optional flag after the two positionals:
 //   --program cpu|optimized   scene/constants of cpu_launcher.cpp (default) or optimized.cu
 //   --scene cat|spheres|demo10   --width W --height H --out FILE --obj FILE --device N --variant N
+//   --devices 0,1,2,...          several GPUs from this one process (interleaved row tiles, rt_render_multi)
+#include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <iostream>
+#include <sstream>
 #include <string>
 
 #include "../../../include/raytracer.hpp"
@@ -22,6 +26,7 @@ int main(int argc, char *argv[]) {
     auto start_time = std::chrono::system_clock::now();
     std::string program = "cpu", scene_name = "cat", out, obj = "cadnav.com_model/Models_F0202A090/cat.obj";
     int W = 512, H = 512, device = 0, variant = RT_VARIANT_AUTO;
+    std::vector<int> devices;
     for (int i = 3; i + 1 < argc; i += 2) {
         const std::string k = argv[i], v = argv[i + 1];
         if (k == "--program") program = v;
@@ -32,6 +37,7 @@ int main(int argc, char *argv[]) {
         else if (k == "--obj") obj = v;
         else if (k == "--device") device = atoi(v.c_str());
         else if (k == "--variant") variant = atoi(v.c_str());
+        else if (k == "--devices") { std::stringstream ss(v); std::string tok; while (std::getline(ss, tok, ',')) devices.push_back(atoi(tok.c_str())); }
         else { std::cerr << "unknown option " << k << "\n"; return 2; }
     }
     const bool optimized = program == "optimized";
@@ -64,9 +70,24 @@ int main(int argc, char *argv[]) {
 
         RenderSettings rs = optimized ? RenderSettings::optimized_cu() : RenderSettings::cpu_launcher();
         rs.W = W; rs.H = H; rs.num_rays = num_rays; rs.num_bounce = num_bounce; rs.variant = variant;
+        std::vector<unsigned char> image;
+        if (!devices.empty()) {                                       // several GPUs, one process
+            MultiRenderer renderer(devices);
+            renderer.upload(s);
+            const std::vector<float> fb = renderer.render_float(rs);
+            image.resize((size_t)W * H * 3);
+            for (size_t px = 0; px < (size_t)W * H; ++px)
+                for (int k = 0; k < 3; ++k) image[3 * px + k] = (unsigned char)std::min(std::pow((double)fb[4 * px + k], 1. / 2.2), 255.);   // cpu:714-716
+            if (!write_png(out.c_str(), W, H, image.data())) { std::cerr << "cannot write " << out << "\n"; return 1; }
+            const rt_multi_stats st = renderer.stats();
+            std::chrono::duration<float> run_time = std::chrono::system_clock::now() - start_time;
+            std::cout << "Rendering time: " << run_time.count() << " s\n";
+            std::cerr << st.n_devices << " devices, frame " << st.frame_ms << " ms, gather " << st.gather_ms << " ms, " << st.rays << " rays\n";
+            return 0;
+        }
         Renderer renderer(device);
         renderer.upload(s);
-        std::vector<unsigned char> image = renderer.render_rgb8(rs);
+        image = renderer.render_rgb8(rs);
         if (!write_png(out.c_str(), W, H, image.data())) { std::cerr << "cannot write " << out << "\n"; return 1; }
         const rt_stats st = renderer.stats();
         auto end_time = std::chrono::system_clock::now();
