@@ -224,7 +224,14 @@ def main():
                           "num_rays": args.spp, "num_bounce": args.bounces, "depth_convention": "cpu_launcher (b+1 segments)",
                           "rays_per_frame": rays_per_frame, "tiling": f"{TILE_ROWS}-row tiles interleaved over {world} rank(s)"
                           + (", RCCL gather to rank 0 per frame" if world > 1 else ""),
-                          "variant": ctx.stats()["variant"], "device": ctx.device_name}}
+                          "variant": ctx.stats()["variant"], "device": ctx.device_name,
+                          "primary_Msamples_per_s": round(W * H * args.spp / (elapsed / args.steps) / 1e6, 1)}}
+        if world == 1:
+            # like-for-like with a host caller -- rt_render (kernels + the 16 B/pixel D2H copy over PCIe), untimed region
+            t1 = time.perf_counter()
+            for _ in range(3):
+                ctx.render(p)
+            res["config"]["host_frame_ms_incl_d2h"] = round((time.perf_counter() - t1) / 3 * 1e3, 3)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(args, rays_per_frame)
