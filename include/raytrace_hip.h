@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1
+#define RT_ABI_VERSION 2
 #define RT_MAX_SPHERES 16      /* reference: Geometry* objects[10], optimized.cu:663 */
 #define RT_MAX_SEGMENTS 16     /* reference: MAX_RAY_DEPTH 10, optimized.cu:22       */
 
@@ -39,7 +39,8 @@ typedef enum rt_status {
     RT_ERR_NO_DEVICE = -2,     /* no gfx950 device / HIP runtime unusable            */
     RT_ERR_HIP = -3,           /* a HIP call failed (message in rt_last_error)       */
     RT_ERR_NO_SCENE = -4,      /* render before rt_scene_upload                      */
-    RT_ERR_UNSUPPORTED = -5    /* e.g. LDS variant that does not fit the mesh        */
+    RT_ERR_UNSUPPORTED = -5,   /* e.g. LDS variant that does not fit the mesh        */
+    RT_ERR_INTERNAL = -6       /* an invariant of the library did not hold (a bug)   */
 } rt_status;
 
 /* kernel variants (BASELINE.json configs 3/4); all produce bit-identical results */
@@ -47,10 +48,14 @@ typedef enum rt_variant {
     RT_VARIANT_AUTO = 0,       /* the fastest measured variant: RT_VARIANT_WAVEFRONT_QUEUE          */
     RT_VARIANT_GLOBAL = 1,     /* persistent lanes (micro-op scheduler); SoA nodes + packed
                                   triangles read from HBM through L2/L1                             */
-    RT_VARIANT_LDS_VERTS = 2,  /* + vertex array staged in LDS per workgroup
-                                  (different-versions/optimized_vertices-in-shared.cu:681-686)      */
-    RT_VARIANT_LDS_TOP = 3,    /* + top BVH levels staged in LDS                                    */
-    RT_VARIANT_LDS_ALL = 4,    /* whole BVH + vertices + indices resident in LDS                    */
+    RT_VARIANT_LDS_VERTS = 2,  /* work-stack traversal (as 8) with the vertex array staged in LDS by a
+                                  cooperative copy per workgroup (different-versions/
+                                  optimized_vertices-in-shared.cu:681-686): a triangle test reads three
+                                  indices + three LDS vertices; one workgroup per CU; RT_ERR_UNSUPPORTED
+                                  when the vertices leave no room for a wave's carve in the 160 KB    */
+    RT_VARIANT_LDS_TOP = 3,    /* work-stack traversal with the top BVH levels (breadth-first prefix of
+                                  the node array, all of it if it fits) staged in LDS                */
+    RT_VARIANT_LDS_ALL = 4,    /* both: vertices + as much of the top of the BVH as fits beside them  */
     RT_VARIANT_LOCKSTEP = 5,   /* one lane bound to one pixel for the whole frame, lock-step ray
                                   queries: the structure of KernelLaunch (optimized.cu:670-772);
                                   kept as the baseline the other variants are measured against      */
@@ -179,6 +184,33 @@ int rt_count_work(rt_ctx *ctx, const rt_params *p, int row_begin, int row_end, r
 
 int rt_synchronize(rt_ctx *ctx);
 int rt_get_stats(rt_ctx *ctx, rt_stats *stats);        /* waits for the last render to finish */
+
+/* --- pinned host memory for frame buffers.  optimized.cu copies its image into pageable memory (`new char[]`,
+ *     optimized.cu:851-856); a buffer from rt_host_alloc lets the D2H copy of rt_render / rt_render_rgb8 /
+ *     rt_render_multi run as one DMA at the PCIe rate instead of being staged by the runtime. ------------------ */
+int rt_host_alloc(void **ptr, size_t bytes);
+int rt_host_free(void *ptr);
+
+/* --- known-answer entry points (test interface; same library, same device functions the render kernels inline).
+ *     One lane per row.  Inputs/outputs use the layouts of tests/golden/kat.npz, which the reference's own functions
+ *     produced (oracle/ref_harness.cpp):
+ *       sphere   in C[3] R O[3] u[3]          out hit t N[3]      Sphere::intersect, cpu:512-527
+ *       box      in mn[3] mx[3] O[3] u[3]     out hit             BoundingBox::intersect, cpu:146-157
+ *                route 0 literal divisions, 1 slab_filtered (root-box pre-test, stackless walks), 2 qbox_filter + literal
+ *                fall-back (work-stack kernels)
+ *       triangle in A[3] B[3] C[3] O[3] u[3]  out hit t N[3]      moller_trumbore, cpu:226-236 (N = e1 x e2, unnormalised)
+ *       mesh     in O[3] u[3]                 out hit t N[3]      TriangleMesh::intersect, cpu:238-313, on the uploaded mesh
+ *                route 0 the work-stack kernels' primitives, 1 the stackless mesh_intersect of the lock-step kernels
+ *     counts: how many tests the error-bounded filters decided and how many fell back to the literal divisions. --- */
+typedef struct rt_kat_counts {
+    uint64_t n;
+    uint64_t box_decided, box_literal;
+    uint64_t tri_decided, tri_literal;
+} rt_kat_counts;
+int rt_kat_sphere(rt_ctx *ctx, const float *in, int n, float *out);
+int rt_kat_box(rt_ctx *ctx, const float *in, int n, int route, float *out, rt_kat_counts *counts);
+int rt_kat_triangle(rt_ctx *ctx, const float *in, int n, float *out, rt_kat_counts *counts);
+int rt_kat_mesh(rt_ctx *ctx, const float *in, int n, float tri_tmin, int route, float *out, rt_kat_counts *counts);
 
 /* --- device-side mesh transform: the `transform` kernel of global_launcher.cu:340-365 / transformMesh
  *     (realtime_render.cu:1151-1166) applied to the uploaded vertices -- v' = R v (row-major 3x3), then += translation --

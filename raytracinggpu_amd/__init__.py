@@ -6,4 +6,4 @@ Python package is plumbing for tests and bench.py: a ctypes binding and the scen
 presets of the reference programs.
 """
 from . import _capi, scenes  # noqa: F401  (tiling imports torch: import it explicitly where needed)
-from ._capi import Context, MultiContext, RtError, camera_basis, device_count, interleaved_rows, make_params, make_pose  # noqa: F401
+from ._capi import Context, MultiContext, PinnedArray, RtError, camera_basis, device_count, interleaved_rows, make_params, make_pose  # noqa: F401

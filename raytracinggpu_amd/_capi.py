@@ -23,7 +23,8 @@ EXPORTS = ["rt_abi_version", "rt_device_count", "rt_ctx_create", "rt_ctx_destroy
            "rt_mesh_transform", "rt_mesh_set_normals", "rt_camera_basis", "rt_render_pose", "rt_render_pose_device", "rt_progressive_reset", "rt_progressive_frame",
            "rt_progressive_frames",
            "rt_multi_create", "rt_multi_destroy", "rt_multi_last_error", "rt_multi_scene_upload", "rt_render_multi",
-           "rt_render_multi_device", "rt_multi_get_stats"]
+           "rt_render_multi_device", "rt_multi_get_stats",
+           "rt_host_alloc", "rt_host_free", "rt_kat_sphere", "rt_kat_box", "rt_kat_triangle", "rt_kat_mesh"]
 MAX_DEVICES = 16
 
 
@@ -71,6 +72,10 @@ class Stats(C.Structure):
     _fields_ = [("kernel_ms", C.c_float), ("tonemap_ms", C.c_float), ("pixels", C.c_uint64), ("variant", C.c_int32),
                 ("lds_bytes", C.c_int32), ("block_threads", C.c_int32), ("grid_blocks", C.c_int32),
                 ("trav_ms", C.c_float), ("trav_launches", C.c_int32), ("parts", C.c_int32), ("reserved", C.c_int32)]
+
+
+class KatCounts(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("box_decided", C.c_uint64), ("box_literal", C.c_uint64), ("tri_decided", C.c_uint64), ("tri_literal", C.c_uint64)]
 
 
 class CameraPose(C.Structure):
@@ -151,8 +156,36 @@ def load():
     L.rt_render_multi.argtypes = [vp, C.POINTER(Params), C.POINTER(C.c_float)]
     L.rt_render_multi_device.argtypes = [vp, C.POINTER(Params), vp]
     L.rt_multi_get_stats.argtypes = [vp, C.POINTER(MultiStats)]
+    L.rt_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
+    L.rt_host_free.argtypes = [vp]
+    L.rt_kat_sphere.argtypes = [vp, fp3, C.c_int, fp3]
+    L.rt_kat_box.argtypes = [vp, fp3, C.c_int, C.c_int, fp3, C.POINTER(KatCounts)]
+    L.rt_kat_triangle.argtypes = [vp, fp3, C.c_int, fp3, C.POINTER(KatCounts)]
+    L.rt_kat_mesh.argtypes = [vp, fp3, C.c_int, C.c_float, C.c_int, fp3, C.POINTER(KatCounts)]
     _lib = L
     return L
+
+
+class PinnedArray:
+    """A float32 / uint8 numpy array over rt_host_alloc memory (frame buffer for rt_render*: the D2H copy is one DMA)."""
+
+    def __init__(self, shape, dtype=np.float32):
+        self._L = load()
+        self._p = C.c_void_p()
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        rc = self._L.rt_host_alloc(C.byref(self._p), max(n, 16))
+        if rc != RT_OK:
+            raise RtError(rc, self._L.rt_last_error(None).decode())
+        buf = (C.c_uint8 * max(n, 16)).from_address(self._p.value)
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def close(self):
+        if getattr(self, "_p", None) is not None and self._p.value:
+            self.array = None
+            self._L.rt_host_free(self._p)
+            self._p = C.c_void_p()
+
+    __del__ = close
 
 
 def camera_basis(pose):
@@ -255,9 +288,12 @@ class Context:
         arr, n, m, lt, cam, self._keep = _marshal_scene(spheres, mesh, light, camera)
         self._check(self._L.rt_scene_upload(self._h, arr, n, C.byref(m) if m is not None else None, C.byref(lt), C.byref(cam)))
 
-    def render(self, params, row_begin=0, row_end=None):
+    def render(self, params, row_begin=0, row_end=None, out=None):
+        """out: optional preallocated [rows, W, 4] float32 array (e.g. PinnedArray(...).array)."""
         row_end = params.height if row_end is None else row_end
-        out = np.empty((max(row_end - row_begin, 0), params.width, 4), np.float32)
+        if out is None:
+            out = np.empty((max(row_end - row_begin, 0), params.width, 4), np.float32)
+        assert out.dtype == np.float32 and out.flags.c_contiguous and out.size == max(row_end - row_begin, 0) * params.width * 4
         self._check(self._L.rt_render(self._h, C.byref(params), row_begin, row_end, out.ctypes.data_as(C.POINTER(C.c_float))))
         return out
 
@@ -323,6 +359,28 @@ class Context:
 
     def synchronize(self):
         self._check(self._L.rt_synchronize(self._h))
+
+    def _kat(self, fn, rows, width, owidth, *extra, counts=True):
+        a = np.ascontiguousarray(rows, np.float32).reshape(-1, width)
+        out = np.zeros((len(a), owidth), np.float32)
+        c = KatCounts()
+        fp = C.POINTER(C.c_float)
+        args = [self._h, a.ctypes.data_as(fp), len(a), *extra, out.ctypes.data_as(fp)] + ([C.byref(c)] if counts else [])
+        self._check(fn(*args))
+        return out, {k: int(getattr(c, k)) for k, _ in KatCounts._fields_}
+
+    def kat_sphere(self, rows):
+        return self._kat(self._L.rt_kat_sphere, rows, 10, 5, counts=False)[0]
+
+    def kat_box(self, rows, route):
+        out, c = self._kat(self._L.rt_kat_box, rows, 12, 1, int(route))
+        return out[:, 0], c
+
+    def kat_triangle(self, rows):
+        return self._kat(self._L.rt_kat_triangle, rows, 15, 5)
+
+    def kat_mesh(self, rows, tri_tmin=1e-4, route=0):
+        return self._kat(self._L.rt_kat_mesh, rows, 6, 5, C.c_float(tri_tmin), int(route))
 
     def stats(self):
         s = Stats()

@@ -29,8 +29,49 @@ struct DevBuf {
 
 }  // namespace
 
+// Tuning / test knobs: environment variables read ONCE, when the context is created (rt_ctx_create).  Defaults are the
+// measured optimum on MI355X; tests create a context under a modified environment to reach the rare code paths.
+struct Knobs {
+    int travq_R = 64;          // RT_TRAVQ_R: ray slots per wave of the work-stack kernel (32 | 64)
+    int travq_cap = 0;         // RT_TRAVQ_CAP: stack capacity (>= 128; tests force the serial drain); 0 = the carve's capacity
+    int travq_lds = 0;         // RT_TRAVQ_LDS: waves of the ONE workgroup per CU that stages the top of the BVH in LDS; 0 = nodes through L1/L2
+    int q_low = 96;            // RT_TRAVQ_LOW: refill while the stack holds fewer sibling pairs than this
+    int q_minfree = 0;         // RT_TRAVQ_MINFREE: ... and at least this many slots are free (0 = R / 4)
+    int parts = 2;             // RT_PARTS: concurrent sub-frames of the wavefront pipeline
+    int bpc5 = 0;              // RT_TRAVQ_BPC5: allow a fifth workgroup per CU
+    int trav_waves = 0;        // RT_TRAV_WAVES: cap on traversal workgroups per CU
+    int oversub = 2;           // RT_TRAVQ_OVERSUB: grid oversubscription of the work-stack kernel
+    int oversub_min = 0;       // RT_TRAVQ_OVERSUB_MIN
+    int min_groups = 16;       // RT_TRAV_MIN_GROUPS: ray groups per wave below which a launch uses fewer workgroups
+    int log2S = -1;            // RT_TRAV_LOG2S: cap on the scramble period (experiment)
+    int debug_trav = -2;       // RT_DEBUG_TRAV: traversal launch whose per-wave records are dumped (-DRT_DEBUG builds only)
+};
+
+static Knobs read_knobs() {
+    Knobs k;
+    auto geti = [](const char *name, int &out) { const char *e = getenv(name); if (e && *e) { out = atoi(e); return true; } return false; };
+    int v;
+    if (geti("RT_TRAVQ_R", v) && v == 32) k.travq_R = 32;
+    if (geti("RT_TRAVQ_CAP", v) && v >= 128) k.travq_cap = v;
+    if (geti("RT_TRAVQ_LDS", v) && v >= 1 && v <= 16) k.travq_lds = v;
+    if (geti("RT_TRAVQ_LOW", v) && v >= 32 && v <= 320) k.q_low = v;
+    if (geti("RT_TRAVQ_MINFREE", v) && v >= 1 && v <= 64) k.q_minfree = v;
+    if (geti("RT_PARTS", v) && v >= 1 && v <= 8) k.parts = v;
+    if (getenv("RT_TRAVQ_BPC5")) k.bpc5 = 1;
+    if (geti("RT_TRAV_WAVES", v) && v >= 1) k.trav_waves = v;
+    if (geti("RT_TRAVQ_OVERSUB", v) && v >= 1 && v <= 16) k.oversub = v;
+    if (geti("RT_TRAVQ_OVERSUB_MIN", v) && v >= 0) k.oversub_min = v;
+    if (geti("RT_TRAV_MIN_GROUPS", v) && v >= 4) k.min_groups = v;
+    if (geti("RT_TRAV_LOG2S", v) && v >= 0) k.log2S = v;
+#ifdef RT_DEBUG
+    if (geti("RT_DEBUG_TRAV", v)) k.debug_trav = v;
+#endif
+    return k;
+}
+
 struct rt_ctx {
     int device = 0;
+    Knobs knobs;
     hipStream_t stream = nullptr;
     hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
     bool have_scene = false, have_kernel_time = false, have_tonemap_time = false;
@@ -43,6 +84,7 @@ struct rt_ctx {
     int n_cus = 0;
     DevBuf wfR0, wfR1, wfM, wfFL, wfS0, wfS1, wfT, wfF, wfLS, wfQ;   // wavefront path state (HBM)
     DevBuf wfQA, wfQB, wfQF;                                        // traversal queue in slot order (work-stack variant)
+    DevBuf dbgbuf;                                                  // -DRT_DEBUG builds: per-wave traversal records
     DevBuf accum;                                                   // progressive mode: sum of the frames so far (float4 per pixel)
     int prog_frames = 0, prog_w = 0, prog_h = 0;
     uint64_t qf_sig = 0;                                            // layout the queue flags were last zeroed for
@@ -81,8 +123,10 @@ int fail(rt_ctx *ctx, int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return fail(ctx, RT_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
     } while (0)
 
+// Every allocation happens on the context's device, whatever the calling thread's current device is.
 int ensure(rt_ctx *ctx, DevBuf &b, size_t bytes) {
     if (b.bytes >= bytes && b.p) return RT_OK;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
     b.release();
     RT_HIP(ctx, hipMalloc(&b.p, bytes ? bytes : 16));
     b.bytes = bytes ? bytes : 16;
@@ -92,6 +136,7 @@ int ensure(rt_ctx *ctx, DevBuf &b, size_t bytes) {
 int upload(rt_ctx *ctx, DevBuf &b, const void *src, size_t bytes) {
     int rc = ensure(ctx, b, bytes);
     if (rc != RT_OK) return rc;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
     if (bytes) RT_HIP(ctx, hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
     return RT_OK;
 }
@@ -179,13 +224,14 @@ int check_params(rt_ctx *ctx, const rt_params *p, int &segs) {
     return RT_OK;
 }
 
-// wf_travq instantiations: [STATS][R == 32][LDSN]
+// wf_travq instantiations: [STATS][R == 32][LDSN][LDSV]
 using TravqFn = void (*)(const rtk::Scene, const rtk::Frame, const rtk::WfState, const int, const int, const int, const int);
-TravqFn travq_fn(bool stats, int R, bool ldsn) {
-    static const TravqFn tab[2][2][2] = {
-        {{rtk::wf_travq<false, 64, false>, rtk::wf_travq<false, 64, true>}, {rtk::wf_travq<false, 32, false>, rtk::wf_travq<false, 32, true>}},
-        {{rtk::wf_travq<true, 64, false>, rtk::wf_travq<true, 64, true>}, {rtk::wf_travq<true, 32, false>, rtk::wf_travq<true, 32, true>}}};
-    return tab[stats ? 1 : 0][R == 32 ? 1 : 0][ldsn ? 1 : 0];
+template <bool S, int R> TravqFn travq_pick(bool ldsn, bool ldsv) {
+    return ldsn ? (ldsv ? rtk::wf_travq<S, R, true, true> : rtk::wf_travq<S, R, true, false>) : (ldsv ? rtk::wf_travq<S, R, false, true> : rtk::wf_travq<S, R, false, false>);
+}
+TravqFn travq_fn(bool stats, int R, bool ldsn, bool ldsv = false) {
+    if (stats) return R == 32 ? travq_pick<true, 32>(ldsn, ldsv) : travq_pick<true, 64>(ldsn, ldsv);
+    return R == 32 ? travq_pick<false, 32>(ldsn, ldsv) : travq_pick<false, 64>(ldsn, ldsv);
 }
 size_t travq_carve_bytes(int R) {
     return R == 64 ? (size_t)rtk::QCarve<64, rtk::QStackCap<64>::value, rtk::kQLeafCap>::kBytes : (size_t)rtk::QCarve<32, rtk::QStackCap<32>::value, rtk::kQLeafCap>::kBytes;
@@ -227,11 +273,20 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
     // measured on MI355X (cat, 1080p): the work-stack traversal (1.67 ms/frame) beats the per-lane stackless walk
     // (2.48 ms/frame; with LDS-staged nodes 2.65), so AUTO is the work-stack variant
     if (variant == RT_VARIANT_AUTO) variant = RT_VARIANT_WAVEFRONT_QUEUE;
+    // BASELINE config 4 / north star: "hot triangle vertices and top BVH levels staged in LDS" = the work-stack traversal kernel
+    // with the vertex array (LDS_VERTS), the breadth-first top of the node array (LDS_TOP) or both (LDS_ALL) staged per workgroup
+    const int variant_req = variant;
+    const bool want_ldsv = variant == RT_VARIANT_LDS_VERTS || variant == RT_VARIANT_LDS_ALL;
+    const bool want_ldsn = variant == RT_VARIANT_LDS_TOP || variant == RT_VARIANT_LDS_ALL;
+    if (want_ldsv || want_ldsn) variant = RT_VARIANT_WAVEFRONT_QUEUE;
     if (variant == RT_VARIANT_WAVEFRONT_LDS && !lds_fits) {
         if (ctx->scene.n_nodes == 0) variant = RT_VARIANT_WAVEFRONT;      // no mesh: nothing to stage
         else return fail(ctx, RT_ERR_UNSUPPORTED, "%d BVH nodes need %zu bytes of LDS (> 160 KiB)", ctx->scene.n_nodes, lds_nodes_bytes);
     }
-    if (variant == RT_VARIANT_WAVEFRONT_QUEUE && ctx->scene.n_nodes + 2 >= (1 << rtk::kQNodeBits)) variant = RT_VARIANT_WAVEFRONT;   // entry = slot << 26 | node
+    if (variant == RT_VARIANT_WAVEFRONT_QUEUE && ctx->scene.n_nodes + 2 >= (1 << rtk::kQNodeBits)) {   // entry = slot << 26 | node
+        if (want_ldsv || want_ldsn) return fail(ctx, RT_ERR_UNSUPPORTED, "%d BVH nodes: the LDS-staged variants need < 2^26 nodes", ctx->scene.n_nodes);
+        variant = RT_VARIANT_WAVEFRONT;
+    }
     if (variant != RT_VARIANT_GLOBAL && variant != RT_VARIANT_LOCKSTEP && variant != RT_VARIANT_WAVEFRONT && variant != RT_VARIANT_WAVEFRONT_LDS &&
         variant != RT_VARIANT_WAVEFRONT_QUEUE)
         return fail(ctx, RT_ERR_UNSUPPORTED, "variant %d is not available in this build", variant);
@@ -263,46 +318,55 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
     }
 
     ctx->stats.pixels = (uint64_t)rows->n_rows * p->width;
-    ctx->stats.variant = variant;
+    ctx->stats.variant = (want_ldsv || want_ldsn) ? variant_req : variant;
     if (rows->n_rows == 0) { ctx->stats.grid_blocks = 0; ctx->have_kernel_time = false; return RT_OK; }
     const int nseg = segs > 0 ? segs : 1;
     ctx->n_trav_events = 0;
     if (variant == RT_VARIANT_WAVEFRONT || variant == RT_VARIANT_WAVEFRONT_LDS || variant == RT_VARIANT_WAVEFRONT_QUEUE) {
         const bool ldsn = variant == RT_VARIANT_WAVEFRONT_LDS;
         const bool queue = variant == RT_VARIANT_WAVEFRONT_QUEUE;
-        int qR = 64;                                                  // ray slots per wave of the work-stack kernel
-        if (const char *e = getenv("RT_TRAVQ_R")) { if (atoi(e) == 32) qR = 32; }
+        const Knobs &kn = ctx->knobs;
+        const int qR = kn.travq_R;                                    // ray slots per wave of the work-stack kernel
         int qcap = qR == 64 ? rtk::QStackCap<64>::value : rtk::QStackCap<32>::value;
-        if (const char *e = getenv("RT_TRAVQ_CAP")) { const int v = atoi(e); if (v >= 128 && v < qcap) qcap = v; }   // tests: force the serial drain
+        if (kn.travq_cap >= 128 && kn.travq_cap < qcap) qcap = kn.travq_cap;   // tests: force the serial drain
         // BVH nodes staged in LDS (breadth-first prefix) by ONE workgroup of qW waves per CU; 0 = nodes through L1/L2
-        int qW = 0;
-        if (const char *e = getenv("RT_TRAVQ_LDS")) { const int v = atoi(e); if (v >= 1 && v <= 16) qW = v; }
+        int qW = kn.travq_lds;
         int q_nlds = 0;
-        if (queue && qW > 0) {
-            const int64_t room = 160 * 1024 - 16 - (int64_t)qW * (int64_t)travq_carve_bytes(qR);
-            q_nlds = room > 0 ? (int)(std::min<int64_t>(room / 32, ctx->scene.n_nodes + 1) & ~(int64_t)1) : 0;   // even: sibling pairs stay together
-            if (q_nlds <= 0) { qW = 0; q_nlds = 0; }
+        const bool mesh_here = ctx->scene.mesh_slot >= 0 && ctx->scene.n_nodes > 0;
+        const bool ldsv = queue && want_ldsv && mesh_here;
+        const bool ldsn_q = queue && mesh_here && (want_ldsn || qW > 0);
+        if (ldsn_q || ldsv) {
+            const int64_t carve = (int64_t)travq_carve_bytes(qR);
+            const int64_t budget = 160 * 1024 - 16 - (ldsv ? (int64_t)ctx->scene.n_verts * 16 : 0);
+            if (budget < carve) return fail(ctx, RT_ERR_UNSUPPORTED, "%d vertices need %lld bytes of LDS: no room for a wave next to them (160 KiB per CU)",
+                                            ctx->scene.n_verts, (long long)ctx->scene.n_verts * 16);
+            if (qW == 0) qW = ldsn_q ? 12 : 16;                       // measured (cat, 1080p): 12 waves + all nodes beats 16 waves + the top levels
+            qW = (int)std::min<int64_t>(qW, budget / carve);
+            const int64_t room = budget - (int64_t)qW * carve;
+            q_nlds = ldsn_q ? (int)(std::min<int64_t>(room / 32, ctx->scene.n_nodes + 1) & ~(int64_t)1) : 0;   // even: sibling pairs stay together
+            if (q_nlds <= 0 && !ldsv) { qW = 0; q_nlds = 0; }        // not even the root's children fit: plain kernel
+        } else {
+            qW = 0;
         }
-        const bool qlds = queue && qW > 0;
-        int q_low = 96, q_minfree = qR / 4;                         // refill thresholds of the work-stack kernel (tuning knobs; stack entries are sibling pairs)
-        if (const char *e = getenv("RT_TRAVQ_LOW")) { const int v = atoi(e); if (v >= 32 && v <= 320) q_low = v; }
-        if (const char *e = getenv("RT_TRAVQ_MINFREE")) { const int v = atoi(e); if (v >= 1 && v <= qR) q_minfree = v; }
+        const bool qlds = queue && qW > 0;                            // ONE workgroup of qW waves per CU
+        const bool qldsn = qlds && q_nlds > 0;
+        const int q_low = kn.q_low;                                   // refill thresholds of the work-stack kernel (stack entries are sibling pairs)
+        const int q_minfree = (kn.q_minfree >= 1 && kn.q_minfree <= qR) ? kn.q_minfree : qR / 4;
         // begin, (trav, advance) x 2*segments per sample; path state SoA in HBM, tile-order path index.
         // The rows are cut into `parts` independent sub-frames (interleaved tiles), each running its own kernel
         // sequence on its own stream: the traversal kernel ends in a latency-bound tail (a few long rays), and
         // the other parts' kernels fill the SIMDs that a tail leaves idle.  (More than 3 concurrent streams fall off
         // a cliff on this runtime: 4 hardware queues per process.)
-        int parts = 2;
-        if (const char *e = getenv("RT_PARTS")) { const int v = atoi(e); if (v >= 1 && v <= rt_ctx::kMaxParts) parts = v; }
+        int parts = std::min(kn.parts, (int)rt_ctx::kMaxParts);
         int R = rows->tile_rows, G = rows->tile_step;
         if (G == 1) R = 8;                                            // contiguous rows: any tile height describes them
         const int T = (rows->n_rows + R - 1) / R;                     // local tiles of this call
-        if (R % 8 != 0 || work_dev || getenv("RT_DEBUG_TRAV")) parts = 1;
+        if (R % 8 != 0 || work_dev || kn.debug_trav != -2) parts = 1;
         if (parts > T) parts = T > 0 ? T : 1;
         const int tiles_x = (p->width + 7) / 8;
         const int tb = qlds ? 64 * qW : queue ? rtk::kQBlock : ldsn ? rtk::kTravBlockLds : rtk::kTravBlock;
         const int wpb = tb / 64;
-        const size_t q_lds = (size_t)wpb * travq_carve_bytes(qR) + 16 + (size_t)q_nlds * 32;
+        const size_t q_lds = (size_t)wpb * travq_carve_bytes(qR) + 16 + (size_t)q_nlds * 32 + (ldsv ? (size_t)ctx->scene.n_verts * 16 : 0);
         const size_t trav_lds = queue ? q_lds : ldsn ? lds_nodes_bytes : (size_t)(rtk::kTravBlock / 64) * rtk::TravCarve<512, 8>::kBytes + 16;
         if (!ctx->trav_attr_set) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(rtk::wf_trav<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -322,23 +386,24 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
             const int qi = (work_dev ? 1 : 0) + (qR == 32 ? 2 : 0);
             if (qlds) {
                 bpc = 1;
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(travq_fn(work_dev != nullptr, qR, true)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(travq_fn(work_dev != nullptr, qR, qldsn, ldsv)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             } else {
                 if (ctx->travq_blocks_per_cu[qi] == 0) {
                     int nb = 0;
-                    RT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, travq_fn(work_dev != nullptr, qR, false), rtk::kQBlock, trav_lds));
+                    RT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, travq_fn(work_dev != nullptr, qR, false, false), rtk::kQBlock, trav_lds));
                     ctx->travq_blocks_per_cu[qi] = nb > 0 ? nb : 1;
                 }
-                bpc = std::min(ctx->travq_blocks_per_cu[qi], (getenv("RT_TRAVQ_BPC5") ? 20 : 16) / (rtk::kQBlock / 64));    // a fifth workgroup per CU fits but does not pay (measured)
+                bpc = std::min(ctx->travq_blocks_per_cu[qi], (kn.bpc5 ? 20 : 16) / (rtk::kQBlock / 64));    // a fifth workgroup per CU fits but does not pay (measured)
             }
         }
-        if (const char *e = getenv("RT_TRAV_WAVES")) { const int v = atoi(e); if (!ldsn && v >= 1 && v <= bpc) bpc = v; }
+        if (!ldsn && kn.trav_waves >= 1 && kn.trav_waves <= bpc) bpc = kn.trav_waves;
         const bool have_mesh = ctx->scene.mesh_slot >= 0 && ctx->scene.n_nodes > 0;
-        static DevBuf dbgbuf;
-        const char *dbg_env = getenv("RT_DEBUG_TRAV");
-        const int dbg_it = dbg_env ? atoi(dbg_env) : -1;
         int rc2;
-        if (dbg_env) { rc2 = ensure(ctx, dbgbuf, 10 * 8 * 65536); if (rc2 != RT_OK) return rc2; }
+#ifdef RT_DEBUG
+        const bool dbg_env = kn.debug_trav != -2;
+        const int dbg_it = kn.debug_trav;
+        if (dbg_env) { rc2 = ensure(ctx, ctx->dbgbuf, 10 * 8 * 65536); if (rc2 != RT_OK) return rc2; }
+#endif
 
         // per-part geometry
         struct Part { rtk::Frame fr; rtk::WfState st; int64_t tblocks; unsigned pblocks; size_t base; size_t qbase; };
@@ -355,7 +420,8 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
             pt.st = rtk::WfState{};
             pt.st.tiles_x = tiles_x;
             const int64_t n_paths64 = (int64_t)tiles_x * ((nrows_j + 7) / 8) * 64;
-            if (n_paths64 >= ((int64_t)1 << 31) - 65536) return fail(ctx, RT_ERR_INVALID, "image too large");
+            // slot arithmetic is 32-bit: ((col << log2S | a) << 2) and 2 * n_paths / 4 must stay below 2^31
+            if (n_paths64 >= ((int64_t)1 << 29)) return fail(ctx, RT_ERR_INVALID, "image too large: %lld paths per sub-frame (limit 2^29)", (long long)n_paths64);
             pt.st.n_paths = (int)n_paths64;
             pt.base = np_total;
             np_total += (size_t)n_paths64;
@@ -365,18 +431,15 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
             int64_t tblocks = std::max<int64_t>(1, (int64_t)ctx->n_cus * bpc / parts);   // all parts co-resident
             // work-stack kernel: more workgroups than fit at once; the dispatcher hands a finished workgroup's CU share to
             // the next one, which evens out the cost differences between the workgroups' shares of the rays
-            int oversub = 2;                                           // measured: 1.85 -> 1.67 ms/frame (cat, 1080p)
-            if (const char *e = getenv("RT_TRAVQ_OVERSUB")) { const int v = atoi(e); if (v >= 1 && v <= 16) oversub = v; }
+            const int oversub = kn.oversub;                            // default 2, measured: 1.85 -> 1.67 ms/frame (cat, 1080p)
             if (queue && !qlds && oversub > 1) {
                 // (measured down to one GPU's share of a 1080p frame split over 8: oversubscribing pays at every size;
                 // RT_TRAVQ_OVERSUB_MIN = ray slots per wave below which a launch is not oversubscribed, for experiments)
-                int min_slots = 0;
-                if (const char *e = getenv("RT_TRAVQ_OVERSUB_MIN")) { const int v = atoi(e); if (v >= 0) min_slots = v; }
+                const int min_slots = kn.oversub_min;
                 const int64_t slots_per_wave = (int64_t)st.n_groups * 4 / (tblocks * oversub * wpb);
                 if (slots_per_wave >= min_slots) tblocks *= oversub;
             }
-            int min_groups = 16 * wpb;                                // >= 64 ray slots per wave on average
-            if (const char *e = getenv("RT_TRAV_MIN_GROUPS")) { const int v = atoi(e); if (v >= 4) min_groups = v * wpb; }
+            const int min_groups = kn.min_groups * wpb;               // default 16: >= 64 ray slots per wave on average
             int64_t groups_per_block = (st.n_groups + tblocks - 1) / tblocks;
             if (groups_per_block < min_groups) {                      // small launch: fewer, fuller workgroups
                 tblocks = (st.n_groups + min_groups - 1) / min_groups;
@@ -387,7 +450,7 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
             // the stride pattern's period S is the largest power of two not above a workgroup's number of groups
             st.log2S = 0;
             while ((2 << st.log2S) <= groups_per_block && st.log2S < 16) ++st.log2S;
-            if (const char *e = getenv("RT_TRAV_LOG2S")) { const int v = atoi(e); if (v >= 0 && v < st.log2S) st.log2S = v; }   // experiment: less scrambling = more coherent rays per workgroup
+            if (kn.log2S >= 0 && kn.log2S < st.log2S) st.log2S = kn.log2S;   // experiment: less scrambling = more coherent rays per workgroup
             const int S = 1 << st.log2S;
             st.Q = (st.n_groups + S - 1) / S;
             const int64_t total_slots = (int64_t)S * st.Q * 4;
@@ -449,12 +512,14 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
                 else hipLaunchKernelGGL(rtk::wf_begin<false>, dim3(pt.pblocks), dim3(256), 0, q, scn, pt.fr, pt.st, s);
                 for (int it = 0; it < (segs > 0 ? segs + 1 : 0); ++it) {
                     if (have_mesh) {
-                        pt.st.dbg = (dbg_env && it == dbg_it) ? static_cast<unsigned long long *>(dbgbuf.p) : nullptr;
+#ifdef RT_DEBUG
+                        pt.st.dbg = (dbg_env && it == dbg_it) ? static_cast<unsigned long long *>(ctx->dbgbuf.p) : nullptr;
+#endif
                         const bool timed = j == 0 && s == fr.spp - 1;   // time part 0's traversal launches of the last sample
                         if (timed) RT_HIP(ctx, hipEventRecord(ctx->ev_trav[2 * it], q));
                         const dim3 tg((unsigned)pt.tblocks), tbd(tb);
                         if (queue) {
-                            hipLaunchKernelGGL(travq_fn(work_dev != nullptr, qR, qlds), tg, tbd, trav_lds, q, scn, pt.fr, pt.st, qcap, q_nlds, q_low, q_minfree);
+                            hipLaunchKernelGGL(travq_fn(work_dev != nullptr, qR, qldsn, ldsv), tg, tbd, trav_lds, q, scn, pt.fr, pt.st, qcap, q_nlds, q_low, q_minfree);
                         } else if (ldsn) {
                             if (work_dev) hipLaunchKernelGGL((rtk::wf_trav<true, true>), tg, tbd, trav_lds, q, scn, pt.fr, pt.st);
                             else hipLaunchKernelGGL((rtk::wf_trav<false, true>), tg, tbd, trav_lds, q, scn, pt.fr, pt.st);
@@ -472,13 +537,15 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
             if (j > 0) { RT_HIP(ctx, hipEventRecord(ctx->part_ev[j], q)); }
         }
         for (int j = 1; j < parts; ++j) RT_HIP(ctx, hipStreamWaitEvent(stream, ctx->part_ev[j], 0));
-        if (dbg_env) {
+#ifdef RT_DEBUG
+        if (dbg_env) {       // tools/dbg_travq.py: per-wave records of one traversal launch
             std::vector<unsigned long long> h(10 * (size_t)65536);
             (void)hipStreamSynchronize(stream);
-            (void)hipMemcpy(h.data(), dbgbuf.p, h.size() * 8, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(h.data(), ctx->dbgbuf.p, h.size() * 8, hipMemcpyDeviceToHost);
             FILE *f = fopen("gpurun_out/trav_dbg.bin", "wb");
             if (f) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
         }
+#endif
     } else if (variant == RT_VARIANT_LOCKSTEP) {
         dim3 grid((p->width + rtk::kTileW - 1) / rtk::kTileW, (rows->n_rows + rtk::kTileH - 1) / rtk::kTileH);
         const size_t lds = (size_t)nseg * rtk::kBlockThreads * sizeof(float);
@@ -565,6 +632,7 @@ int rt_ctx_create(rt_ctx **out, int device_id) {
     rt_ctx *ctx = new (std::nothrow) rt_ctx();
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "out of host memory");
     ctx->device = device_id;
+    ctx->knobs = read_knobs();
     hipDeviceProp_t prop;
     hipError_t e = hipSetDevice(device_id);
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device_id);
@@ -601,7 +669,7 @@ int rt_ctx_destroy(rt_ctx *ctx) {
     ctx->scratch_rgba.release(); ctx->scratch_rgb8.release(); ctx->work.release(); ctx->queue.release();
     ctx->wfR0.release(); ctx->wfR1.release(); ctx->wfM.release(); ctx->wfS0.release(); ctx->wfS1.release();
     ctx->wfT.release(); ctx->wfF.release(); ctx->wfFL.release(); ctx->wfLS.release(); ctx->wfQ.release();
-    ctx->wfQA.release(); ctx->wfQB.release(); ctx->wfQF.release(); ctx->accum.release();
+    ctx->wfQA.release(); ctx->wfQB.release(); ctx->wfQF.release(); ctx->accum.release(); ctx->dbgbuf.release();
     for (hipEvent_t &e : ctx->ev_trav) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t &e : ctx->part_ev) if (e) (void)hipEventDestroy(e);
     for (hipStream_t &q : ctx->part_stream) if (q) (void)hipStreamDestroy(q);
@@ -808,13 +876,13 @@ int rt_count_work(rt_ctx *ctx, const rt_params *p, int row_begin, int row_end, r
     const int n = row_end - row_begin;
     int rc = ensure(ctx, ctx->scratch_rgba, (size_t)n * (p->width > 0 ? p->width : 0) * sizeof(float4));
     if (rc != RT_OK) return rc;
-    if ((rc = ensure(ctx, ctx->work, 4 * sizeof(unsigned long long))) != RT_OK) return rc;
+    if ((rc = ensure(ctx, ctx->work, 8 * sizeof(unsigned long long))) != RT_OK) return rc;
     RT_HIP(ctx, hipSetDevice(ctx->device));
-    RT_HIP(ctx, hipMemsetAsync(ctx->work.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
+    RT_HIP(ctx, hipMemsetAsync(ctx->work.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
     rt_rows rows{row_begin, n, n > 0 ? n : 1, 1};
     rc = launch_render(ctx, p, &rows, ctx->scratch_rgba.p, ctx->stream, static_cast<unsigned long long *>(ctx->work.p));
     if (rc != RT_OK) return rc;
-    unsigned long long h[4];
+    unsigned long long h[8];
     RT_HIP(ctx, hipMemcpyAsync(h, ctx->work.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     std::vector<float> fb((size_t)n * (size_t)p->width * 4);
     RT_HIP(ctx, hipMemcpyAsync(fb.data(), ctx->scratch_rgba.p, fb.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
@@ -822,6 +890,8 @@ int rt_count_work(rt_ctx *ctx, const rt_params *p, int row_begin, int row_end, r
     double rays = 0;                                  // .w of every pixel = rays traced for it (exact in binary32)
     for (size_t k = 3; k < fb.size(); k += 4) rays += fb[k];
     out->rays = (uint64_t)rays; out->box_tests = h[1]; out->nodes = h[2]; out->tri_tests = h[3];
+    // the counting instantiation checks every index that reaches an address (rt_travq.hip.h WQ_CHECK, rt_path.hip.h)
+    if (h[4] != 0) return fail(ctx, RT_ERR_INTERNAL, "traversal invariant violated (mask 0x%llx: 1 path, 2 triangle, 4 node, 8 stack, 16 leaf queue, 32 staging)", h[4]);
     return RT_OK;
 }
 
@@ -954,6 +1024,21 @@ int rt_progressive_frame(rt_ctx *ctx, const rt_params *p, const rt_camera_pose *
     return RT_OK;
 }
 
+int rt_host_alloc(void **ptr, size_t bytes) {
+    if (!ptr) return fail(nullptr, RT_ERR_INVALID, "ptr is NULL");
+    *ptr = nullptr;
+    hipError_t e = hipHostMalloc(ptr, bytes ? bytes : 16, hipHostMallocDefault);
+    if (e != hipSuccess) { *ptr = nullptr; return fail(nullptr, RT_ERR_HIP, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
+    return RT_OK;
+}
+
+int rt_host_free(void *ptr) {
+    if (!ptr) return RT_OK;
+    hipError_t e = hipHostFree(ptr);
+    if (e != hipSuccess) return fail(nullptr, RT_ERR_HIP, "hipHostFree: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
 int rt_synchronize(rt_ctx *ctx) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
     RT_HIP(ctx, hipSetDevice(ctx->device));
@@ -989,3 +1074,4 @@ int rt_get_stats(rt_ctx *ctx, rt_stats *stats) {
 }  // extern "C"
 
 #include "rt_multi.hip.h"
+#include "rt_kat.hip.h"

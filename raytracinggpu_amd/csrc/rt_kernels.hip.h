@@ -65,7 +65,7 @@ struct Frame {
     uint32_t seed;
     int row0, n_rows, tile_rows, tile_step;
     float4 *out;
-    unsigned long long *work;   // STATS kernels only: {rays, box_tests, nodes, tri_tests}
+    unsigned long long *work;   // STATS kernels only: {rays, box_tests, nodes, tri_tests, invariant mask, -, -, -}
     int out_tile0, out_tile_step;   // local row r is stored at output row ((r / tile_rows) * out_tile_step + out_tile0) * tile_rows + r % tile_rows
     // cam_mode 1 = realtime_render.cu's camera and sample averaging (KernelLaunch realtime:1100-1134; wavefront variants only):
     // u_center = C + bz * z + bx * X + by * Y, every sample weighted by inv_n = (float)(1. / num_rays) as it is added
@@ -79,7 +79,7 @@ __device__ __forceinline__ size_t out_index(const Frame &fr, int lrow, int px) {
 }
 
 // per-lane traversal work counters (STATS instantiation only; SURVEY 8d accounting)
-struct Work { uint32_t box = 0, nodes = 0, tris = 0, rays = 0; };
+struct Work { uint32_t box = 0, nodes = 0, tris = 0, rays = 0, lit_box = 0, lit_tri = 0; };   // lit_*: tests decided by the literal divisions (filter undecided)
 
 struct f3 { float x, y, z; };
 __device__ __forceinline__ f3 mk(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
@@ -149,7 +149,9 @@ __device__ __forceinline__ RayInv ray_inv(f3 u) {
 
 // BoundingBox::intersect through the filter.  For finite quotients the literal swap/min_element/max_element
 // sequence (cpu:153-156) equals min over axes of max(t0,t1) > max over axes of min(t0,t1).
-__device__ __forceinline__ bool slab_filtered(float4 lo, float4 hi, f3 O, f3 u, const RayInv &r) {
+// `decided` reports whether the filter settled the test (false: the literal code ran).
+__device__ __forceinline__ bool slab_filtered(float4 lo, float4 hi, f3 O, f3 u, const RayInv &r, bool &decided) {
+    decided = true;
     if (r.safe) {
         const float ax = (lo.x - O.x) * r.x, bx = (hi.x - O.x) * r.x;
         const float ay = (lo.y - O.y) * r.y, by = (hi.y - O.y) * r.y;
@@ -166,7 +168,27 @@ __device__ __forceinline__ bool slab_filtered(float4 lo, float4 hi, f3 O, f3 u, 
             if (d < -band) return false;
         }
     }
+    decided = false;
     return slab(lo, hi, O, u);
+}
+__device__ __forceinline__ bool slab_filtered(float4 lo, float4 hi, f3 O, f3 u, const RayInv &r) {
+    bool decided;
+    return slab_filtered(lo, hi, O, u, r, decided);
+}
+
+// Sphere::intersect, cpu:512-527 (the normal, cpu:524-525, is evaluated by the caller for the winning object only)
+__device__ __forceinline__ bool sphere_test(const Sphere &s, f3 O, f3 u, float &t) {
+    const f3 C = mk(s.cx, s.cy, s.cz);
+    const f3 OC = O - C;
+    const float d = dot(u, OC);
+    const float delta = d * d - (norm2(OC) - s.R * s.R);       // cpu:513
+    if (delta < 0) return false;
+    const float sq = rt_sqrtf(delta);
+    const float b = dot(u, C - O);
+    const float t1 = b - sq, t2 = b + sq;                      // cpu:516-517
+    if (t2 < 0) return false;
+    t = t1 < 0 ? t2 : t1;
+    return true;
 }
 
 // TriangleMesh::intersect, cpu:277-311.  Returns true iff some triangle was accepted
@@ -249,17 +271,8 @@ __device__ __forceinline__ bool intersect_all(const Scene &sc, f3 O, f3 u, float
             continue;
         }
         const Sphere &s = sc.sph[si++];
-        // Sphere::intersect, cpu:512-527
-        const f3 C = mk(s.cx, s.cy, s.cz);
-        const f3 OC = O - C;
-        const float d = dot(u, OC);
-        const float delta = d * d - (norm2(OC) - s.R * s.R);
-        if (delta < 0) continue;
-        const float sq = rt_sqrtf(delta);
-        const float b = dot(u, C - O);
-        const float t1 = b - sq, t2 = b + sq;
-        if (t2 < 0) continue;
-        const float t = t1 < 0 ? t2 : t1;
+        float t;
+        if (!sphere_test(s, O, u, t)) continue;
         if (t < t_min) { t_min = t; id_min = obj; sph_min = si - 1; }
     }
     P = O + t_min * u;   // cpu:560 (also on a miss)

@@ -81,18 +81,25 @@ int multi_render(rt_multi *m, const rt_params *p, void *out_dev_on_root, float *
     if ((rc = ensure(root, m->stage, off[n] * sizeof(float4))) != RT_OK || (rc = ensure(root, m->rays, 8)) != RT_OK ||
         (!out_dev_on_root && (rc = ensure(root, m->frame, frame_bytes)) != RT_OK)) { m->err = root->err; return rc; }
     RT_MHIP(m, hipMemsetAsync(m->rays.p, 0, 8, root->stream));
-    // 1. every device renders its tiles; peers push them to the root as soon as they are done
+    // 1. every device renders its tiles; peers push them to the root as soon as they are done.  A failure part-way
+    //    leaves work in flight on the devices already launched: drain them before returning, so that the caller may
+    //    free or reuse its buffers and the next call starts from idle streams.
+    auto drain = [&](int launched) {
+        for (int j = 0; j < launched; ++j) { (void)hipSetDevice(m->ctx[j]->device); (void)hipStreamSynchronize(m->ctx[j]->stream); }
+        (void)hipSetDevice(root->device);
+    };
     for (int k = 0; k < n; ++k) {
         rt_ctx *c = m->ctx[k];
-        RT_MHIP(m, hipSetDevice(c->device));
-        if ((rc = ensure(c, m->local[k], std::max<size_t>((size_t)nrows[k] * W, 1) * sizeof(float4))) != RT_OK) { m->err = c->err; return rc; }
+        hipError_t e = hipSetDevice(c->device);
+        if (e != hipSuccess) { drain(k); return mfail(m, RT_ERR_HIP, "hipSetDevice(%d): %s", c->device, hipGetErrorString(e)); }
+        if ((rc = ensure(c, m->local[k], std::max<size_t>((size_t)nrows[k] * W, 1) * sizeof(float4))) != RT_OK) { m->err = c->err; drain(k); return rc; }
         rt_rows rows{k * R, nrows[k], R, n};
-        if ((rc = launch_render(c, p, &rows, m->local[k].p, c->stream)) != RT_OK) { m->err = c->err; return rc; }
+        if ((rc = launch_render(c, p, &rows, m->local[k].p, c->stream)) != RT_OK) { m->err = c->err; drain(k + 1); return rc; }
         if (k > 0) {
-            if (nrows[k] > 0)
-                RT_MHIP(m, hipMemcpyPeerAsync(static_cast<float4 *>(m->stage.p) + off[k], root->device, m->local[k].p, c->device,
-                                              (size_t)nrows[k] * W * sizeof(float4), c->stream));
-            RT_MHIP(m, hipEventRecord(m->done[k], c->stream));
+            if (nrows[k] > 0) e = hipMemcpyPeerAsync(static_cast<float4 *>(m->stage.p) + off[k], root->device, m->local[k].p, c->device,
+                                                     (size_t)nrows[k] * W * sizeof(float4), c->stream);
+            if (e == hipSuccess) e = hipEventRecord(m->done[k], c->stream);
+            if (e != hipSuccess) { drain(k + 1); return mfail(m, RT_ERR_HIP, "tile exchange of device %d: %s", c->device, hipGetErrorString(e)); }
         }
     }
     // 2. root: wait for the peers, restore row order

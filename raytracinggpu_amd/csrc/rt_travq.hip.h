@@ -91,8 +91,9 @@ __device__ __forceinline__ bool qbox_filter(const float4 lo, const float4 hi, co
 
 // moller_trumbore (cpu:226-236) + the acceptance test of the leaf loop (cpu:301): beta/gamma through the filter,
 // undecided lanes by the literal divisions, t always by the exact division.
+// `how` reports the route (callers that do not look at it pay nothing): 0 filter rejected, 1 filter accepted, 2 literal divisions.
 __device__ __forceinline__ bool qtri_test(const float4 q0, const float4 q1, const float4 q2, const f3 Oo, const f3 uo,
-                                          const float tri_tmin, float &t_out) {
+                                          const float tri_tmin, float &t_out, int &how) {
     const f3 A = mk(q0.x, q0.y, q0.z), e1 = mk(q0.w, q1.x, q1.y), e2 = mk(q1.z, q1.w, q2.x);
     const f3 N = mk(q2.y, q2.z, q2.w);
     const float det = dot(uo, N);
@@ -108,21 +109,32 @@ __device__ __forceinline__ bool qtri_test(const float4 q0, const float4 q1, cons
     const bool trust = fabsf(det) > kTiny;      // also false for det == 0 and NaN
     const bool reject = trust && (b < -eb || b > 1.f + eb || g < -eg || g > 1.f + eg || sum > 1.f + es);
     bool ok = trust && b >= eb && b <= 1.f - eb && g >= eg && g <= 1.f - eg && sum <= 1.f - es;
+    how = ok ? 1 : 0;
     if (!reject && !ok && det != 0) {           // undecided: the literal tests (rare)
         const float beta = bn / det;
         const float gamma = gn / det;
         ok = (0 <= beta && beta <= 1) && (0 <= gamma && gamma <= 1) && (beta + gamma <= 1);
+        how = 2;
     }
     if (!ok) return false;
     const float t = dot(AO, N) / det;
     t_out = t;
     return t > 0 && t > tri_tmin && t < 1e9f;   // cpu:235, cpu:301; 1e9f = INF narrowed (cpu:283)
 }
+__device__ __forceinline__ bool qtri_test(const float4 q0, const float4 q1, const float4 q2, const f3 Oo, const f3 uo,
+                                          const float tri_tmin, float &t_out) {
+    int how;
+    return qtri_test(q0, q1, q2, Oo, uo, tri_tmin, t_out, how);
+}
 
 // LDSN: the first n_lds nodes (breadth-first order: the top of the tree) are staged in LDS behind the waves' carves and
 // read from there; the launch then uses ONE workgroup per CU (blockDim.x = 64 x waves, up to 1024).
-template <bool STATS, int R, bool LDSN>
-__global__ __launch_bounds__(LDSN ? 1024 : kQBlock, (LDSN || RT_TRAVQ_KP > 1 || kQBlock != 256) ? 4 : 5) void wf_travq(const Scene sc, const Frame fr, const WfState st, const int cap, const int n_lds, const int kLow, const int kMinFree) {
+// LDSV: the vertex array is staged in LDS by a cooperative copy (different-versions/optimized_vertices-in-shared.cu:681-686)
+// and a TRI step reads a triangle as its three vertex indices (global, 16 B) + three LDS vertices, forming e1, e2 and
+// N = e1 x e2 with the operations of moller_trumbore (cpu:227-229) -- the same single roundings rt_scene_upload applies
+// when it precomputes the 48-byte triangle records the other variants read.  Also ONE workgroup per CU.
+template <bool STATS, int R, bool LDSN, bool LDSV>
+__global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || RT_TRAVQ_KP > 1 || kQBlock != 256) ? 4 : 5) void wf_travq(const Scene sc, const Frame fr, const WfState st, const int cap, const int n_lds, const int kLow, const int kMinFree) {
     // kLow: refill while the stack holds fewer entries (sibling pairs) than this (default 96); kMinFree: ... and at least this
     // many slots are free, or the stack is short (default R / 4)
     constexpr int SCAP = QStackCap<R>::value, LCAP = kQLeafCap;
@@ -132,10 +144,11 @@ __global__ __launch_bounds__(LDSN ? 1024 : kQBlock, (LDSN || RT_TRAVQ_KP > 1 || 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wib = tid >> 6;
-    const int wpb = LDSN ? (int)(blockDim.x >> 6) : kQBlock / 64;
+    const int wpb = (LDSN || LDSV) ? (int)(blockDim.x >> 6) : kQBlock / 64;
     unsigned char *const wl = travq_smem + wib * Carve::kBytes;
     int *const blk_cur = reinterpret_cast<int *>(travq_smem + wpb * Carve::kBytes);
     float4 *const lnodes = reinterpret_cast<float4 *>(travq_smem + wpb * Carve::kBytes + 16);
+    float4 *const lverts = lnodes + (LDSN ? 2 * n_lds : 0);        // LDSV: every vertex (x, y, z, -)
     float4 *const tabA = reinterpret_cast<float4 *>(wl + Carve::kTabA);
     float4 *const tabC = reinterpret_cast<float4 *>(wl + Carve::kTabC);
     float2 *const tabD = reinterpret_cast<float2 *>(wl + Carve::kTabD);
@@ -149,6 +162,7 @@ __global__ __launch_bounds__(LDSN ? 1024 : kQBlock, (LDSN || RT_TRAVQ_KP > 1 || 
     marks[lane] = 0; marks[lane + 64] = 0;
     if (lane < R) pend[lane] = 0;
     if (LDSN) for (int k = tid; k < 2 * n_lds; k += (int)blockDim.x) lnodes[k] = sc.nodesq[k];
+    if (LDSV) for (int k = tid; k < sc.n_verts; k += (int)blockDim.x) lverts[k] = sc.verts[k];
     __syncthreads();
 
     const float4 *const nodes = sc.nodesq;        // breadth-first order from index 1 (0 is padding): lo.w = first child (even; the other one is next to it) | first triangle (leaf); hi.w = -1 | end
@@ -164,12 +178,20 @@ __global__ __launch_bounds__(LDSN ? 1024 : kQBlock, (LDSN || RT_TRAVQ_KP > 1 || 
     unsigned int lhead = 0, ltail = 0;            // wave-uniform: leaf-queue cursors (monotonic)
     bool drained = false;
     Work wk;
-    // optional per-wave record (RT_DEBUG_TRAV): st.dbg[16 * wave + k]
+    // optional per-wave record (-DRT_DEBUG builds with RT_DEBUG_TRAV set; tools/dbg_travq.py): st.dbg[16 * wave + k]
+#ifdef RT_DEBUG
     const bool dbg_on = st.dbg != nullptr;
+#else
+    constexpr bool dbg_on = false;
+#endif
     const unsigned long long dbg_t0 = dbg_on ? __builtin_amdgcn_s_memrealtime() : 0ull;
     unsigned long long dbg_tdrain = 0ull, cy_srv = 0, cy_tri = 0, cy_box = 0, stamp = dbg_on ? __builtin_amdgcn_s_memtime() : 0ull;
     unsigned int d_box = 0, d_boxl = 0, d_tri = 0, d_tril = 0, d_rounds = 0, d_rays = 0, d_serial = 0, d_idle = 0, d_fetch = 0, d_maxtop = 0;
 #define WQ_STAMP(acc) do { if (dbg_on) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - stamp; stamp = t_; } } while (0)
+    // Invariants of every index that reaches a global or LDS address.  The counting (STATS) instantiation checks them and raises a
+    // bit in fr.work[4] instead of faulting (rt_count_work then fails with RT_ERR_INTERNAL); the product instantiation
+    // carries no checks.  Bits: 1 path index, 2 triangle index, 4 node index, 8 stack height, 16 leaf queue, 32 staging index.
+#define WQ_CHECK(cond, bit, fixup) do { if (STATS && !(cond)) { atomicOr(&fr.work[4], (unsigned long long)(bit)); fixup; } } while (0)
 
     // the sibling nodes c, c + 1 of a stack entry (c is even: the pair is one 64-byte line): LDS for the staged top of the
     // tree (n_lds is even), L1/L2 otherwise
@@ -255,7 +277,8 @@ __global__ __launch_bounds__(LDSN ? 1024 : kQBlock, (LDSN || RT_TRAVQ_KP > 1 || 
                 const int take = n_free < stage_n - stage_used ? n_free : stage_n - stage_used;
                 const int rank = lanes_below(freem);
                 const bool got = lane < R && path < 0 && rank < take;
-                const int src = got ? (int)sidx[stage_used + rank] : lane;   // the staged record lives in that lane's registers
+                WQ_CHECK(!got || stage_used + rank < 64, 32, (void)0);
+                const int src = got ? (int)sidx[(stage_used + rank) & 63] : lane;   // the staged record lives in that lane's registers
                 const float4 r0 = make_float4(__shfl(sp0.x, src, 64), __shfl(sp0.y, src, 64), __shfl(sp0.z, src, 64), __shfl(sp0.w, src, 64));
                 const float2 r1 = make_float2(__shfl(sp1.x, src, 64), __shfl(sp1.y, src, 64));
                 const int rf = __shfl(spf, src, 64);
@@ -267,6 +290,7 @@ __global__ __launch_bounds__(LDSN ? 1024 : kQBlock, (LDSN || RT_TRAVQ_KP > 1 || 
                     tabD[lane] = r1;
                     best[lane] = WF_NOHIT;
                     path = rf - 1;
+                    WQ_CHECK(path >= 0 && path < 2 * st.n_paths, 1, path = 0);
                 }
                 stage_used += take;
                 // the root box was tested when the ray was emitted (wf_emit_ray): start with what is below it
@@ -320,15 +344,32 @@ __global__ __launch_bounds__(LDSN ? 1024 : kQBlock, (LDSN || RT_TRAVQ_KP > 1 || 
             const unsigned int f1 = (unsigned int)__shfl((int)E.x, j1, 64), y1 = (unsigned int)__shfl((int)E.y, j1, 64), P1 = (unsigned int)__shfl((int)P, j1, 64);
             const bool t0 = (unsigned int)lane < total, t1 = (unsigned int)lane + 64u < total;
             const int o0 = t0 ? (int)(y0 & 0xffu) : 0, o1 = t1 ? (int)(y1 & 0xffu) : 0;
-            const int i0 = t0 ? (int)(f0 + ((unsigned int)lane - P0)) : 0, i1 = t1 ? (int)(f1 + ((unsigned int)lane + 64u - P1)) : 0;
-            const float4 *tp0 = sc.tri + 3 * (size_t)i0, *tp1 = sc.tri + 3 * (size_t)i1;
-            const float4 a0 = tp0[0], a1 = tp0[1], a2 = tp0[2];
-            const float4 b0 = tp1[0], b1 = tp1[1], b2 = tp1[2];
+            int i0 = t0 ? (int)(f0 + ((unsigned int)lane - P0)) : 0, i1 = t1 ? (int)(f1 + ((unsigned int)lane + 64u - P1)) : 0;
+            WQ_CHECK(i0 >= 0 && i0 < sc.n_tris && i1 >= 0 && i1 < sc.n_tris, 2, (i0 = 0, i1 = 0));
+            WQ_CHECK(ltail - lhead <= (unsigned int)LCAP, 16, (void)0);
+            float4 a0, a1, a2, b0, b1, b2;
+            if (LDSV) {
+                const int4 ia = sc.tidx[i0], ib = sc.tidx[i1];
+                auto record = [&](const int4 ix, float4 &q0, float4 &q1, float4 &q2) {
+                    const float4 va = lverts[ix.x], vb = lverts[ix.y], vc = lverts[ix.z];
+                    const f3 A = mk(va.x, va.y, va.z);
+                    const f3 e1 = mk(vb.x, vb.y, vb.z) - A, e2 = mk(vc.x, vc.y, vc.z) - A, N = cross(e1, e2);   // cpu:227-229
+                    q0 = make_float4(A.x, A.y, A.z, e1.x); q1 = make_float4(e1.y, e1.z, e2.x, e2.y); q2 = make_float4(e2.z, N.x, N.y, N.z);
+                };
+                record(ia, a0, a1, a2);
+                record(ib, b0, b1, b2);
+            } else {
+                const float4 *tp0 = sc.tri + 3 * (size_t)i0, *tp1 = sc.tri + 3 * (size_t)i1;
+                a0 = tp0[0]; a1 = tp0[1]; a2 = tp0[2];
+                b0 = tp1[0]; b1 = tp1[1]; b2 = tp1[2];
+            }
             const float4 C0 = tabC[o0], C1 = tabC[o1];
             const float2 D0 = tabD[o0], D1 = tabD[o1];
             float ta, tb;
-            const bool ok0 = qtri_test(a0, a1, a2, mk(C0.x, C0.y, C0.z), mk(C0.w, D0.x, D0.y), fr.tri_tmin, ta) && t0;
-            const bool ok1 = qtri_test(b0, b1, b2, mk(C1.x, C1.y, C1.z), mk(C1.w, D1.x, D1.y), fr.tri_tmin, tb) && t1;
+            int how0, how1;
+            const bool ok0 = qtri_test(a0, a1, a2, mk(C0.x, C0.y, C0.z), mk(C0.w, D0.x, D0.y), fr.tri_tmin, ta, how0) && t0;
+            const bool ok1 = qtri_test(b0, b1, b2, mk(C1.x, C1.y, C1.z), mk(C1.w, D1.x, D1.y), fr.tri_tmin, tb, how1) && t1;
+            if (STATS) wk.lit_tri += ((t0 && how0 == 2) ? 1u : 0u) + ((t1 && how1 == 2) ? 1u : 0u);
             if (ok0) atomicMin(&best[o0], (unsigned long long)__float_as_uint(ta) << 32 | (unsigned int)i0);
             if (ok1) atomicMin(&best[o1], (unsigned long long)__float_as_uint(tb) << 32 | (unsigned int)i1);
             const bool full = part && P + c <= 128u;
@@ -344,19 +385,19 @@ __global__ __launch_bounds__(LDSN ? 1024 : kQBlock, (LDSN || RT_TRAVQ_KP > 1 || 
         }
         if (top == 0) {
             if (drained && stage_used >= stage_n && __ballot(path >= 0) == 0ull) break;   // every wave gets here: each step consumes entries
-            d_idle++;
+            if (dbg_on) d_idle++;
             continue;
         }
         // =============================== BOX step: KP sibling pairs (2 KP boxes) per lane ===============================
         constexpr int KP = RT_TRAVQ_KP;
-#if defined(RT_PAD_SALU)     // sensitivity experiment (tools/pad_experiment.sh): 32 extra scalar / vector issue slots, 4 extra LDS reads per step
+#if defined(RT_DEBUG) && defined(RT_PAD_SALU)     // sensitivity experiment (tools/pad_experiment.sh): 32 extra scalar / vector issue slots, 4 extra LDS reads per step
         asm volatile("s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n"
                      "s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0");
 #endif
-#if defined(RT_PAD_VALU)
+#if defined(RT_DEBUG) && defined(RT_PAD_VALU)
         { int pad_ = lane; for (int k_ = 0; k_ < 32; ++k_) asm volatile("v_add_u32 %0, %0, 1" : "+v"(pad_)); }
 #endif
-#if defined(RT_PAD_LDS)
+#if defined(RT_DEBUG) && defined(RT_PAD_LDS)
         { unsigned int pl_ = marks[lane]; pl_ += marks[lane + 64]; pl_ += marks[lane]; pl_ += marks[lane + 64]; asm volatile("" :: "v"(pl_)); }
 #endif
         const int n = top < 64 * KP ? top : 64 * KP;
@@ -366,7 +407,7 @@ __global__ __launch_bounds__(LDSN ? 1024 : kQBlock, (LDSN || RT_TRAVQ_KP > 1 || 
             const unsigned int ed = actd ? stack[top - 1 - lane] : 0u;
             top -= nd;
             if (actd) { const int od = (int)(ed >> kQNodeBits), cd = (int)(ed & kQNodeMask); drain_serial(od, cd); drain_serial(od, cd + 1); atomicAdd(&pend[od], -1); }
-            d_serial++;
+            if (dbg_on) d_serial++;
             WQ_STAMP(cy_box);
             continue;
         }
@@ -379,13 +420,15 @@ __global__ __launch_bounds__(LDSN ? 1024 : kQBlock, (LDSN || RT_TRAVQ_KP > 1 || 
             c[k] = (int)(e[k] & kQNodeMask);
         }
         top -= n;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) WQ_CHECK(!act[k] || (c[k] >= 2 && c[k] + 1 <= sc.n_nodes), 4, c[k] = 0);
         float4 A[KP], C[KP], lo0[KP], hi0[KP], lo1[KP], hi1[KP];
 #pragma unroll
         for (int k = 0; k < KP; ++k) {                                // all loads first: they are in flight together
             A[k] = tabA[o[k]]; C[k] = tabC[o[k]];                      // siblings belong to one ray: one table read for both
             load_pair(c[k], lo0[k], hi0[k], lo1[k], hi1[k]);
         }
-#if defined(RT_PAD_VMEM)     // sensitivity experiment: the four 16-byte loads of the first pair once more (L1 hits: address / tag pipeline only)
+#if defined(RT_DEBUG) && defined(RT_PAD_VMEM)     // sensitivity experiment: the four 16-byte loads of the first pair once more (L1 hits: address / tag pipeline only)
         {
             const float4 *pp = nodes + 2 * c[0];
             typedef float pad_v4f __attribute__((ext_vector_type(4)));
@@ -402,6 +445,7 @@ __global__ __launch_bounds__(LDSN ? 1024 : kQBlock, (LDSN || RT_TRAVQ_KP > 1 || 
             dec0[k] = qbox_filter(lo0[k], hi0[k], A[k], C[k], hit0[k]);
             dec1[k] = qbox_filter(lo1[k], hi1[k], A[k], C[k], hit1[k]);
             und = und || (act[k] && !(dec0[k] && dec1[k]));
+            if (STATS) wk.lit_box += act[k] ? (dec0[k] ? 0u : 1u) + (dec1[k] ? 0u : 1u) : 0u;
         }
         // literal arithmetic for undecided lanes behind a wave-uniform branch (six IEEE divisions, almost never needed)
         if (__builtin_expect(__ballot(und) != 0ull, 0)) {
@@ -439,10 +483,12 @@ __global__ __launch_bounds__(LDSN ? 1024 : kQBlock, (LDSN || RT_TRAVQ_KP > 1 || 
             const int delta = (hI0 ? 1 : 0) + (hI1 ? 1 : 0) + (hL0 ? 1 : 0) + (hL1 ? 1 : 0) - (act[k] ? 1 : 0);
             if (delta != 0) atomicAdd(&pend[o[k]], delta);
         }
+        WQ_CHECK(top >= 0 && top <= cap && top <= SCAP, 8, (void)0);
         if (dbg_on) { d_box++; d_boxl += 2u * (unsigned int)n; if ((unsigned int)top > d_maxtop) d_maxtop = (unsigned int)top; }
         WQ_STAMP(cy_box);
     }
 #undef WQ_STAMP
+#undef WQ_CHECK
     if (dbg_on && lane == 0) {
         unsigned long long *d = st.dbg + 16 * (size_t)((blockIdx.x * blockDim.x + tid) >> 6);
         d[0] = dbg_t0; d[1] = __builtin_amdgcn_s_memrealtime(); d[2] = d_box; d[3] = d_boxl; d[4] = d_tri; d[5] = d_tril;

@@ -83,17 +83,8 @@ __device__ __forceinline__ SphereHit spheres_split(const Scene &sc, f3 O, f3 u) 
     SphereHit h; h.tA = 1e9f; h.winA = -1; h.tB = 1e9f; h.winB = -1;
     const int nb = sc.mesh_slot < 0 ? sc.n_spheres : sc.mesh_slot;
     for (int k = 0; k < sc.n_spheres; ++k) {
-        const Sphere &s = sc.sph[k];
-        const f3 C = mk(s.cx, s.cy, s.cz);
-        const f3 OC = O - C;
-        const float d = dot(u, OC);
-        const float delta = d * d - (norm2(OC) - s.R * s.R);       // cpu:513
-        if (delta < 0) continue;
-        const float sq = rt_sqrtf(delta);
-        const float b = dot(u, C - O);
-        const float t1 = b - sq, t2 = b + sq;                      // cpu:516-517
-        if (t2 < 0) continue;
-        const float t = t1 < 0 ? t2 : t1;
+        float t;
+        if (!sphere_test(sc.sph[k], O, u, t)) continue;
         if (k < nb) { if (t < h.tA) { h.tA = t; h.winA = k; } }
         else        { if (t < h.tB) { h.tB = t; h.winB = k + 1; } }   // object id = sphere index + 1 after the mesh
     }
@@ -154,10 +145,12 @@ __device__ __forceinline__ float wf_close_query(const Scene &sc, const WfState &
 template <bool STATS>
 __device__ __forceinline__ void wf_flush_work(const Frame &fr, Work &wk) {
     if (STATS) {
-        const uint32_t b = wave_sum(wk.box), n = wave_sum(wk.nodes), t = wave_sum(wk.tris);
+        const uint32_t b = wave_sum(wk.box), n = wave_sum(wk.nodes), t = wave_sum(wk.tris), lb = wave_sum(wk.lit_box), lt = wave_sum(wk.lit_tri);
         if ((threadIdx.x & 63) == 0) {
             atomicAdd(&fr.work[1], (unsigned long long)b);
             atomicAdd(&fr.work[2], (unsigned long long)n); atomicAdd(&fr.work[3], (unsigned long long)t);
+            if (lb) atomicAdd(&fr.work[5], (unsigned long long)lb);
+            if (lt) atomicAdd(&fr.work[6], (unsigned long long)lt);
         }
     }
 }
@@ -313,10 +306,14 @@ __global__ __launch_bounds__(LDSN ? kTravBlockLds : kTravBlock) void wf_trav(con
     bool drained = false;
     unsigned int qhead = 0, qtail = 0;
     Work wk;
-    const unsigned long long dbg_t0 = st.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
+#ifdef RT_DEBUG
+    const bool dbg_on = st.dbg != nullptr;
+#else
+    constexpr bool dbg_on = false;
+#endif
+    const unsigned long long dbg_t0 = dbg_on ? __builtin_amdgcn_s_memrealtime() : 0ull;
     unsigned int dbg_steps = 0, dbg_lanes = 0, dbg_splits = 0;
     unsigned long long cy_box = 0, cy_tri = 0, cy_exp = 0, cy_ref = 0, stamp = 0;
-    const bool dbg_on = st.dbg != nullptr;
 #define WF_STAMP(acc) do { if (dbg_on) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - stamp; stamp = t_; } } while (0)
     if (dbg_on) stamp = __builtin_amdgcn_s_memtime();
     bool boxable = false;
@@ -515,7 +512,7 @@ __global__ __launch_bounds__(LDSN ? kTravBlockLds : kTravBlock) void wf_trav(con
         }
     }
 finished:
-    if (st.dbg && lane == 0) {
+    if (dbg_on && lane == 0) {
         st.dbg[6 * wave + 0] = dbg_t0; st.dbg[6 * wave + 1] = __builtin_amdgcn_s_memrealtime();
         st.dbg[6 * wave + 2] = dbg_steps; st.dbg[6 * wave + 3] = dbg_lanes; st.dbg[6 * wave + 4] = dbg_splits; st.dbg[6 * wave + 5] = 0;
         unsigned long long *d2 = st.dbg + 6 * 65536 + 4 * wave;

@@ -1,4 +1,5 @@
-"""GPU box: per-wave record of one wf_travq launch (RT_DEBUG_TRAV=<launch index>)."""
+"""GPU box: per-wave record of one wf_travq launch (RT_DEBUG_TRAV=<launch index>).  Needs a -DRT_DEBUG build of the library
+(hipcc ... -DRT_DEBUG -o gpurun_out/dbg.so raytracinggpu_amd/csrc/rt_capi.hip; run with RT_LIB=gpurun_out/dbg.so): the product build has no debug records."""
 import os, sys, numpy as np
 sys.path.insert(0, os.getcwd())
 import raytracinggpu_amd as rt
