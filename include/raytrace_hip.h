@@ -65,9 +65,13 @@ typedef enum rt_variant {
     RT_VARIANT_WAVEFRONT_LDS = 7, /* the same with every BVH node staged in LDS (one 1024-thread
                                   workgroup per CU shares the copy); RT_ERR_UNSUPPORTED when the
                                   nodes do not fit the 160 KB                                       */
-    RT_VARIANT_WAVEFRONT_QUEUE = 8 /* wavefront pipeline whose traversal kernel keeps a per-wave LDS
+    RT_VARIANT_WAVEFRONT_QUEUE = 8, /* wavefront pipeline whose traversal kernel keeps a per-wave LDS
                                   work stack of (ray, node) pairs: every lane tests one box or one
                                   triangle per step, no per-lane walk (rt_travq.hip.h)              */
+    RT_VARIANT_PATH = 9        /* the whole render in ONE persistent launch: a wave owns 32 paths from
+                                  camera ray to framebuffer store; the work-stack traversal and the
+                                  shading of ready paths alternate inside the wave, path state lives
+                                  in LDS, nothing but the pixel leaves the CU (rt_path.hip.h)       */
 } rt_variant;
 
 typedef struct rt_ctx rt_ctx;

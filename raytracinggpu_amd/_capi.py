@@ -13,8 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RT_LIB") or os.path.join(HERE, "libraytrace_hip.so")   # RT_LIB: an experimental build (tools/)
 
 RT_OK = 0
-VARIANT_AUTO, VARIANT_GLOBAL, VARIANT_LDS_VERTS, VARIANT_LDS_TOP, VARIANT_LDS_ALL, VARIANT_LOCKSTEP, VARIANT_WAVEFRONT, VARIANT_WAVEFRONT_LDS, VARIANT_WAVEFRONT_QUEUE = range(9)
-VARIANTS = {"auto": 0, "global": 1, "lds_verts": 2, "lds_top": 3, "lds_all": 4, "lockstep": 5, "wavefront": 6, "wavefront_lds": 7, "wavefront_queue": 8}
+VARIANT_AUTO, VARIANT_GLOBAL, VARIANT_LDS_VERTS, VARIANT_LDS_TOP, VARIANT_LDS_ALL, VARIANT_LOCKSTEP, VARIANT_WAVEFRONT, VARIANT_WAVEFRONT_LDS, VARIANT_WAVEFRONT_QUEUE, VARIANT_PATH = range(10)
+VARIANTS = {"auto": 0, "global": 1, "lds_verts": 2, "lds_top": 3, "lds_all": 4, "lockstep": 5, "wavefront": 6, "wavefront_lds": 7, "wavefront_queue": 8, "path": 9}
 
 # every symbol include/raytrace_hip.h declares (tests check the .so exports each)
 EXPORTS = ["rt_abi_version", "rt_device_count", "rt_ctx_create", "rt_ctx_destroy", "rt_last_error",

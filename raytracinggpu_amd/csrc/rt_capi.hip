@@ -6,6 +6,7 @@
 #include "rt_persistent.hip.h"
 #include "rt_wavefront.hip.h"
 #include "rt_travq.hip.h"
+#include "rt_path.hip.h"
 #include "rt_meshops.hip.h"
 
 #include <cmath>
@@ -44,6 +45,12 @@ struct Knobs {
     int oversub_min = 0;       // RT_TRAVQ_OVERSUB_MIN
     int min_groups = 16;       // RT_TRAV_MIN_GROUPS: ray groups per wave below which a launch uses fewer workgroups
     int log2S = -1;            // RT_TRAV_LOG2S: cap on the scramble period (experiment)
+    int path_low = 96;         // RT_PATH_LOW: wf_path runs a SHADE step only while the stack holds fewer sibling pairs than this
+    int path_shade_min = 16;   // RT_PATH_SHADE_MIN: ... and at least this many of the wave's 32 paths are ready (or nothing else is left to do)
+    int path_oversub = 2;      // RT_PATH_OVERSUB: grid oversubscription of wf_path
+    int path_bpc = 4;          // RT_PATH_BPC: workgroups (4 waves) per CU
+    int path_parts = 1;        // RT_PATH_PARTS: concurrent sub-frames (launches on separate streams)
+    long long path_samp_bytes = 2ll << 30;   // RT_PATH_SAMP_MB: budget of the per-sample colour buffer (frames with num_rays > 1)
     int debug_trav = -2;       // RT_DEBUG_TRAV: traversal launch whose per-wave records are dumped (-DRT_DEBUG builds only)
 };
 
@@ -63,6 +70,12 @@ static Knobs read_knobs() {
     if (geti("RT_TRAVQ_OVERSUB_MIN", v) && v >= 0) k.oversub_min = v;
     if (geti("RT_TRAV_MIN_GROUPS", v) && v >= 4) k.min_groups = v;
     if (geti("RT_TRAV_LOG2S", v) && v >= 0) k.log2S = v;
+    if (geti("RT_PATH_LOW", v) && v >= 32 && v <= 320) k.path_low = v;
+    if (geti("RT_PATH_SHADE_MIN", v) && v >= 1 && v <= 32) k.path_shade_min = v;
+    if (geti("RT_PATH_OVERSUB", v) && v >= 1 && v <= 64) k.path_oversub = v;
+    if (geti("RT_PATH_BPC", v) && v >= 1 && v <= 8) k.path_bpc = v;
+    if (geti("RT_PATH_PARTS", v) && v >= 1 && v <= 8) k.path_parts = v;
+    if (geti("RT_PATH_SAMP_MB", v) && v >= 1) k.path_samp_bytes = (long long)v << 20;
 #ifdef RT_DEBUG
     if (geti("RT_DEBUG_TRAV", v)) k.debug_trav = v;
 #endif
@@ -84,6 +97,7 @@ struct rt_ctx {
     int n_cus = 0;
     DevBuf wfR0, wfR1, wfM, wfFL, wfS0, wfS1, wfT, wfF, wfLS, wfQ;   // wavefront path state (HBM)
     DevBuf wfQA, wfQB, wfQF;                                        // traversal queue in slot order (work-stack variant)
+    DevBuf pathSamp, pathT;                                         // wf_path with num_rays > 1: per-sample colours, running sum
     DevBuf dbgbuf;                                                  // -DRT_DEBUG builds: per-wave traversal records
     DevBuf accum;                                                   // progressive mode: sum of the frames so far (float4 per pixel)
     int prog_frames = 0, prog_w = 0, prog_h = 0;
@@ -220,7 +234,7 @@ int check_params(rt_ctx *ctx, const rt_params *p, int &segs) {
         return fail(ctx, RT_ERR_INVALID, "depth_convention must be 0 (cpu_launcher) or 1 (optimized.cu)");
     segs = p->depth_convention == 0 ? p->num_bounce + 1 : p->num_bounce;
     if (segs > RT_MAX_SEGMENTS) return fail(ctx, RT_ERR_INVALID, "more than %d ray segments", RT_MAX_SEGMENTS);
-    if (p->variant < RT_VARIANT_AUTO || p->variant > RT_VARIANT_WAVEFRONT_QUEUE) return fail(ctx, RT_ERR_INVALID, "unknown variant %d", p->variant);
+    if (p->variant < RT_VARIANT_AUTO || p->variant > RT_VARIANT_PATH) return fail(ctx, RT_ERR_INVALID, "unknown variant %d", p->variant);
     return RT_OK;
 }
 
@@ -287,9 +301,7 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
         if (want_ldsv || want_ldsn) return fail(ctx, RT_ERR_UNSUPPORTED, "%d BVH nodes: the LDS-staged variants need < 2^26 nodes", ctx->scene.n_nodes);
         variant = RT_VARIANT_WAVEFRONT;
     }
-    if (variant != RT_VARIANT_GLOBAL && variant != RT_VARIANT_LOCKSTEP && variant != RT_VARIANT_WAVEFRONT && variant != RT_VARIANT_WAVEFRONT_LDS &&
-        variant != RT_VARIANT_WAVEFRONT_QUEUE)
-        return fail(ctx, RT_ERR_UNSUPPORTED, "variant %d is not available in this build", variant);
+    if (variant == RT_VARIANT_PATH && ctx->scene.n_nodes + 2 >= (1 << rtk::kQNodeBits)) variant = RT_VARIANT_WAVEFRONT;
 
     RT_HIP(ctx, hipSetDevice(ctx->device));
     rtk::Frame fr{};
@@ -305,11 +317,11 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
     fr.out_tile0 = 0; fr.out_tile_step = 1;
     rtk::Scene scn = ctx->scene;                                      // per-launch copy: a pose moves the camera
     fr.cam_mode = 0; fr.inv_n = 1.f;
-    if (scn.nrm != nullptr && variant != RT_VARIANT_WAVEFRONT && variant != RT_VARIANT_WAVEFRONT_LDS && variant != RT_VARIANT_WAVEFRONT_QUEUE)
-        return fail(ctx, RT_ERR_UNSUPPORTED, "smooth normals need a wavefront variant");
+    const bool wf_family = variant == RT_VARIANT_WAVEFRONT || variant == RT_VARIANT_WAVEFRONT_LDS || variant == RT_VARIANT_WAVEFRONT_QUEUE || variant == RT_VARIANT_PATH;
+    if (scn.nrm != nullptr && !wf_family)
+        return fail(ctx, RT_ERR_UNSUPPORTED, "smooth normals need a wavefront or path variant");
     if (pose) {                                                       // realtime_render.cu's camera
-        if (variant != RT_VARIANT_WAVEFRONT && variant != RT_VARIANT_WAVEFRONT_LDS && variant != RT_VARIANT_WAVEFRONT_QUEUE)
-            return fail(ctx, RT_ERR_UNSUPPORTED, "a camera pose needs a wavefront variant");
+        if (!wf_family) return fail(ctx, RT_ERR_UNSUPPORTED, "a camera pose needs a wavefront or path variant");
         fr.cam_mode = 1;
         camera_basis(pose->yaw, pose->pitch, fr.bx, fr.by, fr.bz);
         scn.camx = pose->position[0]; scn.camy = pose->position[1]; scn.camz = pose->position[2];
@@ -322,7 +334,97 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
     if (rows->n_rows == 0) { ctx->stats.grid_blocks = 0; ctx->have_kernel_time = false; return RT_OK; }
     const int nseg = segs > 0 ? segs : 1;
     ctx->n_trav_events = 0;
-    if (variant == RT_VARIANT_WAVEFRONT || variant == RT_VARIANT_WAVEFRONT_LDS || variant == RT_VARIANT_WAVEFRONT_QUEUE) {
+    if (variant == RT_VARIANT_PATH) {
+        // ONE persistent launch per sub-frame and sample chunk (rt_path.hip.h): a wave owns 32 paths from camera ray to framebuffer store
+        const Knobs &kn = ctx->knobs;
+        constexpr int wpb = rtk::kQBlock / 64;
+        const size_t lds = (size_t)wpb * rtk::PCarve::bytes(segs) + 16;
+        int nb = 0;                                                   // workgroups per CU the registers and this frame's LDS carve allow
+        if (work_dev) RT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtk::wf_path<true>, rtk::kQBlock, lds));
+        else RT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtk::wf_path<false>, rtk::kQBlock, lds));
+        if (nb < 1) return fail(ctx, RT_ERR_UNSUPPORTED, "wf_path does not fit a CU with %zu bytes of LDS per workgroup", lds);
+        const int bpc = std::min(kn.path_bpc, nb);
+        int parts = std::min(kn.path_parts, (int)rt_ctx::kMaxParts);
+        int R = rows->tile_rows, G = rows->tile_step;
+        if (G == 1) R = 8;                                            // contiguous rows: any tile height describes them
+        const int T = (rows->n_rows + R - 1) / R;                     // local tiles of this call
+        if (R % 8 != 0 || work_dev) parts = 1;
+        if (parts > T) parts = T > 0 ? T : 1;
+        const int tiles_x = (p->width + 7) / 8;
+        int qcap = rtk::kPStack;
+        if (kn.travq_cap >= 128 && kn.travq_cap < qcap) qcap = kn.travq_cap;   // tests: force the serial drain
+        struct PPart { rtk::Frame fr; int n_paths; size_t base; };
+        std::vector<PPart> pv(parts);
+        size_t np_total = 0;
+        for (int j = 0; j < parts; ++j) {
+            const int Tj = (T - j + parts - 1) / parts;               // local tiles j, j+parts, ...
+            int nrows_j = Tj * R;
+            if (Tj > 0 && (T - 1) % parts == j) nrows_j -= T * R - rows->n_rows;   // the last local tile may be partial
+            pv[j].fr = fr;
+            if (parts > 1 || G == 1) {
+                pv[j].fr.row0 = rows->row0 + j * R * G; pv[j].fr.n_rows = nrows_j; pv[j].fr.tile_rows = R; pv[j].fr.tile_step = G * parts;
+                pv[j].fr.out_tile0 = j; pv[j].fr.out_tile_step = parts;
+            }
+            const int64_t n_paths64 = (int64_t)tiles_x * ((pv[j].fr.n_rows + 7) / 8) * 64;
+            if (n_paths64 >= ((int64_t)1 << 29)) return fail(ctx, RT_ERR_INVALID, "image too large: %lld pixel slots per sub-frame (limit 2^29)", (long long)n_paths64);
+            pv[j].n_paths = (int)n_paths64;
+            pv[j].base = np_total;
+            np_total += (size_t)n_paths64;
+        }
+        // samples of a pixel are independent paths; with more than one the per-sample colours are summed in sample order afterwards
+        int chunk = 1;
+        if (fr.spp > 1) {
+            const int64_t biggest = std::max<int64_t>(1, (int64_t)(np_total / parts + 64));
+            int64_t c = std::min<int64_t>(fr.spp, std::min<int64_t>((((int64_t)1 << 29) - 1) / biggest, kn.path_samp_bytes / (int64_t)(np_total * 16 + 1)));
+            chunk = (int)std::max<int64_t>(1, c);
+            int rc2;
+            if ((rc2 = ensure(ctx, ctx->pathSamp, np_total * 16 * (size_t)chunk)) != RT_OK || (rc2 = ensure(ctx, ctx->pathT, np_total * 16)) != RT_OK) return rc2;
+        }
+        ctx->stats.lds_bytes = (int)lds;
+        ctx->stats.block_threads = rtk::kQBlock;
+        ctx->stats.parts = parts;
+        RT_HIP(ctx, hipEventRecord(ctx->ev_k0, stream));
+        if (parts > 1) RT_HIP(ctx, hipEventRecord(ctx->fork_ev, stream));
+        for (int j = 0; j < parts; ++j) {
+            hipStream_t q = j == 0 ? stream : ctx->part_stream[j];
+            if (j > 0) RT_HIP(ctx, hipStreamWaitEvent(q, ctx->fork_ev, 0));
+            if (pv[j].n_paths > 0) {
+                for (int s0 = 0; s0 < fr.spp; s0 += chunk) {
+                    rtk::PathState ps{};
+                    ps.n_paths = pv[j].n_paths; ps.tiles_x = tiles_x;
+                    ps.samp0 = s0; ps.n_samp = std::min(chunk, fr.spp - s0);
+                    ps.samp_out = fr.spp > 1 ? static_cast<float4 *>(ctx->pathSamp.p) + pv[j].base * (size_t)chunk : nullptr;
+                    const int64_t n_items = (int64_t)ps.n_paths * ps.n_samp;
+                    ps.n_groups = (int)(n_items / 4);
+                    // every workgroup owns an equal, spatially scrambled share of the items; its waves draw from it on demand; the grid is
+                    // oversubscribed so that the dispatcher evens out the cost differences between the shares
+                    int64_t tblocks = std::max<int64_t>(1, (int64_t)ctx->n_cus * bpc / parts) * kn.path_oversub;
+                    const int min_groups = kn.min_groups * wpb;       // default 16 per wave: >= 64 items per wave on average
+                    int64_t groups_per_block = (ps.n_groups + tblocks - 1) / tblocks;
+                    if (groups_per_block < min_groups) {              // small launch: fewer, fuller workgroups
+                        tblocks = std::max<int64_t>(1, (ps.n_groups + min_groups - 1) / min_groups);
+                        groups_per_block = (ps.n_groups + tblocks - 1) / tblocks;
+                    }
+                    ps.log2S = 0;
+                    while ((2 << ps.log2S) <= groups_per_block && ps.log2S < 16) ++ps.log2S;
+                    if (kn.log2S >= 0 && kn.log2S < ps.log2S) ps.log2S = kn.log2S;
+                    const int S = 1 << ps.log2S;
+                    ps.Q = (ps.n_groups + S - 1) / S;
+                    const int64_t total_slots = (int64_t)S * ps.Q * 4;
+                    ps.slots_per_block = (int)(((total_slots + tblocks - 1) / tblocks + 3) / 4 * 4);
+                    if (j == 0 && s0 == 0) ctx->stats.grid_blocks = (int)tblocks;
+                    const dim3 tg((unsigned)tblocks), tbd(rtk::kQBlock);
+                    if (work_dev) hipLaunchKernelGGL(rtk::wf_path<true>, tg, tbd, lds, q, scn, pv[j].fr, ps, qcap, kn.path_low, kn.path_shade_min);
+                    else hipLaunchKernelGGL(rtk::wf_path<false>, tg, tbd, lds, q, scn, pv[j].fr, ps, qcap, kn.path_low, kn.path_shade_min);
+                    if (fr.spp > 1)
+                        hipLaunchKernelGGL(rtk::path_reduce, dim3((unsigned)((ps.n_paths + 255) / 256)), dim3(256), 0, q, pv[j].fr, ps,
+                                           static_cast<float4 *>(ctx->pathT.p) + pv[j].base, s0 == 0 ? 1 : 0, s0 + chunk >= fr.spp ? 1 : 0);
+                }
+            }
+            if (j > 0) RT_HIP(ctx, hipEventRecord(ctx->part_ev[j], q));
+        }
+        for (int j = 1; j < parts; ++j) RT_HIP(ctx, hipStreamWaitEvent(stream, ctx->part_ev[j], 0));
+    } else if (variant == RT_VARIANT_WAVEFRONT || variant == RT_VARIANT_WAVEFRONT_LDS || variant == RT_VARIANT_WAVEFRONT_QUEUE) {
         const bool ldsn = variant == RT_VARIANT_WAVEFRONT_LDS;
         const bool queue = variant == RT_VARIANT_WAVEFRONT_QUEUE;
         const Knobs &kn = ctx->knobs;
@@ -670,6 +772,7 @@ int rt_ctx_destroy(rt_ctx *ctx) {
     ctx->wfR0.release(); ctx->wfR1.release(); ctx->wfM.release(); ctx->wfS0.release(); ctx->wfS1.release();
     ctx->wfT.release(); ctx->wfF.release(); ctx->wfFL.release(); ctx->wfLS.release(); ctx->wfQ.release();
     ctx->wfQA.release(); ctx->wfQB.release(); ctx->wfQF.release(); ctx->accum.release(); ctx->dbgbuf.release();
+    ctx->pathSamp.release(); ctx->pathT.release();
     for (hipEvent_t &e : ctx->ev_trav) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t &e : ctx->part_ev) if (e) (void)hipEventDestroy(e);
     for (hipStream_t &q : ctx->part_stream) if (q) (void)hipStreamDestroy(q);

@@ -91,6 +91,7 @@ __device__ __forceinline__ SphereHit spheres_split(const Scene &sc, f3 O, f3 u) 
     return h;
 }
 __device__ __forceinline__ int wf_pack_wins(const SphereHit &h) { return ((h.winA + 1) & 31) << 10 | ((h.winB + 1) & 31) << 15; }
+__device__ __forceinline__ int wf_pack_wins_path(const SphereHit &h) { return ((h.winA + 1) & 31) << 16 | ((h.winB + 1) & 31) << 21; }   // PF_WINS_SHIFT
 
 // Emit ray slot `r`: record, sphere tests, root-box test (cpu:279; wave-uniform node data from kernel arguments).
 template <bool STATS>

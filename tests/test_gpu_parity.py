@@ -38,7 +38,7 @@ def values_equal(a, b):
     return (a == b) | (np.isnan(a) & np.isnan(b))
 
 
-VARIANTS = ["wavefront_queue", "wavefront_lds", "wavefront", "global", "lockstep"]
+VARIANTS = ["path", "wavefront_queue", "wavefront_lds", "wavefront", "global", "lockstep"]
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
