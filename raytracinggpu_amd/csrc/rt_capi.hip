@@ -46,7 +46,7 @@ struct Knobs {
     int min_groups = 16;       // RT_TRAV_MIN_GROUPS: ray groups per wave below which a launch uses fewer workgroups
     int log2S = -1;            // RT_TRAV_LOG2S: cap on the scramble period (experiment)
     int path_low = 96;         // RT_PATH_LOW: wf_path runs a SHADE step only while the stack holds fewer sibling pairs than this
-    int path_shade_min = 16;   // RT_PATH_SHADE_MIN: ... and at least this many of the wave's 32 paths are ready (or nothing else is left to do)
+    int path_shade_min = 32;   // RT_PATH_SHADE_MIN: ... and at least this many of the wave's 64 paths are ready (or nothing else is left to do)
     int path_oversub = 2;      // RT_PATH_OVERSUB: grid oversubscription of wf_path
     int path_bpc = 4;          // RT_PATH_BPC: workgroups (4 waves) per CU
     int path_parts = 1;        // RT_PATH_PARTS: concurrent sub-frames (launches on separate streams)
@@ -71,7 +71,7 @@ static Knobs read_knobs() {
     if (geti("RT_TRAV_MIN_GROUPS", v) && v >= 4) k.min_groups = v;
     if (geti("RT_TRAV_LOG2S", v) && v >= 0) k.log2S = v;
     if (geti("RT_PATH_LOW", v) && v >= 32 && v <= 320) k.path_low = v;
-    if (geti("RT_PATH_SHADE_MIN", v) && v >= 1 && v <= 32) k.path_shade_min = v;
+    if (geti("RT_PATH_SHADE_MIN", v) && v >= 1 && v <= 64) k.path_shade_min = v;
     if (geti("RT_PATH_OVERSUB", v) && v >= 1 && v <= 64) k.path_oversub = v;
     if (geti("RT_PATH_BPC", v) && v >= 1 && v <= 8) k.path_bpc = v;
     if (geti("RT_PATH_PARTS", v) && v >= 1 && v <= 8) k.path_parts = v;
@@ -301,7 +301,7 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
         if (want_ldsv || want_ldsn) return fail(ctx, RT_ERR_UNSUPPORTED, "%d BVH nodes: the LDS-staged variants need < 2^26 nodes", ctx->scene.n_nodes);
         variant = RT_VARIANT_WAVEFRONT;
     }
-    if (variant == RT_VARIANT_PATH && ctx->scene.n_nodes + 2 >= (1 << rtk::kQNodeBits)) variant = RT_VARIANT_WAVEFRONT;
+    if (variant == RT_VARIANT_PATH && ctx->scene.n_nodes + 2 >= (1 << rtk::kPNodeBits)) variant = RT_VARIANT_WAVEFRONT;
 
     RT_HIP(ctx, hipSetDevice(ctx->device));
     rtk::Frame fr{};

@@ -5,18 +5,18 @@
 //
 // The wavefront pipeline (rt_wavefront.hip.h) alternates a traversal kernel with a uniform shading kernel and streams
 // every path's state through HBM between them: per frame 11 dependent launches per sub-frame and ~3 GB of path-state
-// traffic for 33 MB of image.  Here a WAVE owns 32 paths from the camera ray to the framebuffer store and nothing but
+// traffic for 33 MB of image.  Here a WAVE owns 64 paths from the camera ray to the framebuffer store and nothing but
 // the result leaves the CU:
 //
-//   * ray slots 0..31 hold the paths' continuation rays (Y), slots 32..63 their shadow rays (X); the two rays that leave
+//   * ray slots 0..63 hold the paths' continuation rays (Y), slots 64..127 their shadow rays (X); the two rays that leave
 //     a hit point do not depend on each other and are traced together, exactly as launch j of the wavefront pipeline does;
 //   * traversal is the work stack of rt_travq.hip.h: one LIFO of (ray slot, sibling pair) entries per wave, BOX steps of
 //     64 pairs, TRI steps of 128 triangles, per-slot counters of outstanding entries -- lanes carry no per-ray state;
 //   * when a path's two rays have no entries left the path is READY; once enough paths are ready (or nothing else is
-//     left to do) the wave runs one SHADE step: lane p < 32 closes path p's queries (intersect_all's strict '<' replay),
+//     left to do) the wave runs one SHADE step: lane p closes path p's queries (intersect_all's strict '<' replay),
 //     runs getColor's branch for the hit, folds finished paths into the framebuffer and starts new ones from the
-//     workgroup's share of the pixels; then ALL 64 lanes emit rays -- lane p the continuation ray of path p, lane 32 + p
-//     its shadow ray (ray/sphere tests, root-box test, filter constants, stack push);
+//     workgroup's share of the pixels, then emits the path's continuation ray and its shadow ray (ray/sphere tests,
+//     root-box test, filter constants, stack push);
 //   * per-path state (flags, object ids, sphere hits, the l of every diffuse segment) lives in the wave's LDS carve.
 //
 // HBM traffic: the scene (cache resident), 16 B per pixel of output.  No inter-launch tails, no kernel boundaries: a
@@ -29,10 +29,12 @@
 
 namespace rtk {
 
-constexpr int kPP = 32;                       // paths per wave
+constexpr int kPP = 64;                       // paths per wave: one per lane in a SHADE step
 constexpr int kPR = 2 * kPP;                  // ray slots per wave: slot p = continuation ray of path p, slot kPP + p = its shadow ray
-constexpr int kPStack = 652;                  // stack entries (sibling pairs) per wave; fuller -> serial drain, as in wf_travq
+constexpr int kPStack = 896;                  // stack entries (sibling pairs) per wave; fuller -> serial drain, as in wf_travq
 constexpr int kPLeafCap = 256;
+constexpr int kPNodeBits = 25;                // stack entry = slot << 25 | node (7 bits of slot)
+constexpr unsigned kPNodeMask = (1u << kPNodeBits) - 1u;
 
 // path flags (pF[p].x)
 constexpr int PF_ALIVE = 1, PF_HASX = 2, PF_HASY = 4, PF_MESHX = 8, PF_MESHY = 16;
@@ -50,19 +52,19 @@ struct PathState {
 };
 
 struct PCarve {
-    static constexpr int kTabA = 0;                            // float4[64]: (1/u by v_rcp_f32, filter constant | +inf)
-    static constexpr int kTabC = kTabA + 16 * kPR;             // float4[64]: (O.xyz, u.x)
-    static constexpr int kTabD = kTabC + 16 * kPR;             // float2[64]: (u.y, u.z)
-    static constexpr int kBest = kTabD + 8 * kPR;              // u64[64]: nearest accepted hit of the slot's ray
-    static constexpr int kPend = kBest + 8 * kPR;              // int[64]: outstanding stack + leaf-queue entries
-    static constexpr int kPF = kPend + 4 * kPR;                // int4[32]: (flags, diffuse mask, object ids lo, hi)
-    static constexpr int kPS = kPF + 16 * kPP;                 // float4[32]: (tA, tB of the Y ray's spheres; nearest sphere t of the X ray; refraction index)
-    static constexpr int kPL = kPS + 16 * kPP;                 // float[32]: unshadowed l of the segment whose shadow ray is in flight (cpu:623)
-    static constexpr int kPI = kPL + 4 * kPP;                  // int[32]: item index of the path
+    static constexpr int kTabA = 0;                            // float4[128]: (1/u by v_rcp_f32, filter constant | +inf)
+    static constexpr int kTabC = kTabA + 16 * kPR;             // float4[128]: (O.xyz, u.x)
+    static constexpr int kTabD = kTabC + 16 * kPR;             // float2[128]: (u.y, u.z)
+    static constexpr int kBest = kTabD + 8 * kPR;              // u64[128]: nearest accepted hit of the slot's ray
+    static constexpr int kPend = kBest + 8 * kPR;              // int[128]: outstanding stack + leaf-queue entries
+    static constexpr int kPF = kPend + 4 * kPR;                // int4[64]: (flags, diffuse mask, object ids lo, hi)
+    static constexpr int kPS = kPF + 16 * kPP;                 // float4[64]: (tA, tB of the Y ray's spheres; nearest sphere t of the X ray; refraction index)
+    static constexpr int kPL = kPS + 16 * kPP;                 // float[64]: unshadowed l of the segment whose shadow ray is in flight (cpu:623)
+    static constexpr int kPI = kPL + 4 * kPP;                  // int[64]: item index of the path
     static constexpr int kMarks = kPI + 4 * kPP;               // u8[128]
     static constexpr int kStack = kMarks + 128;                // u32[kPStack]
     static constexpr int kLeaf = kStack + 4 * kPStack;         // uint2[kPLeafCap]
-    static constexpr int kLS = kLeaf + 8 * kPLeafCap;          // float[segs][32]: l of every diffuse segment (dynamic: the launch knows segs)
+    static constexpr int kLS = kLeaf + 8 * kPLeafCap;          // float[segs][64]: l of every diffuse segment (dynamic: the launch knows segs)
     static_assert(kLeaf % 8 == 0 && kLS % 16 == 0 && kStack % 4 == 0, "alignment of the carve");
     static constexpr int bytes(int segs) { return kLS + 4 * kPP * (segs > 0 ? segs : 1); }   // multiple of 16
 };
@@ -75,7 +77,7 @@ __device__ __forceinline__ int path_slot_to_item(const PathState &ps, int q) {
 }
 
 template <bool STATS>
-__global__ __launch_bounds__(kQBlock, 4) void wf_path(const Scene sc, const Frame fr, const PathState ps, const int cap, const int kLow, const int kShadeMin) {
+__global__ __launch_bounds__(kQBlock, 2) void wf_path(const Scene sc, const Frame fr, const PathState ps, const int cap, const int kLow, const int kShadeMin) {
     constexpr int P = kPP, SCAP = kPStack, LCAP = kPLeafCap;
     extern __shared__ __attribute__((aligned(16))) unsigned char path_smem[];
     const int tid = threadIdx.x;
@@ -100,8 +102,8 @@ __global__ __launch_bounds__(kQBlock, 4) void wf_path(const Scene sc, const Fram
     float *const lsq = reinterpret_cast<float *>(wl + PCarve::kLS);       // lsq[d * P + p]
     if (tid == 0) *blk_cur = 0;
     marks[lane] = 0; marks[lane + 64] = 0;
-    pend[lane] = 0;
-    if (lane < P) pF[lane] = make_int4(0, 0, 0, 0);
+    pend[lane] = 0; pend[P + lane] = 0;
+    pF[lane] = make_int4(0, 0, 0, 0);
     __syncthreads();
 
     const float4 *const nodes = sc.nodesq;
@@ -149,13 +151,9 @@ __global__ __launch_bounds__(kQBlock, 4) void wf_path(const Scene sc, const Fram
         drained = __builtin_amdgcn_readfirstlane((int)drained) != 0;
         // =============================== SHADE: ready paths ===============================
         if (top < kLow) {
-            int4 F = make_int4(0, 0, 0, 0);
-            bool ready = false, alive = false;
-            if (lane < P) {
-                F = pF[lane];
-                alive = (F.x & PF_ALIVE) != 0;
-                ready = alive ? (pend[lane] == 0 && pend[P + lane] == 0) : !drained;
-            }
+            int4 F = pF[lane];
+            bool alive = (F.x & PF_ALIVE) != 0;
+            const bool ready = alive ? (pend[lane] == 0 && pend[P + lane] == 0) : !drained;
             const unsigned long long rm = __ballot(ready);
             const int n_ready = __popcll(rm);
             const bool idle = top == 0 && ltail == lhead;
@@ -387,62 +385,59 @@ __global__ __launch_bounds__(kQBlock, 4) void wf_path(const Scene sc, const Fram
                         }
                     }
                 }
-                // ---- (4) emission by all 64 lanes: lane p the continuation ray of path p (slot p), lane 32 + p its shadow ray (slot 32 + p) ----
-                {
-                    const unsigned long long xm = __ballot(emitX);                       // bits 0..31
-                    const int src = lane & (P - 1);
-                    const float sx0 = __shfl(Ox.x, src, 64), sx1 = __shfl(Ox.y, src, 64), sx2 = __shfl(Ox.z, src, 64);
-                    const float sx3 = __shfl(ux.x, src, 64), sx4 = __shfl(ux.y, src, 64), sx5 = __shfl(ux.z, src, 64);
-                    const bool upper = lane >= P;
-                    const bool on = upper ? ((xm >> src) & 1ull) != 0ull : emitY;
-                    const f3 O = upper ? mk(sx0, sx1, sx2) : Oy, u = upper ? mk(sx3, sx4, sx5) : uy;
+                // ---- (4) emission: the continuation ray of path p into slot p, then its shadow ray into slot 64 + p ----
+                bool needY = false, needX = false;
+#pragma unroll 1
+                for (int k = 0; k < 2; ++k) {
+                    const bool on = k == 0 ? emitY : emitX;
+                    const f3 O = k == 0 ? Oy : Ox, u = k == 0 ? uy : ux;
+                    const int slot = k * P + lane;
                     bool need = false;
-                    SphereHit h; h.tA = 1e9f; h.winA = -1; h.tB = 1e9f; h.winB = -1;
                     if (on) {
-                        h = spheres_split(sc, O, u);                                     // Sphere::intersect x n (cpu:512-527)
-                        tabC[lane] = make_float4(O.x, O.y, O.z, u.x);
-                        tabD[lane] = make_float2(u.y, u.z);
+                        const SphereHit h = spheres_split(sc, O, u);                     // Sphere::intersect x n (cpu:512-527)
+                        tabC[slot] = make_float4(O.x, O.y, O.z, u.x);
+                        tabD[slot] = make_float2(u.y, u.z);
+                        if (k == 0) {
+                            S.x = h.tA; S.y = h.tB;
+                            F.x = (F.x & ~(1023 << PF_WINS_SHIFT)) | wf_pack_wins_path(h);
+                        } else {
+                            S.z = h.tB < h.tA ? h.tB : h.tA;                             // only the value of the shadow ray's nearest hit matters
+                        }
                         if (have_mesh) {                                                 // root-box test (cpu:279)
                             if (STATS) wk.box++;
                             if (slab_filtered(sc.root_lo, sc.root_hi, O, u, ray_inv(u))) {
                                 if (STATS) wk.nodes++;
                                 need = true;
                                 const RayBox rb = ray_box(O, u);
-                                tabA[lane] = make_float4(rb.rx, rb.ry, rb.rz, rb.safe ? rb.c0 : __builtin_inff());
-                                best[lane] = WF_NOHIT;
+                                tabA[slot] = make_float4(rb.rx, rb.ry, rb.rz, rb.safe ? rb.c0 : __builtin_inff());
+                                best[slot] = WF_NOHIT;
                             }
                         }
                     }
                     const unsigned long long nm = __ballot(need);
                     if (root_hiw < 0) {                                                  // the root (node 1) has the children 2, 3
-                        if (need) { stack[top + lanes_below(nm)] = (unsigned int)lane << kQNodeBits | 2u; pend[lane] = 1; }
+                        if (need) { stack[top + lanes_below(nm)] = (unsigned int)slot << kPNodeBits | 2u; pend[slot] = 1; }
                         top += __popcll(nm);
                     } else {                                                             // the root is a leaf
                         const int first = __float_as_int(sc.root_lo.w), cnt = root_hiw - first;
                         if (cnt > 0) {
                             if (need) {
-                                leafq[(ltail + (unsigned int)lanes_below(nm)) & (LCAP - 1)] = make_uint2((unsigned int)first, (unsigned int)lane | (unsigned int)cnt << 8);
-                                pend[lane] = 1;
+                                leafq[(ltail + (unsigned int)lanes_below(nm)) & (LCAP - 1)] = make_uint2((unsigned int)first, (unsigned int)slot | (unsigned int)cnt << 8);
+                                pend[slot] = 1;
                                 if (STATS) wk.tris += (uint32_t)cnt;
                             }
                             ltail += (unsigned int)__popcll(nm);
                         }
                     }
-                    // the paths' records: lane p writes its own, then lane 32 + p adds the shadow ray's nearest sphere
-                    if (lane < P && ready) {
-                        if (emitY) {
-                            S.x = h.tA; S.y = h.tB;
-                            F.x = (F.x & ~(PF_MESHY | (1023 << PF_WINS_SHIFT))) | wf_pack_wins_path(h) | (((nm >> lane) & 1ull) ? PF_MESHY : 0);
-                        }
-                        if (emitX) F.x = (F.x & ~PF_MESHX) | (((nm >> (P + lane)) & 1ull) ? PF_MESHX : 0);
-                        pF[lane] = F;
-                        pS[lane] = S;
-                        pI[lane] = item;
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    if (upper && on) pS[src].z = h.tB < h.tA ? h.tB : h.tA;
-                    __builtin_amdgcn_wave_barrier();
+                    if (k == 0) needY = need; else needX = need;
                 }
+                if (ready) {
+                    F.x = (F.x & ~(PF_MESHY | PF_MESHX)) | (needY ? PF_MESHY : 0) | (needX ? PF_MESHX : 0);
+                    pF[lane] = F;
+                    pS[lane] = S;
+                    pI[lane] = item;
+                }
+                __builtin_amdgcn_wave_barrier();
                 continue;                                                                // re-evaluate: more paths may be ready, the stack has entries now
             }
         }
@@ -501,13 +496,13 @@ __global__ __launch_bounds__(kQBlock, 4) void wf_path(const Scene sc, const Fram
             const bool actd = lane < n;
             const unsigned int ed = actd ? stack[top - 1 - lane] : 0u;
             top -= n;
-            if (actd) { const int od = (int)(ed >> kQNodeBits), cd = (int)(ed & kQNodeMask); drain_serial(od, cd); drain_serial(od, cd + 1); atomicAdd(&pend[od], -1); }
+            if (actd) { const int od = (int)(ed >> kPNodeBits), cd = (int)(ed & kPNodeMask); drain_serial(od, cd); drain_serial(od, cd + 1); atomicAdd(&pend[od], -1); }
             continue;
         }
         const bool act = lane < n;
         const unsigned int e = act ? stack[top - 1 - lane] : 0u;     // slot << 26 | c: the sibling nodes c, c + 1 (one 64-byte line)
-        const int o = (int)(e >> kQNodeBits);
-        int c = (int)(e & kQNodeMask);
+        const int o = (int)(e >> kPNodeBits);
+        int c = (int)(e & kPNodeMask);
         top -= n;
         PQ_CHECK(!act || (c >= 2 && c + 1 <= sc.n_nodes), 4, c = 0);
         const float4 A = tabA[o], C = tabC[o];
@@ -537,7 +532,7 @@ __global__ __launch_bounds__(kQBlock, 4) void wf_path(const Scene sc, const Fram
             }
             const unsigned long long mI0 = __ballot(hI0), mI1 = __ballot(hI1), mL0 = __ballot(hL0), mL1 = __ballot(hL1);
             const int nI0 = __popcll(mI0), nL0 = __popcll(mL0);
-            const unsigned int sbits = e & ~kQNodeMask;
+            const unsigned int sbits = e & ~kPNodeMask;
             if (hI0) stack[top + lanes_below(mI0)] = sbits | (unsigned int)low0;        // a hit internal node pushes ITS pair of children
             if (hI1) stack[top + nI0 + lanes_below(mI1)] = sbits | (unsigned int)low1;
             top += nI0 + __popcll(mI1);
