@@ -95,8 +95,8 @@ struct rt_ctx {
     int n_levels = 0;
     DevBuf node_lo, node_hi, nodes2, nodesq, q2thr, tri, verts, tidx, scratch_rgba, scratch_rgb8, work, queue;
     int n_cus = 0;
-    DevBuf wfR0, wfR1, wfM, wfFL, wfS0, wfS1, wfT, wfF, wfLS, wfQ;   // wavefront path state (HBM)
-    DevBuf wfQA, wfQB, wfQF;                                        // traversal queue in slot order (work-stack variant)
+    DevBuf wfM, wfST, wfT, wfF, wfLS;                               // wavefront path state (HBM)
+    DevBuf wfQA, wfQB, wfQF;                                        // traversal queue in slot order: the rays
     DevBuf pathSamp, pathT;                                         // wf_path with num_rays > 1: per-sample colours, running sum
     DevBuf dbgbuf;                                                  // -DRT_DEBUG builds: per-wave traversal records
     DevBuf accum;                                                   // progressive mode: sum of the frames so far (float4 per pixel)
@@ -561,15 +561,13 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
             pt.pblocks = (unsigned)((n_paths64 + 255) / 256);
         }
         const size_t np = np_total;
-        if ((rc2 = ensure(ctx, ctx->wfR0, 2 * np * 16)) != RT_OK || (rc2 = ensure(ctx, ctx->wfR1, 2 * np * 16)) != RT_OK ||
-            (rc2 = ensure(ctx, ctx->wfM, 2 * np * 8)) != RT_OK || (rc2 = ensure(ctx, ctx->wfFL, 2 * np * 4)) != RT_OK ||
-            (rc2 = ensure(ctx, ctx->wfS0, np * 16)) != RT_OK ||
-            (rc2 = ensure(ctx, ctx->wfS1, np * 16)) != RT_OK || (rc2 = ensure(ctx, ctx->wfT, np * 16)) != RT_OK ||
+        if ((rc2 = ensure(ctx, ctx->wfM, 2 * np * 8)) != RT_OK || (rc2 = ensure(ctx, ctx->wfST, np * 16)) != RT_OK ||
+            (rc2 = ensure(ctx, ctx->wfT, (fr.spp > 1 ? np : 1) * 16)) != RT_OK ||
             (rc2 = ensure(ctx, ctx->wfF, np * 16)) != RT_OK || (rc2 = ensure(ctx, ctx->wfLS, np * 4 * (size_t)nseg)) != RT_OK)
             return rc2;
         size_t q_slots = 0;                                           // traversal-queue slots of all parts (padding included)
         uint64_t q_sig = 0xcbf29ce484222325ull;
-        if (queue) {
+        {
             for (Part &pt : pv) {
                 pt.qbase = q_slots;
                 q_slots += (size_t)pt.st.slots_per_block * (size_t)pt.tblocks;
@@ -587,14 +585,11 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
         }
         for (Part &pt : pv) {
             rtk::WfState &st = pt.st;
-            if (queue) {
-                st.QA = static_cast<float4 *>(ctx->wfQA.p) + pt.qbase; st.QB = static_cast<float2 *>(ctx->wfQB.p) + pt.qbase;
-                st.QF = static_cast<int *>(ctx->wfQF.p) + pt.qbase;
-            }
-            st.R0 = static_cast<float4 *>(ctx->wfR0.p) + 2 * pt.base; st.R1 = static_cast<float4 *>(ctx->wfR1.p) + 2 * pt.base;
-            st.M = static_cast<unsigned long long *>(ctx->wfM.p) + 2 * pt.base; st.FL = static_cast<int *>(ctx->wfFL.p) + 2 * pt.base;
-            st.S0 = static_cast<float4 *>(ctx->wfS0.p) + pt.base;
-            st.S1 = static_cast<float4 *>(ctx->wfS1.p) + pt.base; st.T = static_cast<float4 *>(ctx->wfT.p) + pt.base;
+            st.QA = static_cast<float4 *>(ctx->wfQA.p) + pt.qbase; st.QB = static_cast<float2 *>(ctx->wfQB.p) + pt.qbase;
+            st.QF = static_cast<int *>(ctx->wfQF.p) + pt.qbase;
+            st.init_m = queue ? 0 : 1;                               // wf_trav merges split traversals with atomicMin
+            st.M = static_cast<unsigned long long *>(ctx->wfM.p) + 2 * pt.base;
+            st.ST = static_cast<float4 *>(ctx->wfST.p) + pt.base; st.T = static_cast<float4 *>(ctx->wfT.p) + (fr.spp > 1 ? pt.base : 0);
             st.F = static_cast<int4 *>(ctx->wfF.p) + pt.base;
             st.LS = static_cast<float *>(ctx->wfLS.p) + pt.base * (size_t)nseg;   // LS[d * n_paths + i] inside the part's block
         }
@@ -610,8 +605,8 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
             if (j > 0) RT_HIP(ctx, hipStreamWaitEvent(q, ctx->fork_ev, 0));
             if (pt.st.n_paths == 0) continue;
             for (int s = 0; s < fr.spp; ++s) {
-                if (work_dev) hipLaunchKernelGGL(rtk::wf_begin<true>, dim3(pt.pblocks), dim3(256), 0, q, scn, pt.fr, pt.st, s);
-                else hipLaunchKernelGGL(rtk::wf_begin<false>, dim3(pt.pblocks), dim3(256), 0, q, scn, pt.fr, pt.st, s);
+                if (work_dev) hipLaunchKernelGGL((rtk::wf_advance<true, true>), dim3(pt.pblocks), dim3(256), 0, q, scn, pt.fr, pt.st, s);
+                else hipLaunchKernelGGL((rtk::wf_advance<false, true>), dim3(pt.pblocks), dim3(256), 0, q, scn, pt.fr, pt.st, s);
                 for (int it = 0; it < (segs > 0 ? segs + 1 : 0); ++it) {
                     if (have_mesh) {
 #ifdef RT_DEBUG
@@ -632,8 +627,8 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
                         if (timed) { RT_HIP(ctx, hipEventRecord(ctx->ev_trav[2 * it + 1], q)); ctx->n_trav_events = it + 1; }
                         pt.st.dbg = nullptr;
                     }
-                    if (work_dev) hipLaunchKernelGGL(rtk::wf_advance<true>, dim3(pt.pblocks), dim3(256), 0, q, scn, pt.fr, pt.st, s);
-                    else hipLaunchKernelGGL(rtk::wf_advance<false>, dim3(pt.pblocks), dim3(256), 0, q, scn, pt.fr, pt.st, s);
+                    if (work_dev) hipLaunchKernelGGL((rtk::wf_advance<true, false>), dim3(pt.pblocks), dim3(256), 0, q, scn, pt.fr, pt.st, s);
+                    else hipLaunchKernelGGL((rtk::wf_advance<false, false>), dim3(pt.pblocks), dim3(256), 0, q, scn, pt.fr, pt.st, s);
                 }
             }
             if (j > 0) { RT_HIP(ctx, hipEventRecord(ctx->part_ev[j], q)); }
@@ -769,8 +764,7 @@ int rt_ctx_destroy(rt_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ctx->node_lo.release(); ctx->node_hi.release(); ctx->nodes2.release(); ctx->nodesq.release(); ctx->q2thr.release(); ctx->left_dev.release(); ctx->lvl_nodes.release(); ctx->lvl_off.release(); ctx->nrm.release(); ctx->tri.release(); ctx->verts.release(); ctx->tidx.release();
     ctx->scratch_rgba.release(); ctx->scratch_rgb8.release(); ctx->work.release(); ctx->queue.release();
-    ctx->wfR0.release(); ctx->wfR1.release(); ctx->wfM.release(); ctx->wfS0.release(); ctx->wfS1.release();
-    ctx->wfT.release(); ctx->wfF.release(); ctx->wfFL.release(); ctx->wfLS.release(); ctx->wfQ.release();
+    ctx->wfM.release(); ctx->wfST.release(); ctx->wfT.release(); ctx->wfF.release(); ctx->wfLS.release();
     ctx->wfQA.release(); ctx->wfQB.release(); ctx->wfQF.release(); ctx->accum.release(); ctx->dbgbuf.release();
     ctx->pathSamp.release(); ctx->pathT.release();
     for (hipEvent_t &e : ctx->ev_trav) if (e) (void)hipEventDestroy(e);

@@ -36,11 +36,7 @@ constexpr int kPLeafCap = 256;
 constexpr int kPNodeBits = 25;                // stack entry = slot << 25 | node (7 bits of slot)
 constexpr unsigned kPNodeMask = (1u << kPNodeBits) - 1u;
 
-// path flags (pF[p].x)
-constexpr int PF_ALIVE = 1, PF_HASX = 2, PF_HASY = 4, PF_MESHX = 8, PF_MESHY = 16;
-constexpr int PF_DEPTH_SHIFT = 5, PF_DEPTH_MASK = 31;       // segment index of the continuation ray in flight (0..16)
-constexpr int PF_RAYS_SHIFT = 10, PF_RAYS_MASK = 63;        // rays traced so far (<= 2 * 16 + 1)
-constexpr int PF_WINS_SHIFT = 16;                           // 10 bits: nearest sphere before / after the mesh slot (id + 1)
+// (path record flags PF_*: rt_wavefront.hip.h)
 
 struct PathState {
     int n_paths;          // pixel slots of the (sub-)frame in tile order: tiles_x * tiles_y * 64

@@ -243,8 +243,7 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || R
         if (top < kLow) {
             if (lane < R && path >= 0) {
                 if (pend[lane] == 0) {
-                    const unsigned long long key = best[lane];
-                    if (key != WF_NOHIT) st.M[path] = key;
+                    st.M[path] = best[lane];          // always: the emitter does not initialise M (WF_NOHIT = no triangle accepted)
                     path = -1;
                 }
             }

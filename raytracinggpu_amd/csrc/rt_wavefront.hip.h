@@ -3,8 +3,8 @@
 // The per-pixel render of cpu_launcher.cpp:693-718 / KernelLaunch (optimized.cu:670-772) split by
 // divergence behaviour instead of by pixel:
 //
-//   wf_begin   one lane per pixel, uniform: camera ray of sample s (cpu:699-709), its ray/sphere tests
-//              (cpu:512-527) and the mesh's root-box test (cpu:279); path state initialised
+//   wf_advance<FIRST>  one lane per pixel, uniform: camera ray of sample s (cpu:699-709), its ray/sphere tests
+//              (cpu:512-527) and the mesh's root-box test (cpu:279); path record initialised
 //   wf_trav    persistent lanes, one RAY (or a sub-range of one ray's traversal) per lane: stackless BVH walk
 //              (BoundingBox::intersect cpu:146-157, moller_trumbore cpu:226-236, traversal cpu:277-311).
 //              Two micro-ops (BOX, TRI) chosen by wave vote; lanes refill from the wave's own, spatially
@@ -17,11 +17,12 @@
 //              sample, stores the pixel as one float4 (cpu:713)
 //
 // A shadow ray and the continuation (bounce / mirror / refraction) ray that leave the same hit point do not
-// depend on each other, so both are traced by the SAME wf_trav launch: per sample the sequence is
-//     begin, (trav, advance) x (segments + 1)
-// with launch j tracing the shadow rays of segment j-1 and the continuation rays of segment j.  Path state lives in HBM as float4 SoA indexed
-// by a TILE-ORDER path index (8x8 pixel tiles: a wave's 64 consecutive paths are one tile, and every state
-// access of wf_begin/wf_advance is a fully coalesced 1 KiB wave transaction).
+// depend on each other, so both are traced by the SAME traversal launch: per sample the sequence is
+//     advance<FIRST>, (trav, advance) x (segments + 1)
+// with launch j tracing the shadow rays of segment j-1 and the continuation rays of segment j.  The path records (32 bytes)
+// live in HBM as float4 / int4 SoA indexed by a TILE-ORDER path index (8x8 pixel tiles: a wave's 64 consecutive paths are one
+// tile, every record access is a fully coalesced 1 KiB wave transaction); the rays themselves live only in the traversal queue
+// (slot order), see WfState.
 //
 // Work splitting.  The reference never prunes by distance, so which nodes and triangles a ray
 // visits does not depend on what it has hit so far, and the nearest hit is  min over visited triangles of
@@ -36,34 +37,35 @@
 
 namespace rtk {
 
-// path flags (F.x, int per path)
-constexpr int WF_ALIVE = 1 << 8;      // path still being traced
-constexpr int WF_HASX = 1 << 9;       // a shadow ray (X) of segment d-1's hit is in flight
-constexpr int WF_HASY = 1 << 21;      // a continuation ray (Y) of segment d is in flight
-constexpr int WF_DEPTH = 0xff;        // segment index d of the continuation ray (or of the next one)
-// ray flags (FL, int per ray: continuation rays at [0, n_paths), shadow rays at [n_paths, 2 n_paths))
-constexpr int WF_ACTIVE = 1 << 8;     // the ray slot holds a ray of the current launch
-constexpr int WF_MESH = 1 << 20;      // the ray passed the mesh's root box: traversal needed
-                                      // bits 10..19: nearest sphere before / after the mesh slot (object id + 1)
+// path record flags (F.x; rt_path.hip.h keeps the same record in LDS)
+constexpr int PF_ALIVE = 1, PF_HASX = 2, PF_HASY = 4;       // path being traced; a shadow ray (X) of segment d-1's hit / a continuation ray (Y) of segment d is in flight
+constexpr int PF_MESHX = 8, PF_MESHY = 16;                  // that ray passed the mesh's root box: its traversal result M[] is meaningful
+constexpr int PF_DEPTH_SHIFT = 5, PF_DEPTH_MASK = 31;       // segment index d of the continuation ray in flight (or of the next one), 0..16
+constexpr int PF_RAYS_SHIFT = 10, PF_RAYS_MASK = 63;        // rays traced so far for this sample (<= 2 * 16 + 1)
+constexpr int PF_WINS_SHIFT = 16;                           // 10 bits: the Y ray's nearest sphere before / after the mesh slot (object id + 1)
+constexpr int PF_XSPHERE = 1 << 26;                         // the X ray is blocked by a sphere already (cpu:615 true whatever the mesh says)
 constexpr unsigned long long WF_NOHIT = ~0ull;
 
+// Path state of the wavefront pipeline, in HBM.  A ray lives in ONE place: its record in the traversal queue (slot order), which
+// the uniform kernel writes when it emits the ray, the traversal kernel reads, and the next uniform launch reads back to compute
+// the hit point.  Per path and launch the uniform kernel moves ~170 bytes (round 1: ~300: every ray was stored twice, the shadow
+// ray and its sphere hits were kept although only one comparison needs them, ray counts and sample sums were streamed).
 struct WfState {
-    float4 *R0, *R1;      // rays [2 n_paths]: (O.xyz, u.x) (u.yz, tA, tB): tA/tB = nearest sphere before/after the mesh slot
-    unsigned long long *M;   // [2 n_paths] traversal result: bits(t) << 32 | triangle index (visit order); WF_NOHIT if none
-    int *FL;              // [2 n_paths] ray flags
-    float4 *S0, *S1;      // surface being shaded: (P.xyz, bits(object id)) (N.xyz, refraction index of the ray)
-    float4 *T;            // (sum of sample colours .xyz, rays traced)
-    int4 *F;              // (flags, diffuse mask, object ids lo, object ids hi)
+    int4 *F;              // [n_paths] (flags | depth | rays | wins, diffuse mask, object ids lo, object ids hi)
+    float4 *ST;           // [n_paths] (tA, tB: the Y ray's nearest sphere before / after the mesh slot; l of the pending shadow test (cpu:623); refraction index of the Y ray)
+    unsigned long long *M;   // [2 n_paths] traversal result by ray (Y rays at [0, n_paths), X rays at [n_paths, 2 n_paths)): bits(t) << 32 | triangle index (visit order); WF_NOHIT if none
+    float4 *T;            // [n_paths] (sum of the sample colours .xyz, rays traced): frames with more than one sample only
     float *LS;            // l of every diffuse segment: LS[d * n_paths + i]
     int n_paths;          // tiles_x * tiles_y * 64
     int tiles_x;
-    // traversal scheduling: ray-slot q in [0, slots) maps to path 4*g + (q & 3), g = ((q>>2) & (S-1)) * Q + ((q>>2) >> log2S)
+    // traversal scheduling: ray-slot q in [0, slots) maps to ray 4*g + (q & 3), g = ((q>>2) & (S-1)) * Q + ((q>>2) >> log2S)
     int log2S, Q, n_groups;   // n_groups = 2 n_paths / 4 (ray groups);  S * Q >= n_groups
     int slots_per_block;      // multiple of 4: ray slots owned by one workgroup, handed to its waves on demand
-    unsigned long long *dbg;  // optional per-wave debug record
-    // traversal queue (work-stack variant only; QA == nullptr otherwise): the rays in TRAVERSAL-SLOT order, so that the
-    // slots a traversal workgroup owns are contiguous and one round trip brings flag and record
-    int *QF;                  // [slots] ray slot + 1 if the ray needs traversal (active and inside the root box), else 0
+    int init_m;               // the traversal kernel merges partial results with atomicMin (wf_trav's work splitting): emitters initialise M
+    unsigned long long *dbg;  // optional per-wave debug record (-DRT_DEBUG)
+    // traversal queue: the rays in TRAVERSAL-SLOT order, so that the slots a traversal workgroup owns are contiguous and one
+    // round trip brings flag and record
+    int *QF;                  // [slots] ray + 1 if the ray needs traversal (emitted and inside the root box), else 0
     float4 *QA;               // [slots] (O.xyz, u.x)
     float2 *QB;               // [slots] (u.y, u.z)
 };
@@ -90,27 +92,7 @@ __device__ __forceinline__ SphereHit spheres_split(const Scene &sc, f3 O, f3 u) 
     }
     return h;
 }
-__device__ __forceinline__ int wf_pack_wins(const SphereHit &h) { return ((h.winA + 1) & 31) << 10 | ((h.winB + 1) & 31) << 15; }
-__device__ __forceinline__ int wf_pack_wins_path(const SphereHit &h) { return ((h.winA + 1) & 31) << 16 | ((h.winB + 1) & 31) << 21; }   // PF_WINS_SHIFT
-
-// Emit ray slot `r`: record, sphere tests, root-box test (cpu:279; wave-uniform node data from kernel arguments).
-template <bool STATS>
-__device__ __forceinline__ bool wf_emit_ray(const Scene &sc, const WfState &st, int r, f3 O, f3 u, Work &wk) {
-    const SphereHit h = spheres_split(sc, O, u);
-    st.R0[r] = make_float4(O.x, O.y, O.z, u.x);
-    st.R1[r] = make_float4(u.y, u.z, h.tA, h.tB);
-    int f = WF_ACTIVE | wf_pack_wins(h);
-    if (sc.mesh_slot >= 0 && sc.n_nodes > 0) {
-        if (STATS) wk.box++;
-        if (slab_filtered(sc.root_lo, sc.root_hi, O, u, ray_inv(u))) {
-            if (STATS) wk.nodes++;
-            f |= WF_MESH;
-            st.M[r] = WF_NOHIT;
-        }
-    }
-    st.FL[r] = f;
-    return (f & WF_MESH) != 0;
-}
+__device__ __forceinline__ int wf_pack_wins_path(const SphereHit &h) { return ((h.winA + 1) & 31) << PF_WINS_SHIFT | ((h.winB + 1) & 31) << (PF_WINS_SHIFT + 5); }
 
 // inverse of wf_slot_to_path: the traversal slot of ray r
 __device__ __forceinline__ int wf_ray_to_slot(const WfState &st, int r) {
@@ -118,29 +100,23 @@ __device__ __forceinline__ int wf_ray_to_slot(const WfState &st, int r) {
     const int a = g / st.Q, col = g - a * st.Q;
     return ((col << st.log2S | a) << 2) | (r & 3);
 }
-// Traversal queue entry of ray r (work-stack variant): written for every ray slot of a live lane, needed or not.
-__device__ __forceinline__ void wf_queue_ray(const WfState &st, int r, bool need, f3 O, f3 u) {
-    if (st.QA == nullptr) return;
-    const int q = wf_ray_to_slot(st, r);
-    st.QF[q] = need ? r + 1 : 0;
-    if (need) { st.QA[q] = make_float4(O.x, O.y, O.z, u.x); st.QB[q] = make_float2(u.y, u.z); }
-}
 
-// Scene::intersect_all's running minimum for ray slot r, replayed in object order: spheres before the mesh,
-// mesh, spheres after (strict '<', cpu:554).  Returns t_min; win = object id or -1; tri_win = winning triangle.
-__device__ __forceinline__ float wf_close_query(const Scene &sc, const WfState &st, int r, float4 r1, int &win, int &tri_win) {
-    const int fl = st.FL[r];
-    float t_min = r1.z; win = ((fl >> 10) & 31) - 1;
-    tri_win = -1;
-    if (fl & WF_MESH) {
-        const unsigned long long m = st.M[r];
-        if (m != WF_NOHIT) {
-            const float tmesh = __uint_as_float((unsigned int)(m >> 32));
-            if (tmesh < t_min) { t_min = tmesh; win = sc.mesh_slot; tri_win = (int)(unsigned int)m; }
+// Emit ray r into queue slot q: the record (always: the next uniform launch reads a continuation ray back), the mesh's root-box
+// test (cpu:279; wave-uniform node data from kernel arguments) and the traversal flag.  Returns whether the ray needs traversal.
+template <bool STATS>
+__device__ __forceinline__ bool wf_emit_ray(const Scene &sc, const WfState &st, int r, int q, f3 O, f3 u, bool keep_record, Work &wk) {
+    bool need = false;
+    if (sc.mesh_slot >= 0 && sc.n_nodes > 0) {
+        if (STATS) wk.box++;
+        if (slab_filtered(sc.root_lo, sc.root_hi, O, u, ray_inv(u))) {
+            if (STATS) wk.nodes++;
+            need = true;
+            if (st.init_m) st.M[r] = WF_NOHIT;
         }
     }
-    if (r1.w < t_min) { t_min = r1.w; win = ((fl >> 15) & 31) - 1; }
-    return t_min;
+    if (need || keep_record) { st.QA[q] = make_float4(O.x, O.y, O.z, u.x); st.QB[q] = make_float2(u.y, u.z); }
+    st.QF[q] = need ? r + 1 : 0;
+    return need;
 }
 
 template <bool STATS>
@@ -154,61 +130,6 @@ __device__ __forceinline__ void wf_flush_work(const Frame &fr, Work &wk) {
             if (lt) atomicAdd(&fr.work[6], (unsigned long long)lt);
         }
     }
-}
-
-// ---- wf_begin: camera rays of sample `samp` ---------------------------------------------------------
-template <bool STATS>
-__global__ __launch_bounds__(256) void wf_begin(const Scene sc, const Frame fr, const WfState st, int samp) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    Work wk;
-    bool qy = false; f3 qO = mk(0, 0, 0), qu = mk(0, 0, 0);
-    if (i < st.n_paths) {
-        int px, lrow; bool valid;
-        wf_decode(st, fr, i, px, lrow, valid);
-        if (!valid || fr.segs <= 0) {
-            st.F[i] = make_int4(0, 0, 0, 0);
-            st.FL[i] = 0; st.FL[st.n_paths + i] = 0;
-            if (samp == 0) st.T[i] = make_float4(0, 0, 0, 0);
-            if (valid && samp == fr.spp - 1) {   // segs == 0 (optimized.cu convention with num_bounce 0): black
-                const float4 t = samp == 0 ? make_float4(0, 0, 0, 0) : st.T[i];
-                fr.out[out_index(fr, lrow, px)] = make_float4(t.x / (float)fr.spp, t.y / (float)fr.spp, t.z / (float)fr.spp, t.w);
-            }
-        } else {
-            const int row = fr.row0 + (lrow / fr.tile_rows) * fr.tile_rows * fr.tile_step + (lrow % fr.tile_rows);
-            // cpu:699: +0.5/-0.5 are double literals, narrowed by the Vector constructor
-            const f3 uc = mk((float)((double)((float)px - (float)fr.W / 2) + 0.5),
-                             (float)((double)((float)fr.H / 2 - (float)row) - 0.5), fr.z);
-            f3 ucm = uc;
-            if (fr.cam_mode == 1) {   // realtime:1115: cam.C + cam.bz * z + cam.bx * X + cam.by * Y (the position is part of the direction there)
-                const f3 Cc = mk(sc.camx, sc.camy, sc.camz), Bx = mk(fr.bx[0], fr.bx[1], fr.bx[2]), By = mk(fr.by[0], fr.by[1], fr.by[2]), Bz = mk(fr.bz[0], fr.bz[1], fr.bz[2]);
-                const f3 a = Cc + mk(Bz.x * fr.z, Bz.y * fr.z, Bz.z * fr.z);
-                const f3 b = a + mk(Bx.x * uc.x, Bx.y * uc.x, Bx.z * uc.x);
-                ucm = b + mk(By.x * uc.y, By.y * uc.y, By.z * uc.y);
-            }
-            f3 uu = ucm;
-            if (fr.sigma != 0.f) {   // cpu:705-707; with sigma == 0 the jitter is exactly +-0
-                const uint32_t hp = mix32(((uint32_t)row * (uint32_t)fr.W + (uint32_t)px) ^ mix32(fr.seed));
-                const uint32_t hs = mix32(hp ^ ((uint32_t)samp * 0x9E3779B1U));
-                const float r1 = uniform01(hs, 0, 2), r2 = uniform01(hs, 0, 3);
-                const float bm = fr.sigma * rt_sqrtf(-2 * logf(r1));
-                double sn, cs;
-                sincos(2 * 3.14159265358979323846 * (double)r2, &sn, &cs);
-                uu = ucm + mk((float)((double)bm * cs), (float)((double)bm * sn), 0.f);
-            }
-            const f3 u = normalize(uu);
-            const f3 O = mk(sc.camx, sc.camy, sc.camz);
-            qy = wf_emit_ray<STATS>(sc, st, i, O, u, wk);              // continuation ray of segment 0
-            qO = O; qu = u;
-            st.FL[st.n_paths + i] = 0;
-            st.F[i] = make_int4(WF_ALIVE | WF_HASY, 0, 0, 0);
-            st.S1[i] = make_float4(0, 0, 0, 1.f);                  // Ray::refraction_index = 1 (cpu:100)
-            float4 t = samp == 0 ? make_float4(0, 0, 0, 0) : st.T[i];
-            t.w += 1.f;                                            // this ray
-            st.T[i] = t;
-        }
-    }
-    if (i < st.n_paths) { wf_queue_ray(st, i, qy, qO, qu); wf_queue_ray(st, st.n_paths + i, false, qO, qu); }
-    wf_flush_work<STATS>(fr, wk);
 }
 
 // ---- wf_trav: persistent stackless traversal -----------------------------------------------------------
@@ -406,11 +327,13 @@ __global__ __launch_bounds__(LDSN ? kTravBlockLds : kTravBlock) void wf_trav(con
                     if (base + n_idle >= blk_n) drained = true;
                     if (ray < 0) {
                         const int qo = base + __popcll(idle & lane_lt);
-                        const int path = qo < blk_n ? wf_slot_to_path(st, blk_base + qo) : -1;
-                        if (path >= 0) {
-                            const int f = st.FL[path];
-                            if ((f & (WF_ACTIVE | WF_MESH)) == (WF_ACTIVE | WF_MESH)) {
-                                const float4 r0 = st.R0[path], r1 = st.R1[path];
+                        const int rf = qo < blk_n ? st.QF[(size_t)blk_base + qo] : 0;     // ray + 1 if the slot's ray needs traversal
+                        if (rf != 0) {
+                            const int path = rf - 1;
+                            {
+                                const float4 r0 = st.QA[(size_t)blk_base + qo];
+                                const float2 rq = st.QB[(size_t)blk_base + qo];
+                                const float4 r1 = make_float4(rq.x, rq.y, 0.f, 0.f);
                                 O = mk(r0.x, r0.y, r0.z); u = mk(r0.w, r1.x, r1.y);
                                 rb = ray_box(O, u);
                                 lray0[lane] = r0; lray1[lane] = r1; lbest[lane] = WF_NOHIT;
@@ -524,54 +447,92 @@ finished:
 }
 
 // ---- wf_advance: close the queries, shade, emit the next rays -----------------------------------------------
-template <bool STATS>
-__global__ __launch_bounds__(256, 8) void wf_advance(const Scene sc, const Frame fr, const WfState st, int samp) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    Work wk;
-    int4 F = i < st.n_paths ? st.F[i] : make_int4(0, 0, 0, 0);
-    bool qx = false, qy = false; f3 qOx = mk(0, 0, 0), qux = mk(0, 0, 0), qOy = mk(0, 0, 0), quy = mk(0, 0, 0);
-    if (F.x & WF_ALIVE) {
-        const float PI_F = (float)3.14159265358979323846;
-        const double PI_D = 3.14159265358979323846;
-        const f3 L = mk(sc.Lx, sc.Ly, sc.Lz);
-        const int rx = st.n_paths + i;                                // shadow-ray slot of this path
-        int d = F.x & WF_DEPTH;                                       // segment of the continuation ray in flight
-        int flags = WF_ALIVE;
-        float n_new = 0.f;
+// FIRST: the launch that opens sample `samp` -- camera rays (cpu:699-709) instead of closing queries.
+template <bool STATS, bool FIRST>
+__device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr, const WfState &st, const int samp, const int i, Work &wk) {
+    int4 F = FIRST ? make_int4(0, 0, 0, 0) : st.F[i];
+    if (!FIRST && !(F.x & PF_ALIVE)) return;                          // finished (or padding): its queue flags are already 0
+    const float PI_F = (float)3.14159265358979323846;
+    const double PI_D = 3.14159265358979323846;
+    const f3 L = mk(sc.Lx, sc.Ly, sc.Lz);
+    const int rx = st.n_paths + i;                                    // ray index of this path's shadow ray
+    const int qy = wf_ray_to_slot(st, i), qx = wf_ray_to_slot(st, rx);
+    float4 ST = make_float4(0, 0, 0, 1.f);                            // Ray::refraction_index = 1 (cpu:100)
+    int d = 0, nrays = 0;
+    bool emitY = false, emitX = false, finished = false;
+    f3 Oy = mk(0, 0, 0), uy = mk(0, 0, 1), Ox = mk(0, 0, 0), ux = mk(0, 0, 1);
+    int px, lrow; bool valid;
+    wf_decode(st, fr, i, px, lrow, valid);
+    const int row = fr.row0 + (lrow / fr.tile_rows) * fr.tile_rows * fr.tile_step + (lrow % fr.tile_rows);
 
-        // ---- (1) the shadow ray of segment d-1's hit came back: direct light (cpu:615-625) ----
-        if (F.x & WF_HASX) {
-            const float4 x0 = st.R0[rx], x1 = st.R1[rx];
-            const f3 Ox = mk(x0.x, x0.y, x0.z), ux = mk(x0.w, x1.x, x1.y);
-            int win, tri_win;
-            const float t_min = wf_close_query(sc, st, rx, x1, win, tri_win);
-            const float4 s0 = st.S0[i], s1 = st.S1[i];
-            const f3 Ps = mk(s0.x, s0.y, s0.z), Ns = mk(s1.x, s1.y, s1.z);
-            const int sid = __float_as_int(s0.w);
-            const int ds = d - 1;                                     // the shaded segment (d counts the continuation ray)
-            const f3 Pp = Ox + t_min * ux;                            // cpu:560 (Ox is P_adjusted)
-            float l = 0.f;
-            if (!(norm2(Pp - Ox) <= norm2(L - Ox))) {                 // cpu:615
-                const f3 wl = normalize(L - Ps);
-                const float dn = dot(Ns, wl);
-                const float mx = (dn < 0.f) ? 0.f : dn;
-                l = (float)((double)sc.intensity / (4 * PI_D * (double)norm2(L - Ps)) * (double)mx);   // cpu:623
+    if (FIRST) {
+        if (!valid) { st.F[i] = F; st.QF[qy] = 0; st.QF[qx] = 0; return; }
+        if (fr.segs <= 0) {
+            finished = true;                                          // optimized.cu convention with num_bounce 0: black
+        } else {
+            // cpu:699: +0.5/-0.5 are double literals, narrowed by the Vector constructor
+            const f3 uc = mk((float)((double)((float)px - (float)fr.W / 2) + 0.5),
+                             (float)((double)((float)fr.H / 2 - (float)row) - 0.5), fr.z);
+            f3 ucm = uc;
+            if (fr.cam_mode == 1) {   // realtime:1115: cam.C + cam.bz * z + cam.bx * X + cam.by * Y (the position is part of the direction there)
+                const f3 Cc = mk(sc.camx, sc.camy, sc.camz), Bx = mk(fr.bx[0], fr.bx[1], fr.bx[2]), By = mk(fr.by[0], fr.by[1], fr.by[2]), Bz = mk(fr.bz[0], fr.bz[1], fr.bz[2]);
+                const f3 a = Cc + mk(Bz.x * fr.z, Bz.y * fr.z, Bz.z * fr.z);
+                const f3 b = a + mk(Bx.x * uc.x, Bx.y * uc.x, Bx.z * uc.x);
+                ucm = b + mk(By.x * uc.y, By.y * uc.y, By.z * uc.y);
             }
-            st.LS[(size_t)ds * st.n_paths + i] = l;
-            const uint64_t ids = ((uint64_t)(uint32_t)F.w << 32 | (uint32_t)F.z) | (uint64_t)(sid & 15) << (4 * ds);
-            F.z = (int)(uint32_t)ids; F.w = (int)(uint32_t)(ids >> 32);
-            F.y |= 1 << ds;
-            st.FL[rx] = 0;
+            f3 uu = ucm;
+            if (fr.sigma != 0.f) {   // cpu:705-707; with sigma == 0 the jitter is exactly +-0
+                const uint32_t hp = mix32(((uint32_t)row * (uint32_t)fr.W + (uint32_t)px) ^ mix32(fr.seed));
+                const uint32_t hs = mix32(hp ^ ((uint32_t)samp * 0x9E3779B1U));
+                const float r1 = uniform01(hs, 0, 2), r2 = uniform01(hs, 0, 3);
+                const float bm = fr.sigma * rt_sqrtf(-2 * logf(r1));
+                double sn, cs;
+                sincos(2 * 3.14159265358979323846 * (double)r2, &sn, &cs);
+                uu = ucm + mk((float)((double)bm * cs), (float)((double)bm * sn), 0.f);
+            }
+            Oy = mk(sc.camx, sc.camy, sc.camz);
+            uy = normalize(uu);
+            emitY = true;                                             // continuation ray of segment 0
+            nrays = 1;
         }
-
+    } else {
+        ST = st.ST[i];
+        d = (F.x >> PF_DEPTH_SHIFT) & PF_DEPTH_MASK;                  // segment of the continuation ray in flight
+        nrays = (F.x >> PF_RAYS_SHIFT) & PF_RAYS_MASK;
+        float refr = ST.w;
+        // ---- (1) the shadow ray of segment d-1's hit came back: direct light or not (cpu:615) ----
+        // cpu:615 compares |P' - P_adj|^2, P' = P_adj + t_min u, with |L - P_adj|^2; it is monotone in t_min (every rounding involved is),
+        // so it holds iff it holds for the nearest sphere (decided when the ray was emitted: PF_XSPHERE) or for the nearest triangle
+        if (F.x & PF_HASX) {
+            bool shadowed = (F.x & PF_XSPHERE) != 0;
+            if (!shadowed && (F.x & PF_MESHX)) {
+                const unsigned long long m = st.M[rx];
+                if (m != WF_NOHIT) {
+                    const float4 x0 = st.QA[qx];
+                    const float2 x1 = st.QB[qx];
+                    const f3 Oxr = mk(x0.x, x0.y, x0.z), uxr = mk(x0.w, x1.x, x1.y);
+                    const f3 Pp = Oxr + __uint_as_float((unsigned int)(m >> 32)) * uxr;   // cpu:560 (Ox is P_adjusted)
+                    shadowed = norm2(Pp - Oxr) <= norm2(L - Oxr);
+                }
+            }
+            st.LS[(size_t)(d - 1) * st.n_paths + i] = shadowed ? 0.f : ST.z;
+        }
         // ---- (2) the continuation ray of segment d came back: Scene::getColor's branch for its hit (cpu:570-614) ----
-        if (F.x & WF_HASY) {
-            const float4 r0 = st.R0[i], r1 = st.R1[i];
+        if (F.x & PF_HASY) {
+            const float4 r0 = st.QA[qy];
+            const float2 r1 = st.QB[qy];
             f3 O = mk(r0.x, r0.y, r0.z), u = mk(r0.w, r1.x, r1.y);
-            int win, tri_win;
-            const float t_min = wf_close_query(sc, st, i, r1, win, tri_win);
-            st.FL[i] = 0;
-            float refr = st.S1[i].w;
+            // Scene::intersect_all's running minimum replayed in object order: spheres before the mesh, mesh, spheres after (strict '<', cpu:554)
+            float t_min = ST.x;
+            int win = ((F.x >> PF_WINS_SHIFT) & 31) - 1, tri_win = -1;
+            if (F.x & PF_MESHY) {
+                const unsigned long long m = st.M[i];
+                if (m != WF_NOHIT) {
+                    const float tm = __uint_as_float((unsigned int)(m >> 32));
+                    if (tm < t_min) { t_min = tm; win = sc.mesh_slot; tri_win = (int)(unsigned int)m; }
+                }
+            }
+            if (ST.y < t_min) { t_min = ST.y; win = ((F.x >> (PF_WINS_SHIFT + 5)) & 31) - 1; }
             if (win >= 0) {                                           // a miss is black (cpu:571): nothing to emit
                 const f3 P = O + t_min * u;                           // cpu:560
                 f3 N;
@@ -614,18 +575,20 @@ __global__ __launch_bounds__(256, 8) void wf_advance(const Scene sc, const Frame
                     }
                     cont = true;
                 } else {                                              // cpu:605-642: diffuse
-                    st.S0[i] = make_float4(P.x, P.y, P.z, __int_as_float(win));
                     const f3 Pa = P + fr.eps * N;
                     const f3 toL = L - Pa;
-                    const f3 us = toL / rt_sqrtf(norm2(toL));         // NORMED_VEC, cpu:614
-                    qx = wf_emit_ray<STATS>(sc, st, rx, Pa, us, wk);  // shadow ray of segment d
-                    qOx = Pa; qux = us;
-                    flags |= WF_HASX;
-                    n_new += 1.f;
+                    Ox = Pa; ux = toL / rt_sqrtf(norm2(toL));         // NORMED_VEC, cpu:614: the shadow ray of segment d
+                    emitX = true;
+                    nrays += 1;
+                    // the segment's direct term if the light turns out to be visible (cpu:620-623); kept until the shadow ray is back
+                    const f3 wl = normalize(L - P);
+                    const float dn = dot(N, wl);
+                    const float mx = (dn < 0.f) ? 0.f : dn;
+                    ST.z = (float)((double)sc.intensity / (4 * PI_D * (double)norm2(L - P)) * (double)mx);
+                    const uint64_t ids = ((uint64_t)(uint32_t)F.w << 32 | (uint32_t)F.z) | (uint64_t)(win & 15) << (4 * d);
+                    F.z = (int)(uint32_t)ids; F.w = (int)(uint32_t)(ids >> 32);
+                    F.y |= 1 << d;
                     if (d + 1 < fr.segs) {                            // the bounce ray (cpu:627-642): needs r1, r2 and N only
-                        int px, lrow; bool valid;
-                        wf_decode(st, fr, i, px, lrow, valid);
-                        const int row = fr.row0 + (lrow / fr.tile_rows) * fr.tile_rows * fr.tile_step + (lrow % fr.tile_rows);
                         const uint32_t hp = mix32(((uint32_t)row * (uint32_t)fr.W + (uint32_t)px) ^ mix32(fr.seed));
                         const uint32_t hs = mix32(hp ^ ((uint32_t)samp * 0x9E3779B1U));
                         const float r1u = uniform01(hs, (uint32_t)d, 0);
@@ -646,50 +609,75 @@ __global__ __launch_bounds__(256, 8) void wf_advance(const Scene sc, const Frame
                         refr = 1.f;                                   // Ray(P_adjusted, random_direction): index 1
                         cont = true;
                     }
-                    st.S1[i] = make_float4(N.x, N.y, N.z, refr);
                 }
                 if (cont && d + 1 < fr.segs) {
-                    qy = wf_emit_ray<STATS>(sc, st, i, O, u, wk);     // continuation ray of segment d+1
-                    qOy = O; quy = u;
-                    flags |= WF_HASY;
-                    n_new += 1.f;
-                    if (!(flags & WF_HASX)) st.S1[i].w = refr;
+                    emitY = true; Oy = O; uy = u;                     // continuation ray of segment d+1
+                    nrays += 1;
                 }
             }
             d = d + 1;
         }
+        ST.w = refr;
+        finished = !(emitX || emitY);
+    }
 
-        if (flags & (WF_HASX | WF_HASY)) {
-            st.F[i] = make_int4(flags | d, F.y, F.z, F.w);
-            st.T[i].w += n_new;
-        } else {   // nothing in flight: fold the path back to front (cpu:642-644), accumulate the sample (cpu:711)
-            f3 ans = mk(0, 0, 0);
-            const int nseg = d < fr.segs ? d : fr.segs;
-            const uint64_t ids = (uint64_t)(uint32_t)F.w << 32 | (uint32_t)F.z;
-            for (int k = nseg - 1; k >= 0; --k) {
-                if (F.y & (1 << k)) {
-                    const Material m = material_of(sc, (int)((ids >> (4 * k)) & 15));
-                    const float l = st.LS[(size_t)k * st.n_paths + i];
-                    const f3 alb = mk(m.ar, m.ag, m.ab);
-                    ans = (l * alb) / PI_F + alb * ans;
-                }
-            }
-            float4 t = st.T[i];
-            if (fr.cam_mode == 1) { t.x += ans.x * fr.inv_n; t.y += ans.y * fr.inv_n; t.z += ans.z * fr.inv_n; }   // realtime:1131
-            else { t.x += ans.x; t.y += ans.y; t.z += ans.z; }
-            st.F[i] = make_int4(0, 0, 0, 0);
-            if (samp == fr.spp - 1) {                                // cpu:713 + the framebuffer store
-                int px, lrow; bool valid;
-                wf_decode(st, fr, i, px, lrow, valid);
-                const float n = fr.cam_mode == 1 ? 1.f : (float)fr.spp;
-                fr.out[out_index(fr, lrow, px)] = make_float4(t.x / n, t.y / n, t.z / n, t.w);
-            } else {
-                st.T[i] = t;
+    if (finished) {   // nothing in flight: fold the path back to front (cpu:642-644), accumulate the sample (cpu:711)
+        f3 ans = mk(0, 0, 0);
+        const int nseg = d < fr.segs ? d : fr.segs;
+        const uint64_t ids = (uint64_t)(uint32_t)F.w << 32 | (uint32_t)F.z;
+        for (int k = nseg - 1; k >= 0; --k) {
+            if (F.y & (1 << k)) {
+                const Material m = material_of(sc, (int)((ids >> (4 * k)) & 15));
+                const float l = st.LS[(size_t)k * st.n_paths + i];
+                const f3 alb = mk(m.ar, m.ag, m.ab);
+                ans = (l * alb) / PI_F + alb * ans;
             }
         }
+        float4 t = samp == 0 ? make_float4(0, 0, 0, 0) : st.T[i];
+        if (fr.cam_mode == 1) { t.x += ans.x * fr.inv_n; t.y += ans.y * fr.inv_n; t.z += ans.z * fr.inv_n; }   // realtime:1131
+        else { t.x += ans.x; t.y += ans.y; t.z += ans.z; }
+        t.w += (float)nrays;
+        if (samp == fr.spp - 1) {                                     // cpu:713 + the framebuffer store
+            const float n = fr.cam_mode == 1 ? 1.f : (float)fr.spp;
+            fr.out[out_index(fr, lrow, px)] = make_float4(t.x / n, t.y / n, t.z / n, t.w);
+        } else {
+            st.T[i] = t;
+        }
+        st.F[i] = make_int4(0, 0, 0, 0);
+        st.QF[qy] = 0; st.QF[qx] = 0;
+        return;
     }
-    if (i < st.n_paths) { wf_queue_ray(st, i, qy, qOy, quy); wf_queue_ray(st, st.n_paths + i, qx, qOx, qux); }
-    wf_flush_work<STATS>(fr, wk);
+
+    // ---- (3) emission: sphere tests (cpu:512-527), root-box test (cpu:279), queue records ----
+    int flags = PF_ALIVE | (d << PF_DEPTH_SHIFT) | (nrays << PF_RAYS_SHIFT);
+    if (emitY) {
+        const SphereHit h = spheres_split(sc, Oy, uy);
+        ST.x = h.tA; ST.y = h.tB;
+        flags |= PF_HASY | wf_pack_wins_path(h);
+        if (wf_emit_ray<STATS>(sc, st, i, qy, Oy, uy, true, wk)) flags |= PF_MESHY;
+    } else {
+        st.QF[qy] = 0;
+    }
+    if (emitX) {
+        const SphereHit h = spheres_split(sc, Ox, ux);
+        const float tS = h.tB < h.tA ? h.tB : h.tA;                   // only the value of the shadow ray's nearest hit matters
+        const f3 Pp = Ox + tS * ux;                                   // cpu:560
+        flags |= PF_HASX;
+        if (norm2(Pp - Ox) <= norm2(L - Ox)) flags |= PF_XSPHERE;      // cpu:615 holds for the sphere already (the mesh is still intersected, as intersect_all does)
+        if (wf_emit_ray<STATS>(sc, st, rx, qx, Ox, ux, false, wk)) flags |= PF_MESHX;
+    } else {
+        st.QF[qx] = 0;
+    }
+    st.F[i] = make_int4(flags, F.y, F.z, F.w);
+    st.ST[i] = ST;
+}
+
+template <bool STATS, bool FIRST>
+__global__ __launch_bounds__(256, 8) void wf_advance(const Scene sc, const Frame fr, const WfState st, int samp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    Work wk;
+    if (i < st.n_paths) wf_advance_path<STATS, FIRST>(sc, fr, st, samp, i, wk);
+    wf_flush_work<STATS>(fr, wk);                                     // every lane of the wave arrives here (wave-level sums)
 }
 
 }  // namespace rtk
