@@ -142,6 +142,87 @@ def reference_check(sc, threads):
             "note": "the reference times its whole program (OBJ parse, BVH build, PNG) and draws from a clock()-seeded mt19937"}
 
 
+def single_stream_launch_ms(rt, args, p, rows, local, stream):
+    """Average duration of ONE launch of the dominant kernel when it owns the chip: a second context created under
+    RT_PARTS=1 (knobs are read once per context) renders the same frames as one sub-frame on one stream; the library
+    brackets the traversal launches with HIP events on the stream they run on."""
+    old = os.environ.get("RT_PARTS")
+    os.environ["RT_PARTS"] = "1"
+    try:
+        c1 = rt.Context(int(os.environ.get("LOCAL_RANK", "0")))
+    finally:
+        if old is None:
+            del os.environ["RT_PARTS"]
+        else:
+            os.environ["RT_PARTS"] = old
+    build_scene(rt, c1, args.scene)
+    ms, launches, frame = [], 0, []
+    for k in range(8):
+        c1.render_device(p, rows, local.data_ptr(), stream)
+        st = c1.stats()
+        if k >= 3 and st["trav_launches"] > 0:
+            ms.append(st["trav_ms"] / st["trav_launches"]); launches = st["trav_launches"]; frame.append(st["kernel_ms"])
+    c1.close()
+    return (statistics.median(ms), launches, statistics.median(frame)) if ms else (None, 0, None)
+
+
+def roofline(rt, ctx, args, p, rows, local, stream, counts, world, W, H, kernel_ms_max, workload):
+    """nominal HBM roofline of the dominant kernel from ALGORITHMIC bytes, plus what really binds it.
+
+    achieved = algorithmic bytes of one launch / that launch's duration, measured live with HIP events by the library on
+    the stream the kernel runs on, in a single-stream context (one launch owns the chip).  The scene (~255 KB) is cache
+    resident, so the nominal fraction is not a utilisation: `binding` quotes the measured HBM traffic and the VALU / SALU
+    issue figures of the same kernel from the committed rocprofv3 summary (profiles/round2/summary.json, produced by
+    tools/round_profile.sh + tools/make_profile_summary.py)."""
+    st = ctx.stats()
+    trav_bytes = 24 * counts["box_tests"] + 16 * counts["nodes"] + 48 * counts["tri_tests"]
+    fb_bytes = 16 * W * H
+    out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
+           "frac_is": "nominal: SURVEY 8d algorithmic bytes (24 B/box test + 16 B/node + 48 B/triangle test) of a cache-resident scene over the "
+                      "HBM peak; it may exceed 1 and is NOT a utilisation -- see `binding`",
+           "frame_algorithmic_bytes": int(trav_bytes + fb_bytes), "frame_kernels_ms": round(kernel_ms_max, 4),
+           "per_ray": {k: round(counts[k] / counts["rays"], 3) for k in ("box_tests", "nodes", "tri_tests")}}
+    if st["trav_launches"] > 0:
+        kname = {6: "rtk::wf_trav<false, false>", 7: "rtk::wf_trav<false, true>"}.get(st["variant"], "rtk::wf_travq<false, 64, false, false>")
+        parts = max(st.get("parts", 1), 1)
+        k_ms_conc = st["trav_ms"] / st["trav_launches"]
+        single_ms, single_launches, single_frame = (None, 0, None)
+        if world == 1:
+            single_ms, single_launches, single_frame = single_stream_launch_ms(rt, args, p, rows, local, stream)
+        if single_ms:
+            alg_launch = trav_bytes / single_launches
+            k_ms = single_ms
+            out.update({"kernel_ms": round(single_ms, 4), "launches_per_frame": single_launches, "concurrent_launches": 1,
+                        "single_stream_frame_ms": round(single_frame, 4)})
+        else:
+            alg_launch = trav_bytes / world / (st["trav_launches"] * parts)
+            k_ms = k_ms_conc
+            out.update({"kernel_ms": round(k_ms, 4), "launches_per_frame": st["trav_launches"] * parts, "concurrent_launches": parts})
+        out["kernel_ms_two_streams"] = round(k_ms_conc, 4)            # the default configuration: the twin launch of the other sub-frame shares the chip
+    else:
+        kname = {1: "rtk::render_persistent<false>", 9: "rtk::wf_path<false>"}.get(st["variant"], "rtk::render_kernel<false>")
+        k_ms, alg_launch = kernel_ms_max, (trav_bytes + fb_bytes) / world
+        out.update({"kernel_ms": round(k_ms, 4), "launches_per_frame": 1, "concurrent_launches": 1})
+    ach = alg_launch / (k_ms * 1e-3) / 1e9
+    out.update({"kernel": kname, "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": int(alg_launch)})
+    spath = os.path.join(ROOT, "profiles", "round2", "summary.json")
+    if os.path.exists(spath) and workload == "cat_1920x1080_spp1_b3" and st["trav_launches"] > 0 and st["variant"] == 8:
+        ks = json.load(open(spath))["kernels"]
+        t, a = ks["wf_travq"], ks["wf_advance"]
+        hbm = t["hbm_read_bytes_per_launch"] + t["hbm_write_bytes_per_launch"]
+        out["traffic"] = hbm                                          # PMC, per single-stream launch like `achieved` (FETCH_SIZE x 2 + WRITE_SIZE)
+        out["traffic_source"] = "profiles/round2/summary.json (rocprofv3 --pmc, RT_PARTS=1)"
+        out["binding"] = {
+            "resource": "VALU issue (wf_travq: bookkeeping of the work stack, ~2/3 of its vector instructions) and, for wf_advance, HBM",
+            "wf_travq": {k: t[k] for k in ("rocprof_avg_us_single_stream", "rocprof_avg_us_two_streams", "share_of_gpu_time", "hbm_frac_of_8TBps", "l2_hit_rate",
+                                           "valu_pipe_busy_frac", "valu_issue_per_simd_cycle", "salu_issue_per_cu_cycle", "valu_lane_utilization",
+                                           "wave_cycles_waiting_frac", "valu_wave_insts_per_launch", "salu_wave_insts_per_launch")},
+            "wf_advance": {k: a[k] for k in ("rocprof_avg_us_single_stream", "rocprof_avg_us_two_streams", "share_of_gpu_time", "hbm_read_bytes_per_launch",
+                                             "hbm_write_bytes_per_launch", "hbm_GBps_single_stream", "hbm_frac_of_8TBps", "valu_pipe_busy_frac", "valu_lane_utilization")},
+            "source": "profiles/round2/summary.json <- pmc_wf_travq.json, pmc_wf_advance.json, bench_kernel_stats.csv, single_stream_kernel_stats.csv"}
+    return out
+
+
 def main():
     args = parse()
     import torch
@@ -232,6 +313,13 @@ def main():
             for _ in range(3):
                 ctx.render(p)
             res["config"]["host_frame_ms_incl_d2h"] = round((time.perf_counter() - t1) / 3 * 1e3, 3)
+            pin = rt.PinnedArray((H, W, 4))                          # the same into a buffer from rt_host_alloc: the copy is one DMA
+            ctx.render(p, out=pin.array)
+            t1 = time.perf_counter()
+            for _ in range(3):
+                ctx.render(p, out=pin.array)
+            res["config"]["host_frame_ms_incl_d2h_pinned"] = round((time.perf_counter() - t1) / 3 * 1e3, 3)
+            pin.close()
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(args, rays_per_frame)
@@ -239,38 +327,7 @@ def main():
                 res["cpu_baseline"] = {"value": None, "unit": "Mrays/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         if counts is not None:
             assert counts["rays"] == rays_per_frame, (counts, rays_per_frame)
-            st = ctx.stats()
-            trav_bytes = 24 * counts["box_tests"] + 16 * counts["nodes"] + 48 * counts["tri_tests"]
-            fb_bytes = 16 * W * H
-            if st["trav_launches"] > 0:
-                # wavefront variant: the dominant kernel is the traversal kernel; its launches of the last timed
-                # frame are bracketed by HIP events inside the library, on the stream they run on
-                kname = {6: "rtk::wf_trav<false, false>", 7: "rtk::wf_trav<false, true>"}.get(st["variant"], "rtk::wf_travq<false, 64, false>")
-                launches = st["trav_launches"]
-                k_ms = st["trav_ms"] / launches
-                # `parts` sub-frames run concurrently on separate streams (one traversal launch per part and step); the
-                # timed launches are part 0's.  achieved = ONE launch's algorithmic bytes / its own duration, although the
-                # twin launch of the other part shares the chip during that time (conservative).
-                parts = max(st.get("parts", 1), 1)
-                alg_launch = trav_bytes / world / (launches * parts)
-            else:
-                kname = "rtk::render_persistent<false>" if st["variant"] == 1 else "rtk::render_kernel<false>"
-                launches, k_ms, alg_launch = 1, kernel_ms_max, (trav_bytes + fb_bytes) / world
-            ach = alg_launch / (k_ms * 1e-3) / 1e9
-            res["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                               "kernel": kname, "kernel_ms": round(k_ms, 4), "launches_per_frame": launches * max(st.get("parts", 1), 1), "concurrent_launches": max(st.get("parts", 1), 1),
-                               "algorithmic_bytes_per_launch": int(alg_launch),
-                               "frame_algorithmic_bytes": int(trav_bytes + fb_bytes), "frame_kernels_ms": round(kernel_ms_max, 4),
-                               "per_ray": {k: round(counts[k] / counts["rays"], 3) for k in ("box_tests", "nodes", "tri_tests")},
-                               "note": "algorithmic bytes (SURVEY 8d: 24 B/box test + 16 B/node + 48 B/triangle test); "
-                                       "the ~150 KB scene is cache resident, see DESIGN.md"}
-            tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-            if os.path.exists(tpath):
-                t = json.load(open(tpath)).get(workload)
-                if t:
-                    res["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
-                    res["roofline"]["traffic_source"] = t["source"]
+            res["roofline"] = roofline(rt, ctx, args, p, rows, local, stream, counts, world, W, H, kernel_ms_max, workload)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -8,7 +8,7 @@ for f in glob.glob(os.path.join(out, "p*", "**", "*counter_collection.csv"), rec
         k = row["Kernel_Name"]
         if pat not in k:
             continue
-        if "<true>" in k:
+        if "<true" in k:
             continue
         c = row["Counter_Name"]; v = float(row["Counter_Value"])
         acc[c] = acc.get(c, 0.0) + v; n[c] = n.get(c, 0) + 1
@@ -26,6 +26,15 @@ if g("SQ_WAVE_CYCLES"):
             d[k + "/WAVE_CYCLES"] = g(k) / g("SQ_WAVE_CYCLES")
 if g("SQ_INSTS_VALU") and g("SQ_WAVES"):
     d["valu_insts_per_wave"] = g("SQ_INSTS_VALU") / g("SQ_WAVES")
+if g("GRBM_GUI_ACTIVE"):
+    cyc = g("GRBM_GUI_ACTIVE") / 8.0                      # rocprofv3 reports the sum over the 8 XCDs (MI355X_MICROARCH.md, DVFS)
+    d["kernel_cycles"] = cyc
+    if g("SQ_INSTS_VALU"):
+        d["valu_issue_per_simd_cycle"] = g("SQ_INSTS_VALU") / (cyc * 1024)           # wave-instructions per SIMD and cycle (1024 SIMDs)
+    if g("SQ_ACTIVE_INST_VALU"):
+        d["valu_pipe_busy_frac"] = g("SQ_ACTIVE_INST_VALU") * 4 / (cyc * 1024)       # SQ_ACTIVE_INST_* count quad-cycles
+    if g("SQ_INSTS_SALU"):
+        d["salu_issue_per_cu_cycle"] = g("SQ_INSTS_SALU") / (cyc * 256)              # one scalar unit per CU
 if g("FETCH_SIZE") is not None:
     d["hbm_read_bytes_corrected"] = g("FETCH_SIZE") * 1024 * 2      # gfx950: FETCH_SIZE reads 1/2 (MI355X_MICROARCH.md HBM)
 if g("WRITE_SIZE") is not None:
