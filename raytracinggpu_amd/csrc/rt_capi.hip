@@ -95,8 +95,8 @@ struct rt_ctx {
     int n_levels = 0;
     DevBuf node_lo, node_hi, nodes2, nodesq, q2thr, tri, verts, tidx, scratch_rgba, scratch_rgb8, work, queue;
     int n_cus = 0;
-    DevBuf wfM, wfST, wfT, wfF, wfLS;                               // wavefront path state (HBM)
-    DevBuf wfQA, wfQB, wfQF;                                        // traversal queue in slot order: the rays
+    DevBuf wfM, wfPR, wfT, wfLS, wfSID;                             // wavefront path state (HBM)
+    DevBuf wfQR;                                                    // traversal queue in slot order: the rays (32 B each)
     DevBuf pathSamp, pathT;                                         // wf_path with num_rays > 1: per-sample colours, running sum
     DevBuf dbgbuf;                                                  // -DRT_DEBUG builds: per-wave traversal records
     DevBuf accum;                                                   // progressive mode: sum of the frames so far (float4 per pixel)
@@ -561,9 +561,9 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
             pt.pblocks = (unsigned)((n_paths64 + 255) / 256);
         }
         const size_t np = np_total;
-        if ((rc2 = ensure(ctx, ctx->wfM, 2 * np * 8)) != RT_OK || (rc2 = ensure(ctx, ctx->wfST, np * 16)) != RT_OK ||
+        if ((rc2 = ensure(ctx, ctx->wfM, 2 * np * 8)) != RT_OK || (rc2 = ensure(ctx, ctx->wfPR, np * 16)) != RT_OK ||
             (rc2 = ensure(ctx, ctx->wfT, (fr.spp > 1 ? np : 1) * 16)) != RT_OK ||
-            (rc2 = ensure(ctx, ctx->wfF, np * 16)) != RT_OK || (rc2 = ensure(ctx, ctx->wfLS, np * 4 * (size_t)nseg)) != RT_OK)
+            (rc2 = ensure(ctx, ctx->wfSID, np * (size_t)nseg)) != RT_OK || (rc2 = ensure(ctx, ctx->wfLS, np * 4 * (size_t)nseg)) != RT_OK)
             return rc2;
         size_t q_slots = 0;                                           // traversal-queue slots of all parts (padding included)
         uint64_t q_sig = 0xcbf29ce484222325ull;
@@ -574,24 +574,21 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
                 for (uint64_t v : {(uint64_t)pt.st.n_paths, (uint64_t)pt.st.log2S, (uint64_t)pt.st.Q, (uint64_t)pt.st.slots_per_block, (uint64_t)pt.tblocks})
                     q_sig = (q_sig ^ v) * 0x100000001b3ull;
             }
-            const size_t had = ctx->wfQF.bytes;
-            if ((rc2 = ensure(ctx, ctx->wfQA, q_slots * 16)) != RT_OK || (rc2 = ensure(ctx, ctx->wfQB, q_slots * 8)) != RT_OK ||
-                (rc2 = ensure(ctx, ctx->wfQF, q_slots * 4)) != RT_OK)
-                return rc2;
-            if (ctx->wfQF.bytes != had || ctx->qf_sig != q_sig) {         // padding slots are never written by the kernels: zero once per layout
-                RT_HIP(ctx, hipMemsetAsync(ctx->wfQF.p, 0, ctx->wfQF.bytes, stream));
+            const size_t had = ctx->wfQR.bytes;
+            if ((rc2 = ensure(ctx, ctx->wfQR, q_slots * 32)) != RT_OK) return rc2;
+            if (ctx->wfQR.bytes != had || ctx->qf_sig != q_sig) {         // padding slots are never written by the kernels: zero once per layout
+                RT_HIP(ctx, hipMemsetAsync(ctx->wfQR.p, 0, ctx->wfQR.bytes, stream));
                 ctx->qf_sig = q_sig;
             }
         }
         for (Part &pt : pv) {
             rtk::WfState &st = pt.st;
-            st.QA = static_cast<float4 *>(ctx->wfQA.p) + pt.qbase; st.QB = static_cast<float2 *>(ctx->wfQB.p) + pt.qbase;
-            st.QF = static_cast<int *>(ctx->wfQF.p) + pt.qbase;
+            st.QR = static_cast<float4 *>(ctx->wfQR.p) + 2 * pt.qbase;
             st.init_m = queue ? 0 : 1;                               // wf_trav merges split traversals with atomicMin
             st.M = static_cast<unsigned long long *>(ctx->wfM.p) + 2 * pt.base;
-            st.ST = static_cast<float4 *>(ctx->wfST.p) + pt.base; st.T = static_cast<float4 *>(ctx->wfT.p) + (fr.spp > 1 ? pt.base : 0);
-            st.F = static_cast<int4 *>(ctx->wfF.p) + pt.base;
+            st.PR = static_cast<float4 *>(ctx->wfPR.p) + pt.base; st.T = static_cast<float4 *>(ctx->wfT.p) + (fr.spp > 1 ? pt.base : 0);
             st.LS = static_cast<float *>(ctx->wfLS.p) + pt.base * (size_t)nseg;   // LS[d * n_paths + i] inside the part's block
+            st.SID = static_cast<unsigned char *>(ctx->wfSID.p) + pt.base * (size_t)nseg;
         }
         ctx->stats.lds_bytes = (int)trav_lds;
         ctx->stats.block_threads = tb;
@@ -764,8 +761,8 @@ int rt_ctx_destroy(rt_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ctx->node_lo.release(); ctx->node_hi.release(); ctx->nodes2.release(); ctx->nodesq.release(); ctx->q2thr.release(); ctx->left_dev.release(); ctx->lvl_nodes.release(); ctx->lvl_off.release(); ctx->nrm.release(); ctx->tri.release(); ctx->verts.release(); ctx->tidx.release();
     ctx->scratch_rgba.release(); ctx->scratch_rgb8.release(); ctx->work.release(); ctx->queue.release();
-    ctx->wfM.release(); ctx->wfST.release(); ctx->wfT.release(); ctx->wfF.release(); ctx->wfLS.release();
-    ctx->wfQA.release(); ctx->wfQB.release(); ctx->wfQF.release(); ctx->accum.release(); ctx->dbgbuf.release();
+    ctx->wfM.release(); ctx->wfPR.release(); ctx->wfT.release(); ctx->wfLS.release(); ctx->wfSID.release();
+    ctx->wfQR.release(); ctx->accum.release(); ctx->dbgbuf.release();
     ctx->pathSamp.release(); ctx->pathT.release();
     for (hipEvent_t &e : ctx->ev_trav) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t &e : ctx->part_ev) if (e) (void)hipEventDestroy(e);

@@ -263,7 +263,8 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || R
                     spf = 0;
                     if (base + lane < blk_n) {
                         const size_t q = (size_t)blk_base + (size_t)(base + lane);
-                        spf = st.QF[q]; sp0 = st.QA[q]; sp1 = st.QB[q];
+                        const float4 qb = st.QR[2 * q + 1];             // the slot's 32-byte record: flag and ray in one round trip
+                        sp0 = st.QR[2 * q]; sp1 = make_float2(qb.x, qb.y); spf = __float_as_int(qb.z);
                     }
                     const unsigned long long am = __ballot(spf != 0);
                     if (spf != 0) sidx[lanes_below(am)] = (unsigned char)lane;

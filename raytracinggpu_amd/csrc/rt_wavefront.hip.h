@@ -46,16 +46,17 @@ constexpr int PF_WINS_SHIFT = 16;                           // 10 bits: the Y ra
 constexpr int PF_XSPHERE = 1 << 26;                         // the X ray is blocked by a sphere already (cpu:615 true whatever the mesh says)
 constexpr unsigned long long WF_NOHIT = ~0ull;
 
-// Path state of the wavefront pipeline, in HBM.  A ray lives in ONE place: its record in the traversal queue (slot order), which
-// the uniform kernel writes when it emits the ray, the traversal kernel reads, and the next uniform launch reads back to compute
-// the hit point.  Per path and launch the uniform kernel moves ~170 bytes (round 1: ~300: every ray was stored twice, the shadow
-// ray and its sphere hits were kept although only one comparison needs them, ray counts and sample sums were streamed).
+// Path state of the wavefront pipeline, in HBM.  A ray lives in ONE place: its 32-byte record in the traversal queue (slot order;
+// the four rays of a group are one 128-byte line), which the uniform kernel writes when it emits the ray, the traversal kernel
+// reads, and the next uniform launch reads back to compute the hit point.  Per path and launch the uniform kernel moves ~150
+// bytes (round 1: ~300: every ray was stored twice, the shadow ray and its sphere hits were kept although one comparison needs
+// them, object ids, ray counts and sample sums were streamed with every launch).
 struct WfState {
-    int4 *F;              // [n_paths] (flags | depth | rays | wins, diffuse mask, object ids lo, object ids hi)
-    float4 *ST;           // [n_paths] (tA, tB: the Y ray's nearest sphere before / after the mesh slot; l of the pending shadow test (cpu:623); refraction index of the Y ray)
+    float4 *PR;           // [n_paths] path record (bits(flags | depth | rays | wins), tA, tB, refraction index): tA / tB = the Y ray's nearest sphere before / after the mesh slot
     unsigned long long *M;   // [2 n_paths] traversal result by ray (Y rays at [0, n_paths), X rays at [n_paths, 2 n_paths)): bits(t) << 32 | triangle index (visit order); WF_NOHIT if none
     float4 *T;            // [n_paths] (sum of the sample colours .xyz, rays traced): frames with more than one sample only
-    float *LS;            // l of every diffuse segment: LS[d * n_paths + i]
+    float *LS;            // l (cpu:623) of every diffuse segment, written when the segment is shaded and zeroed if its shadow ray is blocked: LS[d * n_paths + i]
+    unsigned char *SID;   // object id of the surface shaded at segment d, 0xff if it was not diffuse: SID[d * n_paths + i]
     int n_paths;          // tiles_x * tiles_y * 64
     int tiles_x;
     // traversal scheduling: ray-slot q in [0, slots) maps to ray 4*g + (q & 3), g = ((q>>2) & (S-1)) * Q + ((q>>2) >> log2S)
@@ -65,9 +66,7 @@ struct WfState {
     unsigned long long *dbg;  // optional per-wave debug record (-DRT_DEBUG)
     // traversal queue: the rays in TRAVERSAL-SLOT order, so that the slots a traversal workgroup owns are contiguous and one
     // round trip brings flag and record
-    int *QF;                  // [slots] ray + 1 if the ray needs traversal (emitted and inside the root box), else 0
-    float4 *QA;               // [slots] (O.xyz, u.x)
-    float2 *QB;               // [slots] (u.y, u.z)
+    float4 *QR;               // [2 slots] record of slot q: QR[2q] = (O.xyz, u.x), QR[2q+1] = (u.y, u.z, bits(ray + 1 if the ray needs traversal else 0), -)
 };
 
 __device__ __forceinline__ void wf_decode(const WfState &st, const Frame &fr, int i, int &px, int &lrow, bool &valid) {
@@ -114,8 +113,8 @@ __device__ __forceinline__ bool wf_emit_ray(const Scene &sc, const WfState &st, 
             if (st.init_m) st.M[r] = WF_NOHIT;
         }
     }
-    if (need || keep_record) { st.QA[q] = make_float4(O.x, O.y, O.z, u.x); st.QB[q] = make_float2(u.y, u.z); }
-    st.QF[q] = need ? r + 1 : 0;
+    if (need || keep_record) st.QR[2 * (size_t)q] = make_float4(O.x, O.y, O.z, u.x);
+    st.QR[2 * (size_t)q + 1] = make_float4(u.y, u.z, __int_as_float(need ? r + 1 : 0), 0.f);
     return need;
 }
 
@@ -327,12 +326,12 @@ __global__ __launch_bounds__(LDSN ? kTravBlockLds : kTravBlock) void wf_trav(con
                     if (base + n_idle >= blk_n) drained = true;
                     if (ray < 0) {
                         const int qo = base + __popcll(idle & lane_lt);
-                        const int rf = qo < blk_n ? st.QF[(size_t)blk_base + qo] : 0;     // ray + 1 if the slot's ray needs traversal
+                        const float4 rq = qo < blk_n ? st.QR[2 * ((size_t)blk_base + qo) + 1] : make_float4(0, 0, 0, 0);
+                        const int rf = __float_as_int(rq.z);                            // ray + 1 if the slot's ray needs traversal
                         if (rf != 0) {
                             const int path = rf - 1;
                             {
-                                const float4 r0 = st.QA[(size_t)blk_base + qo];
-                                const float2 rq = st.QB[(size_t)blk_base + qo];
+                                const float4 r0 = st.QR[2 * ((size_t)blk_base + qo)];
                                 const float4 r1 = make_float4(rq.x, rq.y, 0.f, 0.f);
                                 O = mk(r0.x, r0.y, r0.z); u = mk(r0.w, r1.x, r1.y);
                                 rb = ray_box(O, u);
@@ -450,14 +449,15 @@ finished:
 // FIRST: the launch that opens sample `samp` -- camera rays (cpu:699-709) instead of closing queries.
 template <bool STATS, bool FIRST>
 __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr, const WfState &st, const int samp, const int i, Work &wk) {
-    int4 F = FIRST ? make_int4(0, 0, 0, 0) : st.F[i];
-    if (!FIRST && !(F.x & PF_ALIVE)) return;                          // finished (or padding): its queue flags are already 0
+    float4 ST = FIRST ? make_float4(0, 0, 0, 1.f) : st.PR[i];        // Ray::refraction_index = 1 (cpu:100)
+    const int F = __float_as_int(ST.x);
+    if (!FIRST && !(F & PF_ALIVE)) return;                            // finished (or padding): its queue flags are already 0
+    const float4 kDead = make_float4(0, 0, 0, 0);                     // second half of a queue record without a ray
     const float PI_F = (float)3.14159265358979323846;
     const double PI_D = 3.14159265358979323846;
     const f3 L = mk(sc.Lx, sc.Ly, sc.Lz);
     const int rx = st.n_paths + i;                                    // ray index of this path's shadow ray
     const int qy = wf_ray_to_slot(st, i), qx = wf_ray_to_slot(st, rx);
-    float4 ST = make_float4(0, 0, 0, 1.f);                            // Ray::refraction_index = 1 (cpu:100)
     int d = 0, nrays = 0;
     bool emitY = false, emitX = false, finished = false;
     f3 Oy = mk(0, 0, 0), uy = mk(0, 0, 1), Ox = mk(0, 0, 0), ux = mk(0, 0, 1);
@@ -466,7 +466,7 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
     const int row = fr.row0 + (lrow / fr.tile_rows) * fr.tile_rows * fr.tile_step + (lrow % fr.tile_rows);
 
     if (FIRST) {
-        if (!valid) { st.F[i] = F; st.QF[qy] = 0; st.QF[qx] = 0; return; }
+        if (!valid) { st.PR[i] = kDead; st.QR[2 * (size_t)qy + 1] = kDead; st.QR[2 * (size_t)qx + 1] = kDead; return; }
         if (fr.segs <= 0) {
             finished = true;                                          // optimized.cu convention with num_bounce 0: black
         } else {
@@ -496,43 +496,41 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
             nrays = 1;
         }
     } else {
-        ST = st.ST[i];
-        d = (F.x >> PF_DEPTH_SHIFT) & PF_DEPTH_MASK;                  // segment of the continuation ray in flight
-        nrays = (F.x >> PF_RAYS_SHIFT) & PF_RAYS_MASK;
+        d = (F >> PF_DEPTH_SHIFT) & PF_DEPTH_MASK;                    // segment of the continuation ray in flight
+        nrays = (F >> PF_RAYS_SHIFT) & PF_RAYS_MASK;
         float refr = ST.w;
         // ---- (1) the shadow ray of segment d-1's hit came back: direct light or not (cpu:615) ----
         // cpu:615 compares |P' - P_adj|^2, P' = P_adj + t_min u, with |L - P_adj|^2; it is monotone in t_min (every rounding involved is),
         // so it holds iff it holds for the nearest sphere (decided when the ray was emitted: PF_XSPHERE) or for the nearest triangle
-        if (F.x & PF_HASX) {
-            bool shadowed = (F.x & PF_XSPHERE) != 0;
-            if (!shadowed && (F.x & PF_MESHX)) {
+        if (F & PF_HASX) {
+            bool shadowed = (F & PF_XSPHERE) != 0;
+            if (!shadowed && (F & PF_MESHX)) {
                 const unsigned long long m = st.M[rx];
                 if (m != WF_NOHIT) {
-                    const float4 x0 = st.QA[qx];
-                    const float2 x1 = st.QB[qx];
+                    const float4 x0 = st.QR[2 * (size_t)qx], x1 = st.QR[2 * (size_t)qx + 1];
                     const f3 Oxr = mk(x0.x, x0.y, x0.z), uxr = mk(x0.w, x1.x, x1.y);
                     const f3 Pp = Oxr + __uint_as_float((unsigned int)(m >> 32)) * uxr;   // cpu:560 (Ox is P_adjusted)
                     shadowed = norm2(Pp - Oxr) <= norm2(L - Oxr);
                 }
             }
-            st.LS[(size_t)(d - 1) * st.n_paths + i] = shadowed ? 0.f : ST.z;
+            if (shadowed) st.LS[(size_t)(d - 1) * st.n_paths + i] = 0.f;               // the l stored when the segment was shaded does not count
         }
         // ---- (2) the continuation ray of segment d came back: Scene::getColor's branch for its hit (cpu:570-614) ----
-        if (F.x & PF_HASY) {
-            const float4 r0 = st.QA[qy];
-            const float2 r1 = st.QB[qy];
+        if (F & PF_HASY) {
+            const float4 r0 = st.QR[2 * (size_t)qy], r1 = st.QR[2 * (size_t)qy + 1];
             f3 O = mk(r0.x, r0.y, r0.z), u = mk(r0.w, r1.x, r1.y);
+            int sid = 0xff;                                           // object id if the hit is diffuse
             // Scene::intersect_all's running minimum replayed in object order: spheres before the mesh, mesh, spheres after (strict '<', cpu:554)
-            float t_min = ST.x;
-            int win = ((F.x >> PF_WINS_SHIFT) & 31) - 1, tri_win = -1;
-            if (F.x & PF_MESHY) {
+            float t_min = ST.y;
+            int win = ((F >> PF_WINS_SHIFT) & 31) - 1, tri_win = -1;
+            if (F & PF_MESHY) {
                 const unsigned long long m = st.M[i];
                 if (m != WF_NOHIT) {
                     const float tm = __uint_as_float((unsigned int)(m >> 32));
                     if (tm < t_min) { t_min = tm; win = sc.mesh_slot; tri_win = (int)(unsigned int)m; }
                 }
             }
-            if (ST.y < t_min) { t_min = ST.y; win = ((F.x >> (PF_WINS_SHIFT + 5)) & 31) - 1; }
+            if (ST.z < t_min) { t_min = ST.z; win = ((F >> (PF_WINS_SHIFT + 5)) & 31) - 1; }
             if (win >= 0) {                                           // a miss is black (cpu:571): nothing to emit
                 const f3 P = O + t_min * u;                           // cpu:560
                 f3 N;
@@ -584,10 +582,8 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
                     const f3 wl = normalize(L - P);
                     const float dn = dot(N, wl);
                     const float mx = (dn < 0.f) ? 0.f : dn;
-                    ST.z = (float)((double)sc.intensity / (4 * PI_D * (double)norm2(L - P)) * (double)mx);
-                    const uint64_t ids = ((uint64_t)(uint32_t)F.w << 32 | (uint32_t)F.z) | (uint64_t)(win & 15) << (4 * d);
-                    F.z = (int)(uint32_t)ids; F.w = (int)(uint32_t)(ids >> 32);
-                    F.y |= 1 << d;
+                    st.LS[(size_t)d * st.n_paths + i] = (float)((double)sc.intensity / (4 * PI_D * (double)norm2(L - P)) * (double)mx);
+                    sid = win;
                     if (d + 1 < fr.segs) {                            // the bounce ray (cpu:627-642): needs r1, r2 and N only
                         const uint32_t hp = mix32(((uint32_t)row * (uint32_t)fr.W + (uint32_t)px) ^ mix32(fr.seed));
                         const uint32_t hs = mix32(hp ^ ((uint32_t)samp * 0x9E3779B1U));
@@ -615,6 +611,7 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
                     nrays += 1;
                 }
             }
+            st.SID[(size_t)d * st.n_paths + i] = (unsigned char)sid;
             d = d + 1;
         }
         ST.w = refr;
@@ -624,10 +621,10 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
     if (finished) {   // nothing in flight: fold the path back to front (cpu:642-644), accumulate the sample (cpu:711)
         f3 ans = mk(0, 0, 0);
         const int nseg = d < fr.segs ? d : fr.segs;
-        const uint64_t ids = (uint64_t)(uint32_t)F.w << 32 | (uint32_t)F.z;
         for (int k = nseg - 1; k >= 0; --k) {
-            if (F.y & (1 << k)) {
-                const Material m = material_of(sc, (int)((ids >> (4 * k)) & 15));
+            const int sid = st.SID[(size_t)k * st.n_paths + i];
+            if (sid != 0xff) {
+                const Material m = material_of(sc, sid);
                 const float l = st.LS[(size_t)k * st.n_paths + i];
                 const f3 alb = mk(m.ar, m.ag, m.ab);
                 ans = (l * alb) / PI_F + alb * ans;
@@ -643,8 +640,8 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
         } else {
             st.T[i] = t;
         }
-        st.F[i] = make_int4(0, 0, 0, 0);
-        st.QF[qy] = 0; st.QF[qx] = 0;
+        st.PR[i] = kDead;
+        st.QR[2 * (size_t)qy + 1] = kDead; st.QR[2 * (size_t)qx + 1] = kDead;
         return;
     }
 
@@ -652,11 +649,11 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
     int flags = PF_ALIVE | (d << PF_DEPTH_SHIFT) | (nrays << PF_RAYS_SHIFT);
     if (emitY) {
         const SphereHit h = spheres_split(sc, Oy, uy);
-        ST.x = h.tA; ST.y = h.tB;
+        ST.y = h.tA; ST.z = h.tB;
         flags |= PF_HASY | wf_pack_wins_path(h);
         if (wf_emit_ray<STATS>(sc, st, i, qy, Oy, uy, true, wk)) flags |= PF_MESHY;
     } else {
-        st.QF[qy] = 0;
+        st.QR[2 * (size_t)qy + 1] = kDead;
     }
     if (emitX) {
         const SphereHit h = spheres_split(sc, Ox, ux);
@@ -666,10 +663,10 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
         if (norm2(Pp - Ox) <= norm2(L - Ox)) flags |= PF_XSPHERE;      // cpu:615 holds for the sphere already (the mesh is still intersected, as intersect_all does)
         if (wf_emit_ray<STATS>(sc, st, rx, qx, Ox, ux, false, wk)) flags |= PF_MESHX;
     } else {
-        st.QF[qx] = 0;
+        st.QR[2 * (size_t)qx + 1] = kDead;
     }
-    st.F[i] = make_int4(flags, F.y, F.z, F.w);
-    st.ST[i] = ST;
+    ST.x = __int_as_float(flags);
+    st.PR[i] = ST;
 }
 
 template <bool STATS, bool FIRST>
