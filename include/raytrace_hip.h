@@ -223,6 +223,17 @@ int rt_kat_mesh(rt_ctx *ctx, const float *in, int n, float tri_tmin, int route, 
  *     the tree buildBVH would build for the moved mesh, rebuild on the host and call rt_scene_upload.) ------------------ */
 int rt_mesh_transform(rt_ctx *ctx, const float rotation[9], const float translation[3]);
 
+/* --- device-side BVH BUILD: TriangleMesh::buildBVH (cpu_launcher.cpp:190-224; the reference's device twin is the
+ *     one-thread recursive buildBVH of global_launcher.cu:298-331, launched by KernelInit :848-881) over the uploaded triangles
+ *     with the vertices as they are on the device now (i.e. after rt_mesh_transform): level by level, one workgroup per node --
+ *     box of the range, longest axis, midpoint split, the reference's in-place partition, its stop rule -- then the numbering
+ *     of bvhTreeToArray (optimized.cu:512-534).  The tree equals the host builder's bit for bit: boxes, node indices, and the
+ *     order the partition leaves the triangles in.  The library then re-lays the mesh out for its kernels as rt_scene_upload
+ *     does; the uploaded order becomes the new BVH order (the reference partitions `indices` in place too).
+ *     Optional outputs: bvh_arr10_out (capacity (2 * n_triangles + 2) * 10 floats), tri_order_out[n_triangles] (position ->
+ *     index of the triangle in the order before this call), n_nodes_out. ----------------------------------------------- */
+int rt_mesh_rebuild(rt_ctx *ctx, float *bvh_arr10_out, int32_t *tri_order_out, int32_t *n_nodes_out);
+
 /* --- smooth (interpolated) normals: get_smooth_normal of realtime_render.cu:221-245 / global_launcher.cu:207-231
  *     -- beta, gamma by the literal divisions, alpha = 1 - beta - gamma, N = normalize(alpha Na + beta Nb + gamma Nc) --
  *     replaces the flat normal of the winning triangle.  normals_xyz: n_normals * 3; nidx: TriangleIndices::ni,nj,nk of

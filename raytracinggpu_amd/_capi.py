@@ -24,7 +24,7 @@ EXPORTS = ["rt_abi_version", "rt_device_count", "rt_ctx_create", "rt_ctx_destroy
            "rt_progressive_frames",
            "rt_multi_create", "rt_multi_destroy", "rt_multi_last_error", "rt_multi_scene_upload", "rt_render_multi",
            "rt_render_multi_device", "rt_multi_get_stats",
-           "rt_host_alloc", "rt_host_free", "rt_kat_sphere", "rt_kat_box", "rt_kat_triangle", "rt_kat_mesh"]
+           "rt_mesh_rebuild", "rt_host_alloc", "rt_host_free", "rt_kat_sphere", "rt_kat_box", "rt_kat_triangle", "rt_kat_mesh"]
 MAX_DEVICES = 16
 
 
@@ -156,6 +156,7 @@ def load():
     L.rt_render_multi.argtypes = [vp, C.POINTER(Params), C.POINTER(C.c_float)]
     L.rt_render_multi_device.argtypes = [vp, C.POINTER(Params), vp]
     L.rt_multi_get_stats.argtypes = [vp, C.POINTER(MultiStats)]
+    L.rt_mesh_rebuild.argtypes = [vp, fp3, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.rt_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
     L.rt_host_free.argtypes = [vp]
     L.rt_kat_sphere.argtypes = [vp, fp3, C.c_int, fp3]
@@ -324,6 +325,14 @@ class Context:
         r = np.ascontiguousarray(rotation, np.float32).reshape(9)
         t = np.ascontiguousarray(translation, np.float32).reshape(3)
         self._check(self._L.rt_mesh_transform(self._h, r.ctypes.data_as(C.POINTER(C.c_float)), t.ctypes.data_as(C.POINTER(C.c_float))))
+
+    def mesh_rebuild(self, n_triangles):
+        """Device-side buildBVH over the uploaded triangles and the current device vertices -> (bvh_arr10 [n_nodes, 10], order [n_triangles])."""
+        arr = np.zeros(((2 * n_triangles + 2), 10), np.float32)
+        order = np.zeros(n_triangles, np.int32)
+        n = C.c_int32(0)
+        self._check(self._L.rt_mesh_rebuild(self._h, arr.ctypes.data_as(C.POINTER(C.c_float)), order.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(n)))
+        return arr[:n.value].copy(), order
 
     def mesh_set_normals(self, normals, nidx):
         """Smooth shading: vertex normals + per-triangle (ni, nj, nk) rows in the order of the uploaded indices; None = flat."""

@@ -8,6 +8,7 @@
 #include "rt_travq.hip.h"
 #include "rt_path.hip.h"
 #include "rt_meshops.hip.h"
+#include "rt_bvhbuild.hip.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -91,6 +92,10 @@ struct rt_ctx {
     rtk::Scene scene{};
     DevBuf nrm;                                                     // smooth shading: 3 normals per triangle, visit order
     std::vector<int> tri_perm;                                       // visit order -> triangle index in the uploaded (BVH-order) arrays
+    std::vector<int> up_indices;                                     // vertex indices of the uploaded triangles, 3 per triangle
+    int n_up_tris = 0;
+    DevBuf tidx_up;                                                  // the same on the device (int4 per triangle)
+    DevBuf bb_idx, bb_cnt, bb_pa, bb_pb, bb_tmp, bb_nodes_i, bb_nodes_f, bb_counter, bb_lvl, bb_size, bb_pre, bb_arr;   // device BVH build scratch
     DevBuf left_dev, lvl_nodes, lvl_off;                             // tree topology for the device-side refit
     int n_levels = 0;
     DevBuf node_lo, node_hi, nodes2, nodesq, q2thr, tri, verts, tidx, scratch_rgba, scratch_rgb8, work, queue;
@@ -700,111 +705,10 @@ int launch_tonemap(rt_ctx *ctx, const void *rgba_dev, int64_t npix, void *rgb8_d
     return RT_OK;
 }
 
-}  // namespace
-
-extern "C" {
-
-int rt_abi_version(void) { return RT_ABI_VERSION; }
-
-int rt_device_count(int *count) {
-    if (!count) return fail(nullptr, RT_ERR_INVALID, "count is NULL");
-    int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess) { *count = 0; return fail(nullptr, RT_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
-    *count = n;
-    return RT_OK;
-}
-
-int rt_ctx_create(rt_ctx **out, int device_id) {
-    if (!out) return fail(nullptr, RT_ERR_INVALID, "ctx out-pointer is NULL");
-    *out = nullptr;
-    int n = 0;
-    int rc = rt_device_count(&n);
-    if (rc != RT_OK) return rc;
-    if (n == 0) return fail(nullptr, RT_ERR_NO_DEVICE, "no HIP device visible");
-    if (device_id < 0 || device_id >= n) return fail(nullptr, RT_ERR_INVALID, "device %d out of range [0,%d)", device_id, n);
-    rt_ctx *ctx = new (std::nothrow) rt_ctx();
-    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "out of host memory");
-    ctx->device = device_id;
-    ctx->knobs = read_knobs();
-    hipDeviceProp_t prop;
-    hipError_t e = hipSetDevice(device_id);
-    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device_id);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_k0);
-    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_k1);
-    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_t0);
-    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_t1);
-    for (hipEvent_t &ev : ctx->ev_trav) if (e == hipSuccess) e = hipEventCreate(&ev);
-    for (hipEvent_t &ev : ctx->part_ev) if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-    for (hipStream_t &q : ctx->part_stream) if (e == hipSuccess) e = hipStreamCreateWithFlags(&q, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming);
-    if (e != hipSuccess) {
-        int code = fail(nullptr, RT_ERR_HIP, "context creation: %s", hipGetErrorString(e));
-        rt_ctx_destroy(ctx);
-        return code;
-    }
-    snprintf(ctx->name, sizeof(ctx->name), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
-    ctx->n_cus = prop.multiProcessorCount;
-    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
-        int code = fail(nullptr, RT_ERR_NO_DEVICE, "device %d is %s; this library contains gfx950 code only", device_id, prop.gcnArchName);
-        rt_ctx_destroy(ctx);
-        return code;
-    }
-    *out = ctx;
-    return RT_OK;
-}
-
-int rt_ctx_destroy(rt_ctx *ctx) {
-    if (!ctx) return RT_OK;
-    (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    ctx->node_lo.release(); ctx->node_hi.release(); ctx->nodes2.release(); ctx->nodesq.release(); ctx->q2thr.release(); ctx->left_dev.release(); ctx->lvl_nodes.release(); ctx->lvl_off.release(); ctx->nrm.release(); ctx->tri.release(); ctx->verts.release(); ctx->tidx.release();
-    ctx->scratch_rgba.release(); ctx->scratch_rgb8.release(); ctx->work.release(); ctx->queue.release();
-    ctx->wfM.release(); ctx->wfPR.release(); ctx->wfT.release(); ctx->wfLS.release(); ctx->wfSID.release();
-    ctx->wfQR.release(); ctx->accum.release(); ctx->dbgbuf.release();
-    ctx->pathSamp.release(); ctx->pathT.release();
-    for (hipEvent_t &e : ctx->ev_trav) if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t &e : ctx->part_ev) if (e) (void)hipEventDestroy(e);
-    for (hipStream_t &q : ctx->part_stream) if (q) (void)hipStreamDestroy(q);
-    if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
-    if (ctx->ev_k0) (void)hipEventDestroy(ctx->ev_k0);
-    if (ctx->ev_k1) (void)hipEventDestroy(ctx->ev_k1);
-    if (ctx->ev_t0) (void)hipEventDestroy(ctx->ev_t0);
-    if (ctx->ev_t1) (void)hipEventDestroy(ctx->ev_t1);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
-    delete ctx;
-    return RT_OK;
-}
-
-const char *rt_last_error(const rt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
-
-int rt_device_name(const rt_ctx *ctx, char *buf, size_t buflen) {
-    if (!ctx || !buf || buflen == 0) return fail(nullptr, RT_ERR_INVALID, "bad arguments");
-    snprintf(buf, buflen, "%s", ctx->name);
-    return RT_OK;
-}
-
-int rt_scene_upload(rt_ctx *ctx, const rt_sphere *spheres, int n_spheres, const rt_mesh *mesh,
-                    const rt_light *light, const rt_camera *camera) {
-    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
-    if (n_spheres < 0 || (n_spheres > 0 && !spheres)) return fail(ctx, RT_ERR_INVALID, "bad sphere array");
-    if (!light || !camera) return fail(ctx, RT_ERR_INVALID, "light/camera is NULL");
-    const int n_objects = n_spheres + (mesh ? 1 : 0);
-    if (n_spheres > RT_MAX_SPHERES || n_objects > 16)
-        return fail(ctx, RT_ERR_INVALID, "at most %d objects (reference: Geometry* objects[10])", 16);
-    rtk::Scene sc{};
-    for (int i = 0; i < n_spheres; ++i) {
-        const rt_sphere &s = spheres[i];
-        sc.sph[i] = {s.center[0], s.center[1], s.center[2], s.radius, s.albedo[0], s.albedo[1], s.albedo[2],
-                     s.mirror ? 1 : 0, s.in_refraction_index, s.out_refraction_index};
-    }
-    sc.n_spheres = n_spheres;
-    sc.n_objects = n_objects;
-    sc.mesh_slot = -1;
-    sc.Lx = light->position[0]; sc.Ly = light->position[1]; sc.Lz = light->position[2]; sc.intensity = light->intensity;
-    sc.camx = camera->position[0]; sc.camy = camera->position[1]; sc.camz = camera->position[2]; sc.fov = camera->fov;
-
+// The part of rt_scene_upload after validation of the sphere / light / camera arguments: layout conversion of the mesh (the
+// reference's arrays -> traversal-order nodes, visit-order triangle records, breadth-first sibling pairs, refit levels) and
+// the uploads.  `sc` carries the spheres, light and camera; rt_mesh_rebuild re-enters here with the tree it built on the device.
+int install_scene(rt_ctx *ctx, rtk::Scene sc, const rt_mesh *mesh) {
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->have_scene = false;
@@ -813,8 +717,8 @@ int rt_scene_upload(rt_ctx *ctx, const rt_sphere *spheres, int n_spheres, const 
     std::vector<int4> tidx;
     std::vector<int> left_of;
     if (mesh) {
-        if (mesh->object_slot < 0 || mesh->object_slot > n_spheres)
-            return fail(ctx, RT_ERR_INVALID, "mesh object_slot %d outside [0,%d]", mesh->object_slot, n_spheres);
+        if (mesh->object_slot < 0 || mesh->object_slot > sc.n_spheres)
+            return fail(ctx, RT_ERR_INVALID, "mesh object_slot %d outside [0,%d]", mesh->object_slot, sc.n_spheres);
         if (mesh->n_vertices < 0 || mesh->n_triangles < 0 || mesh->n_nodes < 0 || mesh->index_stride < 3)
             return fail(ctx, RT_ERR_INVALID, "bad mesh sizes");
         if ((mesh->n_vertices && !mesh->vertices) || (mesh->n_triangles && !mesh->indices) || (mesh->n_nodes && !mesh->bvh_arr10))
@@ -834,6 +738,15 @@ int rt_scene_upload(rt_ctx *ctx, const rt_sphere *spheres, int n_spheres, const 
         }
         const int n_int = (int)perm.size();
         ctx->tri_perm = perm;
+        ctx->up_indices.resize((size_t)mesh->n_triangles * 3);              // the mesh as uploaded (BVH order): rt_mesh_rebuild starts from it
+        std::vector<int4> tup(mesh->n_triangles);
+        for (int t = 0; t < mesh->n_triangles; ++t) {
+            const int32_t *ix = mesh->indices + (size_t)t * mesh->index_stride;
+            for (int k = 0; k < 3; ++k) ctx->up_indices[3 * (size_t)t + k] = ix[k];
+            tup[t] = make_int4(ix[0], ix[1], ix[2], 0);
+        }
+        ctx->n_up_tris = mesh->n_triangles;
+        if (int rcu = upload(ctx, ctx->tidx_up, tup.data(), tup.size() * sizeof(int4)); rcu != RT_OK) return rcu;
         tri.resize((size_t)n_int * 3);
         tidx.resize(n_int);
         for (int t = 0; t < n_int; ++t) {
@@ -916,6 +829,115 @@ int rt_scene_upload(rt_ctx *ctx, const rt_sphere *spheres, int n_spheres, const 
     ctx->scene = sc;
     ctx->have_scene = true;
     return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_abi_version(void) { return RT_ABI_VERSION; }
+
+int rt_device_count(int *count) {
+    if (!count) return fail(nullptr, RT_ERR_INVALID, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(nullptr, RT_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = n;
+    return RT_OK;
+}
+
+int rt_ctx_create(rt_ctx **out, int device_id) {
+    if (!out) return fail(nullptr, RT_ERR_INVALID, "ctx out-pointer is NULL");
+    *out = nullptr;
+    int n = 0;
+    int rc = rt_device_count(&n);
+    if (rc != RT_OK) return rc;
+    if (n == 0) return fail(nullptr, RT_ERR_NO_DEVICE, "no HIP device visible");
+    if (device_id < 0 || device_id >= n) return fail(nullptr, RT_ERR_INVALID, "device %d out of range [0,%d)", device_id, n);
+    rt_ctx *ctx = new (std::nothrow) rt_ctx();
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "out of host memory");
+    ctx->device = device_id;
+    ctx->knobs = read_knobs();
+    hipDeviceProp_t prop;
+    hipError_t e = hipSetDevice(device_id);
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device_id);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_k0);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_k1);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_t0);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_t1);
+    for (hipEvent_t &ev : ctx->ev_trav) if (e == hipSuccess) e = hipEventCreate(&ev);
+    for (hipEvent_t &ev : ctx->part_ev) if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    for (hipStream_t &q : ctx->part_stream) if (e == hipSuccess) e = hipStreamCreateWithFlags(&q, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        int code = fail(nullptr, RT_ERR_HIP, "context creation: %s", hipGetErrorString(e));
+        rt_ctx_destroy(ctx);
+        return code;
+    }
+    snprintf(ctx->name, sizeof(ctx->name), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    ctx->n_cus = prop.multiProcessorCount;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        int code = fail(nullptr, RT_ERR_NO_DEVICE, "device %d is %s; this library contains gfx950 code only", device_id, prop.gcnArchName);
+        rt_ctx_destroy(ctx);
+        return code;
+    }
+    *out = ctx;
+    return RT_OK;
+}
+
+int rt_ctx_destroy(rt_ctx *ctx) {
+    if (!ctx) return RT_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    ctx->node_lo.release(); ctx->node_hi.release(); ctx->nodes2.release(); ctx->nodesq.release(); ctx->q2thr.release(); ctx->left_dev.release(); ctx->lvl_nodes.release(); ctx->lvl_off.release(); ctx->nrm.release(); ctx->tri.release(); ctx->verts.release(); ctx->tidx.release();
+    ctx->scratch_rgba.release(); ctx->scratch_rgb8.release(); ctx->work.release(); ctx->queue.release();
+    ctx->wfM.release(); ctx->wfPR.release(); ctx->wfT.release(); ctx->wfLS.release(); ctx->wfSID.release();
+    ctx->wfQR.release(); ctx->accum.release(); ctx->dbgbuf.release();
+    ctx->pathSamp.release(); ctx->pathT.release(); ctx->tidx_up.release();
+    for (DevBuf *b : {&ctx->bb_idx, &ctx->bb_cnt, &ctx->bb_pa, &ctx->bb_pb, &ctx->bb_tmp, &ctx->bb_nodes_i, &ctx->bb_nodes_f, &ctx->bb_counter, &ctx->bb_lvl, &ctx->bb_size, &ctx->bb_pre, &ctx->bb_arr}) b->release();
+    for (hipEvent_t &e : ctx->ev_trav) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t &e : ctx->part_ev) if (e) (void)hipEventDestroy(e);
+    for (hipStream_t &q : ctx->part_stream) if (q) (void)hipStreamDestroy(q);
+    if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
+    if (ctx->ev_k0) (void)hipEventDestroy(ctx->ev_k0);
+    if (ctx->ev_k1) (void)hipEventDestroy(ctx->ev_k1);
+    if (ctx->ev_t0) (void)hipEventDestroy(ctx->ev_t0);
+    if (ctx->ev_t1) (void)hipEventDestroy(ctx->ev_t1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return RT_OK;
+}
+
+const char *rt_last_error(const rt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+int rt_device_name(const rt_ctx *ctx, char *buf, size_t buflen) {
+    if (!ctx || !buf || buflen == 0) return fail(nullptr, RT_ERR_INVALID, "bad arguments");
+    snprintf(buf, buflen, "%s", ctx->name);
+    return RT_OK;
+}
+
+int rt_scene_upload(rt_ctx *ctx, const rt_sphere *spheres, int n_spheres, const rt_mesh *mesh,
+                    const rt_light *light, const rt_camera *camera) {
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    if (n_spheres < 0 || (n_spheres > 0 && !spheres)) return fail(ctx, RT_ERR_INVALID, "bad sphere array");
+    if (!light || !camera) return fail(ctx, RT_ERR_INVALID, "light/camera is NULL");
+    const int n_objects = n_spheres + (mesh ? 1 : 0);
+    if (n_spheres > RT_MAX_SPHERES || n_objects > 16)
+        return fail(ctx, RT_ERR_INVALID, "at most %d objects (reference: Geometry* objects[10])", 16);
+    rtk::Scene sc{};
+    for (int i = 0; i < n_spheres; ++i) {
+        const rt_sphere &s = spheres[i];
+        sc.sph[i] = {s.center[0], s.center[1], s.center[2], s.radius, s.albedo[0], s.albedo[1], s.albedo[2],
+                     s.mirror ? 1 : 0, s.in_refraction_index, s.out_refraction_index};
+    }
+    sc.n_spheres = n_spheres;
+    sc.n_objects = n_objects;
+    sc.mesh_slot = -1;
+    sc.Lx = light->position[0]; sc.Ly = light->position[1]; sc.Lz = light->position[2]; sc.intensity = light->intensity;
+    sc.camx = camera->position[0]; sc.camy = camera->position[1]; sc.camz = camera->position[2]; sc.fov = camera->fov;
+
+    return install_scene(ctx, sc, mesh);
 }
 
 int rt_render_device(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *out_rgba_dev, void *stream) {
@@ -1045,6 +1067,101 @@ int rt_mesh_transform(rt_ctx *ctx, const float rotation[9], const float translat
     RT_HIP(ctx, hipMemcpyAsync(&root[1], ctx->node_hi.p, sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     sc.root_lo = root[0]; sc.root_hi = root[1];
+    return RT_OK;
+}
+
+int rt_mesh_rebuild(rt_ctx *ctx, float *bvh_arr10_out, int32_t *tri_order_out, int32_t *n_nodes_out) {
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    if (!ctx->have_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_scene_upload has not been called");
+    if (n_nodes_out) *n_nodes_out = 0;
+    const rtk::Scene old = ctx->scene;
+    const int nt = ctx->n_up_tris, nv = old.n_verts;
+    if (old.mesh_slot < 0 || nt <= 0 || nv <= 0) return RT_OK;                     // no mesh: nothing to build
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t cap = 2 * (size_t)nt + 2;                                          // nodes: every split makes two
+    int rc;
+    if ((rc = ensure(ctx, ctx->bb_idx, nt * sizeof(int))) != RT_OK || (rc = ensure(ctx, ctx->bb_cnt, nt * sizeof(int))) != RT_OK ||
+        (rc = ensure(ctx, ctx->bb_pa, nt * sizeof(int))) != RT_OK || (rc = ensure(ctx, ctx->bb_pb, nt * sizeof(int))) != RT_OK ||
+        (rc = ensure(ctx, ctx->bb_tmp, nt * sizeof(int))) != RT_OK || (rc = ensure(ctx, ctx->bb_nodes_i, 4 * cap * sizeof(int))) != RT_OK ||
+        (rc = ensure(ctx, ctx->bb_nodes_f, 2 * cap * sizeof(float4))) != RT_OK || (rc = ensure(ctx, ctx->bb_counter, sizeof(int))) != RT_OK ||
+        (rc = ensure(ctx, ctx->bb_lvl, (cap + 1) * sizeof(int))) != RT_OK || (rc = ensure(ctx, ctx->bb_size, cap * sizeof(int))) != RT_OK ||
+        (rc = ensure(ctx, ctx->bb_pre, cap * sizeof(int))) != RT_OK || (rc = ensure(ctx, ctx->bb_arr, cap * 10 * sizeof(float))) != RT_OK)
+        return rc;
+    rtk::BuildArgs a{};
+    a.verts = static_cast<const float4 *>(ctx->verts.p); a.tidx_up = static_cast<const int4 *>(ctx->tidx_up.p);
+    a.idx = static_cast<int *>(ctx->bb_idx.p); a.cnt = static_cast<int *>(ctx->bb_cnt.p);
+    a.ptr_a = static_cast<int *>(ctx->bb_pa.p); a.ptr_b = static_cast<int *>(ctx->bb_pb.p); a.tmp = static_cast<int *>(ctx->bb_tmp.p);
+    int *ni = static_cast<int *>(ctx->bb_nodes_i.p);
+    a.n_start = ni; a.n_end = ni + cap; a.n_left = ni + 2 * cap; a.n_right = ni + 3 * cap;
+    a.n_mn = static_cast<float4 *>(ctx->bb_nodes_f.p); a.n_mx = a.n_mn + cap;
+    a.counter = static_cast<int *>(ctx->bb_counter.p); a.n_tris = nt;
+    hipStream_t q = ctx->stream;
+    // root = node 0 over all triangles (buildBVH(&bvh, 0, T), cpu:684); the permutation starts as the identity
+    hipLaunchKernelGGL(rtk::iota_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, q, a.idx, nt);
+    const int root_range[2] = {0, nt}, one = 1;
+    RT_HIP(ctx, hipMemcpyAsync(a.n_start, &root_range[0], sizeof(int), hipMemcpyHostToDevice, q));
+    RT_HIP(ctx, hipMemcpyAsync(a.n_end, &root_range[1], sizeof(int), hipMemcpyHostToDevice, q));
+    RT_HIP(ctx, hipMemcpyAsync(a.counter, &one, sizeof(int), hipMemcpyHostToDevice, q));
+    RT_HIP(ctx, hipStreamSynchronize(q));                                           // the three sources above live on this stack frame
+    std::vector<int> lvl_first{0};
+    int first = 0, count = 1;
+    while (count > 0) {                                                             // one launch per level, one workgroup per node
+        hipLaunchKernelGGL(rtk::bvh_level_kernel, dim3((unsigned)count), dim3(rtk::kBuildThreads), 0, q, a, first);
+        RT_HIP(ctx, hipGetLastError());
+        int total = 0;
+        RT_HIP(ctx, hipMemcpyAsync(&total, a.counter, sizeof(int), hipMemcpyDeviceToHost, q));
+        RT_HIP(ctx, hipStreamSynchronize(q));
+        first += count;
+        lvl_first.push_back(first);
+        count = total - first;
+        if ((size_t)total > cap) return fail(ctx, RT_ERR_INTERNAL, "BVH build allocated %d nodes for %d triangles", total, nt);
+    }
+    const int n_nodes = first, n_levels = (int)lvl_first.size() - 1;
+    if (n_nodes >= (1 << 24)) return fail(ctx, RT_ERR_INVALID, "node indices are stored as floats: < 2^24 nodes");
+    RT_HIP(ctx, hipMemcpyAsync(ctx->bb_lvl.p, lvl_first.data(), lvl_first.size() * sizeof(int), hipMemcpyHostToDevice, q));
+    hipLaunchKernelGGL(rtk::bvh_flatten_kernel, dim3(1), dim3(1024), 0, q, a, static_cast<const int *>(ctx->bb_lvl.p), n_levels,
+                       static_cast<int *>(ctx->bb_size.p), static_cast<int *>(ctx->bb_pre.p), static_cast<float *>(ctx->bb_arr.p));
+    RT_HIP(ctx, hipGetLastError());
+    // The tree is built.  The O(n) re-layout for the kernels (traversal order, visit-order triangle records, sibling pairs, refit
+    // levels) reuses the upload path on the host: ~30 bytes per triangle over PCIe each way.
+    std::vector<float> arr((size_t)n_nodes * 10);
+    std::vector<int> order(nt);
+    std::vector<float4> hv(nv);
+    RT_HIP(ctx, hipMemcpyAsync(arr.data(), ctx->bb_arr.p, arr.size() * sizeof(float), hipMemcpyDeviceToHost, q));
+    RT_HIP(ctx, hipMemcpyAsync(order.data(), a.idx, order.size() * sizeof(int), hipMemcpyDeviceToHost, q));
+    RT_HIP(ctx, hipMemcpyAsync(hv.data(), ctx->verts.p, hv.size() * sizeof(float4), hipMemcpyDeviceToHost, q));
+    std::vector<float4> old_nrm;
+    if (old.nrm != nullptr) {
+        old_nrm.resize((size_t)old.n_tris * 3);
+        RT_HIP(ctx, hipMemcpyAsync(old_nrm.data(), ctx->nrm.p, old_nrm.size() * sizeof(float4), hipMemcpyDeviceToHost, q));
+    }
+    RT_HIP(ctx, hipStreamSynchronize(q));
+    std::vector<float> vx((size_t)nv * 3);
+    for (int i = 0; i < nv; ++i) { vx[3 * (size_t)i] = hv[i].x; vx[3 * (size_t)i + 1] = hv[i].y; vx[3 * (size_t)i + 2] = hv[i].z; }
+    std::vector<int32_t> ix((size_t)nt * 3);
+    for (int t = 0; t < nt; ++t) for (int k = 0; k < 3; ++k) ix[3 * (size_t)t + k] = ctx->up_indices[3 * (size_t)order[t] + k];
+    const std::vector<int> old_perm = ctx->tri_perm;                               // old visit order -> old uploaded order
+    rt_mesh m{};
+    m.vertices = vx.data(); m.n_vertices = nv; m.indices = ix.data(); m.index_stride = 3; m.n_triangles = nt;
+    m.bvh_arr10 = arr.data(); m.n_nodes = n_nodes;
+    m.albedo[0] = old.mar; m.albedo[1] = old.mag; m.albedo[2] = old.mab; m.object_slot = old.mesh_slot;
+    rtk::Scene sc = old;
+    sc.n_nodes = sc.n_tris = sc.n_verts = 0; sc.nrm = nullptr;
+    if ((rc = install_scene(ctx, sc, &m)) != RT_OK) return rc;
+    if (!old_nrm.empty()) {                                                        // smooth normals travel with their triangles
+        std::vector<int> old_visit_of(nt, -1);
+        for (size_t t = 0; t < old_perm.size(); ++t) old_visit_of[old_perm[t]] = (int)t;
+        std::vector<float4> nn(ctx->tri_perm.size() * 3);
+        for (size_t t = 0; t < ctx->tri_perm.size(); ++t) {
+            const int ov = old_visit_of[order[ctx->tri_perm[t]]];
+            for (int k = 0; k < 3; ++k) nn[3 * t + k] = ov >= 0 ? old_nrm[3 * (size_t)ov + k] : make_float4(0, 0, 0, 0);
+        }
+        if ((rc = upload(ctx, ctx->nrm, nn.data(), nn.size() * sizeof(float4))) != RT_OK) return rc;
+        ctx->scene.nrm = static_cast<const float4 *>(ctx->nrm.p);
+    }
+    if (bvh_arr10_out) memcpy(bvh_arr10_out, arr.data(), arr.size() * sizeof(float));
+    if (tri_order_out) memcpy(tri_order_out, order.data(), order.size() * sizeof(int));
+    if (n_nodes_out) *n_nodes_out = n_nodes;
     return RT_OK;
 }
 
