@@ -194,6 +194,11 @@ int rt_get_stats(rt_ctx *ctx, rt_stats *stats);        /* waits for the last ren
  *     rt_render_multi run as one DMA at the PCIe rate instead of being staged by the runtime. ------------------ */
 int rt_host_alloc(void **ptr, size_t bytes);
 int rt_host_free(void *ptr);
+/* device memory on the context's device for rt_render_device / rt_tonemap_device callers that have no HIP of their own
+ * (the C++ host API stays free of hip_runtime.h) */
+int rt_device_alloc(rt_ctx *ctx, void **ptr, size_t bytes);
+int rt_device_free(void *ptr);
+int rt_device_to_host(rt_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);   /* synchronous copy on the context's stream */
 
 /* --- known-answer entry points (test interface; same library, same device functions the render kernels inline).
  *     One lane per row.  Inputs/outputs use the layouts of tests/golden/kat.npz, which the reference's own functions
@@ -275,6 +280,9 @@ typedef struct rt_multi_stats {
     float    gather_ms;                   /* root: end of its own render -> frame assembled (waits for peers) */
     float    frame_ms;                    /* host wall clock of the whole call                                */
     uint64_t rays;                        /* rays traced for the frame (sum of the .w channel)                */
+    uint64_t gather_bytes;                /* bytes the peers moved into the root device for the last frame   */
+    int32_t  peer_access[RT_MAX_DEVICES]; /* 1: device k writes the root's memory directly (peer access over xGMI),
+                                             0: no peer path, the runtime stages the copy; -1: same device as the root */
 } rt_multi_stats;
 int rt_multi_create(rt_multi **m, const int *device_ids, int n_devices);
 int rt_multi_destroy(rt_multi *m);
@@ -284,6 +292,10 @@ int rt_multi_scene_upload(rt_multi *m, const rt_sphere *spheres, int n_spheres, 
 /* full frame, height*width float4, to host memory / to memory of the root device */
 int rt_render_multi(rt_multi *m, const rt_params *p, float *out_rgba_host);
 int rt_render_multi_device(rt_multi *m, const rt_params *p, void *out_rgba_dev_on_root);
+/* the PNG path: every device tonemaps its tiles (cpu:714-716) and the exchange moves the 8-bit image, 3 bytes per pixel
+ * instead of 16 (the reference copies its 8-bit image off the device too, optimized.cu:856); height*width*3 bytes, the
+ * bytes rt_render_rgb8 gives on one device */
+int rt_render_multi_rgb8(rt_multi *m, const rt_params *p, uint8_t *out_rgb8_host);
 int rt_multi_get_stats(rt_multi *m, rt_multi_stats *stats);
 
 #ifdef __cplusplus

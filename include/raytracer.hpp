@@ -396,6 +396,35 @@ public:
     rt_stats stats() { rt_stats st{}; check(rt_get_stats(ctx_, &st), "rt_get_stats"); return st; }
     rt_ctx *handle() { return ctx_; }
 
+    // One process per GPU: rank `rank` of `world` owns the 8-row tiles rank, rank + world, ... of the frame.
+    // tile_rows_of() lists the image rows of its dense tile buffer; render_tiles_rgb8() renders exactly those rows
+    // (rt_render_device with an interleaved rt_rows, tonemap on the device) and returns them as RGB8.  The exchange between
+    // the processes is the caller's (an RCCL gather over xGMI, MPI, files: INTEGRATION.md); assemble_tiles() is its inverse.
+    static std::vector<int> tile_rows_of(int H, int rank, int world, int tile_rows = RT_MULTI_TILE_ROWS) {
+        std::vector<int> rows;
+        for (int t = rank; t * tile_rows < H; t += world)
+            for (int r = t * tile_rows; r < std::min(H, (t + 1) * tile_rows); ++r) rows.push_back(r);
+        return rows;
+    }
+    std::vector<unsigned char> render_tiles_rgb8(const RenderSettings &s, int rank, int world, int tile_rows = RT_MULTI_TILE_ROWS) {
+        rt_params p = params(s);
+        const int n = (int)tile_rows_of(s.H, rank, world, tile_rows).size();
+        std::vector<unsigned char> img((size_t)n * s.W * 3);
+        if (n == 0) return img;
+        DeviceBuffer rgba(ctx_, (size_t)n * s.W * 16), rgb8(ctx_, (size_t)n * s.W * 3 + 16);
+        rt_rows rows{rank * tile_rows, n, tile_rows, world};
+        check(rt_render_device(ctx_, &p, &rows, rgba.p, nullptr), "rt_render_device");
+        check(rt_tonemap_device(ctx_, rgba.p, (int64_t)n * s.W, rgb8.p, nullptr), "rt_tonemap_device");
+        check(rt_synchronize(ctx_), "rt_synchronize");
+        check(rt_device_to_host(ctx_, img.data(), rgb8.p, img.size()), "rt_device_to_host");
+        return img;
+    }
+    static void assemble_tiles(std::vector<unsigned char> &frame, const std::vector<unsigned char> &tiles, int W, int H, int rank, int world,
+                               int tile_rows = RT_MULTI_TILE_ROWS) {
+        const std::vector<int> rows = tile_rows_of(H, rank, world, tile_rows);
+        for (size_t k = 0; k < rows.size(); ++k) std::copy(tiles.begin() + k * (size_t)W * 3, tiles.begin() + (k + 1) * (size_t)W * 3, frame.begin() + (size_t)rows[k] * W * 3);
+    }
+
     // --- the pieces of realtime_render.cu / global_launcher.cu behind the same boundary ---
     // transformMesh (global_launcher.cu:932-946) on the uploaded mesh, then triangle precompute + BVH refit on the device
     void transform_mesh(const float rotation[9], const Vector &translation) {
@@ -430,6 +459,13 @@ public:
     }
 
 private:
+    struct DeviceBuffer {                  // device memory through the C-ABI (no HIP above it)
+        void *p = nullptr;
+        DeviceBuffer(rt_ctx *c, size_t bytes) { if (rt_device_alloc(c, &p, bytes) != RT_OK) throw Error(RT_ERR_HIP, std::string("rt_device_alloc: ") + rt_last_error(c)); }
+        ~DeviceBuffer() { rt_device_free(p); }
+        DeviceBuffer(const DeviceBuffer &) = delete;
+        DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+    };
     void check(int rc, const char *what) { if (rc != RT_OK) throw Error(rc, std::string(what) + ": " + rt_last_error(ctx_)); }
     rt_ctx *ctx_ = nullptr;
 };
@@ -454,6 +490,13 @@ public:
         std::vector<float> fb((size_t)s.W * s.H * 4);
         check(rt_render_multi(m_, &p, fb.data()), "rt_render_multi");
         return fb;
+    }
+    // the PNG path: tonemap on every device, 8-bit tiles exchanged (what stbi_write_png gets, cpu:719)
+    std::vector<unsigned char> render_rgb8(const RenderSettings &s) {
+        rt_params p = Renderer::params(s);
+        std::vector<unsigned char> img((size_t)s.W * s.H * 3);
+        check(rt_render_multi_rgb8(m_, &p, img.data()), "rt_render_multi_rgb8");
+        return img;
     }
     rt_multi_stats stats() { rt_multi_stats st{}; check(rt_multi_get_stats(m_, &st), "rt_multi_get_stats"); return st; }
 private:

@@ -23,8 +23,8 @@ EXPORTS = ["rt_abi_version", "rt_device_count", "rt_ctx_create", "rt_ctx_destroy
            "rt_mesh_transform", "rt_mesh_set_normals", "rt_camera_basis", "rt_render_pose", "rt_render_pose_device", "rt_progressive_reset", "rt_progressive_frame",
            "rt_progressive_frames",
            "rt_multi_create", "rt_multi_destroy", "rt_multi_last_error", "rt_multi_scene_upload", "rt_render_multi",
-           "rt_render_multi_device", "rt_multi_get_stats",
-           "rt_mesh_rebuild", "rt_host_alloc", "rt_host_free", "rt_kat_sphere", "rt_kat_box", "rt_kat_triangle", "rt_kat_mesh"]
+           "rt_render_multi_device", "rt_render_multi_rgb8", "rt_multi_get_stats",
+           "rt_mesh_rebuild", "rt_host_alloc", "rt_host_free", "rt_device_alloc", "rt_device_free", "rt_device_to_host", "rt_kat_sphere", "rt_kat_box", "rt_kat_triangle", "rt_kat_mesh"]
 MAX_DEVICES = 16
 
 
@@ -93,7 +93,8 @@ def make_pose(position=(0.0, 0.0, 55.0), yaw=0.0, pitch=0.3, fov=None):
 
 class MultiStats(C.Structure):
     _fields_ = [("n_devices", C.c_int32), ("device_id", C.c_int32 * MAX_DEVICES), ("kernel_ms", C.c_float * MAX_DEVICES),
-                ("gather_ms", C.c_float), ("frame_ms", C.c_float), ("rays", C.c_uint64)]
+                ("gather_ms", C.c_float), ("frame_ms", C.c_float), ("rays", C.c_uint64), ("gather_bytes", C.c_uint64),
+                ("peer_access", C.c_int32 * MAX_DEVICES)]
 
 
 _lib = None
@@ -155,6 +156,7 @@ def load():
     L.rt_multi_scene_upload.argtypes = [vp, C.POINTER(Sphere), C.c_int, C.POINTER(Mesh), C.POINTER(Light), C.POINTER(Camera)]
     L.rt_render_multi.argtypes = [vp, C.POINTER(Params), C.POINTER(C.c_float)]
     L.rt_render_multi_device.argtypes = [vp, C.POINTER(Params), vp]
+    L.rt_render_multi_rgb8.argtypes = [vp, C.POINTER(Params), C.POINTER(C.c_uint8)]
     L.rt_multi_get_stats.argtypes = [vp, C.POINTER(MultiStats)]
     L.rt_mesh_rebuild.argtypes = [vp, fp3, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.rt_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
@@ -432,9 +434,16 @@ class MultiContext:
     def render_device(self, params, out_ptr):
         self._check(self._L.rt_render_multi_device(self._h, C.byref(params), C.c_void_p(out_ptr)))
 
+    def render_rgb8(self, params):
+        """Every device tonemaps its tiles; the exchange moves the 8-bit image (3 bytes per pixel)."""
+        out = np.empty((params.height, params.width, 3), np.uint8)
+        self._check(self._L.rt_render_multi_rgb8(self._h, C.byref(params), out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
+
     def stats(self):
         s = MultiStats()
         self._check(self._L.rt_multi_get_stats(self._h, C.byref(s)))
         n = s.n_devices
         return {"n_devices": n, "device_id": list(s.device_id)[:n], "kernel_ms": list(s.kernel_ms)[:n],
-                "gather_ms": s.gather_ms, "frame_ms": s.frame_ms, "rays": int(s.rays)}
+                "gather_ms": s.gather_ms, "frame_ms": s.frame_ms, "rays": int(s.rays), "gather_bytes": int(s.gather_bytes),
+                "peer_access": list(s.peer_access)[:n]}

@@ -5,10 +5,14 @@
 // optional flag after the two positionals:
 //   --program cpu|optimized   scene/constants of cpu_launcher.cpp (default) or optimized.cu
 //   --scene cat|spheres|demo10   --width W --height H --out FILE --obj FILE --device N --variant N
-//   --devices 0,1,2,...          several GPUs from this one process (interleaved row tiles, rt_render_multi)
+//   --devices 0,1,2,...          several GPUs from this one process (interleaved row tiles, rt_render_multi_rgb8)
+//   --tile-rank R --tile-world G --tiles FILE   one process per GPU: render only rank R's interleaved 8-row tiles and write
+//                                them (raw RGB8) to FILE; the processes' exchange is the caller's (RCCL / MPI / files)
+//   --assemble F0,F1,...         put the tile files of ranks 0..G-1 together and write the PNG (no GPU needed)
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <fstream>
 #include <iostream>
 #include <sstream>
 #include <string>
@@ -27,6 +31,9 @@ int main(int argc, char *argv[]) {
     std::string program = "cpu", scene_name = "cat", out, obj = "cadnav.com_model/Models_F0202A090/cat.obj";
     int W = 512, H = 512, device = 0, variant = RT_VARIANT_AUTO;
     std::vector<int> devices;
+    int tile_rank = -1, tile_world = 0;
+    std::string tiles_file;
+    std::vector<std::string> assemble;
     for (int i = 3; i + 1 < argc; i += 2) {
         const std::string k = argv[i], v = argv[i + 1];
         if (k == "--program") program = v;
@@ -37,11 +44,29 @@ int main(int argc, char *argv[]) {
         else if (k == "--obj") obj = v;
         else if (k == "--device") device = atoi(v.c_str());
         else if (k == "--variant") variant = atoi(v.c_str());
+        else if (k == "--tile-rank") tile_rank = atoi(v.c_str());
+        else if (k == "--tile-world") tile_world = atoi(v.c_str());
+        else if (k == "--tiles") tiles_file = v;
+        else if (k == "--assemble") { std::stringstream ss(v); std::string tok; while (std::getline(ss, tok, ',')) assemble.push_back(tok); }
         else if (k == "--devices") { std::stringstream ss(v); std::string tok; while (std::getline(ss, tok, ',')) devices.push_back(atoi(tok.c_str())); }
         else { std::cerr << "unknown option " << k << "\n"; return 2; }
     }
     const bool optimized = program == "optimized";
     if (out.empty()) out = optimized ? "image_optimized.png" : "image.png";   // opt:862 / cpu:719
+
+    if (!assemble.empty()) {                                           // the root of a process-per-GPU run: tiles -> frame -> PNG
+        std::vector<unsigned char> frame((size_t)W * H * 3);
+        const int G = (int)assemble.size();
+        for (int r = 0; r < G; ++r) {
+            std::ifstream f(assemble[r], std::ios::binary);
+            std::vector<unsigned char> tiles((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+            if (tiles.size() != Renderer::tile_rows_of(H, r, G).size() * (size_t)W * 3) { std::cerr << assemble[r] << ": wrong size for rank " << r << " of " << G << "\n"; return 1; }
+            Renderer::assemble_tiles(frame, tiles, W, H, r, G);
+        }
+        if (!write_png(out.c_str(), W, H, frame.data())) { std::cerr << "cannot write " << out << "\n"; return 1; }
+        return 0;
+    }
+    if (tile_rank >= 0 && (tile_world < 1 || tile_rank >= tile_world || tiles_file.empty())) { std::cerr << "--tile-rank needs --tile-world and --tiles\n"; return 2; }
 
     try {
         Scene s;
@@ -74,15 +99,23 @@ int main(int argc, char *argv[]) {
         if (!devices.empty()) {                                       // several GPUs, one process
             MultiRenderer renderer(devices);
             renderer.upload(s);
-            const std::vector<float> fb = renderer.render_float(rs);
-            image.resize((size_t)W * H * 3);
-            for (size_t px = 0; px < (size_t)W * H; ++px)
-                for (int k = 0; k < 3; ++k) image[3 * px + k] = (unsigned char)std::min(std::pow((double)fb[4 * px + k], 1. / 2.2), 255.);   // cpu:714-716
+            image = renderer.render_rgb8(rs);                          // tonemap (cpu:714-716) on every device, 8-bit tiles exchanged
             if (!write_png(out.c_str(), W, H, image.data())) { std::cerr << "cannot write " << out << "\n"; return 1; }
             const rt_multi_stats st = renderer.stats();
             std::chrono::duration<float> run_time = std::chrono::system_clock::now() - start_time;
             std::cout << "Rendering time: " << run_time.count() << " s\n";
-            std::cerr << st.n_devices << " devices, frame " << st.frame_ms << " ms, gather " << st.gather_ms << " ms, " << st.rays << " rays\n";
+            std::cerr << st.n_devices << " devices, frame " << st.frame_ms << " ms, gather " << st.gather_ms << " ms (" << st.gather_bytes << " bytes), " << st.rays << " rays\n";
+            return 0;
+        }
+        if (tile_rank >= 0) {                                         // one process per GPU: this rank's tiles only
+            Renderer renderer(device);
+            renderer.upload(s);
+            const std::vector<unsigned char> tiles = renderer.render_tiles_rgb8(rs, tile_rank, tile_world);
+            std::ofstream f(tiles_file, std::ios::binary);
+            f.write(reinterpret_cast<const char *>(tiles.data()), (std::streamsize)tiles.size());
+            if (!f) { std::cerr << "cannot write " << tiles_file << "\n"; return 1; }
+            std::chrono::duration<float> run_time = std::chrono::system_clock::now() - start_time;
+            std::cout << "Rendering time: " << run_time.count() << " s\n";
             return 0;
         }
         Renderer renderer(device);

@@ -1250,6 +1250,32 @@ int rt_host_free(void *ptr) {
     return RT_OK;
 }
 
+int rt_device_alloc(rt_ctx *ctx, void **ptr, size_t bytes) {
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    if (!ptr) return fail(ctx, RT_ERR_INVALID, "ptr is NULL");
+    *ptr = nullptr;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(ptr, bytes ? bytes : 16);
+    if (e != hipSuccess) { *ptr = nullptr; return fail(ctx, RT_ERR_HIP, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
+    return RT_OK;
+}
+
+int rt_device_free(void *ptr) {
+    if (!ptr) return RT_OK;
+    hipError_t e = hipFree(ptr);
+    if (e != hipSuccess) return fail(nullptr, RT_ERR_HIP, "hipFree: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_device_to_host(rt_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes) {
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    if (bytes && (!dst_host || !src_dev)) return fail(ctx, RT_ERR_INVALID, "bad copy arguments");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    if (bytes) RT_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
 int rt_synchronize(rt_ctx *ctx) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
     RT_HIP(ctx, hipSetDevice(ctx->device));

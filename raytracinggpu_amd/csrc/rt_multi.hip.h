@@ -30,12 +30,38 @@ __global__ __launch_bounds__(256) void deinterleave_kernel(const MultiSrc src, i
     if ((threadIdx.x & 63) == 0 && s) atomicAdd(rays, (unsigned long long)s);
 }
 
+// the same for the tonemapped image: out[row][x] (3 bytes) <- the dense RGB8 buffer of the device that rendered `row`.
+// One thread per 4 output bytes (W * 3 is a multiple of 4 whenever W is; the tail is copied bytewise).
+struct MultiSrc8 { const uint8_t *base[RT_MAX_DEVICES]; };
+__global__ __launch_bounds__(256) void deinterleave_rgb8_kernel(const MultiSrc8 src, int n_dev, int W, int H, int tile_rows, uint8_t *__restrict__ frame) {
+    const int64_t row_bytes = (int64_t)W * 3;
+    const int64_t words_per_row = (row_bytes + 3) / 4;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= words_per_row * H) return;
+    const int row = (int)(i / words_per_row);
+    const int64_t b0 = (i - (int64_t)row * words_per_row) * 4;
+    const int tile = row / tile_rows, k = tile % n_dev;
+    const int lrow = (tile / n_dev) * tile_rows + row % tile_rows;
+    const uint8_t *s = src.base[k] + (int64_t)lrow * row_bytes + b0;
+    uint8_t *d = frame + (int64_t)row * row_bytes + b0;
+    for (int j = 0; j < 4 && b0 + j < row_bytes; ++j) d[j] = s[j];
+}
+
+// rays traced by one device = sum of the .w channel of its tiles (small exact integers)
+__global__ __launch_bounds__(256) void sum_rays_kernel(const float4 *__restrict__ rgba, int64_t npix, unsigned long long *__restrict__ rays) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t s = wave_sum(i < npix ? (uint32_t)rgba[i].w : 0u);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(rays, (unsigned long long)s);
+}
+
 }  // namespace rtk
 
 struct rt_multi {
     int n = 0;
     rt_ctx *ctx[RT_MAX_DEVICES] = {};
     DevBuf local[RT_MAX_DEVICES];           // dense tiles of device k (on device k)
+    DevBuf local8[RT_MAX_DEVICES], rays_k[RT_MAX_DEVICES];   // RGB8 gather: tonemapped tiles and ray count of device k (on device k)
+    int peer_access[RT_MAX_DEVICES] = {};   // 1: device k writes into the root's memory directly (peer access), 0: staged by the runtime, -1: k is the root's device
     DevBuf stage, frame, rays;              // on the root device (device of ctx[0])
     hipEvent_t done[RT_MAX_DEVICES] = {};   // device k's tiles have arrived on the root
     hipEvent_t g0 = nullptr, g1 = nullptr;
@@ -61,7 +87,9 @@ int mfail(rt_multi *m, int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return mfail(m, RT_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
     } while (0)
 
-int multi_render(rt_multi *m, const rt_params *p, void *out_dev_on_root, float *out_host) {
+// rgb8: every device tonemaps its tiles (cpu:714-716) and the exchange moves 3 bytes per pixel instead of 16
+// (optimized.cu:856 copies the 8-bit image too); the float path stays for parity checks and ray counts per pixel.
+int multi_render(rt_multi *m, const rt_params *p, void *out_dev_on_root, void *out_host, bool rgb8 = false) {
     if (!m) return mfail(nullptr, RT_ERR_INVALID, "multi context is NULL");
     if (!p) return mfail(m, RT_ERR_INVALID, "params is NULL");
     if (p->width <= 0 || p->height <= 0) return mfail(m, RT_ERR_INVALID, "width/height must be positive");
@@ -73,12 +101,14 @@ int multi_render(rt_multi *m, const rt_params *p, void *out_dev_on_root, float *
     int nrows[RT_MAX_DEVICES] = {0};
     for (int k = 0; k < n; ++k) {
         for (int t = k; t < n_tiles; t += n) nrows[k] += std::min(R, H - t * R);
-        off[k + 1] = off[k] + (k == 0 ? 0 : (size_t)nrows[k] * W);          // device 0's tiles are read in place
+        off[k + 1] = off[k] + (k == 0 ? 0 : (size_t)nrows[k] * W);          // device 0's tiles are read in place (units: pixels)
     }
+    const size_t px_bytes = rgb8 ? 3 : sizeof(float4);
+    auto stage_off = [&](int k) { return (off[k] * px_bytes + 15) / 16 * 16 + 16 * (size_t)k; };   // 16-byte aligned pieces
     int rc;
     RT_MHIP(m, hipSetDevice(root->device));
-    const size_t frame_bytes = (size_t)W * H * sizeof(float4);
-    if ((rc = ensure(root, m->stage, off[n] * sizeof(float4))) != RT_OK || (rc = ensure(root, m->rays, 8)) != RT_OK ||
+    const size_t frame_bytes = (size_t)W * H * px_bytes;
+    if ((rc = ensure(root, m->stage, stage_off(n) + 16)) != RT_OK || (rc = ensure(root, m->rays, 8)) != RT_OK ||
         (!out_dev_on_root && (rc = ensure(root, m->frame, frame_bytes)) != RT_OK)) { m->err = root->err; return rc; }
     RT_MHIP(m, hipMemsetAsync(m->rays.p, 0, 8, root->stream));
     // 1. every device renders its tiles; peers push them to the root as soon as they are done.  A failure part-way
@@ -95,9 +125,22 @@ int multi_render(rt_multi *m, const rt_params *p, void *out_dev_on_root, float *
         if ((rc = ensure(c, m->local[k], std::max<size_t>((size_t)nrows[k] * W, 1) * sizeof(float4))) != RT_OK) { m->err = c->err; drain(k); return rc; }
         rt_rows rows{k * R, nrows[k], R, n};
         if ((rc = launch_render(c, p, &rows, m->local[k].p, c->stream)) != RT_OK) { m->err = c->err; drain(k + 1); return rc; }
+        const int64_t npix_k = (int64_t)nrows[k] * W;
+        const void *piece = m->local[k].p;
+        if (rgb8) {
+            if ((rc = ensure(c, m->local8[k], (size_t)std::max<int64_t>(npix_k, 1) * 3 + 16)) != RT_OK || (rc = ensure(c, m->rays_k[k], 8)) != RT_OK) { m->err = c->err; drain(k + 1); return rc; }
+            e = hipMemsetAsync(m->rays_k[k].p, 0, 8, c->stream);
+            if (e == hipSuccess && npix_k > 0) {
+                hipLaunchKernelGGL(rtk::sum_rays_kernel, dim3((unsigned)((npix_k + 255) / 256)), dim3(256), 0, c->stream,
+                                   static_cast<const float4 *>(m->local[k].p), npix_k, static_cast<unsigned long long *>(m->rays_k[k].p));
+                if ((rc = launch_tonemap(c, m->local[k].p, npix_k, m->local8[k].p, c->stream)) != RT_OK) { m->err = c->err; drain(k + 1); return rc; }
+            }
+            if (e != hipSuccess) { drain(k + 1); return mfail(m, RT_ERR_HIP, "tonemap of device %d: %s", c->device, hipGetErrorString(e)); }
+            piece = m->local8[k].p;
+        }
         if (k > 0) {
-            if (nrows[k] > 0) e = hipMemcpyPeerAsync(static_cast<float4 *>(m->stage.p) + off[k], root->device, m->local[k].p, c->device,
-                                                     (size_t)nrows[k] * W * sizeof(float4), c->stream);
+            if (nrows[k] > 0) e = hipMemcpyPeerAsync(static_cast<uint8_t *>(m->stage.p) + stage_off(k), root->device, piece, c->device,
+                                                     (size_t)npix_k * px_bytes, c->stream);
             if (e == hipSuccess) e = hipEventRecord(m->done[k], c->stream);
             if (e != hipSuccess) { drain(k + 1); return mfail(m, RT_ERR_HIP, "tile exchange of device %d: %s", c->device, hipGetErrorString(e)); }
         }
@@ -106,22 +149,42 @@ int multi_render(rt_multi *m, const rt_params *p, void *out_dev_on_root, float *
     RT_MHIP(m, hipSetDevice(root->device));
     RT_MHIP(m, hipEventRecord(m->g0, root->stream));
     for (int k = 1; k < n; ++k) RT_MHIP(m, hipStreamWaitEvent(root->stream, m->done[k], 0));
-    rtk::MultiSrc src{};
-    src.base[0] = static_cast<const float4 *>(m->local[0].p);
-    for (int k = 1; k < n; ++k) src.base[k] = static_cast<const float4 *>(m->stage.p) + off[k];
-    float4 *frame = static_cast<float4 *>(out_dev_on_root ? out_dev_on_root : m->frame.p);
+    void *frame = out_dev_on_root ? out_dev_on_root : m->frame.p;
     const int64_t npix = (int64_t)W * H;
-    hipLaunchKernelGGL(rtk::deinterleave_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, root->stream, src, n, W, H, R, frame,
-                       static_cast<unsigned long long *>(m->rays.p));
+    if (rgb8) {
+        rtk::MultiSrc8 src{};
+        src.base[0] = static_cast<const uint8_t *>(m->local8[0].p);
+        for (int k = 1; k < n; ++k) src.base[k] = static_cast<const uint8_t *>(m->stage.p) + stage_off(k);
+        const int64_t words = ((int64_t)W * 3 + 3) / 4 * H;
+        hipLaunchKernelGGL(rtk::deinterleave_rgb8_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, root->stream, src, n, W, H, R, static_cast<uint8_t *>(frame));
+    } else {
+        rtk::MultiSrc src{};
+        src.base[0] = static_cast<const float4 *>(m->local[0].p);
+        for (int k = 1; k < n; ++k) src.base[k] = reinterpret_cast<const float4 *>(static_cast<const uint8_t *>(m->stage.p) + stage_off(k));
+        hipLaunchKernelGGL(rtk::deinterleave_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, root->stream, src, n, W, H, R, static_cast<float4 *>(frame),
+                           static_cast<unsigned long long *>(m->rays.p));
+    }
     RT_MHIP(m, hipGetLastError());
     RT_MHIP(m, hipEventRecord(m->g1, root->stream));
     unsigned long long rays = 0;
-    RT_MHIP(m, hipMemcpyAsync(&rays, m->rays.p, 8, hipMemcpyDeviceToHost, root->stream));
+    if (!rgb8) RT_MHIP(m, hipMemcpyAsync(&rays, m->rays.p, 8, hipMemcpyDeviceToHost, root->stream));
     if (out_host) RT_MHIP(m, hipMemcpyAsync(out_host, frame, frame_bytes, hipMemcpyDeviceToHost, root->stream));
     RT_MHIP(m, hipStreamSynchronize(root->stream));
+    if (rgb8) {                                                       // every device counted its own rays; their streams are drained by now or here
+        for (int k = 0; k < n; ++k) {
+            unsigned long long rk = 0;
+            RT_MHIP(m, hipSetDevice(m->ctx[k]->device));
+            RT_MHIP(m, hipMemcpyAsync(&rk, m->rays_k[k].p, 8, hipMemcpyDeviceToHost, m->ctx[k]->stream));
+            RT_MHIP(m, hipStreamSynchronize(m->ctx[k]->stream));
+            rays += rk;
+        }
+        RT_MHIP(m, hipSetDevice(root->device));
+    }
     // 3. statistics
     m->stats.n_devices = n;
     m->stats.rays = rays;
+    m->stats.gather_bytes = (uint64_t)(off[n] * px_bytes);            // bytes the peers moved into the root device
+    for (int k = 0; k < n; ++k) m->stats.peer_access[k] = m->peer_access[k];
     RT_MHIP(m, hipEventElapsedTime(&m->stats.gather_ms, m->g0, m->g1));
     for (int k = 0; k < n; ++k) {
         rt_stats s{};
@@ -149,17 +212,21 @@ int rt_multi_create(rt_multi **out, const int *device_ids, int n_devices) {
         const int rc = rt_ctx_create(&m->ctx[k], device_ids[k]);
         if (rc != RT_OK) { rt_multi_destroy(m); return rc; }
     }
+    m->peer_access[0] = -1;                                               // the root itself
     hipError_t e = hipSetDevice(m->ctx[0]->device);
     if (e == hipSuccess) e = hipEventCreate(&m->g0);
     if (e == hipSuccess) e = hipEventCreate(&m->g1);
     for (int k = 1; k < n_devices && e == hipSuccess; ++k) {
         e = hipSetDevice(m->ctx[k]->device);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&m->done[k], hipEventDisableTiming);
+        m->peer_access[k] = -1;                                                            // same device as the root: a local copy
         if (e == hipSuccess && m->ctx[k]->device != m->ctx[0]->device) {
             int can = 0;
+            m->peer_access[k] = 0;                                                         // reported in rt_multi_stats: the copy is then staged by the runtime
             if (hipDeviceCanAccessPeer(&can, m->ctx[k]->device, m->ctx[0]->device) == hipSuccess && can) {
                 const hipError_t pe = hipDeviceEnablePeerAccess(m->ctx[0]->device, 0);   // direct xGMI writes into the root's staging area
-                if (pe != hipSuccess) (void)hipGetLastError();                             // already enabled: fine
+                if (pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled) m->peer_access[k] = 1;
+                if (pe != hipSuccess) (void)hipGetLastError();
             }
         }
     }
@@ -181,7 +248,7 @@ int rt_multi_destroy(rt_multi *m) {
         if (!m->ctx[k]) continue;
         (void)hipSetDevice(m->ctx[k]->device);
         if (m->ctx[k]->stream) (void)hipStreamSynchronize(m->ctx[k]->stream);
-        m->local[k].release();
+        m->local[k].release(); m->local8[k].release(); m->rays_k[k].release();
         if (m->done[k]) (void)hipEventDestroy(m->done[k]);
         rt_ctx_destroy(m->ctx[k]);
     }
@@ -204,6 +271,11 @@ int rt_multi_scene_upload(rt_multi *m, const rt_sphere *spheres, int n_spheres, 
 int rt_render_multi(rt_multi *m, const rt_params *p, float *out_rgba_host) {
     if (m && !out_rgba_host) return mfail(m, RT_ERR_INVALID, "output pointer is NULL");
     return multi_render(m, p, nullptr, out_rgba_host);
+}
+
+int rt_render_multi_rgb8(rt_multi *m, const rt_params *p, uint8_t *out_rgb8_host) {
+    if (m && !out_rgb8_host) return mfail(m, RT_ERR_INVALID, "output pointer is NULL");
+    return multi_render(m, p, nullptr, out_rgb8_host, true);
 }
 
 int rt_render_multi_device(rt_multi *m, const rt_params *p, void *out_rgba_dev_on_root) {

@@ -165,10 +165,21 @@ def test_launcher_cli_reproduces_reference_png(tmp_path, cat_golden):
     assert r.returncode == 0, r.stderr
     assert r.stdout.startswith("Rendering time: ") and r.stdout.rstrip().endswith(" s")
     np.testing.assert_array_equal(np.array(Image.open(tmp_path / "image.png").convert("RGB")), g["cat"])
-    # the same through rt_render_multi (three contexts on the one GPU, host-side tonemap as cpu:714-716)
+    # the same through rt_render_multi_rgb8 (three contexts on the one GPU, tonemapped tiles exchanged)
     r = subprocess.run([launcher, "1", "0", "--devices", "0,0,0", "--out", "multi.png"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert r.returncode == 0, r.stderr
     np.testing.assert_array_equal(np.array(Image.open(tmp_path / "multi.png").convert("RGB")), g["cat"])
+    # one process per GPU from C++: three launcher processes render their interleaved tiles (here on the one GPU),
+    # a fourth assembles the PNG without touching a GPU: the reference's bytes again
+    files = []
+    for r in range(3):
+        fn = str(tmp_path / f"tiles{r}.rgb")
+        q = subprocess.run([launcher, "1", "0", "--tile-rank", str(r), "--tile-world", "3", "--tiles", fn], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert q.returncode == 0, q.stderr
+        files.append(fn)
+    q = subprocess.run([launcher, "1", "0", "--assemble", ",".join(files), "--out", "ranks.png"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert q.returncode == 0, q.stderr
+    np.testing.assert_array_equal(np.array(Image.open(tmp_path / "ranks.png").convert("RGB")), g["cat"])
     # no OBJ in the working directory: "Error opening file!" and the spheres-only image (cpu:322-325)
     e = tmp_path / "empty"
     e.mkdir()

@@ -130,3 +130,32 @@ def test_single_process_multi_device_frame_is_bitwise_the_single_device_frame():
     with pytest.raises(rt.RtError):
         rt.MultiContext([0, 99])
     one.close()
+
+
+@pytest.mark.gpu
+def test_multi_device_rgb8_gather_equals_single_device_png_bytes():
+    """rt_render_multi_rgb8: every device tonemaps its tiles and the exchange moves the 8-bit image (3 bytes per pixel instead
+    of 16).  The assembled bytes equal rt_render_rgb8's on one device -- at 400x250 and, with eight contexts, at 7680x4320
+    (BASELINE config 5) -- and the statistics report the gathered bytes and the peer paths."""
+    import raytracinggpu_amd as rt
+    from tests.conftest import load_golden
+    g = load_golden("cat_mesh.npz")
+    mesh = dict(vertices=g["vertices"], indices=g["tri_bvh_order"], bvh_arr10=g["bvh_arr10"], albedo=rt.scenes.CAT_ALBEDO, object_slot=6)
+    one = rt.Context(0)
+    one.scene_upload(rt.scenes.spheres("cpu"), mesh)
+    for world, W, H in ((3, 400, 250), (8, 7680, 4320), (2, 333, 77)):
+        p = rt.make_params(W, H, 1, 1, **rt.scenes.CPU_LAUNCHER)
+        exp = one.render_rgb8(p)
+        m = rt.MultiContext([0] * world)
+        m.scene_upload(rt.scenes.spheres("cpu"), mesh)
+        got = m.render_rgb8(p)
+        np.testing.assert_array_equal(got, exp)
+        st = m.stats()
+        f32 = m.render(p)
+        assert st["rays"] == int(f32[..., 3].astype(np.float64).sum())
+        rows0 = len(rt.interleaved_rows(H, 8, 0, world)[1])
+        assert st["gather_bytes"] == (H - rows0) * W * 3                  # everything but the root's own tiles, 3 bytes per pixel
+        assert m.stats()["gather_bytes"] == (H - rows0) * W * 16          # the float4 exchange moves 16
+        assert st["peer_access"] == [-1] * world                          # all contexts on the one GPU of the test box
+        m.close()
+    one.close()
