@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--bounces", type=int, default=3)
     ap.add_argument("--scene", default="cpu", choices=["cpu", "spheres", "demo10"])
     ap.add_argument("--variant", default="auto")
+    ap.add_argument("--gather", default="f32", choices=["f32", "rgb8"],
+                    help="N > 1: what rank 0 gathers -- the float4 tiles (parity path, default) or the tonemapped RGB8 tiles (PNG path, 3 B/pixel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     return ap.parse_args()
@@ -248,7 +250,9 @@ def main():
     p = rt.make_params(W, H, args.spp, args.bounces, variant=args.variant, **rt.scenes.CPU_LAUNCHER)
     rows, idx = rt.interleaved_rows(H, TILE_ROWS, rank, world)
     local = tiling.local_buffer(H, W, world, dev)
-    gathered = tiling.gather_buffer(local, world) if (world > 1 and rank == 0) else None
+    rgb8 = args.gather == "rgb8" and world > 1
+    local8 = tiling.local_buffer(H, W, world, dev, rgb8=True) if rgb8 else None
+    gathered = tiling.gather_buffer(local8 if rgb8 else local, world) if (world > 1 and rank == 0) else None
     frame = None
     # a non-default torch stream: its handle is non-NULL (NULL means "the context's own stream" in the C-ABI),
     # so the render kernel, torch's timing events and the RCCL gather are all ordered on ONE stream
@@ -257,10 +261,16 @@ def main():
     stream = side.cuda_stream
     assert stream != 0
 
+    def exchange():
+        if rgb8:                                                      # tonemap this rank's tiles (cpu:714-716), gather 3 bytes per pixel
+            ctx.tonemap_device(local.data_ptr(), rows.n_rows * W, local8.data_ptr(), stream)
+            return tiling.gather_frame(local8, H, world, rank, gathered)
+        return tiling.gather_frame(local, H, world, rank, gathered)
+
     def step():
         nonlocal frame
         ctx.render_device(p, rows, local.data_ptr(), stream)
-        frame = tiling.gather_frame(local, H, world, rank, gathered)
+        frame = exchange()
 
     # exact ray count of one frame (deterministic; outside the timed region)
     step()
@@ -283,7 +293,7 @@ def main():
         ev[k][0].record()
         ctx.render_device(p, rows, local.data_ptr(), stream)
         ev[k][1].record()
-        frame = tiling.gather_frame(local, H, world, rank, gathered)
+        frame = exchange()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -304,7 +314,7 @@ def main():
                "config": {"workload": workload, "scene": "cpu_launcher.cpp walls + cat.obj (3954 tris, 2019-node array BVH)",
                           "num_rays": args.spp, "num_bounce": args.bounces, "depth_convention": "cpu_launcher (b+1 segments)",
                           "rays_per_frame": rays_per_frame, "tiling": f"{TILE_ROWS}-row tiles interleaved over {world} rank(s)"
-                          + (", RCCL gather to rank 0 per frame" if world > 1 else ""),
+                          + (f", RCCL gather of the {'RGB8' if rgb8 else 'float4'} tiles to rank 0 per frame" if world > 1 else ""),
                           "variant": ctx.stats()["variant"], "device": ctx.device_name,
                           "primary_Msamples_per_s": round(W * H * args.spp / (elapsed / args.steps) / 1e6, 1)}}
         if world == 1:

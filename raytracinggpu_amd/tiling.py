@@ -17,9 +17,14 @@ def tiles_per_rank(height, world, tile_rows=TILE_ROWS):
     return (n_tiles + world - 1) // world
 
 
-def local_buffer(height, width, world, device, tile_rows=TILE_ROWS):
-    """Dense per-rank buffer [tiles_local * tile_rows, W, 4] (zero-filled so padding tiles are defined)."""
-    return torch.zeros((tiles_per_rank(height, world, tile_rows) * tile_rows, width, 4), dtype=torch.float32, device=device)
+def local_buffer(height, width, world, device, tile_rows=TILE_ROWS, rgb8=False):
+    """Dense per-rank buffer [tiles_local * tile_rows, W, 4] float32 (zero-filled so padding tiles are defined); rgb8: the
+    tonemapped twin [.., W, 3] uint8 (float tiles for the parity check, 8-bit tiles -- 3 bytes per pixel instead of
+    16 -- for the PNG path)."""
+    rows = tiles_per_rank(height, world, tile_rows) * tile_rows
+    if rgb8:
+        return torch.zeros((rows, width, 3), dtype=torch.uint8, device=device)
+    return torch.zeros((rows, width, 4), dtype=torch.float32, device=device)
 
 
 def assemble(stacked, height, tile_rows=TILE_ROWS):

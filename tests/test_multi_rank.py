@@ -72,6 +72,37 @@ def test_gathered_tiles_equal_full_frame_gloo_cpu(oracle, oracle_cat, tmp_path, 
     np.testing.assert_array_equal(got.view(np.uint32), exp.view(np.uint32))
 
 
+def _worker_rgb8(rank, world, port, W, H, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import raytracinggpu_amd as rt
+    from raytracinggpu_amd import tiling
+    from oracle import oracle_py as orc
+    g = np.load(rt.scenes.CAT_FIXTURE, allow_pickle=False)
+    rows, idx = rt.interleaved_rows(H, tiling.TILE_ROWS, rank, world)
+    local8 = tiling.local_buffer(H, W, world, "cpu", rgb8=True)
+    mesh = orc.Mesh.from_arrays(g["vertices"], g["tri_obj_order"]).build_bvh()
+    if rows.n_rows:
+        _, part8, _ = orc.Scene.preset("cpu", mesh).render(W, H, 1, 0, rows=(rank * tiling.TILE_ROWS, H), tile_rows=tiling.TILE_ROWS, tile_step=world, threads=2)
+        local8[:rows.n_rows] = torch.from_numpy(part8)
+    frame = tiling.gather_frame(local8, H, world, rank)
+    if rank == 0:
+        np.save(out_path, frame.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rgb8_gather_equals_full_image_gloo_cpu(oracle, oracle_cat, tmp_path):
+    """The 8-bit exchange of bench.py --gather rgb8 (3 bytes per pixel): gathered tiles == the full tonemapped image."""
+    W, H = 96, 50
+    out = str(tmp_path / "frame8.npy")
+    mp.spawn(_worker_rgb8, args=(2, _free_port(), W, H, out), nprocs=2, join=True)
+    _, exp8, _ = oracle.Scene.preset("cpu", oracle_cat).render(W, H, 1, 0)
+    np.testing.assert_array_equal(np.load(out), exp8)
+
+
 def test_assemble_is_the_inverse_of_the_partition():
     from raytracinggpu_amd import tiling
     import raytracinggpu_amd as rt
