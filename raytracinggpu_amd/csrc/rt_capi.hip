@@ -37,7 +37,7 @@ struct Knobs {
     int travq_R = 64;          // RT_TRAVQ_R: ray slots per wave of the work-stack kernel (32 | 64)
     int travq_cap = 0;         // RT_TRAVQ_CAP: stack capacity (>= 128; tests force the serial drain); 0 = the carve's capacity
     int travq_lds = 0;         // RT_TRAVQ_LDS: waves of the ONE workgroup per CU that stages the top of the BVH in LDS; 0 = nodes through L1/L2
-    int q_low = 96;            // RT_TRAVQ_LOW: refill while the stack holds fewer sibling pairs than this
+    int q_low = 64;            // RT_TRAVQ_LOW: refill while the stack holds fewer sibling pairs than this (measured: 64 beats 96 by 3 % since the uniform kernel went on its byte diet)
     int q_minfree = 0;         // RT_TRAVQ_MINFREE: ... and at least this many slots are free (0 = R / 4)
     int parts = 2;             // RT_PARTS: concurrent sub-frames of the wavefront pipeline
     int bpc5 = 0;              // RT_TRAVQ_BPC5: allow a fifth workgroup per CU

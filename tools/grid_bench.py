@@ -1,5 +1,5 @@
 """GPU box: SURVEY 8d measurement table -- BASELINE configs 2..5 on one GPU and the benchmark.py grid subset
-(spp in {1,8,64} x num_bounce in {1,3,5}) on the cat at 1920x1080.  Kernel time from HIP events (rt_get_stats), median of
+(num_rays in 1..256 x num_bounce in 1..10, the whole sweep of the reference's benchmark.py) on the cat at 512x512 and 1920x1080.  Kernel time from HIP events (rt_get_stats), median of
 `reps` frames after a warm-up; rays counted exactly (framebuffer .w).  Prints a markdown table."""
 import os, sys, statistics, json
 import numpy as np
@@ -40,15 +40,22 @@ for name, sc, W, H, spp, b in rows_:
     m, r = run(sc, W, H, spp, b)
     print(f"| {name} | {W}x{H} | {spp} | {b} | {m:.3f} | {r:,.0f} |", flush=True)
     out.append(dict(name=name, W=W, H=H, spp=spp, b=b, ms=m, mrays=r))
-m, r = run("cpu", 3840, 2160, 1, 3, variant="wavefront_lds")
-print(f"| config 4, every BVH node staged in LDS (variant wavefront_lds) | 3840x2160 | 1 | 3 | {m:.3f} | {r:,.0f} |", flush=True)
-out.append(dict(name="config4_wavefront_lds", ms=m, mrays=r))
-print("\n| cat 1920x1080 | b=1 | b=3 | b=5 |\n|---|---|---|---|")
-for spp in (1, 8, 64):
-    cells = []
-    for b in (1, 3, 5):
-        m, r = run("cpu", 1920, 1080, spp, b, reps=3 if spp == 64 else 5)
-        cells.append(f"{m:.2f} ms, {r:,.0f} Mrays/s")
-        out.append(dict(name="grid", spp=spp, b=b, ms=m, mrays=r))
-    print(f"| spp={spp} | " + " | ".join(cells) + " |", flush=True)
+for variant, what in (("lds_verts", "vertex array staged in LDS (optimized_vertices-in-shared.cu:681-686)"), ("lds_top", "top of the BVH staged in LDS"),
+                      ("lds_all", "vertices + top of the BVH staged in LDS"), ("wavefront_lds", "per-lane walk, every node staged in LDS"),
+                      ("path", "one persistent launch (wf_path)")):
+    m, r = run("cpu", 3840, 2160, 1, 3, variant=variant)
+    print(f"| config 4, variant {variant}: {what} | 3840x2160 | 1 | 3 | {m:.3f} | {r:,.0f} |", flush=True)
+    out.append(dict(name="config4_" + variant, ms=m, mrays=r))
+# benchmark.py's sweep (/root/reference/benchmark.py:10-33): num_rays in 1, 2, 4 .. 256 (rows) x num_bounce in 1 .. 10 (columns); the
+# reference times its whole 512x512 program, here: kernel ms per frame, at the reference's own size and at the BASELINE size
+for W, H in ((512, 512), (1920, 1080)):
+    print(f"\ncat {W}x{H}: ms per frame, rows = num_rays, columns = num_bounce 1..10\n")
+    print("| num_rays | " + " | ".join(str(b) for b in range(1, 11)) + " |\n|---|" + "---|" * 10)
+    for spp in (1, 2, 4, 8, 16, 32, 64, 128, 256):
+        cells = []
+        for b in range(1, 11):
+            m, r = run("cpu", W, H, spp, b, reps=5 if spp <= 4 else 3 if spp <= 32 else 1)
+            cells.append(f"{m:.2f}")
+            out.append(dict(name="grid", W=W, H=H, spp=spp, b=b, ms=m, mrays=r))
+        print(f"| {spp} | " + " | ".join(cells) + " |", flush=True)
 json.dump(out, open("gpurun_out/grid_bench.json", "w"), indent=1)
