@@ -37,7 +37,7 @@ struct Knobs {
     int travq_R = 64;          // RT_TRAVQ_R: ray slots per wave of the work-stack kernel (32 | 64)
     int travq_cap = 0;         // RT_TRAVQ_CAP: stack capacity (>= 128; tests force the serial drain); 0 = the carve's capacity
     int travq_lds = 0;         // RT_TRAVQ_LDS: waves of the ONE workgroup per CU that stages the top of the BVH in LDS; 0 = nodes through L1/L2
-    int q_low = 64;            // RT_TRAVQ_LOW: refill while the stack holds fewer sibling pairs than this (measured: 64 beats 96 by 3 % since the uniform kernel went on its byte diet)
+    int q_low = 48;            // RT_TRAVQ_LOW: refill while the stack holds fewer sibling pairs than this (measured 1.19 / 1.21 / 1.25 ms per frame for 48 / 64 / 96)
     int q_minfree = 0;         // RT_TRAVQ_MINFREE: ... and at least this many slots are free (0 = R / 4)
     int parts = 2;             // RT_PARTS: concurrent sub-frames of the wavefront pipeline
     int bpc5 = 0;              // RT_TRAVQ_BPC5: allow a fifth workgroup per CU
@@ -929,7 +929,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_sphere *spheres, int n_spheres, const 
     for (int i = 0; i < n_spheres; ++i) {
         const rt_sphere &s = spheres[i];
         sc.sph[i] = {s.center[0], s.center[1], s.center[2], s.radius, s.albedo[0], s.albedo[1], s.albedo[2],
-                     s.mirror ? 1 : 0, s.in_refraction_index, s.out_refraction_index};
+                     s.mirror ? 1 : 0, s.in_refraction_index, s.out_refraction_index, s.radius * s.radius};   // R * R: one binary32 product (-ffp-contract=off), as cpu:513
     }
     sc.n_spheres = n_spheres;
     sc.n_objects = n_objects;

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void kat_sphere_kernel(const float *__restrict
     if (i >= n) return;
     const float *r = in + 10 * (size_t)i;
     Sphere s{};
-    s.cx = r[0]; s.cy = r[1]; s.cz = r[2]; s.R = r[3];
+    s.cx = r[0]; s.cy = r[1]; s.cz = r[2]; s.R = r[3]; s.R2 = r[3] * r[3];
     const f3 O = mk(r[4], r[5], r[6]), u = mk(r[7], r[8], r[9]);
     float t = 0.f;
     const bool hit = sphere_test(s, O, u, t);

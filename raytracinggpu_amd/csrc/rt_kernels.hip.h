@@ -35,6 +35,7 @@ struct Sphere {           // rt_sphere, cpu:505-511
     float ar, ag, ab;
     int mirror;
     float n_in, n_out;
+    float R2;             // R * R as the reference evaluates it in cpu:513 (one binary32 product), computed once by rt_scene_upload
 };
 
 struct Scene {
@@ -176,20 +177,33 @@ __device__ __forceinline__ bool slab_filtered(float4 lo, float4 hi, f3 O, f3 u, 
     return slab_filtered(lo, hi, O, u, r, decided);
 }
 
-// Sphere::intersect, cpu:512-527 (the normal, cpu:524-525, is evaluated by the caller for the winning object only)
-__device__ __forceinline__ bool sphere_test(const Sphere &s, f3 O, f3 u, float &t) {
-    const f3 C = mk(s.cx, s.cy, s.cz);
-    const f3 OC = O - C;
-    const float d = dot(u, OC);
-    const float delta = d * d - (norm2(OC) - s.R * s.R);       // cpu:513
+// Sphere::intersect, cpu:512-527 (the normal, cpu:524-525, is evaluated by the caller for the winning object only), in two
+// parts: what depends on the ray's origin only -- shared by the shadow ray and the bounce ray that leave one hit point -- and
+// the rest.  cpu:516-517 evaluate dot(u, C - O) next to dot(u, O - C) = d: every difference, product and sum of the one is the
+// exact negation of the other's (round-to-nearest is symmetric), so b = -d bit for bit -- except for the SIGN of a zero result
+// (x - x is +0 either way round), which can only reach b when d == 0: then, and only then, b is evaluated literally.
+struct SphereOrigin { f3 OC; float c; };
+__device__ __forceinline__ SphereOrigin sphere_origin(const Sphere &s, f3 O) {
+    SphereOrigin so;
+    so.OC = O - mk(s.cx, s.cy, s.cz);
+    so.c = norm2(so.OC) - s.R2;                                // cpu:513: (O - C).norm2() - R * R
+    return so;
+}
+__device__ __forceinline__ bool sphere_dir(const Sphere &s, const SphereOrigin &so, f3 O, f3 u, float &t) {
+    const float d = dot(u, so.OC);
+    const float delta = d * d - so.c;                          // cpu:513
     if (delta < 0) return false;
     const float sq = rt_sqrtf(delta);
-    const float b = dot(u, C - O);
+    float b = -d;
+    if (__builtin_expect(__ballot(d == 0.f) != 0ull, 0)) {     // wave-uniform: the literal dot product only where a zero's sign could differ
+        if (d == 0.f) b = dot(u, mk(s.cx, s.cy, s.cz) - O);
+    }
     const float t1 = b - sq, t2 = b + sq;                      // cpu:516-517
     if (t2 < 0) return false;
     t = t1 < 0 ? t2 : t1;
     return true;
 }
+__device__ __forceinline__ bool sphere_test(const Sphere &s, f3 O, f3 u, float &t) { return sphere_dir(s, sphere_origin(s, O), O, u, t); }
 
 // TriangleMesh::intersect, cpu:277-311.  Returns true iff some triangle was accepted
 // (SURVEY H4); t/Nraw are the nearest accepted t and its unnormalised e1 x e2.

@@ -91,6 +91,24 @@ __device__ __forceinline__ SphereHit spheres_split(const Scene &sc, f3 O, f3 u) 
     }
     return h;
 }
+// the same for the two rays that leave one point (origins equal bit for bit): the origin part of every sphere test is shared
+__device__ __forceinline__ void spheres_split2(const Scene &sc, f3 O, f3 uy, bool on_y, f3 ux, bool on_x, SphereHit &hy, SphereHit &hx) {
+    hy.tA = 1e9f; hy.winA = -1; hy.tB = 1e9f; hy.winB = -1;
+    hx = hy;
+    const int nb = sc.mesh_slot < 0 ? sc.n_spheres : sc.mesh_slot;
+    for (int k = 0; k < sc.n_spheres; ++k) {
+        const SphereOrigin so = sphere_origin(sc.sph[k], O);
+        float t;
+        if (on_y && sphere_dir(sc.sph[k], so, O, uy, t)) {
+            if (k < nb) { if (t < hy.tA) { hy.tA = t; hy.winA = k; } }
+            else        { if (t < hy.tB) { hy.tB = t; hy.winB = k + 1; } }
+        }
+        if (on_x && sphere_dir(sc.sph[k], so, O, ux, t)) {
+            if (k < nb) { if (t < hx.tA) { hx.tA = t; hx.winA = k; } }
+            else        { if (t < hx.tB) { hx.tB = t; hx.winB = k + 1; } }
+        }
+    }
+}
 __device__ __forceinline__ int wf_pack_wins_path(const SphereHit &h) { return ((h.winA + 1) & 31) << PF_WINS_SHIFT | ((h.winB + 1) & 31) << (PF_WINS_SHIFT + 5); }
 
 // inverse of wf_slot_to_path: the traversal slot of ray r
@@ -647,8 +665,9 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
 
     // ---- (3) emission: sphere tests (cpu:512-527), root-box test (cpu:279), queue records ----
     int flags = PF_ALIVE | (d << PF_DEPTH_SHIFT) | (nrays << PF_RAYS_SHIFT);
+    SphereHit h, hx;
+    spheres_split2(sc, emitX ? Ox : Oy, uy, emitY, ux, emitX, h, hx);   // a shadow ray and a bounce ray leave the same point (Oy == Ox == P_adjusted)
     if (emitY) {
-        const SphereHit h = spheres_split(sc, Oy, uy);
         ST.y = h.tA; ST.z = h.tB;
         flags |= PF_HASY | wf_pack_wins_path(h);
         if (wf_emit_ray<STATS>(sc, st, i, qy, Oy, uy, true, wk)) flags |= PF_MESHY;
@@ -656,8 +675,7 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
         st.QR[2 * (size_t)qy + 1] = kDead;
     }
     if (emitX) {
-        const SphereHit h = spheres_split(sc, Ox, ux);
-        const float tS = h.tB < h.tA ? h.tB : h.tA;                   // only the value of the shadow ray's nearest hit matters
+        const float tS = hx.tB < hx.tA ? hx.tB : hx.tA;               // only the value of the shadow ray's nearest hit matters
         const f3 Pp = Ox + tS * ux;                                   // cpu:560
         flags |= PF_HASX;
         if (norm2(Pp - Ox) <= norm2(L - Ox)) flags |= PF_XSPHERE;      // cpu:615 holds for the sphere already (the mesh is still intersected, as intersect_all does)
