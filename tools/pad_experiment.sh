@@ -5,7 +5,7 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p raytracinggpu_amd/pad
-F="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fPIC -shared"
+F="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize -fPIC -shared"
 for v in SALU VALU LDS VMEM; do
   /opt/rocm/bin/hipcc $F -DRT_DEBUG -DRT_PAD_$v -o raytracinggpu_amd/pad/$(echo $v | tr A-Z a-z).so raytracinggpu_amd/csrc/rt_capi.hip &
 done
