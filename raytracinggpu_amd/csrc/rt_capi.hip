@@ -51,7 +51,7 @@ struct Knobs {
     int path_oversub = 2;      // RT_PATH_OVERSUB: grid oversubscription of wf_path
     int path_bpc = 4;          // RT_PATH_BPC: workgroups (4 waves) per CU
     int path_parts = 1;        // RT_PATH_PARTS: concurrent sub-frames (launches on separate streams)
-    long long path_samp_bytes = 2ll << 30;   // RT_PATH_SAMP_MB: budget of the per-sample colour buffer (frames with num_rays > 1)
+    long long path_samp_bytes = 4ll << 30;   // RT_PATH_SAMP_MB: budget of the state of the samples traced together (frames with num_rays > 1; ~130 B per sample and pixel)
     int debug_trav = -2;       // RT_DEBUG_TRAV: traversal launch whose per-wave records are dumped (-DRT_DEBUG builds only)
 };
 
@@ -100,7 +100,7 @@ struct rt_ctx {
     int n_levels = 0;
     DevBuf node_lo, node_hi, nodes2, nodesq, q2thr, tri, verts, tidx, scratch_rgba, scratch_rgb8, work, queue;
     int n_cus = 0;
-    DevBuf wfM, wfPR, wfT, wfLS, wfSID;                             // wavefront path state (HBM)
+    DevBuf wfM, wfPR, wfT, wfLS, wfSID, wfSamp;                     // wavefront path state (HBM); wfSamp / wfT: per-sample colours and their running sum (num_rays > 1)
     DevBuf wfQR;                                                    // traversal queue in slot order: the rays (32 B each)
     DevBuf pathSamp, pathT;                                         // wf_path with num_rays > 1: per-sample colours, running sum
     DevBuf dbgbuf;                                                  // -DRT_DEBUG builds: per-wave traversal records
@@ -380,8 +380,9 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
         int chunk = 1;
         if (fr.spp > 1) {
             const int64_t biggest = std::max<int64_t>(1, (int64_t)(np_total / parts + 64));
-            int64_t c = std::min<int64_t>(fr.spp, std::min<int64_t>((((int64_t)1 << 29) - 1) / biggest, kn.path_samp_bytes / (int64_t)(np_total * 16 + 1)));
-            chunk = (int)std::max<int64_t>(1, c);
+            const int64_t cmax = std::max<int64_t>(1, std::min<int64_t>(fr.spp, std::min<int64_t>((((int64_t)1 << 29) - 1) / biggest, kn.path_samp_bytes / (int64_t)(np_total * 16 + 1))));
+            const int64_t chains = (fr.spp + cmax - 1) / cmax;
+            chunk = (int)((fr.spp + chains - 1) / chains);
             int rc2;
             if ((rc2 = ensure(ctx, ctx->pathSamp, np_total * 16 * (size_t)chunk)) != RT_OK || (rc2 = ensure(ctx, ctx->pathT, np_total * 16)) != RT_OK) return rc2;
         }
@@ -422,8 +423,8 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
                     if (work_dev) hipLaunchKernelGGL(rtk::wf_path<true>, tg, tbd, lds, q, scn, pv[j].fr, ps, qcap, kn.path_low, kn.path_shade_min);
                     else hipLaunchKernelGGL(rtk::wf_path<false>, tg, tbd, lds, q, scn, pv[j].fr, ps, qcap, kn.path_low, kn.path_shade_min);
                     if (fr.spp > 1)
-                        hipLaunchKernelGGL(rtk::path_reduce, dim3((unsigned)((ps.n_paths + 255) / 256)), dim3(256), 0, q, pv[j].fr, ps,
-                                           static_cast<float4 *>(ctx->pathT.p) + pv[j].base, s0 == 0 ? 1 : 0, s0 + chunk >= fr.spp ? 1 : 0);
+                        hipLaunchKernelGGL(rtk::path_reduce, dim3((unsigned)((ps.n_paths + 255) / 256)), dim3(256), 0, q, pv[j].fr, ps.n_paths, ps.tiles_x, ps.n_samp,
+                                           static_cast<const float4 *>(ps.samp_out), static_cast<float4 *>(ctx->pathT.p) + pv[j].base, s0 == 0 ? 1 : 0, s0 + chunk >= fr.spp ? 1 : 0);
                 }
             }
             if (j > 0) RT_HIP(ctx, hipEventRecord(ctx->part_ev[j], q));
@@ -512,10 +513,20 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
         if (dbg_env) { rc2 = ensure(ctx, ctx->dbgbuf, 10 * 8 * 65536); if (rc2 != RT_OK) return rc2; }
 #endif
 
+        // samples of a pixel are independent paths: a launch chain traces `chunk` of them at once (bigger launches, fewer tails);
+        // the state costs ~130 bytes per item, so the chunk is sized to RT_PATH_SAMP_MB (default 2 GiB) of it
+        int chunk = 1;
+        if (fr.spp > 1) {
+            const int64_t px_all = (int64_t)tiles_x * ((rows->n_rows + 7) / 8 + parts) * 64;
+            const int64_t per_item = 16 + 16 + 64 + 16 + 5 * (int64_t)nseg;
+            const int64_t cmax = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(fr.spp, kn.path_samp_bytes / (px_all * per_item)), (((int64_t)1 << 29) - 1) / (px_all / parts + 64)));
+            const int64_t chains = (fr.spp + cmax - 1) / cmax;
+            chunk = (int)((fr.spp + chains - 1) / chains);            // chains of (almost) equal size: 64 samples at 15 per chain = 4 x 13 + 12
+        }
         // per-part geometry
-        struct Part { rtk::Frame fr; rtk::WfState st; int64_t tblocks; unsigned pblocks; size_t base; size_t qbase; };
+        struct Part { rtk::Frame fr; rtk::WfState st; int64_t tblocks; unsigned pblocks; size_t base; size_t qbase; size_t pxbase; };
         std::vector<Part> pv(parts);
-        size_t np_total = 0;
+        size_t np_total = 0, px_total = 0;
         for (int j = 0; j < parts; ++j) {
             Part &pt = pv[j];
             const int Tj = (T - j + parts - 1) / parts;               // local tiles j, j+parts, ...
@@ -526,12 +537,16 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
             pt.fr.out_tile0 = j; pt.fr.out_tile_step = parts;
             pt.st = rtk::WfState{};
             pt.st.tiles_x = tiles_x;
-            const int64_t n_paths64 = (int64_t)tiles_x * ((nrows_j + 7) / 8) * 64;
+            const int64_t n_px64 = (int64_t)tiles_x * ((nrows_j + 7) / 8) * 64;
+            const int64_t n_paths64 = n_px64 * chunk;
             // slot arithmetic is 32-bit: ((col << log2S | a) << 2) and 2 * n_paths / 4 must stay below 2^31
             if (n_paths64 >= ((int64_t)1 << 29)) return fail(ctx, RT_ERR_INVALID, "image too large: %lld paths per sub-frame (limit 2^29)", (long long)n_paths64);
             pt.st.n_paths = (int)n_paths64;
+            pt.st.n_px = (int)n_px64;
             pt.base = np_total;
+            pt.pxbase = px_total;
             np_total += (size_t)n_paths64;
+            px_total += (size_t)n_px64;
             // every workgroup owns an equal, spatially scrambled share of the ray slots; its waves draw from it on demand
             rtk::WfState &st = pt.st;
             st.n_groups = 2 * st.n_paths / 4;                         // two ray slots per path (continuation + shadow)
@@ -567,7 +582,7 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
         }
         const size_t np = np_total;
         if ((rc2 = ensure(ctx, ctx->wfM, 2 * np * 8)) != RT_OK || (rc2 = ensure(ctx, ctx->wfPR, np * 16)) != RT_OK ||
-            (rc2 = ensure(ctx, ctx->wfT, (fr.spp > 1 ? np : 1) * 16)) != RT_OK ||
+            (rc2 = ensure(ctx, ctx->wfT, (fr.spp > 1 ? px_total : 1) * 16)) != RT_OK || (rc2 = ensure(ctx, ctx->wfSamp, (fr.spp > 1 ? np : 1) * 16)) != RT_OK ||
             (rc2 = ensure(ctx, ctx->wfSID, np * (size_t)nseg)) != RT_OK || (rc2 = ensure(ctx, ctx->wfLS, np * 4 * (size_t)nseg)) != RT_OK)
             return rc2;
         size_t q_slots = 0;                                           // traversal-queue slots of all parts (padding included)
@@ -591,7 +606,8 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
             st.QR = static_cast<float4 *>(ctx->wfQR.p) + 2 * pt.qbase;
             st.init_m = queue ? 0 : 1;                               // wf_trav merges split traversals with atomicMin
             st.M = static_cast<unsigned long long *>(ctx->wfM.p) + 2 * pt.base;
-            st.PR = static_cast<float4 *>(ctx->wfPR.p) + pt.base; st.T = static_cast<float4 *>(ctx->wfT.p) + (fr.spp > 1 ? pt.base : 0);
+            st.PR = static_cast<float4 *>(ctx->wfPR.p) + pt.base;
+            st.samp_out = fr.spp > 1 ? static_cast<float4 *>(ctx->wfSamp.p) + pt.base : nullptr;
             st.LS = static_cast<float *>(ctx->wfLS.p) + pt.base * (size_t)nseg;   // LS[d * n_paths + i] inside the part's block
             st.SID = static_cast<unsigned char *>(ctx->wfSID.p) + pt.base * (size_t)nseg;
         }
@@ -606,15 +622,16 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
             hipStream_t q = j == 0 ? stream : ctx->part_stream[j];
             if (j > 0) RT_HIP(ctx, hipStreamWaitEvent(q, ctx->fork_ev, 0));
             if (pt.st.n_paths == 0) continue;
-            for (int s = 0; s < fr.spp; ++s) {
-                if (work_dev) hipLaunchKernelGGL((rtk::wf_advance<true, true>), dim3(pt.pblocks), dim3(256), 0, q, scn, pt.fr, pt.st, s);
-                else hipLaunchKernelGGL((rtk::wf_advance<false, true>), dim3(pt.pblocks), dim3(256), 0, q, scn, pt.fr, pt.st, s);
+            for (int s = 0; s < fr.spp; s += chunk) {
+                pt.st.samp0 = s;
+                if (work_dev) hipLaunchKernelGGL((rtk::wf_advance<true, true>), dim3(pt.pblocks), dim3(256), 0, q, scn, pt.fr, pt.st);
+                else hipLaunchKernelGGL((rtk::wf_advance<false, true>), dim3(pt.pblocks), dim3(256), 0, q, scn, pt.fr, pt.st);
                 for (int it = 0; it < (segs > 0 ? segs + 1 : 0); ++it) {
                     if (have_mesh) {
 #ifdef RT_DEBUG
                         pt.st.dbg = (dbg_env && it == dbg_it) ? static_cast<unsigned long long *>(ctx->dbgbuf.p) : nullptr;
 #endif
-                        const bool timed = j == 0 && s == fr.spp - 1;   // time part 0's traversal launches of the last sample
+                        const bool timed = j == 0 && s + chunk >= fr.spp;   // time part 0's traversal launches of the last chain
                         if (timed) RT_HIP(ctx, hipEventRecord(ctx->ev_trav[2 * it], q));
                         const dim3 tg((unsigned)pt.tblocks), tbd(tb);
                         if (queue) {
@@ -629,9 +646,12 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
                         if (timed) { RT_HIP(ctx, hipEventRecord(ctx->ev_trav[2 * it + 1], q)); ctx->n_trav_events = it + 1; }
                         pt.st.dbg = nullptr;
                     }
-                    if (work_dev) hipLaunchKernelGGL((rtk::wf_advance<true, false>), dim3(pt.pblocks), dim3(256), 0, q, scn, pt.fr, pt.st, s);
-                    else hipLaunchKernelGGL((rtk::wf_advance<false, false>), dim3(pt.pblocks), dim3(256), 0, q, scn, pt.fr, pt.st, s);
+                    if (work_dev) hipLaunchKernelGGL((rtk::wf_advance<true, false>), dim3(pt.pblocks), dim3(256), 0, q, scn, pt.fr, pt.st);
+                    else hipLaunchKernelGGL((rtk::wf_advance<false, false>), dim3(pt.pblocks), dim3(256), 0, q, scn, pt.fr, pt.st);
                 }
+                if (fr.spp > 1)                                       // the chain's samples, added in sample order (cpu:711), into the running sum / the frame
+                    hipLaunchKernelGGL(rtk::path_reduce, dim3((unsigned)((pt.st.n_px + 255) / 256)), dim3(256), 0, q, pt.fr, pt.st.n_px, tiles_x, std::min(chunk, fr.spp - s),
+                                       static_cast<const float4 *>(pt.st.samp_out), static_cast<float4 *>(ctx->wfT.p) + pt.pxbase, s == 0 ? 1 : 0, s + chunk >= fr.spp ? 1 : 0);
             }
             if (j > 0) { RT_HIP(ctx, hipEventRecord(ctx->part_ev[j], q)); }
         }
@@ -892,7 +912,7 @@ int rt_ctx_destroy(rt_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ctx->node_lo.release(); ctx->node_hi.release(); ctx->nodes2.release(); ctx->nodesq.release(); ctx->q2thr.release(); ctx->left_dev.release(); ctx->lvl_nodes.release(); ctx->lvl_off.release(); ctx->nrm.release(); ctx->tri.release(); ctx->verts.release(); ctx->tidx.release();
     ctx->scratch_rgba.release(); ctx->scratch_rgb8.release(); ctx->work.release(); ctx->queue.release();
-    ctx->wfM.release(); ctx->wfPR.release(); ctx->wfT.release(); ctx->wfLS.release(); ctx->wfSID.release();
+    ctx->wfM.release(); ctx->wfPR.release(); ctx->wfT.release(); ctx->wfLS.release(); ctx->wfSID.release(); ctx->wfSamp.release();
     ctx->wfQR.release(); ctx->accum.release(); ctx->dbgbuf.release();
     ctx->pathSamp.release(); ctx->pathT.release(); ctx->tidx_up.release();
     for (DevBuf *b : {&ctx->bb_idx, &ctx->bb_cnt, &ctx->bb_pa, &ctx->bb_pb, &ctx->bb_tmp, &ctx->bb_nodes_i, &ctx->bb_nodes_f, &ctx->bb_counter, &ctx->bb_lvl, &ctx->bb_size, &ctx->bb_pre, &ctx->bb_arr}) b->release();

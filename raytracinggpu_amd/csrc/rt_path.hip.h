@@ -546,15 +546,16 @@ __global__ __launch_bounds__(kQBlock, 2) void wf_path(const Scene sc, const Fram
 
 // Sum of the samples of every pixel in sample order (cpu:701-713: color_avg += color; color_avg /= num_rays), from the
 // per-sample colours wf_path wrote.  A frame's samples may come in several chunks (launches): T carries the running sum.
-__global__ __launch_bounds__(256) void path_reduce(const Frame fr, const PathState ps, float4 *__restrict__ T, int first, int last) {
+__global__ __launch_bounds__(256) void path_reduce(const Frame fr, const int n_px, const int tiles_x, const int n_samp, const float4 *__restrict__ samp_out,
+                                                   float4 *__restrict__ T, int first, int last) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ps.n_paths) return;
+    if (i >= n_px) return;
     const int tile = i >> 6, p = i & 63;
-    const int px = (tile % ps.tiles_x) * 8 + (p & 7), lrow = (tile / ps.tiles_x) * 8 + (p >> 3);
+    const int px = (tile % tiles_x) * 8 + (p & 7), lrow = (tile / tiles_x) * 8 + (p >> 3);
     if (!(px < fr.W && lrow < fr.n_rows)) return;
     float4 t = first ? make_float4(0, 0, 0, 0) : T[i];
-    for (int s = 0; s < ps.n_samp; ++s) {
-        const float4 a = ps.samp_out[(size_t)s * ps.n_paths + i];
+    for (int s = 0; s < n_samp; ++s) {
+        const float4 a = samp_out[(size_t)s * n_px + i];
         if (fr.cam_mode == 1) { t.x += a.x * fr.inv_n; t.y += a.y * fr.inv_n; t.z += a.z * fr.inv_n; }   // realtime:1131
         else { t.x += a.x; t.y += a.y; t.z += a.z; }
         t.w += a.w;

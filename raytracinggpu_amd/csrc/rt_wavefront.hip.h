@@ -54,10 +54,12 @@ constexpr unsigned long long WF_NOHIT = ~0ull;
 struct WfState {
     float4 *PR;           // [n_paths] path record (bits(flags | depth | rays | wins), tA, tB, refraction index): tA / tB = the Y ray's nearest sphere before / after the mesh slot
     unsigned long long *M;   // [2 n_paths] traversal result by ray (Y rays at [0, n_paths), X rays at [n_paths, 2 n_paths)): bits(t) << 32 | triangle index (visit order); WF_NOHIT if none
-    float4 *T;            // [n_paths] (sum of the sample colours .xyz, rays traced): frames with more than one sample only
+    float4 *samp_out;     // frames with more than one sample: [n_paths] (colour of the item's sample, rays traced); path_reduce adds them in sample order
     float *LS;            // l (cpu:623) of every diffuse segment, written when the segment is shaded and zeroed if its shadow ray is blocked: LS[d * n_paths + i]
     unsigned char *SID;   // object id of the surface shaded at segment d, 0xff if it was not diffuse: SID[d * n_paths + i]
-    int n_paths;          // tiles_x * tiles_y * 64
+    int n_paths;          // items of this launch chain: n_px * (samples traced together); item i = sample (samp0 + i / n_px) of pixel slot i % n_px
+    int n_px;             // pixel slots of the sub-frame: tiles_x * tiles_y * 64
+    int samp0;            // first sample of the chain
     int tiles_x;
     // traversal scheduling: ray-slot q in [0, slots) maps to ray 4*g + (q & 3), g = ((q>>2) & (S-1)) * Q + ((q>>2) >> log2S)
     int log2S, Q, n_groups;   // n_groups = 2 n_paths / 4 (ray groups);  S * Q >= n_groups
@@ -69,8 +71,8 @@ struct WfState {
     float4 *QR;               // [2 slots] record of slot q: QR[2q] = (O.xyz, u.x), QR[2q+1] = (u.y, u.z, bits(ray + 1 if the ray needs traversal else 0), -)
 };
 
-__device__ __forceinline__ void wf_decode(const WfState &st, const Frame &fr, int i, int &px, int &lrow, bool &valid) {
-    const int tile = i >> 6, p = i & 63;
+__device__ __forceinline__ void wf_decode(const WfState &st, const Frame &fr, int slot, int &px, int &lrow, bool &valid) {
+    const int tile = slot >> 6, p = slot & 63;
     px = (tile % st.tiles_x) * 8 + (p & 7);
     lrow = (tile / st.tiles_x) * 8 + (p >> 3);
     valid = px < fr.W && lrow < fr.n_rows;
@@ -464,9 +466,11 @@ finished:
 }
 
 // ---- wf_advance: close the queries, shade, emit the next rays -----------------------------------------------
-// FIRST: the launch that opens sample `samp` -- camera rays (cpu:699-709) instead of closing queries.
+// FIRST: the launch that opens the chain's samples -- camera rays (cpu:699-709) instead of closing queries.
+// The samples of a pixel are independent paths (the reference's loop cpu:701-712 carries nothing but the sum): a chain traces
+// several of them at once as items, each writes its colour, and path_reduce adds the colours in sample order.
 template <bool STATS, bool FIRST>
-__device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr, const WfState &st, const int samp, const int i, Work &wk) {
+__device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr, const WfState &st, const int i, Work &wk) {
     float4 ST = FIRST ? make_float4(0, 0, 0, 1.f) : st.PR[i];        // Ray::refraction_index = 1 (cpu:100)
     const int F = __float_as_int(ST.x);
     if (!FIRST && !(F & PF_ALIVE)) return;                            // finished (or padding): its queue flags are already 0
@@ -480,7 +484,11 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
     bool emitY = false, emitX = false, finished = false;
     f3 Oy = mk(0, 0, 0), uy = mk(0, 0, 1), Ox = mk(0, 0, 0), ux = mk(0, 0, 1);
     int px, lrow; bool valid;
-    wf_decode(st, fr, i, px, lrow, valid);
+    int s_rel = 0;
+    if (st.n_paths != st.n_px) s_rel = i / st.n_px;
+    const int samp = st.samp0 + s_rel;
+    wf_decode(st, fr, i - s_rel * st.n_px, px, lrow, valid);
+    valid = valid && samp < fr.spp;                                   // the last chain of a frame may be short of samples
     const int row = fr.row0 + (lrow / fr.tile_rows) * fr.tile_rows * fr.tile_step + (lrow % fr.tile_rows);
 
     if (FIRST) {
@@ -648,15 +656,15 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
                 ans = (l * alb) / PI_F + alb * ans;
             }
         }
-        float4 t = samp == 0 ? make_float4(0, 0, 0, 0) : st.T[i];
-        if (fr.cam_mode == 1) { t.x += ans.x * fr.inv_n; t.y += ans.y * fr.inv_n; t.z += ans.z * fr.inv_n; }   // realtime:1131
-        else { t.x += ans.x; t.y += ans.y; t.z += ans.z; }
-        t.w += (float)nrays;
-        if (samp == fr.spp - 1) {                                     // cpu:713 + the framebuffer store
+        if (st.samp_out != nullptr) {                                 // more than one sample per pixel: path_reduce sums in sample order
+            st.samp_out[i] = make_float4(ans.x, ans.y, ans.z, (float)nrays);
+        } else {                                                      // one sample: T = 0 + ans, out = T / n (cpu:711-713 + the framebuffer store)
+            float4 t = make_float4(0, 0, 0, 0);
+            if (fr.cam_mode == 1) { t.x += ans.x * fr.inv_n; t.y += ans.y * fr.inv_n; t.z += ans.z * fr.inv_n; }   // realtime:1131
+            else { t.x += ans.x; t.y += ans.y; t.z += ans.z; }
+            t.w += (float)nrays;
             const float n = fr.cam_mode == 1 ? 1.f : (float)fr.spp;
             fr.out[out_index(fr, lrow, px)] = make_float4(t.x / n, t.y / n, t.z / n, t.w);
-        } else {
-            st.T[i] = t;
         }
         st.PR[i] = kDead;
         st.QR[2 * (size_t)qy + 1] = kDead; st.QR[2 * (size_t)qx + 1] = kDead;
@@ -688,10 +696,10 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
 }
 
 template <bool STATS, bool FIRST>
-__global__ __launch_bounds__(256, 8) void wf_advance(const Scene sc, const Frame fr, const WfState st, int samp) {
+__global__ __launch_bounds__(256, 8) void wf_advance(const Scene sc, const Frame fr, const WfState st) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     Work wk;
-    if (i < st.n_paths) wf_advance_path<STATS, FIRST>(sc, fr, st, samp, i, wk);
+    if (i < st.n_paths) wf_advance_path<STATS, FIRST>(sc, fr, st, i, wk);
     wf_flush_work<STATS>(fr, wk);                                     // every lane of the wave arrives here (wave-level sums)
 }
 
