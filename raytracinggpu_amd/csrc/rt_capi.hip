@@ -51,7 +51,9 @@ struct Knobs {
     int path_oversub = 2;      // RT_PATH_OVERSUB: grid oversubscription of wf_path
     int path_bpc = 4;          // RT_PATH_BPC: workgroups (4 waves) per CU
     int path_parts = 1;        // RT_PATH_PARTS: concurrent sub-frames (launches on separate streams)
-    long long path_samp_bytes = 4ll << 30;   // RT_PATH_SAMP_MB: budget of the state of the samples traced together (frames with num_rays > 1; ~130 B per sample and pixel)
+    long long path_samp_bytes = 400ll << 20; // RT_PATH_SAMP_MB: state of the samples traced together (frames with num_rays > 1; ~130 B per sample and pixel slot).
+                                             // Measured: a chain is fastest while its state stays near the 256 MB Infinity Cache -- 512x512, 64 samples: 23.5 / 8.8 / 8.0 /
+                                             // 8.8 ms for 30 / 192 / 400 / 4096 MB; 1920x1080 (277 MB per sample): one sample per chain is best (71.5 vs 76.9 ms at 13)
     int debug_trav = -2;       // RT_DEBUG_TRAV: traversal launch whose per-wave records are dumped (-DRT_DEBUG builds only)
 };
 
@@ -513,8 +515,8 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
         if (dbg_env) { rc2 = ensure(ctx, ctx->dbgbuf, 10 * 8 * 65536); if (rc2 != RT_OK) return rc2; }
 #endif
 
-        // samples of a pixel are independent paths: a launch chain traces `chunk` of them at once (bigger launches, fewer tails);
-        // the state costs ~130 bytes per item, so the chunk is sized to RT_PATH_SAMP_MB (default 2 GiB) of it
+        // samples of a pixel are independent paths: a launch chain traces `chunk` of them at once (bigger launches, fewer tails) as
+        // long as the chain's state (~130 bytes per item) stays around the size of the Infinity Cache (RT_PATH_SAMP_MB, default 400)
         int chunk = 1;
         if (fr.spp > 1) {
             const int64_t px_all = (int64_t)tiles_x * ((rows->n_rows + 7) / 8 + parts) * 64;
