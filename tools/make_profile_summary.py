@@ -29,7 +29,7 @@ for key, pat in (("wf_travq", "wf_travq<false"), ("wf_advance", "wf_advance<fals
     hbm = dv.get("hbm_read_bytes_corrected", 0) + dv.get("hbm_write_bytes", 0)
     res["kernels"][key] = {
         "rocprof_avg_us_two_streams": round(n2["avg_us"], 2), "share_of_gpu_time": round(n2["share_of_gpu_time"], 4),
-        "rocprof_avg_us_single_stream": round(n1["avg_us"], 2), "launches_per_frame_single_stream": n1["calls"] // 39 if n1["calls"] % 39 == 0 else None,
+        "rocprof_avg_us_single_stream": round(n1["avg_us"], 2),
         "hbm_read_bytes_per_launch": int(dv.get("hbm_read_bytes_corrected", 0)), "hbm_write_bytes_per_launch": int(dv.get("hbm_write_bytes", 0)),
         "hbm_GBps_single_stream": round(hbm / (n1["avg_us"] * 1e-6) / 1e9, 1), "hbm_frac_of_8TBps": round(hbm / (n1["avg_us"] * 1e-6) / HBM_PEAK, 4),
         "l2_hit_rate": round(dv.get("l2_hit_rate", 0), 4),
