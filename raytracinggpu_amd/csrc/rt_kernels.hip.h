@@ -22,6 +22,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "rt_sincos.h"
 
 namespace rtk {
 
@@ -370,7 +371,7 @@ __device__ __forceinline__ f3 get_color(const Scene &sc, const Frame &fr, f3 O, 
             const float r1 = uniform01(hs, (uint32_t)d, 0);         // cpu:628-629
             const float r2 = uniform01(hs, (uint32_t)d, 1);
             double sn, cs;
-            sincos(2 * PI_D * (double)r1, &sn, &cs);
+            rt_sincos_2pi(2 * PI_D * (double)r1, sn, cs);
             const float s1 = rt_sqrtf(1 - r2);
             const float x = (float)(cs * (double)s1);               // cpu:630
             const float y = (float)(sn * (double)s1);               // cpu:631
@@ -432,7 +433,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(const Scene sc, c
             const float r1 = uniform01(hs, 0, 2), r2 = uniform01(hs, 0, 3);
             const float bm = fr.sigma * rt_sqrtf(-2 * logf(r1));
             double sn, cs;
-            sincos(2 * 3.14159265358979323846 * (double)r2, &sn, &cs);
+            rt_sincos_2pi(2 * 3.14159265358979323846 * (double)r2, sn, cs);
             uu = uc + mk((float)((double)bm * cs), (float)((double)bm * sn), 0.f);
         }
         const f3 u = normalize(uu);

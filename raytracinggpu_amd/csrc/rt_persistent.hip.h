@@ -238,7 +238,7 @@ __global__ __launch_bounds__(kPBlock) void render_persistent(const Scene sc, con
                     const float r1 = uniform01(hs, (uint32_t)d, 0);
                     const float r2 = uniform01(hs, (uint32_t)d, 1);
                     double sn, cs;
-                    sincos(2 * PI_D * (double)r1, &sn, &cs);
+                    rt_sincos_2pi(2 * PI_D * (double)r1, sn, cs);
                     const float s1 = rt_sqrtf(1 - r2);
                     const float x = (float)(cs * (double)s1);
                     const float y = (float)(sn * (double)s1);
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(kPBlock) void render_persistent(const Scene sc, con
                     const float r1 = uniform01(hs, 0, 2), r2 = uniform01(hs, 0, 3);
                     const float bm = fr.sigma * rt_sqrtf(-2 * logf(r1));
                     double sn, cs;
-                    sincos(2 * PI_D * (double)r2, &sn, &cs);
+                    rt_sincos_2pi(2 * PI_D * (double)r2, sn, cs);
                     uu = uc + mk((float)((double)bm * cs), (float)((double)bm * sn), 0.f);
                 }
                 u = normalize(uu);

@@ -513,7 +513,7 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
                 const float r1 = uniform01(hs, 0, 2), r2 = uniform01(hs, 0, 3);
                 const float bm = fr.sigma * rt_sqrtf(-2 * logf(r1));
                 double sn, cs;
-                sincos(2 * 3.14159265358979323846 * (double)r2, &sn, &cs);
+                rt_sincos_2pi(2 * 3.14159265358979323846 * (double)r2, sn, cs);
                 uu = ucm + mk((float)((double)bm * cs), (float)((double)bm * sn), 0.f);
             }
             Oy = mk(sc.camx, sc.camy, sc.camz);
@@ -616,7 +616,7 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
                         const float r1u = uniform01(hs, (uint32_t)d, 0);
                         const float r2u = uniform01(hs, (uint32_t)d, 1);
                         double sn, cs;
-                        sincos(2 * PI_D * (double)r1u, &sn, &cs);
+                        rt_sincos_2pi(2 * PI_D * (double)r1u, sn, cs);
                         const float s1f = rt_sqrtf(1 - r2u);
                         const float x = (float)(cs * (double)s1f);
                         const float y = (float)(sn * (double)s1f);
