@@ -189,7 +189,7 @@ def main():
         tri_obj = i32(os.path.join(md, "tri_obj_order.i32"), 3)
         tri_bvh = i32(os.path.join(md, "tri_bvh_order.i32"), 3)
         arr10 = f32(os.path.join(md, "bvh_arr10.f32"), 10)
-        np.savez_compressed(os.path.join(GOLD, "cat_mesh.npz"), vertices=verts, tri_obj_order=tri_obj,
+        np.savez_compressed(os.path.join(ROOT, "raytracinggpu_amd", "data", "cat_mesh.npz"), vertices=verts, tri_obj_order=tri_obj,
                             tri_bvh_order=tri_bvh, bvh_arr10=arr10)
 
         # 3. primitive KATs

@@ -21,8 +21,9 @@ CAT_ALBEDO = (0.25, 0.25, 0.25)
 CPU_LAUNCHER = dict(depth_convention=0, sigma=0.0, eps=1e-3, tri_tmin=1e-4)
 OPTIMIZED_CU = dict(depth_convention=1, sigma=0.2, eps=1e-4, tri_tmin=0.0)
 
-_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CAT_FIXTURE = os.path.join(_ROOT, "tests", "golden", "cat_mesh.npz")
+# the benchmark mesh as arrays (vertices after readOBJ's v*0.8+(0,-10,0), faces in OBJ order, the reference's BVH): package data,
+# produced from the reference's asset by oracle/make_golden.py; tests and bench.py read it from here
+CAT_FIXTURE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "cat_mesh.npz")
 
 
 def load_cat_arrays(path=CAT_FIXTURE):
