@@ -107,8 +107,11 @@ __device__ __forceinline__ bool qtri_test(const float4 q0, const float4 q1, cons
     const float sum = b + g;
     const float es = fmaf(fabsf(sum), 0x1p-22f, eb + eg);
     const bool trust = fabsf(det) > kTiny;      // also false for det == 0 and NaN
-    const bool reject = trust && (b < -eb || b > 1.f + eb || g < -eg || g > 1.f + eg || sum > 1.f + es);
-    bool ok = trust && b >= eb && b <= 1.f - eb && g >= eg && g <= 1.f - eg && sum <= 1.f - es;
+    // cpu:232-235 accept iff 0 <= beta <= 1, 0 <= gamma <= 1 and fl(beta + gamma) <= 1.  For finite values the two "<= 1" follow from
+    // the rest (gamma >= 0 => fl(beta + gamma) >= beta: rounding is monotone and beta is representable), so three comparisons
+    // decide; whatever they leave open -- including beta or gamma above 1 next to an inconclusive sum -- takes the literal tests.
+    const bool reject = trust && (b < -eb || g < -eg || sum > 1.f + es);
+    bool ok = trust && b >= eb && g >= eg && sum <= 1.f - es;
     how = ok ? 1 : 0;
     if (!reject && !ok && det != 0) {           // undecided: the literal tests (rare)
         const float beta = bn / det;
@@ -119,7 +122,7 @@ __device__ __forceinline__ bool qtri_test(const float4 q0, const float4 q1, cons
     if (!ok) return false;
     const float t = dot(AO, N) / det;
     t_out = t;
-    return t > 0 && t > tri_tmin && t < 1e9f;   // cpu:235, cpu:301; 1e9f = INF narrowed (cpu:283)
+    return t > (tri_tmin > 0.f ? tri_tmin : 0.f) && t < 1e9f;   // cpu:235 (t > 0) and cpu:301 (t > 1e-4); 1e9f = INF narrowed (cpu:283)
 }
 __device__ __forceinline__ bool qtri_test(const float4 q0, const float4 q1, const float4 q2, const f3 Oo, const f3 uo,
                                           const float tri_tmin, float &t_out) {
