@@ -1,7 +1,7 @@
 // rt_travq.hip.h -- wf_travq: BVH traversal as a wave-level work stack of (ray, node) pairs.
 //
 // Replaces the walk of TriangleMesh::intersect (cpu_launcher.cpp:277-311; optimized.cu:245-285) inside the
-// wavefront pipeline of rt_wavefront.hip.h (same path state, same wf_begin / wf_advance kernels).
+// wavefront pipeline of rt_wavefront.hip.h (same path state, same wf_advance kernel).
 //
 // The reference pushes EVERY child whose box is hit (no distance pruning), so the set of nodes and
 // triangles a ray visits does not depend on the order they are visited in, and the nearest hit is the minimum

@@ -271,6 +271,29 @@ def test_work_stack_traversal_bounded_stack_and_slot_counts(ctx, cat_golden, mon
     tuned.close()
 
 
+def test_samples_as_parallel_items_equal_the_serial_sample_loop(ctx, oracle, oracle_cat, cat_golden, monkeypatch):
+    """The samples of a pixel traced together as items of one launch chain (default while the chain's state fits the Infinity
+    Cache), one chain per sample (RT_PATH_SAMP_MB=1), and uneven chains (5 samples, 2 per chain): the ordered reduction gives the
+    same bits as the reference's serial loop (cpu:701-713), through the wavefront pipeline and through wf_path."""
+    upload(ctx, "cpu", cat_golden)
+    W, H, spp, b = 320, 200, 5, 2
+    exp, _, _ = oracle.Scene.preset("cpu", oracle_cat).render(W, H, spp, b, sigma=0.2, want_rgb8=False)
+    kw = dict(rt.scenes.CPU_LAUNCHER, sigma=0.2)
+    ref = ctx.render(rt.make_params(W, H, spp, b, **kw))
+    assert linf(oracle, ref, exp) <= TOL
+    np.testing.assert_array_equal(ref[..., 3], exp[..., 3])
+    per_item_mb = W * H * 132 / 2**20
+    for mb in (1, int(2.2 * per_item_mb) + 1):
+        monkeypatch.setenv("RT_PATH_SAMP_MB", str(mb))
+        tuned = rt.Context(0)
+        upload(tuned, "cpu", cat_golden)
+        for variant in ("auto", "path"):
+            got = tuned.render(rt.make_params(W, H, spp, b, variant=variant, **kw))
+            np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
+        tuned.close()
+    monkeypatch.delenv("RT_PATH_SAMP_MB")
+
+
 def test_jitter_sigma_0p2_matches_oracle(ctx, oracle, oracle_cat, cat_golden):
     """anti-aliasing jitter sigma = 0.2 (optimized.cu:753; cpu:705-707 with its sigma line enabled),
     Box-Muller from the counter RNG's dims 2,3: same estimator as the oracle, within the stated tolerance."""
