@@ -122,6 +122,20 @@ def test_row_ranges_and_interleaved_tiles_are_bitwise_the_full_frame(ctx, cat_go
         np.testing.assert_array_equal(frame.view(np.uint32), full.view(np.uint32))
 
 
+def test_pinned_frame_buffer_gives_the_same_frame(ctx, cat_golden):
+    """rt_host_alloc: a frame buffer the D2H copy reaches by DMA; same bits as the pageable path, for rt_render and row ranges."""
+    upload(ctx, "cpu", cat_golden)
+    p = rt.make_params(400, 250, 2, 2, **rt.scenes.CPU_LAUNCHER)
+    ref = ctx.render(p)
+    pin = rt.PinnedArray((250, 400, 4))
+    got = ctx.render(p, out=pin.array)
+    assert got is pin.array
+    np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
+    part = rt.PinnedArray((84, 400, 4))
+    np.testing.assert_array_equal(ctx.render(p, 37, 121, out=part.array).view(np.uint32), ref[37:121].view(np.uint32))
+    pin.close(); part.close()
+
+
 def test_error_paths(ctx, cat_golden):
     upload(ctx, "cpu", cat_golden)
     with pytest.raises(rt.RtError):
