@@ -538,13 +538,13 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
             pt.fr.row0 = rows->row0 + j * R * G; pt.fr.n_rows = nrows_j; pt.fr.tile_rows = R; pt.fr.tile_step = G * parts;
             pt.fr.out_tile0 = j; pt.fr.out_tile_step = parts;
             pt.st = rtk::WfState{};
-            pt.st.tiles_x = tiles_x;
+            pt.st.tiles_x = tiles_x; pt.st.tiles_x_m = rtk::wf_div_magic(tiles_x);
             const int64_t n_px64 = (int64_t)tiles_x * ((nrows_j + 7) / 8) * 64;
             const int64_t n_paths64 = n_px64 * chunk;
             // slot arithmetic is 32-bit: ((col << log2S | a) << 2) and 2 * n_paths / 4 must stay below 2^31
             if (n_paths64 >= ((int64_t)1 << 29)) return fail(ctx, RT_ERR_INVALID, "image too large: %lld paths per sub-frame (limit 2^29)", (long long)n_paths64);
             pt.st.n_paths = (int)n_paths64;
-            pt.st.n_px = (int)n_px64;
+            pt.st.n_px = (int)n_px64; pt.st.n_px_m = rtk::wf_div_magic((int)n_px64);
             pt.base = np_total;
             pt.pxbase = px_total;
             np_total += (size_t)n_paths64;
@@ -576,7 +576,7 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
             while ((2 << st.log2S) <= groups_per_block && st.log2S < 16) ++st.log2S;
             if (kn.log2S >= 0 && kn.log2S < st.log2S) st.log2S = kn.log2S;   // experiment: less scrambling = more coherent rays per workgroup
             const int S = 1 << st.log2S;
-            st.Q = (st.n_groups + S - 1) / S;
+            st.Q = (st.n_groups + S - 1) / S; st.Q_m = rtk::wf_div_magic(st.Q);
             const int64_t total_slots = (int64_t)S * st.Q * 4;
             st.slots_per_block = (int)(((total_slots + tblocks - 1) / tblocks + 3) / 4 * 4);
             pt.tblocks = tblocks;
