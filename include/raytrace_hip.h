@@ -188,6 +188,9 @@ int rt_count_work(rt_ctx *ctx, const rt_params *p, int row_begin, int row_end, r
 
 int rt_synchronize(rt_ctx *ctx);
 int rt_get_stats(rt_ctx *ctx, rt_stats *stats);        /* waits for the last render to finish */
+/* every device buffer of the context lives on the context's device (RT_ERR_INTERNAL otherwise): a context used from a thread
+ * whose current device is another GPU must not allocate there (the CUDA programs of the reference only ever see device 0) */
+int rt_ctx_selfcheck(rt_ctx *ctx);
 
 /* --- pinned host memory for frame buffers.  optimized.cu copies its image into pageable memory (`new char[]`,
  *     optimized.cu:851-856); a buffer from rt_host_alloc lets the D2H copy of rt_render / rt_render_rgb8 /

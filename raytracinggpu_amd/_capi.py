@@ -19,7 +19,7 @@ VARIANTS = {"auto": 0, "global": 1, "lds_verts": 2, "lds_top": 3, "lds_all": 4, 
 # every symbol include/raytrace_hip.h declares (tests check the .so exports each)
 EXPORTS = ["rt_abi_version", "rt_device_count", "rt_ctx_create", "rt_ctx_destroy", "rt_last_error",
            "rt_device_name", "rt_scene_upload", "rt_render", "rt_render_device", "rt_tonemap_device",
-           "rt_render_rgb8", "rt_synchronize", "rt_get_stats", "rt_count_work",
+           "rt_render_rgb8", "rt_synchronize", "rt_get_stats", "rt_ctx_selfcheck", "rt_count_work",
            "rt_mesh_transform", "rt_mesh_set_normals", "rt_camera_basis", "rt_render_pose", "rt_render_pose_device", "rt_progressive_reset", "rt_progressive_frame",
            "rt_progressive_frames",
            "rt_multi_create", "rt_multi_destroy", "rt_multi_last_error", "rt_multi_scene_upload", "rt_render_multi",
@@ -139,6 +139,7 @@ def load():
     L.rt_render_rgb8.argtypes = [vp, C.POINTER(Params), C.c_int, C.c_int, C.POINTER(C.c_uint8)]
     L.rt_count_work.argtypes = [vp, C.POINTER(Params), C.c_int, C.c_int, C.POINTER(Work)]
     L.rt_synchronize.argtypes = [vp]
+    L.rt_ctx_selfcheck.argtypes = [vp]
     L.rt_get_stats.argtypes = [vp, C.POINTER(Stats)]
     fp3 = C.POINTER(C.c_float)
     L.rt_mesh_transform.argtypes = [vp, fp3, fp3]
@@ -370,6 +371,10 @@ class Context:
 
     def synchronize(self):
         self._check(self._L.rt_synchronize(self._h))
+
+    def selfcheck(self):
+        """Every device buffer of the context lives on the context's device."""
+        self._check(self._L.rt_ctx_selfcheck(self._h))
 
     def _kat(self, fn, rows, width, owidth, *extra, counts=True):
         a = np.ascontiguousarray(rows, np.float32).reshape(-1, width)

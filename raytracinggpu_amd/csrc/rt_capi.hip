@@ -1272,6 +1272,21 @@ int rt_host_free(void *ptr) {
     return RT_OK;
 }
 
+int rt_ctx_selfcheck(rt_ctx *ctx) {
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const DevBuf *bufs[] = {&ctx->node_lo, &ctx->node_hi, &ctx->nodes2, &ctx->nodesq, &ctx->q2thr, &ctx->tri, &ctx->verts, &ctx->tidx, &ctx->tidx_up, &ctx->nrm,
+                            &ctx->scratch_rgba, &ctx->scratch_rgb8, &ctx->work, &ctx->queue, &ctx->wfM, &ctx->wfPR, &ctx->wfT, &ctx->wfLS, &ctx->wfSID, &ctx->wfSamp,
+                            &ctx->wfQR, &ctx->pathSamp, &ctx->pathT, &ctx->accum, &ctx->left_dev, &ctx->lvl_nodes, &ctx->lvl_off, &ctx->bb_idx, &ctx->bb_arr};
+    for (const DevBuf *b : bufs) {
+        if (!b->p) continue;
+        hipPointerAttribute_t at{};
+        RT_HIP(ctx, hipPointerGetAttributes(&at, b->p));
+        if (at.device != ctx->device) return fail(ctx, RT_ERR_INTERNAL, "a buffer of the context of device %d lives on device %d", ctx->device, at.device);
+    }
+    return RT_OK;
+}
+
 int rt_device_alloc(rt_ctx *ctx, void **ptr, size_t bytes) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
     if (!ptr) return fail(ctx, RT_ERR_INVALID, "ptr is NULL");

@@ -156,6 +156,12 @@ def test_error_paths(ctx, cat_golden):
     # the context is still usable after errors
     upload(ctx, "spheres", cat_golden)
     assert np.isfinite(ctx.render(rt.make_params(64, 64))).all()
+    # and everything it allocated (scene, path state, queues, scratch) lives on its own device
+    upload(ctx, "cpu", cat_golden)
+    ctx.render(rt.make_params(128, 96, 3, 2, **rt.scenes.CPU_LAUNCHER))
+    ctx.render(rt.make_params(128, 96, 2, 1, variant="path", **rt.scenes.CPU_LAUNCHER))
+    ctx.mesh_rebuild(len(cat_golden["tri_bvh_order"]))
+    ctx.selfcheck()
 
 
 def test_launcher_cli_reproduces_reference_png(tmp_path, cat_golden):
