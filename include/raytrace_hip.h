@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 2
+#define RT_ABI_VERSION 3
 #define RT_MAX_SPHERES 16      /* reference: Geometry* objects[10], optimized.cu:663 */
 #define RT_MAX_SEGMENTS 16     /* reference: MAX_RAY_DEPTH 10, optimized.cu:22       */
 
@@ -183,6 +183,11 @@ typedef struct rt_work {
     uint64_t box_tests;            /* BoundingBox::intersect calls, root included             */
     uint64_t nodes;                /* BVH nodes whose box was hit (= nodes the reference pops) */
     uint64_t tri_tests;            /* moller_trumbore calls                                   */
+    uint64_t box_literal;          /* of box_tests: decided by the literal divisions of cpu:147-152 (the error-bounded filter deferred) */
+    uint64_t tri_literal;          /* of tri_tests: barycentrics by the literal divisions of cpu:232-233                                */
+    uint64_t steps[8];             /* work-stack traversal kernel, summed over its waves and launches: loop iterations, refill passes,
+                                    * refill rounds, queue fetches, TRI steps (128 triangle tests), BOX steps (64 sibling pairs),
+                                    * literal-box fall-backs, serial drains.  bench.py prices the vector-issue roofline with them. */
 } rt_work;
 int rt_count_work(rt_ctx *ctx, const rt_params *p, int row_begin, int row_end, rt_work *out);
 

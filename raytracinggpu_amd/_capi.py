@@ -65,7 +65,8 @@ class Rows(C.Structure):
 
 
 class Work(C.Structure):
-    _fields_ = [("rays", C.c_uint64), ("box_tests", C.c_uint64), ("nodes", C.c_uint64), ("tri_tests", C.c_uint64)]
+    _fields_ = [("rays", C.c_uint64), ("box_tests", C.c_uint64), ("nodes", C.c_uint64), ("tri_tests", C.c_uint64),
+                ("box_literal", C.c_uint64), ("tri_literal", C.c_uint64), ("steps", C.c_uint64 * 8)]
 
 
 class Stats(C.Structure):
@@ -316,12 +317,20 @@ class Context:
         self._check(self._L.rt_tonemap_device(self._h, C.c_void_p(rgba_ptr), n_pixels, C.c_void_p(rgb8_ptr),
                                               C.c_void_p(stream) if stream else None))
 
-    def count_work(self, params, row_begin=0, row_end=None):
-        """Traversal work of a frame from the counting instantiation of the kernel."""
+    def count_work(self, params, row_begin=0, row_end=None, detail=False):
+        """Traversal work of a frame from the counting instantiation of the kernel: rays, box tests, nodes, triangle
+        tests -- what the oracle counts.  detail=True adds the tests the literal divisions decided and the work-stack kernel's
+        step counters."""
         row_end = params.height if row_end is None else row_end
         w = Work()
         self._check(self._L.rt_count_work(self._h, C.byref(params), row_begin, row_end, C.byref(w)))
-        return {k: int(getattr(w, k)) for k, _ in Work._fields_}
+        out = {k: int(getattr(w, k)) for k in ("rays", "box_tests", "nodes", "tri_tests")}
+        if not detail:
+            return out
+        out.update(box_literal=int(w.box_literal), tri_literal=int(w.tri_literal))
+        out["steps"] = dict(zip(("iterations", "refill_passes", "refill_rounds", "fetches", "tri_steps", "box_steps", "literal_box_fallbacks", "serial_drains"),
+                                (int(v) for v in w.steps)))
+        return out
 
     def mesh_transform(self, rotation, translation):
         """Device-side `transform` kernel (global_launcher.cu:340-365) on the uploaded mesh + triangle precompute + BVH refit."""

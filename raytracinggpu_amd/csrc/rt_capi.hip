@@ -100,7 +100,7 @@ struct rt_ctx {
     DevBuf bb_idx, bb_cnt, bb_pa, bb_pb, bb_tmp, bb_nodes_i, bb_nodes_f, bb_counter, bb_lvl, bb_size, bb_pre, bb_arr;   // device BVH build scratch
     DevBuf left_dev, lvl_nodes, lvl_off;                             // tree topology for the device-side refit
     int n_levels = 0;
-    DevBuf node_lo, node_hi, nodes2, nodesq, q2thr, tri, verts, tidx, scratch_rgba, scratch_rgb8, work, queue;
+    DevBuf node_lo, node_hi, nodes2, nodesq, nodesb, q2thr, tri, verts, tidx, scratch_rgba, scratch_rgb8, work, queue;
     int n_cus = 0;
     DevBuf wfM, wfPR, wfT, wfLS, wfSID, wfSamp;                     // wavefront path state (HBM); wfSamp / wfT: per-sample colours and their running sum (num_rays > 1)
     DevBuf wfQR;                                                    // traversal queue in slot order: the rays (32 B each)
@@ -116,6 +116,7 @@ struct rt_ctx {
     hipEvent_t part_ev[kMaxParts] = {};
     hipEvent_t fork_ev = nullptr;
     bool trav_attr_set = false;
+    bool travq_ok = true;                                           // the uploaded tree fits wf_travq's entry formats (leaf sizes, triangle offsets)
     static constexpr int kMaxTravEvents = 2 * RT_MAX_SEGMENTS;
     hipEvent_t ev_trav[2 * kMaxTravEvents] = {};
     int n_trav_events = 0;
@@ -304,8 +305,8 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
         if (ctx->scene.n_nodes == 0) variant = RT_VARIANT_WAVEFRONT;      // no mesh: nothing to stage
         else return fail(ctx, RT_ERR_UNSUPPORTED, "%d BVH nodes need %zu bytes of LDS (> 160 KiB)", ctx->scene.n_nodes, lds_nodes_bytes);
     }
-    if (variant == RT_VARIANT_WAVEFRONT_QUEUE && ctx->scene.n_nodes + 2 >= (1 << rtk::kQNodeBits)) {   // entry = slot << 26 | node
-        if (want_ldsv || want_ldsn) return fail(ctx, RT_ERR_UNSUPPORTED, "%d BVH nodes: the LDS-staged variants need < 2^26 nodes", ctx->scene.n_nodes);
+    if (variant == RT_VARIANT_WAVEFRONT_QUEUE && (ctx->scene.n_nodes + 2 >= (1 << rtk::kQNodeBits) || !ctx->travq_ok)) {   // entry = node << 10 | slot << 4
+        if (want_ldsv || want_ldsn) return fail(ctx, RT_ERR_UNSUPPORTED, "%d BVH nodes: the LDS-staged variants need < 2^22 nodes and leaves below 2^21 triangles", ctx->scene.n_nodes);
         variant = RT_VARIANT_WAVEFRONT;
     }
     if (variant == RT_VARIANT_PATH && ctx->scene.n_nodes + 2 >= (1 << rtk::kPNodeBits)) variant = RT_VARIANT_WAVEFRONT;
@@ -821,6 +822,36 @@ int install_scene(rt_ctx *ctx, rtk::Scene sc, const rt_mesh *mesh) {
             q2t[k + 1] = x;
         }
         if ((rc = upload(ctx, ctx->nodesq, q.data(), q.size() * sizeof(float4))) != RT_OK) return rc;
+        // wf_travq's form of the same array (rt_travq.hip.h): box as centre / half extent, payload and kind pre-shifted the way stack
+        // and leaf-queue entries carry them; and the scene-wide quantities its box filter needs
+        std::vector<float4> qb(q.size(), make_float4(0, 0, 0, 0));
+        float bm[3] = {0.f, 0.f, 0.f};
+        bool fast = true, travq_ok = true;
+        for (size_t k = 0; k < order.size(); ++k) {
+            const int x = order[k];
+            const float4 l = lo[x], h = hi[x];
+            float4 cb = make_float4(rtk::box_centre(l.x, h.x), rtk::box_centre(l.y, h.y), rtk::box_centre(l.z, h.z), 0.f);
+            float4 hb = make_float4(rtk::box_half(l.x, h.x), rtk::box_half(l.y, h.y), rtk::box_half(l.z, h.z), 0.f);
+            const float v[6] = {l.x, l.y, l.z, h.x, h.y, h.z};
+            for (int a = 0; a < 3; ++a) {
+                if (!(v[a] <= v[a + 3]) || !(std::fabs(v[a]) < 1e8f) || !(std::fabs(v[a + 3]) < 1e8f)) fast = false;   // also false for NaN
+                bm[a] = std::max(bm[a], std::max(std::fabs(v[a]), std::fabs(v[a + 3])));
+            }
+            if (left_of[x] >= 0) {
+                cb.w = __builtin_bit_cast(float, (bfs_of[x + 1] + 1) << rtk::kQNodeShift);
+                hb.w = __builtin_bit_cast(float, (int)0x80000000);
+            } else {
+                const int first = __builtin_bit_cast(int, l.w), cnt = __builtin_bit_cast(int, h.w) - first;
+                if (cnt >= rtk::kQMaxLeaf) travq_ok = false;
+                cb.w = __builtin_bit_cast(float, first);
+                hb.w = __builtin_bit_cast(float, cnt > 0 && cnt < rtk::kQMaxLeaf ? cnt << rtk::kQNodeShift : 0);
+            }
+            qb[2 * (k + 1)] = cb; qb[2 * (k + 1) + 1] = hb;
+        }
+        if ((rc = upload(ctx, ctx->nodesb, qb.data(), qb.size() * sizeof(float4))) != RT_OK) return rc;
+        sc.bmx = bm[0]; sc.bmy = bm[1]; sc.bmz = bm[2];
+        sc.fast_box = fast ? 1 : 0;
+        ctx->travq_ok = travq_ok && (uint64_t)tri.size() * 16 < ((uint64_t)1 << 32);   // 32-bit byte offsets into the triangle records
         if ((rc = upload(ctx, ctx->q2thr, q2t.data(), q2t.size() * sizeof(int))) != RT_OK) return rc;
         // levels of the tree (pre-order indices sorted by depth) for the device-side refit (rt_mesh_transform)
         std::vector<int> depth(n, 0), lvl_off, lvl_nodes(n);
@@ -844,6 +875,7 @@ int install_scene(rt_ctx *ctx, rtk::Scene sc, const rt_mesh *mesh) {
     sc.node_hi = static_cast<const float4 *>(ctx->node_hi.p);
     sc.nodes = static_cast<const float4 *>(ctx->nodes2.p);
     sc.nodesq = static_cast<const float4 *>(ctx->nodesq.p);
+    sc.nodesb = static_cast<const float4 *>(ctx->nodesb.p);
     sc.q2thr = static_cast<const int *>(ctx->q2thr.p);
     sc.tri = static_cast<const float4 *>(ctx->tri.p);
     sc.verts = static_cast<const float4 *>(ctx->verts.p);
@@ -912,7 +944,7 @@ int rt_ctx_destroy(rt_ctx *ctx) {
     if (!ctx) return RT_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    ctx->node_lo.release(); ctx->node_hi.release(); ctx->nodes2.release(); ctx->nodesq.release(); ctx->q2thr.release(); ctx->left_dev.release(); ctx->lvl_nodes.release(); ctx->lvl_off.release(); ctx->nrm.release(); ctx->tri.release(); ctx->verts.release(); ctx->tidx.release();
+    ctx->node_lo.release(); ctx->node_hi.release(); ctx->nodes2.release(); ctx->nodesq.release(); ctx->nodesb.release(); ctx->q2thr.release(); ctx->left_dev.release(); ctx->lvl_nodes.release(); ctx->lvl_off.release(); ctx->nrm.release(); ctx->tri.release(); ctx->verts.release(); ctx->tidx.release();
     ctx->scratch_rgba.release(); ctx->scratch_rgb8.release(); ctx->work.release(); ctx->queue.release();
     ctx->wfM.release(); ctx->wfPR.release(); ctx->wfT.release(); ctx->wfLS.release(); ctx->wfSID.release(); ctx->wfSamp.release();
     ctx->wfQR.release(); ctx->accum.release(); ctx->dbgbuf.release();
@@ -1014,13 +1046,13 @@ int rt_count_work(rt_ctx *ctx, const rt_params *p, int row_begin, int row_end, r
     const int n = row_end - row_begin;
     int rc = ensure(ctx, ctx->scratch_rgba, (size_t)n * (p->width > 0 ? p->width : 0) * sizeof(float4));
     if (rc != RT_OK) return rc;
-    if ((rc = ensure(ctx, ctx->work, 8 * sizeof(unsigned long long))) != RT_OK) return rc;
+    if ((rc = ensure(ctx, ctx->work, 16 * sizeof(unsigned long long))) != RT_OK) return rc;
     RT_HIP(ctx, hipSetDevice(ctx->device));
-    RT_HIP(ctx, hipMemsetAsync(ctx->work.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    RT_HIP(ctx, hipMemsetAsync(ctx->work.p, 0, 16 * sizeof(unsigned long long), ctx->stream));
     rt_rows rows{row_begin, n, n > 0 ? n : 1, 1};
     rc = launch_render(ctx, p, &rows, ctx->scratch_rgba.p, ctx->stream, static_cast<unsigned long long *>(ctx->work.p));
     if (rc != RT_OK) return rc;
-    unsigned long long h[8];
+    unsigned long long h[16];
     RT_HIP(ctx, hipMemcpyAsync(h, ctx->work.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     std::vector<float> fb((size_t)n * (size_t)p->width * 4);
     RT_HIP(ctx, hipMemcpyAsync(fb.data(), ctx->scratch_rgba.p, fb.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
@@ -1028,6 +1060,8 @@ int rt_count_work(rt_ctx *ctx, const rt_params *p, int row_begin, int row_end, r
     double rays = 0;                                  // .w of every pixel = rays traced for it (exact in binary32)
     for (size_t k = 3; k < fb.size(); k += 4) rays += fb[k];
     out->rays = (uint64_t)rays; out->box_tests = h[1]; out->nodes = h[2]; out->tri_tests = h[3];
+    out->box_literal = h[5]; out->tri_literal = h[6];
+    for (int k = 0; k < 8; ++k) out->steps[k] = h[8 + k];
     // the counting instantiation checks every index that reaches an address (rt_travq.hip.h WQ_CHECK, rt_path.hip.h)
     if (h[4] != 0) return fail(ctx, RT_ERR_INTERNAL, "traversal invariant violated (mask 0x%llx: 1 path, 2 triangle, 4 node, 8 stack, 16 leaf queue, 32 staging)", h[4]);
     return RT_OK;
@@ -1076,7 +1110,7 @@ int rt_mesh_transform(rt_ctx *ctx, const float rotation[9], const float translat
                        static_cast<const int4 *>(ctx->tidx.p), static_cast<const float4 *>(ctx->verts.p), static_cast<float4 *>(ctx->tri.p), sc.n_tris);
     rtk::RefitArgs a{};
     a.node_lo = static_cast<float4 *>(ctx->node_lo.p); a.node_hi = static_cast<float4 *>(ctx->node_hi.p);
-    a.nodes2 = static_cast<float4 *>(ctx->nodes2.p); a.nodesq = static_cast<float4 *>(ctx->nodesq.p);
+    a.nodes2 = static_cast<float4 *>(ctx->nodes2.p); a.nodesq = static_cast<float4 *>(ctx->nodesq.p); a.nodesb = static_cast<float4 *>(ctx->nodesb.p);
     a.q2thr = static_cast<const int *>(ctx->q2thr.p); a.left_of = static_cast<const int *>(ctx->left_dev.p);
     a.lvl_nodes = static_cast<const int *>(ctx->lvl_nodes.p); a.lvl_off = static_cast<const int *>(ctx->lvl_off.p);
     a.tidx = static_cast<const int4 *>(ctx->tidx.p); a.verts = static_cast<const float4 *>(ctx->verts.p);
@@ -1089,6 +1123,16 @@ int rt_mesh_transform(rt_ctx *ctx, const float rotation[9], const float translat
     RT_HIP(ctx, hipMemcpyAsync(&root[1], ctx->node_hi.p, sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     sc.root_lo = root[0]; sc.root_hi = root[1];
+    // the refitted root box contains every node's (unions, bottom-up): it bounds the magnitudes wf_travq's box filter needs
+    const float rv[6] = {root[0].x, root[0].y, root[0].z, root[1].x, root[1].y, root[1].z};
+    bool fast = true;
+    float bm[3];
+    for (int a = 0; a < 3; ++a) {
+        if (!(rv[a] <= rv[a + 3]) || !(std::fabs(rv[a]) < 1e8f) || !(std::fabs(rv[a + 3]) < 1e8f)) fast = false;
+        bm[a] = std::max(std::fabs(rv[a]), std::fabs(rv[a + 3]));
+    }
+    sc.bmx = bm[0]; sc.bmy = bm[1]; sc.bmz = bm[2];
+    sc.fast_box = fast ? 1 : 0;
     return RT_OK;
 }
 
@@ -1275,7 +1319,7 @@ int rt_host_free(void *ptr) {
 int rt_ctx_selfcheck(rt_ctx *ctx) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
     RT_HIP(ctx, hipSetDevice(ctx->device));
-    const DevBuf *bufs[] = {&ctx->node_lo, &ctx->node_hi, &ctx->nodes2, &ctx->nodesq, &ctx->q2thr, &ctx->tri, &ctx->verts, &ctx->tidx, &ctx->tidx_up, &ctx->nrm,
+    const DevBuf *bufs[] = {&ctx->node_lo, &ctx->node_hi, &ctx->nodes2, &ctx->nodesq, &ctx->nodesb, &ctx->q2thr, &ctx->tri, &ctx->verts, &ctx->tidx, &ctx->tidx_up, &ctx->nrm,
                             &ctx->scratch_rgba, &ctx->scratch_rgb8, &ctx->work, &ctx->queue, &ctx->wfM, &ctx->wfPR, &ctx->wfT, &ctx->wfLS, &ctx->wfSID, &ctx->wfSamp,
                             &ctx->wfQR, &ctx->pathSamp, &ctx->pathT, &ctx->accum, &ctx->left_dev, &ctx->lvl_nodes, &ctx->lvl_off, &ctx->bb_idx, &ctx->bb_arr};
     for (const DevBuf *b : bufs) {

@@ -53,6 +53,9 @@ struct Scene {
                               // sibling pairs are aligned 64-byte lines): lo.w of an internal node = its first child (even), the second
                               // one is stored next to it (the root is node 1, its children 2 and 3)
     const int *q2thr;         // nodesq index -> index of the same node in `nodes`
+    const float4 *nodesb;     // the same breadth-first array in the form wf_travq reads (rt_travq.hip.h): (centre.xyz, payload) (half extent.xyz, kind)
+    float bmx, bmy, bmz;      // per axis: max |bound| over every node box (the absolute term of wf_travq's box filter)
+    int fast_box;             // every node box is finite, ordered (lo <= hi) and below 1e8 in magnitude: the centre / half-extent filter may decide
     const float4 *nrm;        // smooth shading (wavefront variants): 3 vertex normals per triangle, visit order; nullptr = flat
     const float4 *tri;
     const float4 *verts;
@@ -67,7 +70,8 @@ struct Frame {
     uint32_t seed;
     int row0, n_rows, tile_rows, tile_step;
     float4 *out;
-    unsigned long long *work;   // STATS kernels only: {rays, box_tests, nodes, tri_tests, invariant mask, -, -, -}
+    unsigned long long *work;   // STATS kernels only: [16] {rays, box_tests, nodes, tri_tests, invariant mask, literal box tests, literal triangle tests, -,
+                                // wf_travq step counters: loop iterations, refill passes, refill rounds, queue fetches, TRI steps, BOX steps, literal-box fall-backs, serial drains}
     int out_tile0, out_tile_step;   // local row r is stored at output row ((r / tile_rows) * out_tile_step + out_tile0) * tile_rows + r % tile_rows
     // cam_mode 1 = realtime_render.cu's camera and sample averaging (KernelLaunch realtime:1100-1134; wavefront variants only):
     // u_center = C + bz * z + bx * X + by * Y, every sample weighted by inv_n = (float)(1. / num_rays) as it is added

@@ -11,7 +11,7 @@
 // The reference never refits (its transform variant has no BVH and buildBVH runs once on the host); rebuilding on the
 // host after a transform remains possible through rt_scene_upload.
 #pragma once
-#include "rt_kernels.hip.h"
+#include "rt_travq.hip.h"
 
 namespace rtk {
 
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void retri_kernel(const int4 *__restrict__ tid
 }
 
 struct RefitArgs {
-    float4 *node_lo, *node_hi, *nodes2, *nodesq;   // the three node layouts (pre-order SoA, pre-order interleaved, breadth-first)
+    float4 *node_lo, *node_hi, *nodes2, *nodesq, *nodesb;   // the node layouts (pre-order SoA, pre-order interleaved, breadth-first as boxes and as centre / half extent)
     const int *q2thr, *left_of, *lvl_nodes, *lvl_off;
     const int4 *tidx;
     const float4 *verts;
@@ -92,6 +92,10 @@ __global__ __launch_bounds__(1024) void refit_kernel(const RefitArgs a) {
         float4 lq = a.nodesq[2 * k], hq = a.nodesq[2 * k + 1];
         lq.x = lo.x; lq.y = lo.y; lq.z = lo.z; hq.x = hi.x; hq.y = hi.y; hq.z = hi.z;
         a.nodesq[2 * k] = lq; a.nodesq[2 * k + 1] = hq;
+        float4 cb = a.nodesb[2 * k], hb = a.nodesb[2 * k + 1];        // wf_travq's form of the same box (their .w fields keep payload and kind)
+        cb.x = box_centre(lo.x, hi.x); cb.y = box_centre(lo.y, hi.y); cb.z = box_centre(lo.z, hi.z);
+        hb.x = box_half(lo.x, hi.x); hb.y = box_half(lo.y, hi.y); hb.z = box_half(lo.z, hi.z);
+        a.nodesb[2 * k] = cb; a.nodesb[2 * k + 1] = hb;
     }
 }
 

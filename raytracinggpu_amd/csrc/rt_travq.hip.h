@@ -31,26 +31,35 @@ namespace rtk {
 #define RT_TRAVQ_BLOCK 256
 #endif
 constexpr int kQBlock = RT_TRAVQ_BLOCK;      // 4 waves per workgroup share one ray-slot cursor (128 / 512 measured: no better)
-#ifndef RT_TRAVQ_KP
-#define RT_TRAVQ_KP 1                        // sibling pairs per lane and BOX step
-#endif
-constexpr int kQLeafCap = 256 * RT_TRAVQ_KP;  // leaf-queue entries per wave: < 64 before a BOX step, which appends up to 128 per pair
-constexpr int kQNodeBits = 26;               // entry = slot << 26 | node
-constexpr unsigned kQNodeMask = (1u << kQNodeBits) - 1u;
+constexpr int kQLeafCap = 256;               // leaf-queue entries per wave: < 64 before a BOX step, which appends up to 128
+// Stack entry (32 bits) = node << 10 | slot << 4: the sibling pair of nodes (node, node + 1) of the ray in slot `slot`.  Both fields are
+// stored the way they are used: entry & 0x3f0 is the byte offset of the slot's row in the four per-slot tables (16-byte rows),
+// (entry >> 5) & ~31 the byte offset of the pair in the node array (32 bytes per node).  A leaf-queue entry is (first triangle,
+// count << 10 | slot << 4).  Decoding costs two full-rate instructions per field (and, shift) instead of the shift-and-add forms
+// that issue at half rate on gfx950 (tools/ubench/issue_table: v_lshlrev_b32, v_lshl_add_u32, v_and_or_b32 ... take twice the
+// issue time of v_and_b32 / v_lshrrev_b32 / v_add_u32 / v_fma_f32).
+constexpr int kQNodeShift = 10, kQNodeBits = 22;
+constexpr unsigned int kQSlotMask = 0x3f0u;
+constexpr int kQMaxLeaf = 1 << 21;           // triangles per leaf: count << 10 must stay a positive int (the sign says "internal")
 
-// stack capacity: sized so that four waves' carves (+ the cursor) fill 32 KiB (R = 64: 5 workgroups per CU) or less;
+// stack capacity: sized so that four waves' carves (+ the cursor) fill 36 KiB (R = 64: 4 workgroups per CU) or less;
 // a fuller stack is drained serially (see above), which the cat never needs
 template <int R> struct QStackCap { static constexpr int value = 652; };
 
+// Per-wave LDS carve.  Four tables of 16-byte rows indexed by ray slot, so that ONE address register (wave base + slot * 16)
+// reaches everything a step needs about a ray through the instructions' immediate offsets:
+//   A = (1/u.xyz by v_rcp_f32, c0 | +inf if the filter must not decide)      BOX step
+//   O = (fl(O.x / u.x) .., int: outstanding stack + leaf-queue entries)      BOX step (the counter shares the row: no address arithmetic)
+//   C = (O.xyz, u.x)                                                         TRI step, literal box test
+//   D = (u.y, u.z, u64: nearest accepted hit)                                TRI step
 template <int R, int SCAP, int LCAP> struct QCarve {
-    static constexpr int kTabA = 0;                       // float4[R]: (1/u.xyz by v_rcp_f32, c0 | +inf if the filter must not decide)
-    static constexpr int kTabC = kTabA + 16 * R;          // float4[R]: (O.xyz, u.x)
-    static constexpr int kTabD = kTabC + 16 * R;          // float2[R]: (u.y, u.z)
-    static constexpr int kBest = kTabD + 8 * R;           // u64[R]: nearest accepted hit
-    static constexpr int kPend = kBest + 8 * R;           // int[R]: outstanding stack + leaf-queue entries
-    static constexpr int kMarks = kPend + 4 * R;          // u8[128]: TRI-step expansion marks (all zero between steps)
+    static constexpr int kTabA = 0;
+    static constexpr int kTabO = kTabA + 16 * R;
+    static constexpr int kTabC = kTabO + 16 * R;
+    static constexpr int kTabD = kTabC + 16 * R;
+    static constexpr int kMarks = kTabD + 16 * R;         // u8[128]: TRI-step expansion marks (all zero between steps)
     static constexpr int kStack = kMarks + 128;           // u32[SCAP]
-    static constexpr int kLeaf = kStack + 4 * SCAP;       // uint2[LCAP]: (first triangle, slot | count << 8)
+    static constexpr int kLeaf = kStack + 4 * SCAP;       // uint2[LCAP]: (first triangle, count << 10 | slot << 4)
     static constexpr int kStage = kLeaf + 8 * LCAP;       // u8[64]: lanes whose registers hold a fetched ray record that has no slot yet
     static constexpr int kBytes = kStage + 64;
     static_assert(kBytes % 16 == 0 && kLeaf % 8 == 0 && kStack % 4 == 0, "the next wave's float4 tables start at kBytes");
@@ -70,11 +79,25 @@ __device__ __forceinline__ unsigned int wave_incl_scan(unsigned int x) {
 __device__ __forceinline__ int lanes_below(unsigned long long m) {   // set bits of m below this lane
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
 }
+__device__ __forceinline__ int lanes_below2(unsigned long long m0, unsigned long long m1) {   // ... of m0 plus those of m1: v_mbcnt accumulates
+    const unsigned int a = __builtin_amdgcn_mbcnt_hi((unsigned int)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m0, 0u));
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m1, a));
+}
+// number of the four lane masks that contain this lane, minus one if `act` contains it: the masks stay scalar registers and enter
+// as carry-ins (five half-rate instructions; written out in C++ the compiler materialises every mask as 0 / 1 in a vector
+// register and compares it back into a mask for the ballots)
+__device__ __forceinline__ int lane_count4_minus(unsigned long long m0, unsigned long long m1, unsigned long long m2, unsigned long long m3, unsigned long long act) {
+    int d;
+    asm("v_cndmask_b32_e64 %0, 0, -1, %5\n\tv_addc_co_u32_e64 %0, vcc, 0, %0, %1\n\tv_addc_co_u32_e64 %0, vcc, 0, %0, %2\n\t"
+        "v_addc_co_u32_e64 %0, vcc, 0, %0, %3\n\tv_addc_co_u32_e64 %0, vcc, 0, %0, %4"
+        : "=&v"(d) : "s"(m0), "s"(m1), "s"(m2), "s"(m3), "s"(act) : "vcc");
+    return d;
+}
 
 // BoundingBox::intersect (cpu:146-157) through the fused filter (see RayBox in rt_wavefront.hip.h): returns whether
 // the filter decided; `hit` is then the reference's result.  A = (r.xyz, c0) with r = v_rcp_f32(u), C = (O.xyz, -);
 // c0 = +inf for rays the filter must not decide (0 / denormal / inf / NaN components), which makes every comparison
-// below false.
+// below false.  (wf_path and the known-answer entry use this form; wf_travq the centre / half-extent form below.)
 __device__ __forceinline__ bool qbox_filter(const float4 lo, const float4 hi, const float4 A, const float4 C, bool &hit) {
     const float ox = C.x * A.x, oy = C.y * A.y, oz = C.z * A.z;       // RayBox::ox.. (single roundings, as in ray_box)
     const float ax = fmaf(lo.x, A.x, -ox), bx = fmaf(hi.x, A.x, -ox);
@@ -89,9 +112,64 @@ __device__ __forceinline__ bool qbox_filter(const float4 lo, const float4 hi, co
     return M < kBig && (hit || d < -band);
 }
 
+// ---- the box filter of wf_travq: centre / half-extent form -----------------------------------------------------------------
+// The slab test through min / max costs 6 fma + 6 min/max + max3 + min3 per box, and min / max / compares issue at HALF the rate
+// of fma / mul / add on gfx950.  With the box stored as centre c and half extent h >= 0 the near and far planes of an axis are
+//     k = fma(c, r, -o),   near = fma(-h, |r|, k),   far = fma(h, |r|, k)            (r = v_rcp_f32(u), o = fl(O * r))
+// -- nine full-rate instructions and no min / max per axis pair.  Error against the reference's q = RN(RN(bound - O) / u), for
+// the plane bound = c* -/+ h* (c* = (lo + hi) / 2, h* = (hi - lo) / 2 exactly; c = RN(c*), h = RN(h*), formed in binary64 by
+// the upload): with R = 1 / u,
+//     near~ = R (1 + e_r) [ (c* - O + c* e_c - O e_o)(1 + e_1) - h* (1 + e_h) ] (1 + e_2),   |e_r| <= 2^-23, the others <= 2^-24
+//  => |near~ - q| <= (2^-23 + 2^-24 + 2 * 2^-24) |q|  +  2^-24 |R| (|c* - O| + |c*| + |O| + |h*|)  (+ second order, + denormal slack)
+//                 <= 1.25 * 2^-22 |q|  +  2^-24 |r| (2 |O| + 3 B)                    B >= |lo|, |hi| of every node on that axis.
+// max3 / min3 are 1-Lipschitz and the reference's per-axis min / max IS the near / far plane (RN is monotone, h >= 0), so
+// tn~, tf~ carry the same bound with |q| read off the computed values; band = kRel (|tn~| + |tf~|) + c0 with kRel = 2^-21
+// (1.6 x the relative part) and c0 = 1.125 * 2^-23 max_k |r_k| (2 |O_k| + 3 B_k) + 2e-35 (2 x the absolute part + slack)
+// covers both ends, the rounding of d and of the band itself.  Decide only when |d| > band; c0 = +inf (rays with a 0 / denormal /
+// huge / NaN component, scenes whose boxes are not finite, ordered and below 1e8 in magnitude: Scene::fast_box) makes both
+// comparisons false, and so does any NaN.  Within those guards no intermediate overflows: |c r|, |h r| < 1e8 * 1e30.
+struct RayBoxC { float rx, ry, rz, ox, oy, oz, c0; };
+__device__ __forceinline__ RayBoxC ray_box_c(const Scene &sc, f3 O, f3 u) {
+    RayBoxC b;
+    b.rx = __builtin_amdgcn_rcpf(u.x); b.ry = __builtin_amdgcn_rcpf(u.y); b.rz = __builtin_amdgcn_rcpf(u.z);
+    b.ox = O.x * b.rx; b.oy = O.y * b.ry; b.oz = O.z * b.rz;
+    const float omax = vmax3abs(b.ox, b.oy, b.oz);
+    const float wx = fabsf(b.rx) * fmaf(3.f, sc.bmx, 2.f * fabsf(O.x)), wy = fabsf(b.ry) * fmaf(3.f, sc.bmy, 2.f * fabsf(O.y)), wz = fabsf(b.rz) * fmaf(3.f, sc.bmz, 2.f * fabsf(O.z));
+    const float w = vmax3(wx, wy, wz);
+    const float umin = fminf(fminf(fabsf(u.x), fabsf(u.y)), fabsf(u.z)), umax = fmaxf(fmaxf(fabsf(u.x), fabsf(u.y)), fabsf(u.z));
+    const bool safe = sc.fast_box != 0 && umin > kTiny && umax < kBig && omax < kBig && w < kBig;      // false for 0, denormal, inf, NaN anywhere
+    b.c0 = safe ? fmaf(w, 0x1.2p-23f, 2e-35f) : __builtin_inff();
+    return b;
+}
+// n0 = (c.xyz, -), n1 = (h.xyz, -), A = (r.xyz, c0), Oo = (o.xyz, -): `hit` / `miss` are the reference's result when one of them is set
+__device__ __forceinline__ void cbox_filter(const float4 n0, const float4 n1, const float4 A, const float4 Oo, bool &hit, bool &miss) {
+    const float kx = fmaf(n0.x, A.x, -Oo.x), ky = fmaf(n0.y, A.y, -Oo.y), kz = fmaf(n0.z, A.z, -Oo.z);
+    const float tn = vmax3(fmaf(-n1.x, fabsf(A.x), kx), fmaf(-n1.y, fabsf(A.y), ky), fmaf(-n1.z, fabsf(A.z), kz));
+    const float tf = vmin3(fmaf(n1.x, fabsf(A.x), kx), fmaf(n1.y, fabsf(A.y), ky), fmaf(n1.z, fabsf(A.z), kz));
+    const float d = tf - tn;
+    const float band = fmaf(fabsf(tf), kRel, fmaf(fabsf(tn), kRel, A.w));
+    hit = d > band;
+    miss = d < -band;
+}
+// centre / half extent of one axis as the upload and the device-side refit form them (binary64 sum / difference: exact; one rounding)
+__host__ __device__ inline float box_centre(float lo, float hi) { return (float)(((double)lo + (double)hi) * 0.5); }
+__host__ __device__ inline float box_half(float lo, float hi) { return (float)(((double)hi - (double)lo) * 0.5); }
+
 // moller_trumbore (cpu:226-236) + the acceptance test of the leaf loop (cpu:301): beta/gamma through the filter,
 // undecided lanes by the literal divisions, t always by the exact division.
 // `how` reports the route (callers that do not look at it pay nothing): 0 filter rejected, 1 filter accepted, 2 literal divisions.
+//
+// Filter.  b = bn * rcp(det), g = gn * rcp(det) differ from the reference's beta' = RN(bn / det), gamma' by at most 2^-22 of their
+// magnitude (+ denormal slack) whenever rd = rcp(det) is a NORMAL number (one v_cmp_class: excludes det = 0, denormal or beyond
+// 8.5e37, inf, NaN at either end).  cpu:232-235 accept iff 0 <= beta' <= 1, 0 <= gamma' <= 1 and fl(beta' + gamma') <= 1; for
+// finite values the two "<= 1" follow from the rest.  With E = 2^-18 and s = fl(b + g):
+//   accept  iff  min(b, g) >= E  and  s <= 1 - 3E     (then 0 < beta', gamma' and beta' + gamma' <= s + 2^-24 + 2^-21 < 1)
+//   reject  iff  min(b, g) < -E  or   s > 1 + 3E      (a negative value stays negative under a relative error; and if the reference
+//                                                      accepted, beta' + gamma' <= 1 + 2^-24 would give s < 1 + 2^-20)
+// everything else -- including every NaN: v_min drops one, but s keeps it and then neither line holds, or the surviving operand is
+// itself < -E, which the reference rejects too -- takes the literal expression.  Constant thresholds instead of the earlier
+// per-value bands: 7 half-rate + 1 full-rate instruction instead of 12 + 7; the undecided band is 2^-16 wide instead of 2^-20,
+// still one test in ~10^4.
 __device__ __forceinline__ bool qtri_test(const float4 q0, const float4 q1, const float4 q2, const f3 Oo, const f3 uo,
                                           const float tri_tmin, float &t_out, int &how) {
     const f3 A = mk(q0.x, q0.y, q0.z), e1 = mk(q0.w, q1.x, q1.y), e2 = mk(q1.z, q1.w, q2.x);
@@ -103,21 +181,20 @@ __device__ __forceinline__ bool qtri_test(const float4 q0, const float4 q1, cons
     const float gn = -dot(e1, c);
     const float rd = __builtin_amdgcn_rcpf(det);
     const float b = bn * rd, g = gn * rd;
-    const float eb = fmaf(fabsf(b), kRel, kAbs), eg = fmaf(fabsf(g), kRel, kAbs);
+    constexpr float kE = 0x1p-18f;
     const float sum = b + g;
-    const float es = fmaf(fabsf(sum), 0x1p-22f, eb + eg);
-    const bool trust = fabsf(det) > kTiny;      // also false for det == 0 and NaN
-    // cpu:232-235 accept iff 0 <= beta <= 1, 0 <= gamma <= 1 and fl(beta + gamma) <= 1.  For finite values the two "<= 1" follow from
-    // the rest (gamma >= 0 => fl(beta + gamma) >= beta: rounding is monotone and beta is representable), so three comparisons
-    // decide; whatever they leave open -- including beta or gamma above 1 next to an inconclusive sum -- takes the literal tests.
-    const bool reject = trust && (b < -eb || g < -eg || sum > 1.f + es);
-    bool ok = trust && b >= eb && g >= eg && sum <= 1.f - es;
+    const float mbg = vmin(b, g);
+    const bool trust = __builtin_amdgcn_classf(rd, 0x108);      // rd is +-normal
+    const bool reject = trust && (mbg < -kE || sum > 1.f + 3.f * kE);
+    bool ok = trust && mbg >= kE && sum <= 1.f - 3.f * kE;
     how = ok ? 1 : 0;
-    if (!reject && !ok && det != 0) {           // undecided: the literal tests (rare)
-        const float beta = bn / det;
-        const float gamma = gn / det;
-        ok = (0 <= beta && beta <= 1) && (0 <= gamma && gamma <= 1) && (beta + gamma <= 1);
+    if (!reject && !ok) {                       // undecided: the literal tests (rare)
         how = 2;
+        if (det != 0) {                         // cpu:230
+            const float beta = bn / det;
+            const float gamma = gn / det;
+            ok = (0 <= beta && beta <= 1) && (0 <= gamma && gamma <= 1) && (beta + gamma <= 1);
+        }
     }
     if (!ok) return false;
     const float t = dot(AO, N) / det;
@@ -136,9 +213,13 @@ __device__ __forceinline__ bool qtri_test(const float4 q0, const float4 q1, cons
 // and a TRI step reads a triangle as its three vertex indices (global, 16 B) + three LDS vertices, forming e1, e2 and
 // N = e1 x e2 with the operations of moller_trumbore (cpu:227-229) -- the same single roundings rt_scene_upload applies
 // when it precomputes the 48-byte triangle records the other variants read.  Also ONE workgroup per CU.
+//
+// Step counters of the counting (STATS) instantiation, fr.work[8..15] (bench.py prices the vector-issue roofline with them and the
+// static per-step instruction counts of the production code object, tools/static_counts.py): loop iterations, refill passes
+// entered, refill rounds, queue fetches, TRI steps, BOX steps, literal-box fall-backs taken, serial drains.
 template <bool STATS, int R, bool LDSN, bool LDSV>
-__global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || RT_TRAVQ_KP > 1 || kQBlock != 256) ? 4 : 5) void wf_travq(const Scene sc, const Frame fr, const WfState st, const int cap, const int n_lds, const int kLow, const int kMinFree) {
-    // kLow: refill while the stack holds fewer entries (sibling pairs) than this (default 96); kMinFree: ... and at least this
+__global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || kQBlock != 256) ? 4 : 5) void wf_travq(const Scene sc, const Frame fr, const WfState st, const int cap, const int n_lds, const int kLow, const int kMinFree) {
+    // kLow: refill while the stack holds fewer entries (sibling pairs) than this (default 48); kMinFree: ... and at least this
     // many slots are free, or the stack is short (default R / 4)
     constexpr int SCAP = QStackCap<R>::value, LCAP = kQLeafCap;
     using Carve = QCarve<R, SCAP, LCAP>;
@@ -152,23 +233,29 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || R
     int *const blk_cur = reinterpret_cast<int *>(travq_smem + wpb * Carve::kBytes);
     float4 *const lnodes = reinterpret_cast<float4 *>(travq_smem + wpb * Carve::kBytes + 16);
     float4 *const lverts = lnodes + (LDSN ? 2 * n_lds : 0);        // LDSV: every vertex (x, y, z, -)
-    float4 *const tabA = reinterpret_cast<float4 *>(wl + Carve::kTabA);
-    float4 *const tabC = reinterpret_cast<float4 *>(wl + Carve::kTabC);
-    float2 *const tabD = reinterpret_cast<float2 *>(wl + Carve::kTabD);
-    unsigned long long *const best = reinterpret_cast<unsigned long long *>(wl + Carve::kBest);
-    int *const pend = reinterpret_cast<int *>(wl + Carve::kPend);
     unsigned char *const marks = wl + Carve::kMarks;
     unsigned int *const stack = reinterpret_cast<unsigned int *>(wl + Carve::kStack);
     uint2 *const leafq = reinterpret_cast<uint2 *>(wl + Carve::kLeaf);
     unsigned char *const sidx = wl + Carve::kStage;
+    // row `sb` (= slot * 16, the form entries carry it in) of the four per-slot tables
+    auto rowA = [&](unsigned int sb) -> float4 & { return *reinterpret_cast<float4 *>(wl + Carve::kTabA + sb); };
+    auto rowO = [&](unsigned int sb) -> float4 & { return *reinterpret_cast<float4 *>(wl + Carve::kTabO + sb); };
+    auto rowC = [&](unsigned int sb) -> float4 & { return *reinterpret_cast<float4 *>(wl + Carve::kTabC + sb); };
+    auto rowD = [&](unsigned int sb) -> float4 & { return *reinterpret_cast<float4 *>(wl + Carve::kTabD + sb); };
+    auto pend = [&](unsigned int sb) -> int * { return reinterpret_cast<int *>(wl + Carve::kTabO + sb + 12); };
+    auto best = [&](unsigned int sb) -> unsigned long long * { return reinterpret_cast<unsigned long long *>(wl + Carve::kTabD + sb + 8); };
+    const unsigned int my_sb = (unsigned int)lane << 4;            // lane r < R owns ray slot r
     if (tid == 0) *blk_cur = 0;
     marks[lane] = 0; marks[lane + 64] = 0;
-    if (lane < R) pend[lane] = 0;
-    if (LDSN) for (int k = tid; k < 2 * n_lds; k += (int)blockDim.x) lnodes[k] = sc.nodesq[k];
+    if (lane < R) *pend(my_sb) = 0;
+    if (LDSN) for (int k = tid; k < 2 * n_lds; k += (int)blockDim.x) lnodes[k] = sc.nodesb[k];
     if (LDSV) for (int k = tid; k < sc.n_verts; k += (int)blockDim.x) lverts[k] = sc.verts[k];
     __syncthreads();
 
-    const float4 *const nodes = sc.nodesq;        // breadth-first order from index 1 (0 is padding): lo.w = first child (even; the other one is next to it) | first triangle (leaf); hi.w = -1 | end
+    // breadth-first order from index 1 (0 is padding), 32 bytes per node: (centre.xyz, payload) (half extent.xyz, kind);
+    // internal node: payload = first child << 10 (even; the other child is next to it), kind < 0;  leaf: payload = first triangle,
+    // kind = triangle count << 10 (0 for an empty leaf)
+    const unsigned char *const nodes = reinterpret_cast<const unsigned char *>(sc.nodesb);
     const size_t blk_base = (size_t)blockIdx.x * (size_t)st.slots_per_block;
     const int blk_n = st.slots_per_block;
     int stage_n = 0, stage_used = 0;              // wave-uniform: staged records and how many of them have been given a slot
@@ -181,6 +268,7 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || R
     unsigned int lhead = 0, ltail = 0;            // wave-uniform: leaf-queue cursors (monotonic)
     bool drained = false;
     Work wk;
+    unsigned int n_iter = 0, n_refill = 0, n_round = 0, n_fetch = 0, n_tri = 0, n_box = 0, n_lit = 0, n_serial = 0;   // STATS: step counters (wave-uniform)
     // optional per-wave record (-DRT_DEBUG builds with RT_DEBUG_TRAV set; tools/dbg_travq.py): st.dbg[16 * wave + k]
 #ifdef RT_DEBUG
     const bool dbg_on = st.dbg != nullptr;
@@ -195,31 +283,38 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || R
     // bit in fr.work[4] instead of faulting (rt_count_work then fails with RT_ERR_INTERNAL); the product instantiation
     // carries no checks.  Bits: 1 path index, 2 triangle index, 4 node index, 8 stack height, 16 leaf queue, 32 staging index.
 #define WQ_CHECK(cond, bit, fixup) do { if (STATS && !(cond)) { atomicOr(&fr.work[4], (unsigned long long)(bit)); fixup; } } while (0)
+    // code-object markers: labels, not instructions (tools/static_counts.py counts the instructions between them)
+#ifdef RT_NO_MARKS
+#define WQ_MARK(name) do { } while (0)
+#else
+#define WQ_MARK(name) asm volatile("rt_mark_" name "_%=:" ::)
+#endif
 
-    // the sibling nodes c, c + 1 of a stack entry (c is even: the pair is one 64-byte line): LDS for the staged top of the
+    // the sibling nodes of a stack entry at byte offset `off` (the pair is one 64-byte line): LDS for the staged top of the
     // tree (n_lds is even), L1/L2 otherwise
-    auto load_pair = [&](int c, float4 &lo0, float4 &hi0, float4 &lo1, float4 &hi1) {
+    auto load_pair = [&](unsigned int off, float4 &c0, float4 &h0, float4 &c1, float4 &h1) {
+        const float4 *gp = reinterpret_cast<const float4 *>(nodes + off);
         if (LDSN) {
-            const bool inl = c < n_lds;
-            if (inl) { lo0 = lnodes[2 * c]; hi0 = lnodes[2 * c + 1]; lo1 = lnodes[2 * c + 2]; hi1 = lnodes[2 * c + 3]; }
-            if (__ballot(!inl) != 0ull) { if (!inl) { lo0 = nodes[2 * c]; hi0 = nodes[2 * c + 1]; lo1 = nodes[2 * c + 2]; hi1 = nodes[2 * c + 3]; } }
+            const bool inl = off < (unsigned int)n_lds * 32u;
+            const float4 *lp = reinterpret_cast<const float4 *>(reinterpret_cast<const unsigned char *>(lnodes) + off);
+            if (inl) { c0 = lp[0]; h0 = lp[1]; c1 = lp[2]; h1 = lp[3]; }
+            if (__ballot(!inl) != 0ull) { if (!inl) { c0 = gp[0]; h0 = gp[1]; c1 = gp[2]; h1 = gp[3]; } }
         } else {
-            lo0 = nodes[2 * c]; hi0 = nodes[2 * c + 1]; lo1 = nodes[2 * c + 2]; hi1 = nodes[2 * c + 3];
+            c0 = gp[0]; h0 = gp[1]; c1 = gp[2]; h1 = gp[3];
         }
     };
     // stack nearly full: walk the subtree of one popped entry serially with the stackless (skip-pointer) node array
-    auto drain_serial = [&](int o, int node) {
-        const float4 A = tabA[o], C = tabC[o];
-        const float2 D = tabD[o];
+    auto drain_serial = [&](unsigned int sb, int node) {
+        const float4 C = rowC(sb), D = rowD(sb);
         const f3 O = mk(C.x, C.y, C.z), u = mk(C.w, D.x, D.y);
+        const RayInv ri = ray_inv(u);
         const int xt = sc.q2thr[node];                                // the same node in the stackless array
         const float4 h0 = sc.nodes[2 * xt + 1];
         const int end = __float_as_int(h0.w) >= 0 ? xt + 1 : __float_as_int(sc.nodes[2 * xt].w);
         for (int x = xt; x < end;) {
             const float4 lo = sc.nodes[2 * x], hi = sc.nodes[2 * x + 1];
             const int hiw = __float_as_int(hi.w), low = __float_as_int(lo.w);
-            bool hit;
-            if (!qbox_filter(lo, hi, A, C, hit)) hit = slab(lo, hi, O, u);
+            const bool hit = slab_filtered(lo, hi, O, u, ri);
             if (STATS) { wk.box++; if (hit) wk.nodes++; }
             if (hit && hiw >= 0) {
                 if (STATS) wk.tris += (uint32_t)(hiw - low);
@@ -227,7 +322,7 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || R
                     const float4 *tp = sc.tri + 3 * (size_t)i;
                     float t;
                     if (qtri_test(tp[0], tp[1], tp[2], O, u, fr.tri_tmin, t))
-                        atomicMin(&best[o], (unsigned long long)__float_as_uint(t) << 32 | (unsigned int)i);
+                        atomicMin(best(sb), (unsigned long long)__float_as_uint(t) << 32 | (unsigned int)i);
                 }
             }
             x = (hit || hiw >= 0) ? x + 1 : low;
@@ -242,21 +337,25 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || R
         drained = __builtin_amdgcn_readfirstlane((int)drained) != 0;
         stage_n = __builtin_amdgcn_readfirstlane(stage_n);
         stage_used = __builtin_amdgcn_readfirstlane(stage_used);
+        if (STATS) n_iter++;
+        WQ_MARK("head");
         // =============================== retire + refill ===============================
         if (top < kLow) {
+            if (STATS) n_refill++;
             if (lane < R && path >= 0) {
-                if (pend[lane] == 0) {
-                    st.M[path] = best[lane];          // always: the emitter does not initialise M (WF_NOHIT = no triangle accepted)
+                if (*pend(my_sb) == 0) {
+                    st.M[path] = *best(my_sb);        // always: the emitter does not initialise M (WF_NOHIT = no triangle accepted)
                     path = -1;
                 }
             }
             // refill free slots.  The workgroup owns a spatially scrambled, contiguous share of the traversal queue; its
             // waves take 64 slots at a time through an LDS cursor, flag and record in ONE round trip, and park the rays that
-            // need traversal in the LDS staging area, from where free slots are filled.
+            // need traversal in registers (the LDS staging index says which lane holds the k-th of them), from where free slots are filled.
             for (int round = 0; round < 6 && top < kLow; ++round) {
                 const unsigned long long freem = __ballot(lane < R && path < 0);
                 const int n_free = __popcll(freem);
                 if (n_free == 0 || (n_free < kMinFree && top >= 64)) break;
+                if (STATS) n_round++;
                 if (stage_used >= stage_n) {
                     if (drained) break;
                     int base = 0;
@@ -274,6 +373,7 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || R
                     __builtin_amdgcn_wave_barrier();
                     stage_n = __popcll(am);
                     stage_used = 0;
+                    if (STATS) n_fetch++;
                     if (dbg_on) d_fetch++;
                     if (stage_n == 0) continue;
                 }
@@ -285,50 +385,48 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || R
                 const float4 r0 = make_float4(__shfl(sp0.x, src, 64), __shfl(sp0.y, src, 64), __shfl(sp0.z, src, 64), __shfl(sp0.w, src, 64));
                 const float2 r1 = make_float2(__shfl(sp1.x, src, 64), __shfl(sp1.y, src, 64));
                 const int rf = __shfl(spf, src, 64);
+                // the root box was tested when the ray was emitted (wf_emit_ray): start with what is below it
+                const int first = __float_as_int(sc.root_lo.w), cnt = root_hiw - first;
+                const bool work = root_hiw < 0 || cnt > 0;
                 if (got) {
                     const f3 O = mk(r0.x, r0.y, r0.z), u = mk(r0.w, r1.x, r1.y);
-                    const RayBox rb = ray_box(O, u);
-                    tabA[lane] = make_float4(rb.rx, rb.ry, rb.rz, rb.safe ? rb.c0 : __builtin_inff());
-                    tabC[lane] = r0;
-                    tabD[lane] = r1;
-                    best[lane] = WF_NOHIT;
+                    const RayBoxC rb = ray_box_c(sc, O, u);
+                    rowA(my_sb) = make_float4(rb.rx, rb.ry, rb.rz, rb.c0);
+                    rowO(my_sb) = make_float4(rb.ox, rb.oy, rb.oz, __int_as_float(work ? 1 : 0));      // .w: one outstanding entry
+                    rowC(my_sb) = r0;
+                    rowD(my_sb) = make_float4(r1.x, r1.y, __uint_as_float(0xffffffffu), __uint_as_float(0xffffffffu));   // .zw: WF_NOHIT
                     path = rf - 1;
                     WQ_CHECK(path >= 0 && path < 2 * st.n_paths, 1, path = 0);
                 }
                 stage_used += take;
-                // the root box was tested when the ray was emitted (wf_emit_ray): start with what is below it
                 const unsigned long long gm = __ballot(got);
                 if (dbg_on) { d_rounds++; d_rays += (unsigned int)__popcll(gm); }
                 if (root_hiw < 0) {
-                    if (got) {
-                        stack[top + lanes_below(gm)] = (unsigned int)lane << kQNodeBits | 2u;   // the root (node 1) has the children 2, 3
-                        pend[lane] = 1;
-                    }
+                    if (got) stack[top + lanes_below(gm)] = 2u << kQNodeShift | my_sb;   // the root (node 1) has the children 2, 3
                     top += __popcll(gm);
                 } else {                           // the root is a leaf
-                    const int first = __float_as_int(sc.root_lo.w), cnt = root_hiw - first;
                     if (cnt > 0) {
                         if (got) {
-                            leafq[(ltail + (unsigned int)lanes_below(gm)) & (LCAP - 1)] = make_uint2((unsigned int)first, (unsigned int)lane | (unsigned int)cnt << 8);
-                            pend[lane] = 1;
+                            leafq[(ltail + (unsigned int)lanes_below(gm)) & (LCAP - 1)] = make_uint2((unsigned int)first, (unsigned int)cnt << kQNodeShift | my_sb);
                             if (STATS) wk.tris += (uint32_t)cnt;
                         }
                         ltail += (unsigned int)__popcll(gm);
-                    } else if (got) {
-                        pend[lane] = 0;
                     }
                     break;                         // at most R leaf entries per pass: the TRI steps below drain them
                 }
             }
         }
         WQ_STAMP(cy_srv);
+        WQ_MARK("refill_end");
         // =============================== TRI step: two triangles per lane ===============================
         const unsigned int lcount = ltail - lhead;
         if (lcount >= 64u || (top == 0 && lcount > 0u)) {
+            if (STATS) n_tri++;
+            WQ_MARK("tri_begin");
             const unsigned int m = lcount < 64u ? lcount : 64u;
             uint2 E = make_uint2(0u, 0u);
             if ((unsigned int)lane < m) E = leafq[(lhead + (unsigned int)lane) & (LCAP - 1)];
-            const unsigned int c = E.y >> 8;                         // >= 1 for queued entries, 0 beyond them
+            const unsigned int c = E.y >> kQNodeShift;               // >= 1 for queued entries, 0 beyond them
             const unsigned int incl = wave_incl_scan(c);
             const unsigned int P = incl - c;                         // position of this entry's first triangle
             const bool part = c > 0u && P < 128u;
@@ -346,7 +444,7 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || R
             const unsigned int f0 = (unsigned int)__shfl((int)E.x, j0, 64), y0 = (unsigned int)__shfl((int)E.y, j0, 64), P0 = (unsigned int)__shfl((int)P, j0, 64);
             const unsigned int f1 = (unsigned int)__shfl((int)E.x, j1, 64), y1 = (unsigned int)__shfl((int)E.y, j1, 64), P1 = (unsigned int)__shfl((int)P, j1, 64);
             const bool t0 = (unsigned int)lane < total, t1 = (unsigned int)lane + 64u < total;
-            const int o0 = t0 ? (int)(y0 & 0xffu) : 0, o1 = t1 ? (int)(y1 & 0xffu) : 0;
+            const unsigned int o0 = t0 ? (y0 & kQSlotMask) : 0u, o1 = t1 ? (y1 & kQSlotMask) : 0u;      // the owners' table rows
             int i0 = t0 ? (int)(f0 + ((unsigned int)lane - P0)) : 0, i1 = t1 ? (int)(f1 + ((unsigned int)lane + 64u - P1)) : 0;
             WQ_CHECK(i0 >= 0 && i0 < sc.n_tris && i1 >= 0 && i1 < sc.n_tris, 2, (i0 = 0, i1 = 0));
             WQ_CHECK(ltail - lhead <= (unsigned int)LCAP, 16, (void)0);
@@ -362,28 +460,31 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || R
                 record(ia, a0, a1, a2);
                 record(ib, b0, b1, b2);
             } else {
-                const float4 *tp0 = sc.tri + 3 * (size_t)i0, *tp1 = sc.tri + 3 * (size_t)i1;
+                // 32-bit byte offsets: the loads take the scalar base + vector offset form (n_tris * 48 < 2^32 is checked by the upload)
+                const unsigned char *tb = reinterpret_cast<const unsigned char *>(sc.tri);
+                const float4 *tp0 = reinterpret_cast<const float4 *>(tb + (unsigned int)i0 * 48u), *tp1 = reinterpret_cast<const float4 *>(tb + (unsigned int)i1 * 48u);
                 a0 = tp0[0]; a1 = tp0[1]; a2 = tp0[2];
                 b0 = tp1[0]; b1 = tp1[1]; b2 = tp1[2];
             }
-            const float4 C0 = tabC[o0], C1 = tabC[o1];
-            const float2 D0 = tabD[o0], D1 = tabD[o1];
-            float ta, tb;
+            const float4 C0 = rowC(o0), C1 = rowC(o1);
+            const float2 D0 = *reinterpret_cast<const float2 *>(&rowD(o0)), D1 = *reinterpret_cast<const float2 *>(&rowD(o1));
+            float ta, tb_;
             int how0, how1;
             const bool ok0 = qtri_test(a0, a1, a2, mk(C0.x, C0.y, C0.z), mk(C0.w, D0.x, D0.y), fr.tri_tmin, ta, how0) && t0;
-            const bool ok1 = qtri_test(b0, b1, b2, mk(C1.x, C1.y, C1.z), mk(C1.w, D1.x, D1.y), fr.tri_tmin, tb, how1) && t1;
+            const bool ok1 = qtri_test(b0, b1, b2, mk(C1.x, C1.y, C1.z), mk(C1.w, D1.x, D1.y), fr.tri_tmin, tb_, how1) && t1;
             if (STATS) wk.lit_tri += ((t0 && how0 == 2) ? 1u : 0u) + ((t1 && how1 == 2) ? 1u : 0u);
-            if (ok0) atomicMin(&best[o0], (unsigned long long)__float_as_uint(ta) << 32 | (unsigned int)i0);
-            if (ok1) atomicMin(&best[o1], (unsigned long long)__float_as_uint(tb) << 32 | (unsigned int)i1);
+            if (ok0) atomicMin(best(o0), (unsigned long long)__float_as_uint(ta) << 32 | (unsigned int)i0);
+            if (ok1) atomicMin(best(o1), (unsigned long long)__float_as_uint(tb_) << 32 | (unsigned int)i1);
             const bool full = part && P + c <= 128u;
             if (part && !full) {                                     // at most one entry straddles position 127: keep its rest
                 const unsigned int took = 128u - P;
-                leafq[(lhead + (unsigned int)lane) & (LCAP - 1)] = make_uint2(E.x + took, (E.y & 0xffu) | (c - took) << 8);
+                leafq[(lhead + (unsigned int)lane) & (LCAP - 1)] = make_uint2(E.x + took, (E.y & kQSlotMask) | (c - took) << kQNodeShift);
             }
             lhead += (unsigned int)__popcll(__ballot(full));
-            if (full) atomicAdd(&pend[E.y & 0xffu], -1);            // after the mins above (LDS operations stay in order)
+            if (full) atomicAdd(pend(E.y & kQSlotMask), -1);        // after the mins above (LDS operations stay in order)
             if (dbg_on) { d_tri++; d_tril += total; }
             WQ_STAMP(cy_tri);
+            WQ_MARK("tri_end");
             continue;
         }
         if (top == 0) {
@@ -391,8 +492,7 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || R
             if (dbg_on) d_idle++;
             continue;
         }
-        // =============================== BOX step: KP sibling pairs (2 KP boxes) per lane ===============================
-        constexpr int KP = RT_TRAVQ_KP;
+        // =============================== BOX step: one sibling pair (2 boxes) per lane ===============================
 #if defined(RT_DEBUG) && defined(RT_PAD_SALU)     // sensitivity experiment (tools/pad_experiment.sh): 32 extra scalar / vector issue slots, 4 extra LDS reads per step
         asm volatile("s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n"
                      "s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0");
@@ -403,37 +503,31 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || R
 #if defined(RT_DEBUG) && defined(RT_PAD_LDS)
         { unsigned int pl_ = marks[lane]; pl_ += marks[lane + 64]; pl_ += marks[lane]; pl_ += marks[lane + 64]; asm volatile("" :: "v"(pl_)); }
 #endif
-        const int n = top < 64 * KP ? top : 64 * KP;
-        if (cap - top < 64 * KP) {                                    // no room for up to 128 KP pushes: serial drain of 64 entries
-            const int nd = top < 64 ? top : 64;
-            const bool actd = lane < nd;
+        const int n = top < 64 ? top : 64;
+        if (cap - top < 64) {                                         // no room for up to 128 pushes: serial drain of 64 entries
+            if (STATS) n_serial++;
+            const bool actd = lane < n;
             const unsigned int ed = actd ? stack[top - 1 - lane] : 0u;
-            top -= nd;
-            if (actd) { const int od = (int)(ed >> kQNodeBits), cd = (int)(ed & kQNodeMask); drain_serial(od, cd); drain_serial(od, cd + 1); atomicAdd(&pend[od], -1); }
+            top -= n;
+            if (actd) { const unsigned int sd = ed & kQSlotMask; const int cd = (int)(ed >> kQNodeShift); drain_serial(sd, cd); drain_serial(sd, cd + 1); atomicAdd(pend(sd), -1); }
             if (dbg_on) d_serial++;
             WQ_STAMP(cy_box);
             continue;
         }
-        bool act[KP]; unsigned int e[KP]; int o[KP], c[KP];
-#pragma unroll
-        for (int k = 0; k < KP; ++k) {
-            act[k] = lane + 64 * k < n;
-            e[k] = act[k] ? stack[top - 1 - lane - 64 * k] : 0u;      // slot << 26 | c: the sibling nodes c, c + 1 (one 64-byte line)
-            o[k] = (int)(e[k] >> kQNodeBits);
-            c[k] = (int)(e[k] & kQNodeMask);
-        }
+        if (STATS) n_box++;
+        WQ_MARK("box_begin");
+        const bool act = lane < n;
+        const unsigned int e = act ? stack[top - 1 - lane] : 0u;      // node << 10 | slot << 4: the sibling nodes (one 64-byte line) of the ray in that slot
         top -= n;
-#pragma unroll
-        for (int k = 0; k < KP; ++k) WQ_CHECK(!act[k] || (c[k] >= 2 && c[k] + 1 <= sc.n_nodes), 4, c[k] = 0);
-        float4 A[KP], C[KP], lo0[KP], hi0[KP], lo1[KP], hi1[KP];
-#pragma unroll
-        for (int k = 0; k < KP; ++k) {                                // all loads first: they are in flight together
-            A[k] = tabA[o[k]]; C[k] = tabC[o[k]];                      // siblings belong to one ray: one table read for both
-            load_pair(c[k], lo0[k], hi0[k], lo1[k], hi1[k]);
-        }
-#if defined(RT_DEBUG) && defined(RT_PAD_VMEM)     // sensitivity experiment: the four 16-byte loads of the first pair once more (L1 hits: address / tag pipeline only)
+        const unsigned int sb = e & kQSlotMask;                       // the slot's table row
+        unsigned int off = (e >> 5) & ~31u;                           // the pair's byte offset in the node array
+        WQ_CHECK(!act || ((e >> kQNodeShift) >= 2u && (int)(e >> kQNodeShift) + 1 <= sc.n_nodes && ((e >> kQNodeShift) & 1u) == 0u), 4, off = 0u);
+        const float4 A = rowA(sb), Oo = rowO(sb);                     // siblings belong to one ray: one table read for both
+        float4 c0, h0, c1, h1;
+        load_pair(off, c0, h0, c1, h1);                               // all loads first: they are in flight together
+#if defined(RT_DEBUG) && defined(RT_PAD_VMEM)     // sensitivity experiment: the four 16-byte loads of the pair once more (L1 hits: address / tag pipeline only)
         {
-            const float4 *pp = nodes + 2 * c[0];
+            const unsigned char *pp = nodes + off;
             typedef float pad_v4f __attribute__((ext_vector_type(4)));
             pad_v4f x0, x1, x2, x3;
             asm volatile("global_load_dwordx4 %0, %4, off\n global_load_dwordx4 %1, %4, off offset:16\n global_load_dwordx4 %2, %4, off offset:32\n"
@@ -441,62 +535,77 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || R
             asm volatile("" :: "v"(x0), "v"(x1), "v"(x2), "v"(x3));
         }
 #endif
-        bool hit0[KP], hit1[KP], und = false;
-        bool dec0[KP], dec1[KP];
-#pragma unroll
-        for (int k = 0; k < KP; ++k) {
-            dec0[k] = qbox_filter(lo0[k], hi0[k], A[k], C[k], hit0[k]);
-            dec1[k] = qbox_filter(lo1[k], hi1[k], A[k], C[k], hit1[k]);
-            und = und || (act[k] && !(dec0[k] && dec1[k]));
-            if (STATS) wk.lit_box += act[k] ? (dec0[k] ? 0u : 1u) + (dec1[k] ? 0u : 1u) : 0u;
-        }
-        // literal arithmetic for undecided lanes behind a wave-uniform branch (six IEEE divisions, almost never needed)
-        if (__builtin_expect(__ballot(und) != 0ull, 0)) {
-#pragma unroll
-            for (int k = 0; k < KP; ++k) {
-                if (act[k] && !(dec0[k] && dec1[k])) {
-                    const float2 D = tabD[o[k]];
-                    const f3 O = mk(C[k].x, C[k].y, C[k].z), u = mk(C[k].w, D.x, D.y);
-                    if (!dec0[k]) hit0[k] = slab(lo0[k], hi0[k], O, u);
-                    if (!dec1[k]) hit1[k] = slab(lo1[k], hi1[k], O, u);
-                }
+        // From here on every predicate of the step is a 64-bit LANE MASK in scalar registers: a ballot of a plain comparison is the
+        // comparison's result register, masks combine on the scalar unit, and __builtin_amdgcn_inverse_ballot_w64 turns one into the
+        // execution mask of an `if` (or the selector of a v_cndmask) for free.  Written with bools the compiler materialises each
+        // combined predicate as 0 / 1 in a vector register and compares it back into a mask for its ballot: ten half-rate
+        // instructions per step.
+        bool hit0, miss0, hit1, miss1;
+        cbox_filter(c0, h0, A, Oo, hit0, miss0);
+        cbox_filter(c1, h1, A, Oo, hit1, miss1);
+        const unsigned long long mact = __ballot(act);
+        unsigned long long mh0 = __ballot(hit0), mh1 = __ballot(hit1);
+        const unsigned long long md0 = mh0 | __ballot(miss0), md1 = mh1 | __ballot(miss1);
+        const unsigned long long und = mact & ~(md0 & md1);
+        // literal arithmetic for undecided lanes behind a wave-uniform branch (six IEEE divisions per box, almost never needed)
+        if (__builtin_expect(und != 0ull, 0)) {
+            if (STATS) n_lit++;
+            bool l0 = false, l1 = false;
+            const bool u0 = __builtin_amdgcn_inverse_ballot_w64(mact & ~md0), u1 = __builtin_amdgcn_inverse_ballot_w64(mact & ~md1);
+            if (STATS) wk.lit_box += (u0 ? 1u : 0u) + (u1 ? 1u : 0u);
+            if (u0 || u1) {
+                const float4 C = rowC(sb), D = rowD(sb);
+                const f3 O = mk(C.x, C.y, C.z), u = mk(C.w, D.x, D.y);
+                const float4 *bp = sc.nodesq + (off >> 4);            // the same pair as (lo, hi): the breadth-first array of the boxes themselves
+                if (u0) l0 = slab(bp[0], bp[1], O, u);
+                if (u1) l1 = slab(bp[2], bp[3], O, u);
             }
+            mh0 = (mh0 & md0) | __ballot(l0);
+            mh1 = (mh1 & md1) | __ballot(l1);
         }
-#pragma unroll
-        for (int k = 0; k < KP; ++k) {
-            const int hiw0 = __float_as_int(hi0[k].w), low0 = __float_as_int(lo0[k].w), cnt0 = hiw0 - low0;
-            const int hiw1 = __float_as_int(hi1[k].w), low1 = __float_as_int(lo1[k].w), cnt1 = hiw1 - low1;
-            const bool h0 = hit0[k] && act[k], h1 = hit1[k] && act[k];
-            const bool hI0 = h0 && hiw0 < 0, hI1 = h1 && hiw1 < 0;
-            const bool hL0 = h0 && hiw0 >= 0 && cnt0 > 0, hL1 = h1 && hiw1 >= 0 && cnt1 > 0;
+        {
+            const int k0 = __float_as_int(h0.w), k1 = __float_as_int(h1.w);               // kind: < 0 internal, > 0 leaf (count << 10), 0 empty leaf
+            const unsigned int p0 = __float_as_uint(c0.w), p1 = __float_as_uint(c1.w);   // payload: first child << 10 | first triangle
+            const unsigned long long g0 = mh0 & mact, g1 = mh1 & mact;
+            const unsigned long long mI0 = g0 & __ballot(k0 < 0), mI1 = g1 & __ballot(k1 < 0), mL0 = g0 & __ballot(k0 > 0), mL1 = g1 & __ballot(k1 > 0);
             if (STATS) {
-                wk.box += act[k] ? 2u : 0u; wk.nodes += (h0 ? 1u : 0u) + (h1 ? 1u : 0u);
-                wk.tris += ((h0 && hiw0 >= 0) ? (uint32_t)cnt0 : 0u) + ((h1 && hiw1 >= 0) ? (uint32_t)cnt1 : 0u);
+                const bool b0 = __builtin_amdgcn_inverse_ballot_w64(g0), b1 = __builtin_amdgcn_inverse_ballot_w64(g1);
+                wk.box += act ? 2u : 0u; wk.nodes += (b0 ? 1u : 0u) + (b1 ? 1u : 0u);
+                wk.tris += ((b0 && k0 > 0) ? (uint32_t)(k0 >> kQNodeShift) : 0u) + ((b1 && k1 > 0) ? (uint32_t)(k1 >> kQNodeShift) : 0u);
             }
-            const unsigned long long mI0 = __ballot(hI0), mI1 = __ballot(hI1), mL0 = __ballot(hL0), mL1 = __ballot(hL1);
-            const int nI0 = __popcll(mI0), nL0 = __popcll(mL0);
-            const unsigned int sbits = e[k] & ~kQNodeMask;
-            if (hI0) stack[top + lanes_below(mI0)] = sbits | (unsigned int)low0;        // a hit internal node pushes ITS pair of children
-            if (hI1) stack[top + nI0 + lanes_below(mI1)] = sbits | (unsigned int)low1;
-            top += nI0 + __popcll(mI1);
-            if (hL0) leafq[(ltail + (unsigned int)lanes_below(mL0)) & (LCAP - 1)] = make_uint2((unsigned int)low0, (unsigned int)o[k] | (unsigned int)cnt0 << 8);
-            if (hL1) leafq[(ltail + (unsigned int)(nL0 + lanes_below(mL1))) & (LCAP - 1)] = make_uint2((unsigned int)low1, (unsigned int)o[k] | (unsigned int)cnt1 << 8);
-            ltail += (unsigned int)(nL0 + __popcll(mL1));
+            // a hit internal node pushes ITS pair of children; the order of entries on the stack does not matter (the traversal is a bag),
+            // so a lane's one or two entries go next to each other: one prefix count over both masks, one address
+            const int oI = lanes_below2(mI0, mI1);
+            unsigned int *const sp = stack + top + oI;
+            const bool sI0 = __builtin_amdgcn_inverse_ballot_w64(mI0), sL0 = __builtin_amdgcn_inverse_ballot_w64(mL0);
+            if (__builtin_amdgcn_inverse_ballot_w64(mI0 | mI1)) sp[0] = (sI0 ? p0 : p1) | sb;
+            if (__builtin_amdgcn_inverse_ballot_w64(mI0 & mI1)) sp[1] = p1 | sb;
+            top += __popcll(mI0) + __popcll(mI1);
+            const unsigned int oL = ltail + (unsigned int)lanes_below2(mL0, mL1);
+            if (__builtin_amdgcn_inverse_ballot_w64(mL0 | mL1)) leafq[oL & (LCAP - 1)] = make_uint2(sL0 ? p0 : p1, (unsigned int)(sL0 ? k0 : k1) | sb);
+            if (__builtin_amdgcn_inverse_ballot_w64(mL0 & mL1)) leafq[(oL + 1u) & (LCAP - 1)] = make_uint2(p1, (unsigned int)k1 | sb);
+            ltail += (unsigned int)(__popcll(mL0) + __popcll(mL1));
             // outstanding entries of the ray: this pair is gone (-1), every pushed pair and leaf entry counts +1: one LDS add per lane
-            const int delta = (hI0 ? 1 : 0) + (hI1 ? 1 : 0) + (hL0 ? 1 : 0) + (hL1 ? 1 : 0) - (act[k] ? 1 : 0);
-            if (delta != 0) atomicAdd(&pend[o[k]], delta);
+            const int delta = lane_count4_minus(mI0, mI1, mL0, mL1, mact);
+            if (delta != 0) atomicAdd(pend(sb), delta);
         }
         WQ_CHECK(top >= 0 && top <= cap && top <= SCAP, 8, (void)0);
         if (dbg_on) { d_box++; d_boxl += 2u * (unsigned int)n; if ((unsigned int)top > d_maxtop) d_maxtop = (unsigned int)top; }
         WQ_STAMP(cy_box);
+        WQ_MARK("box_end");
     }
 #undef WQ_STAMP
 #undef WQ_CHECK
+#undef WQ_MARK
     if (dbg_on && lane == 0) {
         unsigned long long *d = st.dbg + 16 * (size_t)((blockIdx.x * blockDim.x + tid) >> 6);
         d[0] = dbg_t0; d[1] = __builtin_amdgcn_s_memrealtime(); d[2] = d_box; d[3] = d_boxl; d[4] = d_tri; d[5] = d_tril;
         d[6] = d_rounds; d[7] = d_rays; d[8] = d_serial; d[9] = cy_srv; d[10] = cy_tri; d[11] = cy_box; d[12] = dbg_tdrain; d[13] = d_idle;
         d[14] = d_fetch; d[15] = d_maxtop;
+    }
+    if (STATS && lane == 0) {
+        const unsigned int v[8] = {n_iter, n_refill, n_round, n_fetch, n_tri, n_box, n_lit, n_serial};
+        for (int k = 0; k < 8; ++k) if (v[k]) atomicAdd(&fr.work[8 + k], (unsigned long long)v[k]);
     }
     wf_flush_work<STATS>(fr, wk);
 }

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_capi.EXPORTS) == names
-    assert lib.rt_abi_version() == 2
+    assert lib.rt_abi_version() == 3
 
 
 def test_struct_sizes_match_header():
