@@ -31,7 +31,10 @@ namespace rtk {
 #define RT_TRAVQ_BLOCK 256
 #endif
 constexpr int kQBlock = RT_TRAVQ_BLOCK;      // 4 waves per workgroup share one ray-slot cursor (128 / 512 measured: no better)
-constexpr int kQLeafCap = 256;               // leaf-queue entries per wave: < 64 before a BOX step, which appends up to 128
+#ifndef RT_TRAVQ_KP
+#define RT_TRAVQ_KP 1                        // sibling pairs per lane and BOX step
+#endif
+constexpr int kQLeafCap = 256 * RT_TRAVQ_KP;  // leaf-queue entries per wave: < 64 before a BOX step, which appends up to 128 per pair
 // Stack entry (32 bits) = node << 10 | slot << 4: the sibling pair of nodes (node, node + 1) of the ray in slot `slot`.  Both fields are
 // stored the way they are used: entry & 0x3f0 is the byte offset of the slot's row in the four per-slot tables (16-byte rows),
 // (entry >> 5) & ~31 the byte offset of the pair in the node array (32 bytes per node).  A leaf-queue entry is (first triangle,
@@ -44,7 +47,10 @@ constexpr int kQMaxLeaf = 1 << 21;           // triangles per leaf: count << 10 
 
 // stack capacity: sized so that four waves' carves (+ the cursor) fill 36 KiB (R = 64: 4 workgroups per CU) or less;
 // a fuller stack is drained serially (see above), which the cat never needs
-template <int R> struct QStackCap { static constexpr int value = 652; };
+#ifndef RT_TRAVQ_SCAP
+#define RT_TRAVQ_SCAP 652
+#endif
+template <int R> struct QStackCap { static constexpr int value = RT_TRAVQ_SCAP; };
 
 // Per-wave LDS carve.  Four tables of 16-byte rows indexed by ray slot, so that ONE address register (wave base + slot * 16)
 // reaches everything a step needs about a ray through the instructions' immediate offsets:
@@ -170,8 +176,9 @@ __host__ __device__ inline float box_half(float lo, float hi) { return (float)((
 // itself < -E, which the reference rejects too -- takes the literal expression.  Constant thresholds instead of the earlier
 // per-value bands: 7 half-rate + 1 full-rate instruction instead of 12 + 7; the undecided band is 2^-16 wide instead of 2^-20,
 // still one test in ~10^4.
+// `valid` = false: the lane holds no test (padding of a TRI step); it takes neither the literal nor the division branch.
 __device__ __forceinline__ bool qtri_test(const float4 q0, const float4 q1, const float4 q2, const f3 Oo, const f3 uo,
-                                          const float tri_tmin, float &t_out, int &how) {
+                                          const float tri_tmin, float &t_out, int &how, const bool valid = true) {
     const f3 A = mk(q0.x, q0.y, q0.z), e1 = mk(q0.w, q1.x, q1.y), e2 = mk(q1.z, q1.w, q2.x);
     const f3 N = mk(q2.y, q2.z, q2.w);
     const float det = dot(uo, N);
@@ -186,9 +193,9 @@ __device__ __forceinline__ bool qtri_test(const float4 q0, const float4 q1, cons
     const float mbg = vmin(b, g);
     const bool trust = __builtin_amdgcn_classf(rd, 0x108);      // rd is +-normal
     const bool reject = trust && (mbg < -kE || sum > 1.f + 3.f * kE);
-    bool ok = trust && mbg >= kE && sum <= 1.f - 3.f * kE;
+    bool ok = trust && mbg >= kE && sum <= 1.f - 3.f * kE && valid;
     how = ok ? 1 : 0;
-    if (!reject && !ok) {                       // undecided: the literal tests (rare)
+    if (!reject && !ok && valid) {              // undecided: the literal tests (rare)
         how = 2;
         if (det != 0) {                         // cpu:230
             const float beta = bn / det;
@@ -218,7 +225,7 @@ __device__ __forceinline__ bool qtri_test(const float4 q0, const float4 q1, cons
 // static per-step instruction counts of the production code object, tools/static_counts.py): loop iterations, refill passes
 // entered, refill rounds, queue fetches, TRI steps, BOX steps, literal-box fall-backs taken, serial drains.
 template <bool STATS, int R, bool LDSN, bool LDSV>
-__global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || kQBlock != 256) ? 4 : 5) void wf_travq(const Scene sc, const Frame fr, const WfState st, const int cap, const int n_lds, const int kLow, const int kMinFree) {
+__global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || kQBlock != 256 || RT_TRAVQ_KP > 1) ? 4 : 5) void wf_travq(const Scene sc, const Frame fr, const WfState st, const int cap, const int n_lds, const int kLow, const int kMinFree) {
     // kLow: refill while the stack holds fewer entries (sibling pairs) than this (default 48); kMinFree: ... and at least this
     // many slots are free, or the stack is short (default R / 4)
     constexpr int SCAP = QStackCap<R>::value, LCAP = kQLeafCap;
@@ -438,13 +445,14 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
             const unsigned long long B0 = __ballot(mk0 != 0u), B1 = __ballot(mk1 != 0u);
             __builtin_amdgcn_wave_barrier();
             if (part) marks[P] = 0;
-            // entry whose triangle range covers position lane (j0) and position lane + 64 (j1)
-            const int j0 = lanes_below(B0) + (int)((B0 >> lane) & 1ull) - 1;
-            const int j1 = __popcll(B0) + lanes_below(B1) + (int)((B1 >> lane) & 1ull) - 1;
-            const unsigned int f0 = (unsigned int)__shfl((int)E.x, j0, 64), y0 = (unsigned int)__shfl((int)E.y, j0, 64), P0 = (unsigned int)__shfl((int)P, j0, 64);
-            const unsigned int f1 = (unsigned int)__shfl((int)E.x, j1, 64), y1 = (unsigned int)__shfl((int)E.y, j1, 64), P1 = (unsigned int)__shfl((int)P, j1, 64);
+            // entry whose triangle range covers position lane (j0) and position lane + 64 (j1): marks at or below the position, minus one
+            // (a mark byte is the lane's own bit of B0 / B1); ds_bpermute takes the source lane as a byte address
+            const int j0 = (lanes_below(B0) + (int)mk0 - 1) << 2;
+            const int j1 = (__popcll(B0) + lanes_below(B1) + (int)mk1 - 1) << 2;
+            const unsigned int f0 = (unsigned int)__builtin_amdgcn_ds_bpermute(j0, (int)E.x), y0 = (unsigned int)__builtin_amdgcn_ds_bpermute(j0, (int)E.y), P0 = (unsigned int)__builtin_amdgcn_ds_bpermute(j0, (int)P);
+            const unsigned int f1 = (unsigned int)__builtin_amdgcn_ds_bpermute(j1, (int)E.x), y1 = (unsigned int)__builtin_amdgcn_ds_bpermute(j1, (int)E.y), P1 = (unsigned int)__builtin_amdgcn_ds_bpermute(j1, (int)P);
             const bool t0 = (unsigned int)lane < total, t1 = (unsigned int)lane + 64u < total;
-            const unsigned int o0 = t0 ? (y0 & kQSlotMask) : 0u, o1 = t1 ? (y1 & kQSlotMask) : 0u;      // the owners' table rows
+            const unsigned int o0 = y0 & kQSlotMask, o1 = y1 & kQSlotMask;      // the owners' table rows (positions beyond `total` read some entry's row: harmless)
             int i0 = t0 ? (int)(f0 + ((unsigned int)lane - P0)) : 0, i1 = t1 ? (int)(f1 + ((unsigned int)lane + 64u - P1)) : 0;
             WQ_CHECK(i0 >= 0 && i0 < sc.n_tris && i1 >= 0 && i1 < sc.n_tris, 2, (i0 = 0, i1 = 0));
             WQ_CHECK(ltail - lhead <= (unsigned int)LCAP, 16, (void)0);
@@ -470,8 +478,8 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
             const float2 D0 = *reinterpret_cast<const float2 *>(&rowD(o0)), D1 = *reinterpret_cast<const float2 *>(&rowD(o1));
             float ta, tb_;
             int how0, how1;
-            const bool ok0 = qtri_test(a0, a1, a2, mk(C0.x, C0.y, C0.z), mk(C0.w, D0.x, D0.y), fr.tri_tmin, ta, how0) && t0;
-            const bool ok1 = qtri_test(b0, b1, b2, mk(C1.x, C1.y, C1.z), mk(C1.w, D1.x, D1.y), fr.tri_tmin, tb_, how1) && t1;
+            const bool ok0 = qtri_test(a0, a1, a2, mk(C0.x, C0.y, C0.z), mk(C0.w, D0.x, D0.y), fr.tri_tmin, ta, how0, t0);
+            const bool ok1 = qtri_test(b0, b1, b2, mk(C1.x, C1.y, C1.z), mk(C1.w, D1.x, D1.y), fr.tri_tmin, tb_, how1, t1);
             if (STATS) wk.lit_tri += ((t0 && how0 == 2) ? 1u : 0u) + ((t1 && how1 == 2) ? 1u : 0u);
             if (ok0) atomicMin(best(o0), (unsigned long long)__float_as_uint(ta) << 32 | (unsigned int)i0);
             if (ok1) atomicMin(best(o1), (unsigned long long)__float_as_uint(tb_) << 32 | (unsigned int)i1);
@@ -503,12 +511,14 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
 #if defined(RT_DEBUG) && defined(RT_PAD_LDS)
         { unsigned int pl_ = marks[lane]; pl_ += marks[lane + 64]; pl_ += marks[lane]; pl_ += marks[lane + 64]; asm volatile("" :: "v"(pl_)); }
 #endif
-        const int n = top < 64 ? top : 64;
-        if (cap - top < 64) {                                         // no room for up to 128 pushes: serial drain of 64 entries
+        constexpr int KP = RT_TRAVQ_KP;                             // sibling pairs per lane and step: the loads of all of them are in flight together
+        const int n = top < 64 * KP ? top : 64 * KP;
+        if (cap - top < 64 * KP) {                                         // no room for up to 128 pushes: serial drain of 64 entries
             if (STATS) n_serial++;
-            const bool actd = lane < n;
+            const int nd = top < 64 ? top : 64;
+            const bool actd = lane < nd;
             const unsigned int ed = actd ? stack[top - 1 - lane] : 0u;
-            top -= n;
+            top -= nd;
             if (actd) { const unsigned int sd = ed & kQSlotMask; const int cd = (int)(ed >> kQNodeShift); drain_serial(sd, cd); drain_serial(sd, cd + 1); atomicAdd(pend(sd), -1); }
             if (dbg_on) d_serial++;
             WQ_STAMP(cy_box);
@@ -516,18 +526,25 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
         }
         if (STATS) n_box++;
         WQ_MARK("box_begin");
-        const bool act = lane < n;
-        const unsigned int e = act ? stack[top - 1 - lane] : 0u;      // node << 10 | slot << 4: the sibling nodes (one 64-byte line) of the ray in that slot
+        bool act_[KP]; unsigned int e_[KP], sb_[KP], off_[KP];
+        float4 A_[KP], Oo_[KP], c0_[KP], h0_[KP], c1_[KP], h1_[KP];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            act_[k] = lane + 64 * k < n;
+            e_[k] = act_[k] ? stack[top - 1 - lane - 64 * k] : 0u;   // node << 10 | slot << 4: the sibling nodes (one 64-byte line) of the ray in that slot
+            sb_[k] = e_[k] & kQSlotMask;                             // the slot's table row
+            off_[k] = (e_[k] >> 5) & ~31u;                           // the pair's byte offset in the node array
+            WQ_CHECK(!act_[k] || ((e_[k] >> kQNodeShift) >= 2u && (int)(e_[k] >> kQNodeShift) + 1 <= sc.n_nodes && ((e_[k] >> kQNodeShift) & 1u) == 0u), 4, off_[k] = 0u);
+        }
         top -= n;
-        const unsigned int sb = e & kQSlotMask;                       // the slot's table row
-        unsigned int off = (e >> 5) & ~31u;                           // the pair's byte offset in the node array
-        WQ_CHECK(!act || ((e >> kQNodeShift) >= 2u && (int)(e >> kQNodeShift) + 1 <= sc.n_nodes && ((e >> kQNodeShift) & 1u) == 0u), 4, off = 0u);
-        const float4 A = rowA(sb), Oo = rowO(sb);                     // siblings belong to one ray: one table read for both
-        float4 c0, h0, c1, h1;
-        load_pair(off, c0, h0, c1, h1);                               // all loads first: they are in flight together
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {                                // all loads first: they are in flight together
+            A_[k] = rowA(sb_[k]); Oo_[k] = rowO(sb_[k]);              // siblings belong to one ray: one table read for both
+            load_pair(off_[k], c0_[k], h0_[k], c1_[k], h1_[k]);
+        }
 #if defined(RT_DEBUG) && defined(RT_PAD_VMEM)     // sensitivity experiment: the four 16-byte loads of the pair once more (L1 hits: address / tag pipeline only)
         {
-            const unsigned char *pp = nodes + off;
+            const unsigned char *pp = nodes + off_[0];
             typedef float pad_v4f __attribute__((ext_vector_type(4)));
             pad_v4f x0, x1, x2, x3;
             asm volatile("global_load_dwordx4 %0, %4, off\n global_load_dwordx4 %1, %4, off offset:16\n global_load_dwordx4 %2, %4, off offset:32\n"
@@ -535,59 +552,65 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
             asm volatile("" :: "v"(x0), "v"(x1), "v"(x2), "v"(x3));
         }
 #endif
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const bool act = act_[k];
+            const unsigned int sb = sb_[k], off = off_[k];
+            const float4 A = A_[k], Oo = Oo_[k], c0 = c0_[k], h0 = h0_[k], c1 = c1_[k], h1 = h1_[k];
         // From here on every predicate of the step is a 64-bit LANE MASK in scalar registers: a ballot of a plain comparison is the
-        // comparison's result register, masks combine on the scalar unit, and __builtin_amdgcn_inverse_ballot_w64 turns one into the
-        // execution mask of an `if` (or the selector of a v_cndmask) for free.  Written with bools the compiler materialises each
-        // combined predicate as 0 / 1 in a vector register and compares it back into a mask for its ballot: ten half-rate
-        // instructions per step.
-        bool hit0, miss0, hit1, miss1;
-        cbox_filter(c0, h0, A, Oo, hit0, miss0);
-        cbox_filter(c1, h1, A, Oo, hit1, miss1);
-        const unsigned long long mact = __ballot(act);
-        unsigned long long mh0 = __ballot(hit0), mh1 = __ballot(hit1);
-        const unsigned long long md0 = mh0 | __ballot(miss0), md1 = mh1 | __ballot(miss1);
-        const unsigned long long und = mact & ~(md0 & md1);
-        // literal arithmetic for undecided lanes behind a wave-uniform branch (six IEEE divisions per box, almost never needed)
-        if (__builtin_expect(und != 0ull, 0)) {
-            if (STATS) n_lit++;
-            bool l0 = false, l1 = false;
-            const bool u0 = __builtin_amdgcn_inverse_ballot_w64(mact & ~md0), u1 = __builtin_amdgcn_inverse_ballot_w64(mact & ~md1);
-            if (STATS) wk.lit_box += (u0 ? 1u : 0u) + (u1 ? 1u : 0u);
-            if (u0 || u1) {
-                const float4 C = rowC(sb), D = rowD(sb);
-                const f3 O = mk(C.x, C.y, C.z), u = mk(C.w, D.x, D.y);
-                const float4 *bp = sc.nodesq + (off >> 4);            // the same pair as (lo, hi): the breadth-first array of the boxes themselves
-                if (u0) l0 = slab(bp[0], bp[1], O, u);
-                if (u1) l1 = slab(bp[2], bp[3], O, u);
+            // comparison's result register, masks combine on the scalar unit, and __builtin_amdgcn_inverse_ballot_w64 turns one into the
+            // execution mask of an `if` (or the selector of a v_cndmask) for free.  Written with bools the compiler materialises each
+            // combined predicate as 0 / 1 in a vector register and compares it back into a mask for its ballot: ten half-rate
+            // instructions per step.
+            bool hit0, miss0, hit1, miss1;
+            cbox_filter(c0, h0, A, Oo, hit0, miss0);
+            cbox_filter(c1, h1, A, Oo, hit1, miss1);
+            const unsigned long long mact = __ballot(act);
+            unsigned long long mh0 = __ballot(hit0), mh1 = __ballot(hit1);
+            const unsigned long long md0 = mh0 | __ballot(miss0), md1 = mh1 | __ballot(miss1);
+            const unsigned long long und = mact & ~(md0 & md1);
+            // literal arithmetic for undecided lanes behind a wave-uniform branch (six IEEE divisions per box, almost never needed)
+            if (__builtin_expect(und != 0ull, 0)) {
+                if (STATS) n_lit++;
+                bool l0 = false, l1 = false;
+                const bool u0 = __builtin_amdgcn_inverse_ballot_w64(mact & ~md0), u1 = __builtin_amdgcn_inverse_ballot_w64(mact & ~md1);
+                if (STATS) wk.lit_box += (u0 ? 1u : 0u) + (u1 ? 1u : 0u);
+                if (u0 || u1) {
+                    const float4 C = rowC(sb), D = rowD(sb);
+                    const f3 O = mk(C.x, C.y, C.z), u = mk(C.w, D.x, D.y);
+                    const float4 *bp = sc.nodesq + (off >> 4);            // the same pair as (lo, hi): the breadth-first array of the boxes themselves
+                    if (u0) l0 = slab(bp[0], bp[1], O, u);
+                    if (u1) l1 = slab(bp[2], bp[3], O, u);
+                }
+                mh0 = (mh0 & md0) | __ballot(l0);
+                mh1 = (mh1 & md1) | __ballot(l1);
             }
-            mh0 = (mh0 & md0) | __ballot(l0);
-            mh1 = (mh1 & md1) | __ballot(l1);
-        }
-        {
-            const int k0 = __float_as_int(h0.w), k1 = __float_as_int(h1.w);               // kind: < 0 internal, > 0 leaf (count << 10), 0 empty leaf
-            const unsigned int p0 = __float_as_uint(c0.w), p1 = __float_as_uint(c1.w);   // payload: first child << 10 | first triangle
-            const unsigned long long g0 = mh0 & mact, g1 = mh1 & mact;
-            const unsigned long long mI0 = g0 & __ballot(k0 < 0), mI1 = g1 & __ballot(k1 < 0), mL0 = g0 & __ballot(k0 > 0), mL1 = g1 & __ballot(k1 > 0);
-            if (STATS) {
-                const bool b0 = __builtin_amdgcn_inverse_ballot_w64(g0), b1 = __builtin_amdgcn_inverse_ballot_w64(g1);
-                wk.box += act ? 2u : 0u; wk.nodes += (b0 ? 1u : 0u) + (b1 ? 1u : 0u);
-                wk.tris += ((b0 && k0 > 0) ? (uint32_t)(k0 >> kQNodeShift) : 0u) + ((b1 && k1 > 0) ? (uint32_t)(k1 >> kQNodeShift) : 0u);
+            {
+                const int k0 = __float_as_int(h0.w), k1 = __float_as_int(h1.w);               // kind: < 0 internal, > 0 leaf (count << 10), 0 empty leaf
+                const unsigned int p0 = __float_as_uint(c0.w), p1 = __float_as_uint(c1.w);   // payload: first child << 10 | first triangle
+                const unsigned long long g0 = mh0 & mact, g1 = mh1 & mact;
+                const unsigned long long mI0 = g0 & __ballot(k0 < 0), mI1 = g1 & __ballot(k1 < 0), mL0 = g0 & __ballot(k0 > 0), mL1 = g1 & __ballot(k1 > 0);
+                if (STATS) {
+                    const bool b0 = __builtin_amdgcn_inverse_ballot_w64(g0), b1 = __builtin_amdgcn_inverse_ballot_w64(g1);
+                    wk.box += act ? 2u : 0u; wk.nodes += (b0 ? 1u : 0u) + (b1 ? 1u : 0u);
+                    wk.tris += ((b0 && k0 > 0) ? (uint32_t)(k0 >> kQNodeShift) : 0u) + ((b1 && k1 > 0) ? (uint32_t)(k1 >> kQNodeShift) : 0u);
+                }
+                // a hit internal node pushes ITS pair of children; the order of entries on the stack does not matter (the traversal is a bag),
+                // so a lane's one or two entries go next to each other: one prefix count over both masks, one address
+                const int oI = lanes_below2(mI0, mI1);
+                unsigned int *const sp = stack + top + oI;
+                const bool sI0 = __builtin_amdgcn_inverse_ballot_w64(mI0), sL0 = __builtin_amdgcn_inverse_ballot_w64(mL0);
+                if (__builtin_amdgcn_inverse_ballot_w64(mI0 | mI1)) sp[0] = (sI0 ? p0 : p1) | sb;
+                if (__builtin_amdgcn_inverse_ballot_w64(mI0 & mI1)) sp[1] = p1 | sb;
+                top += __popcll(mI0) + __popcll(mI1);
+                const unsigned int oL = ltail + (unsigned int)lanes_below2(mL0, mL1);
+                if (__builtin_amdgcn_inverse_ballot_w64(mL0 | mL1)) leafq[oL & (LCAP - 1)] = make_uint2(sL0 ? p0 : p1, (unsigned int)(sL0 ? k0 : k1) | sb);
+                if (__builtin_amdgcn_inverse_ballot_w64(mL0 & mL1)) leafq[(oL + 1u) & (LCAP - 1)] = make_uint2(p1, (unsigned int)k1 | sb);
+                ltail += (unsigned int)(__popcll(mL0) + __popcll(mL1));
+                // outstanding entries of the ray: this pair is gone (-1), every pushed pair and leaf entry counts +1: one LDS add per lane
+                const int delta = lane_count4_minus(mI0, mI1, mL0, mL1, mact);
+                if (delta != 0) atomicAdd(pend(sb), delta);
             }
-            // a hit internal node pushes ITS pair of children; the order of entries on the stack does not matter (the traversal is a bag),
-            // so a lane's one or two entries go next to each other: one prefix count over both masks, one address
-            const int oI = lanes_below2(mI0, mI1);
-            unsigned int *const sp = stack + top + oI;
-            const bool sI0 = __builtin_amdgcn_inverse_ballot_w64(mI0), sL0 = __builtin_amdgcn_inverse_ballot_w64(mL0);
-            if (__builtin_amdgcn_inverse_ballot_w64(mI0 | mI1)) sp[0] = (sI0 ? p0 : p1) | sb;
-            if (__builtin_amdgcn_inverse_ballot_w64(mI0 & mI1)) sp[1] = p1 | sb;
-            top += __popcll(mI0) + __popcll(mI1);
-            const unsigned int oL = ltail + (unsigned int)lanes_below2(mL0, mL1);
-            if (__builtin_amdgcn_inverse_ballot_w64(mL0 | mL1)) leafq[oL & (LCAP - 1)] = make_uint2(sL0 ? p0 : p1, (unsigned int)(sL0 ? k0 : k1) | sb);
-            if (__builtin_amdgcn_inverse_ballot_w64(mL0 & mL1)) leafq[(oL + 1u) & (LCAP - 1)] = make_uint2(p1, (unsigned int)k1 | sb);
-            ltail += (unsigned int)(__popcll(mL0) + __popcll(mL1));
-            // outstanding entries of the ray: this pair is gone (-1), every pushed pair and leaf entry counts +1: one LDS add per lane
-            const int delta = lane_count4_minus(mI0, mI1, mL0, mL1, mact);
-            if (delta != 0) atomicAdd(pend(sb), delta);
         }
         WQ_CHECK(top >= 0 && top <= cap && top <= SCAP, 8, (void)0);
         if (dbg_on) { d_box++; d_boxl += 2u * (unsigned int)n; if ((unsigned int)top > d_maxtop) d_maxtop = (unsigned int)top; }
