@@ -2,7 +2,7 @@
 """bench.py -- headline benchmark of the render hot path (BASELINE.json: Mrays/s + ms/frame, cat mesh
 1920x1080, at 1/2/4/8 MI355X).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts its own N ranks, see self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one frame of the workload: the cat scene of cpu_launcher.cpp (walls + cat mesh + array BVH),
@@ -13,14 +13,19 @@ tiles to rank 0, which de-interleaves them (all inside the timed region).  Total
 
 Rank 0 prints one JSON line.  `value` = rays traced per second (1 ray = 1 Scene::intersect_all call:
 primary, shadow or bounce segment; counted exactly by the kernel in the framebuffer's .w channel).
-`roofline` prices the render kernel against the HBM roofline with the ALGORITHMIC bytes of SURVEY 8d
-(24 B/box test + 16 B/node + 48 B/triangle test + 16 B/pixel).  `cpu_baseline` is the CPU restatement of
+`roofline` prices the dominant kernel (wf_travq) against what binds it, vector-instruction issue: the vector wave-instructions of
+one launch -- step counts of the counting instantiation in THIS run x the static per-step instruction counts of the production
+code object (tools/static_counts.py, written by build()) -- over that launch's duration (HIP events on its stream), against
+1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction.  The nominal HBM figure of SURVEY 8d (24 B/box test + 16 B/node +
+48 B/triangle test of a cache-resident scene) stays beside it as `nominal_hbm_frac`.  `cpu_baseline` is the CPU restatement of
 cpu_launcher.cpp (oracle/, OpenMP schedule(dynamic,1) over rows like cpu:695) timed on this host.
 """
 import argparse
 import json
 import os
+import socket
 import statistics
+import subprocess
 import sys
 import time
 
@@ -30,6 +35,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+VALU_PEAK_GINST = 1024 * 2.4 / 4   # vector wave-instructions per ns the chip can issue: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64
+                                   # instruction (the guide's single-issue cost; min / max / compares take exactly that, fma / mul / add about
+                                   # half of it when several waves share a SIMD: tools/ubench/issue_table.hip, profiles/round3/issue_table.jsonl)
 TILE_ROWS = 8              # == raytracinggpu_amd.tiling.TILE_ROWS
 
 def parse():
@@ -47,7 +55,45 @@ def parse():
                     help="N > 1: what rank 0 gathers -- the float4 tiles (parity path, default) or the tonemapped RGB8 tiles (PNG path, 3 B/pixel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--large-steps", type=int, default=4, help="frames of the second timed point (cat 7680x4320, BASELINE config 5) in the same run; 0 = skip")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="TEST: every rank renders on GPU 0 and the exchange runs over gloo (RCCL refuses several ranks on one device); rehearses the N-rank path on a one-GPU box")
+    ap.add_argument("--renderer", default="hip", choices=["hip", "oracle"],
+                    help="TEST: 'oracle' renders every rank's tiles with the CPU restatement over gloo (launcher / partition / gather plumbing without a GPU); its line carries value = null")
+    ap.add_argument("--dump-frame", default="", help="rank 0 saves the (gathered) float4 frame of the first step as .npy (tests)")
+    ap.add_argument("--check-frame", action="store_true", help="rank 0 renders the whole frame alone as well and reports whether the gathered frame equals it bit for bit")
     return ap.parse_args()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no torch.distributed environment: start the N ranks ourselves, BEFORE anything
+    in this process touches the GPU (the reference's harness starts its workers itself too, benchmark.py:19-33), relay rank 0's
+    JSON line and the exit code.  Nothing here imports torch.cuda or the library."""
+    n = args.gpus
+    if args.renderer == "hip" and not args.share_gpu:
+        import torch                                                  # device_count() does not initialise the GPU on this image
+        have = torch.cuda.device_count()
+        if have < n:
+            raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible to this process; one rank per GPU is required "
+                             f"(--share-gpu rehearses the {n}-rank path on one device over gloo)")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    elif r.stdout:
+        sys.stderr.write(r.stdout)
+    sys.exit(r.returncode if r.returncode else (0 if lines else 1))
 
 
 def build_scene(rt, ctx, scene):
@@ -147,17 +193,18 @@ def reference_check(sc, threads):
 def single_stream_launch_ms(rt, args, p, rows, local, stream):
     """Average duration of ONE launch of the dominant kernel when it owns the chip: a second context created under
     RT_PARTS=1 (knobs are read once per context) renders the same frames as one sub-frame on one stream; the library
-    brackets the traversal launches with HIP events on the stream they run on."""
+    brackets the traversal launches with HIP events on the stream they run on (rt_stats_enable: production frames record none)."""
     old = os.environ.get("RT_PARTS")
     os.environ["RT_PARTS"] = "1"
     try:
-        c1 = rt.Context(int(os.environ.get("LOCAL_RANK", "0")))
+        c1 = rt.Context(int(os.environ.get("LOCAL_RANK", "0")) if not args.share_gpu else 0)
     finally:
         if old is None:
             del os.environ["RT_PARTS"]
         else:
             os.environ["RT_PARTS"] = old
     build_scene(rt, c1, args.scene)
+    c1.stats_enable(True)
     ms, launches, frame = [], 0, []
     for k in range(8):
         c1.render_device(p, rows, local.data_ptr(), stream)
@@ -168,65 +215,129 @@ def single_stream_launch_ms(rt, args, p, rows, local, stream):
     return (statistics.median(ms), launches, statistics.median(frame)) if ms else (None, 0, None)
 
 
-def roofline(rt, ctx, args, p, rows, local, stream, counts, world, W, H, kernel_ms_max, workload):
-    """nominal HBM roofline of the dominant kernel from ALGORITHMIC bytes, plus what really binds it.
+def static_counts():
+    path = os.path.join(ROOT, "raytracinggpu_amd", "static_counts.json")
+    try:
+        return json.load(open(path))
+    except (OSError, ValueError):
+        return None
 
-    achieved = algorithmic bytes of one launch / that launch's duration, measured live with HIP events by the library on
-    the stream the kernel runs on, in a single-stream context (one launch owns the chip).  The scene (~255 KB) is cache
-    resident, so the nominal fraction is not a utilisation: `binding` quotes the measured HBM traffic and the VALU / SALU
-    issue figures of the same kernel from the committed rocprofv3 summary (profiles/round2/summary.json, produced by
-    tools/round_profile.sh + tools/make_profile_summary.py)."""
+
+def travq_instructions(counts, sc):
+    """Vector / scalar wave-instructions of the frame's wf_travq launches: the step counters of the counting instantiation (this run)
+    x the static per-region counts of the production code object (tools/static_counts.py)."""
+    st, t = counts["steps"], sc["wf_travq"]
+    weights = (("loop_head", st["iterations"]), ("dispatch", st["iterations"]), ("retire", st["refill_passes"]), ("round", st["refill_rounds"]),
+               ("fetch", st["fetches"]), ("tri", st["tri_steps"]), ("box", st["box_steps"]))
+    out = {k: int(sum(t[r][k] * n for r, n in weights)) for k in ("valu", "valu_weight", "salu")}
+    out["by_region_valu"] = {r: int(t[r]["valu"] * n) for r, n in weights}
+    return out
+
+
+def roofline(rt, ctx, args, p, rows, local, stream, counts, world, W, H, kernel_ms_max, workload):
+    """What binds the dominant kernel, measured in this run; the nominal HBM roofline of SURVEY 8d beside it.
+
+    wf_travq is bound by vector-instruction issue (HBM 9 % of peak, scene cache resident).  achieved = vector
+    wave-instructions of one launch / that launch's duration (HIP events by the library on the stream the kernel runs on, in a
+    single-stream context: one launch owns the chip); peak = 1024 SIMDs x 2.4 GHz / 4 cycles.  The instruction count is the
+    counting instantiation's step counters of THIS run x the static per-step counts of the production code object; it is checked
+    against rocprofv3's SQ_INSTS_VALU in profiles/ (tools/round_profile.sh).  `traffic` quotes the measured HBM bytes of the same
+    launch from the committed PMC summary when that summary was taken from this code (library hash), else null."""
+    ctx.stats_enable(True)                                            # one more frame, outside the timed region, with the traversal launches bracketed by events
+    ctx.render_device(p, rows, local.data_ptr(), stream)
     st = ctx.stats()
+    ctx.stats_enable(False)
     trav_bytes = 24 * counts["box_tests"] + 16 * counts["nodes"] + 48 * counts["tri_tests"]
     fb_bytes = 16 * W * H
-    out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
-           "frac_is": "nominal: SURVEY 8d algorithmic bytes (24 B/box test + 16 B/node + 48 B/triangle test) of a cache-resident scene over the "
-                      "HBM peak; it may exceed 1 and is NOT a utilisation -- see `binding`",
+    out = {"bound": "valu_issue", "peak": round(VALU_PEAK_GINST, 1), "unit": "Gwave-inst/s", "traffic": None,
            "frame_algorithmic_bytes": int(trav_bytes + fb_bytes), "frame_kernels_ms": round(kernel_ms_max, 4),
            "per_ray": {k: round(counts[k] / counts["rays"], 3) for k in ("box_tests", "nodes", "tri_tests")}}
-    if st["trav_launches"] > 0:
-        kname = {6: "rtk::wf_trav<false, false>", 7: "rtk::wf_trav<false, true>"}.get(st["variant"], "rtk::wf_travq<false, 64, false, false>")
-        parts = max(st.get("parts", 1), 1)
-        k_ms_conc = st["trav_ms"] / st["trav_launches"]
-        single_ms, single_launches, single_frame = (None, 0, None)
-        if world == 1:
-            single_ms, single_launches, single_frame = single_stream_launch_ms(rt, args, p, rows, local, stream)
-        if single_ms:
-            alg_launch = trav_bytes / single_launches
-            k_ms = single_ms
-            out.update({"kernel_ms": round(single_ms, 4), "launches_per_frame": single_launches, "concurrent_launches": 1,
-                        "single_stream_frame_ms": round(single_frame, 4)})
-        else:
-            alg_launch = trav_bytes / world / (st["trav_launches"] * parts)
-            k_ms = k_ms_conc
-            out.update({"kernel_ms": round(k_ms, 4), "launches_per_frame": st["trav_launches"] * parts, "concurrent_launches": parts})
-        out["kernel_ms_two_streams"] = round(k_ms_conc, 4)            # the default configuration: the twin launch of the other sub-frame shares the chip
+    sc = static_counts()
+    is_travq = st["variant"] == 8 and st["trav_launches"] > 0
+    if not (is_travq and sc and "steps" in counts):
+        # other variants: the nominal HBM roofline only
+        k_ms = kernel_ms_max
+        ach = (trav_bytes + fb_bytes) / world / (k_ms * 1e-3) / 1e9
+        out.update({"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": "whole frame", "kernel_ms": round(k_ms, 4), "achieved": round(ach, 1),
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "frac_is": "nominal: SURVEY 8d algorithmic bytes of a cache-resident scene over the HBM peak; not a utilisation"})
+        return out
+    parts = max(st.get("parts", 1), 1)
+    k_ms_conc = st["trav_ms"] / st["trav_launches"]
+    single_ms, single_launches, single_frame = (None, 0, None)
+    if world == 1:
+        single_ms, single_launches, single_frame = single_stream_launch_ms(rt, args, p, rows, local, stream)
+    ins = travq_instructions(counts, sc)
+    if single_ms:
+        launches, k_ms = single_launches, single_ms
+        out.update({"kernel_ms": round(single_ms, 4), "launches_per_frame": single_launches, "concurrent_launches": 1, "single_stream_frame_ms": round(single_frame, 4)})
     else:
-        kname = {1: "rtk::render_persistent<false>", 9: "rtk::wf_path<false>"}.get(st["variant"], "rtk::render_kernel<false>")
-        k_ms, alg_launch = kernel_ms_max, (trav_bytes + fb_bytes) / world
-        out.update({"kernel_ms": round(k_ms, 4), "launches_per_frame": 1, "concurrent_launches": 1})
-    ach = alg_launch / (k_ms * 1e-3) / 1e9
-    out.update({"kernel": kname, "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": int(alg_launch)})
-    spath = os.path.join(ROOT, "profiles", "round2", "summary.json")
-    if os.path.exists(spath) and workload == "cat_1920x1080_spp1_b3" and st["trav_launches"] > 0 and st["variant"] == 8:
-        ks = json.load(open(spath))["kernels"]
-        t, a = ks["wf_travq"], ks["wf_advance"]
-        hbm = t["hbm_read_bytes_per_launch"] + t["hbm_write_bytes_per_launch"]
-        out["traffic"] = hbm                                          # PMC, per single-stream launch like `achieved` (FETCH_SIZE x 2 + WRITE_SIZE)
-        out["traffic_source"] = "profiles/round2/summary.json (rocprofv3 --pmc, RT_PARTS=1)"
-        out["binding"] = {
-            "resource": "VALU issue (wf_travq: bookkeeping of the work stack, ~2/3 of its vector instructions) and, for wf_advance, HBM",
-            "wf_travq": {k: t[k] for k in ("rocprof_avg_us_single_stream", "rocprof_avg_us_two_streams", "share_of_gpu_time", "hbm_frac_of_8TBps", "l2_hit_rate",
-                                           "valu_pipe_busy_frac", "valu_issue_per_simd_cycle", "salu_issue_per_cu_cycle", "valu_lane_utilization",
-                                           "wave_cycles_waiting_frac", "valu_wave_insts_per_launch", "salu_wave_insts_per_launch")},
-            "wf_advance": {k: a[k] for k in ("rocprof_avg_us_single_stream", "rocprof_avg_us_two_streams", "share_of_gpu_time", "hbm_read_bytes_per_launch",
-                                             "hbm_write_bytes_per_launch", "hbm_GBps_single_stream", "hbm_frac_of_8TBps", "valu_pipe_busy_frac", "valu_lane_utilization")},
-            "source": "profiles/round2/summary.json <- pmc_wf_travq.json, pmc_wf_advance.json, bench_kernel_stats.csv, single_stream_kernel_stats.csv"}
+        launches, k_ms = st["trav_launches"] * parts * world, k_ms_conc
+        out.update({"kernel_ms": round(k_ms, 4), "launches_per_frame": launches, "concurrent_launches": parts})
+    out["kernel_ms_two_streams"] = round(k_ms_conc, 4)                # the default configuration: the twin launch of the other sub-frame shares the chip
+    valu_launch = ins["valu"] / launches
+    ach = valu_launch / (k_ms * 1e-3) / 1e9
+    hbm_ach = trav_bytes / launches / (k_ms * 1e-3) / 1e9
+    out.update({"kernel": "rtk::wf_travq<false, 64, false, false>", "achieved": round(ach, 1), "frac": round(ach / VALU_PEAK_GINST, 4),
+                "frac_is": "vector wave-instructions of one launch (step counters of this run x static per-step counts of the code object) / launch duration, "
+                           "over 1024 SIMDs x 2.4 GHz / 4 cycles; the kernel also leans on L1 bandwidth, LDS and the scalar unit (DESIGN.md section 5)",
+                "valu_wave_insts_per_launch": int(valu_launch), "salu_wave_insts_per_launch": int(ins["salu"] / launches),
+                "valu_issue_weighted_frac": round(ins["valu_weight"] / launches * 2 / (k_ms * 1e-3 * 2.4e9 * 1024), 4),
+                "valu_by_region_per_frame": ins["by_region_valu"], "steps_per_frame": counts["steps"],
+                "box_step_lane_occupancy": round((counts["box_tests"] - counts["rays"]) / (128.0 * max(counts["steps"]["box_steps"], 1)), 4),   # the root-box test of every ray belongs to the uniform kernel
+                "tri_step_lane_occupancy": round(counts["tri_tests"] / (128.0 * max(counts["steps"]["tri_steps"], 1)), 4),
+                "literal_box_tests": counts["box_literal"], "literal_tri_tests": counts["tri_literal"],
+                "algorithmic_bytes_per_launch": int(trav_bytes / launches), "nominal_hbm_GBps": round(hbm_ach, 1), "nominal_hbm_frac": round(hbm_ach / HBM_PEAK_GBS, 4),
+                "nominal_hbm_frac_is": "SURVEY 8d: 24 B/box test + 16 B/node + 48 B/triangle test of a cache-resident scene over 8 TB/s; may exceed 1, NOT a utilisation"})
+    # measured HBM traffic of the same launch: only from a PMC summary taken from THIS library
+    for rnd in ("round3", "round2"):
+        spath = os.path.join(ROOT, "profiles", rnd, "summary.json")
+        if os.path.exists(spath) and workload == "cat_1920x1080_spp1_b3":
+            summ = json.load(open(spath))
+            if summ.get("code_hash") and summ.get("code_hash") == code_hash():
+                t = summ["kernels"]["wf_travq"]
+                out["traffic"] = int(t["hbm_read_bytes_per_launch"] + t["hbm_write_bytes_per_launch"])
+                out["traffic_source"] = f"profiles/{rnd}/summary.json (rocprofv3 --pmc, RT_PARTS=1, same source hash)"
+                out["pmc"] = {"valu_wave_insts_per_launch": t.get("valu_wave_insts_per_launch"), "salu_wave_insts_per_launch": t.get("salu_wave_insts_per_launch"),
+                              "valu_lane_utilization": t.get("valu_lane_utilization"), "l2_hit_rate": t.get("l2_hit_rate"),
+                              "rocprof_avg_us_single_stream": t.get("rocprof_avg_us_single_stream"), "rocprof_avg_us_two_streams": t.get("rocprof_avg_us_two_streams")}
+            else:
+                out["traffic_note"] = f"profiles/{rnd}/summary.json was taken from other code (hash differs): profile stale, traffic not quoted"
+            break
     return out
+
+
+def code_hash():
+    """Hash of the kernel sources: ties a committed PMC summary to the code it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "raytracinggpu_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+class OracleRenderer:
+    """TEST stand-in for the HIP path (--renderer oracle): the CPU restatement renders a rank's tiles.  Plumbing only."""
+    def __init__(self, args):
+        from oracle import oracle_py as orc
+        import raytracinggpu_amd as rt
+        mesh = None
+        if args.scene == "cpu":
+            verts, tris = rt.scenes.load_cat_arrays()
+            mesh = orc.Mesh.from_arrays(verts, tris).build_bvh()
+        self.sc = orc.Scene.preset(args.scene, mesh)
+
+    def render(self, W, H, spp, b, rank, world, local):
+        import torch
+        part, _, _ = self.sc.render(W, H, spp, b, rows=(rank * TILE_ROWS, H), tile_rows=TILE_ROWS, tile_step=world, threads=2, want_rgb8=False)
+        local[:part.shape[0]] = torch.from_numpy(part)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)                                             # does not return
     import torch
     import torch.distributed as dist
     import raytracinggpu_amd as rt
@@ -236,111 +347,208 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    cpu_only = args.renderer == "oracle"
+    gloo = cpu_only or args.share_gpu
+    dev_index = 0 if args.share_gpu else local_rank
+    if not cpu_only:
+        if torch.cuda.device_count() <= dev_index:
+            raise SystemExit(f"rank {rank}: GPU {dev_index} not visible ({torch.cuda.device_count()} device(s)); one rank per GPU is required")
+        torch.cuda.set_device(dev_index)
+    dev = torch.device("cpu") if cpu_only else torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if gloo:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    xdev = torch.device("cpu") if gloo else dev                       # where the exchange runs (gloo moves host tensors)
 
-    ctx = rt.Context(local_rank)
-    build_scene(rt, ctx, args.scene)
     W, H = args.width, args.height
-    p = rt.make_params(W, H, args.spp, args.bounces, variant=args.variant, **rt.scenes.CPU_LAUNCHER)
-    rows, idx = rt.interleaved_rows(H, TILE_ROWS, rank, world)
-    local = tiling.local_buffer(H, W, world, dev)
-    rgb8 = args.gather == "rgb8" and world > 1
-    local8 = tiling.local_buffer(H, W, world, dev, rgb8=True) if rgb8 else None
-    gathered = tiling.gather_buffer(local8 if rgb8 else local, world) if (world > 1 and rank == 0) else None
-    frame = None
-    # a non-default torch stream: its handle is non-NULL (NULL means "the context's own stream" in the C-ABI),
-    # so the render kernel, torch's timing events and the RCCL gather are all ordered on ONE stream
-    side = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(side)
-    stream = side.cuda_stream
-    assert stream != 0
+    ctx = None
+    if cpu_only:
+        oren = OracleRenderer(args)
+        stream = None
+    else:
+        ctx = rt.Context(dev_index)
+        build_scene(rt, ctx, args.scene)
+        # a non-default torch stream: its handle is non-NULL (NULL means "the context's own stream" in the C-ABI),
+        # so the render kernel, torch's timing events and the RCCL gather are all ordered on ONE stream
+        side = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(side)
+        stream = side.cuda_stream
+        assert stream != 0
+    rgb8 = args.gather == "rgb8" and world > 1 and not cpu_only
 
-    def exchange():
-        if rgb8:                                                      # tonemap this rank's tiles (cpu:714-716), gather 3 bytes per pixel
-            ctx.tonemap_device(local.data_ptr(), rows.n_rows * W, local8.data_ptr(), stream)
-            return tiling.gather_frame(local8, H, world, rank, gathered)
-        return tiling.gather_frame(local, H, world, rank, gathered)
+    class Point:
+        """One timed workload: its parameters, this rank's tiles and the buffers of the exchange."""
+        def __init__(self, W, H):
+            self.W, self.H = W, H
+            self.p = rt.make_params(W, H, args.spp, args.bounces, variant=args.variant, **rt.scenes.CPU_LAUNCHER)
+            self.rows, self.idx = rt.interleaved_rows(H, TILE_ROWS, rank, world)
+            self.local = tiling.local_buffer(H, W, world, dev)
+            self.local8 = tiling.local_buffer(H, W, world, dev, rgb8=True) if rgb8 else None
+            src = self.local8 if rgb8 else self.local
+            self.xlocal = torch.empty(src.shape, dtype=src.dtype, device=xdev, pin_memory=not cpu_only) if (gloo and world > 1 and not cpu_only) else src
+            self.gathered = tiling.gather_buffer(self.xlocal, world) if (world > 1 and rank == 0) else None
+            self.frame = None
 
-    def step():
-        nonlocal frame
-        ctx.render_device(p, rows, local.data_ptr(), stream)
-        frame = exchange()
+        def render(self):
+            if cpu_only:
+                oren.render(self.W, self.H, args.spp, args.bounces, rank, world, self.local)
+            else:
+                ctx.render_device(self.p, self.rows, self.local.data_ptr(), stream)
 
+        def exchange(self):
+            src = self.local
+            if rgb8:                                                  # tonemap this rank's tiles (cpu:714-716), gather 3 bytes per pixel
+                ctx.tonemap_device(self.local.data_ptr(), self.rows.n_rows * self.W, self.local8.data_ptr(), stream)
+                src = self.local8
+            if self.xlocal is not src:                                # --share-gpu: the exchange runs over gloo on host tensors
+                self.xlocal.copy_(src, non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+            self.frame = tiling.gather_frame(self.xlocal, self.H, world, rank, self.gathered)
+
+        def step(self):
+            self.render()
+            self.exchange()
+
+    def sync():
+        if not cpu_only:
+            torch.cuda.synchronize()
+
+    def timed(pt, steps, warmup):
+        """W warm-up steps, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
+        for _ in range(warmup):
+            pt.step()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)] if not cpu_only else []
+        if world > 1:
+            dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            if ev:
+                ev[k][0].record()
+            pt.render()
+            if ev:
+                ev[k][1].record()
+            pt.exchange()
+        sync()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        kernel_ms = statistics.mean(a.elapsed_time(b) for a, b in ev) if ev else 0.0
+        tmax = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=xdev)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return float(tmax[0]), float(tmax[1])
+
+    def rays_of(pt):
+        r = torch.tensor([float(pt.local[:pt.rows.n_rows, :, 3].double().sum().item())], dtype=torch.float64, device=xdev)
+        if world > 1:
+            dist.all_reduce(r)
+        return int(r.item())
+
+    main_pt = Point(W, H)
     # exact ray count of one frame (deterministic; outside the timed region)
-    step()
-    torch.cuda.synchronize()
-    rays_local = torch.tensor([float(local[:rows.n_rows, :, 3].double().sum().item())], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(rays_local)
-    rays_per_frame = int(rays_local.item())
+    main_pt.step()
+    sync()
+    rays_per_frame = rays_of(main_pt)
     # traversal work of one frame from the counting instantiation of the kernel (SURVEY 8d), rank 0
-    counts = ctx.count_work(p) if rank == 0 else None
+    counts = ctx.count_work(main_pt.p, detail=True) if (rank == 0 and not cpu_only) else None
+    if args.dump_frame and rank == 0:
+        np.save(args.dump_frame, (main_pt.frame if world > 1 else main_pt.local[:H]).cpu().numpy())
+    frame_ok = None
+    if args.check_frame and rank == 0 and not cpu_only and not rgb8:
+        full = ctx.render(main_pt.p)
+        got = main_pt.frame.cpu().numpy() if world > 1 else main_pt.local[:H].cpu().numpy()
+        frame_ok = bool((got.view(np.uint32) == full.view(np.uint32)).all())
 
-    for _ in range(args.warmup):
-        step()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        ev[k][0].record()
-        ctx.render_device(p, rows, local.data_ptr(), stream)
-        ev[k][1].record()
-        frame = exchange()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = statistics.mean(a.elapsed_time(b) for a, b in ev)
-    tmax = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed, kernel_ms_max = float(tmax[0]), float(tmax[1])
+    elapsed, kernel_ms_max = timed(main_pt, args.steps, args.warmup)
+
+    large = None
+    if args.large_steps > 0 and args.scene == "cpu" and not cpu_only and (W, H) == (1920, 1080):
+        # BASELINE config 5's size in the same run (the >= 7x tile-scaling claim is feasible there; `value` stays the 1080p metric)
+        lp = Point(7680, 4320)
+        lp.step()
+        sync()
+        lrays = rays_of(lp)
+        lel, lk = timed(lp, args.large_steps, 1)
+        large = {"workload": f"cat_7680x4320_spp{args.spp}_b{args.bounces}", "steps": args.large_steps, "ms_per_step": round(1e3 * lel / args.large_steps, 4),
+                 "value": round(lrays / (lel / args.large_steps) / 1e6, 2), "unit": "Mrays/s", "rays_per_frame": lrays, "kernels_ms_max_over_ranks": round(lk, 4)}
+        del lp
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = rays_per_frame / (elapsed / args.steps) / 1e6
         workload = f"cat_{W}x{H}_spp{args.spp}_b{args.bounces}" if args.scene == "cpu" else f"{args.scene}_{W}x{H}_spp{args.spp}_b{args.bounces}"
-        res = {"metric": "Mrays/s, cat mesh 1920x1080 (ms/frame in ms_per_step)", "value": round(value, 2), "unit": "Mrays/s",
+        backend = "gloo (test: ranks share GPU 0)" if args.share_gpu else "gloo (test: CPU stand-in renderer)" if cpu_only else "nccl (RCCL)"
+        res = {"metric": "Mrays/s, cat mesh 1920x1080 (ms/frame in ms_per_step)", "value": None if cpu_only else round(value, 2), "unit": "Mrays/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": workload, "scene": "cpu_launcher.cpp walls + cat.obj (3954 tris, 2019-node array BVH)",
                           "num_rays": args.spp, "num_bounce": args.bounces, "depth_convention": "cpu_launcher (b+1 segments)",
-                          "rays_per_frame": rays_per_frame, "tiling": f"{TILE_ROWS}-row tiles interleaved over {world} rank(s)"
-                          + (f", RCCL gather of the {'RGB8' if rgb8 else 'float4'} tiles to rank 0 per frame" if world > 1 else ""),
-                          "variant": ctx.stats()["variant"], "device": ctx.device_name,
+                          "rays_per_frame": rays_per_frame, "ranks": dist.get_world_size() if world > 1 else 1,
+                          "tiling": f"{TILE_ROWS}-row tiles interleaved over {world} rank(s)"
+                          + (f", one gather ({backend}) of the {'RGB8' if rgb8 else 'float4'} tiles to rank 0 per frame" if world > 1 else ""),
+                          "variant": ctx.stats()["variant"] if ctx else None, "device": ctx.device_name if ctx else "cpu (oracle stand-in: not a measurement)",
                           "primary_Msamples_per_s": round(W * H * args.spp / (elapsed / args.steps) / 1e6, 1)}}
-        if world == 1:
-            # like-for-like with a host caller -- rt_render (kernels + the 16 B/pixel D2H copy over PCIe), untimed region
-            t1 = time.perf_counter()
-            for _ in range(3):
-                ctx.render(p)
-            res["config"]["host_frame_ms_incl_d2h"] = round((time.perf_counter() - t1) / 3 * 1e3, 3)
-            pin = rt.PinnedArray((H, W, 4))                          # the same into a buffer from rt_host_alloc: the copy is one DMA
-            ctx.render(p, out=pin.array)
-            t1 = time.perf_counter()
-            for _ in range(3):
-                ctx.render(p, out=pin.array)
-            res["config"]["host_frame_ms_incl_d2h_pinned"] = round((time.perf_counter() - t1) / 3 * 1e3, 3)
-            pin.close()
-        if world == 1 and not args.no_cpu_baseline:
+        if frame_ok is not None:
+            res["config"]["frame_equals_single_device_frame"] = frame_ok
+        if large:
+            res["config"]["large"] = large
+        if world == 1 and not cpu_only:
+            res["config"].update(host_frame_timings(rt, ctx, main_pt.p, W, H))
+        if world == 1 and not args.no_cpu_baseline and not cpu_only:
             try:
                 res["cpu_baseline"] = cpu_baseline(args, rays_per_frame)
             except Exception as e:  # the baseline must never take the GPU number down with it
                 res["cpu_baseline"] = {"value": None, "unit": "Mrays/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         if counts is not None:
             assert counts["rays"] == rays_per_frame, (counts, rays_per_frame)
-            res["roofline"] = roofline(rt, ctx, args, p, rows, local, stream, counts, world, W, H, kernel_ms_max, workload)
+            res["roofline"] = roofline(rt, ctx, args, main_pt.p, main_pt.rows, main_pt.local, stream, counts, world, W, H, kernel_ms_max, workload)
         print(json.dumps(res), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def host_frame_timings(rt, ctx, p, W, H):
+    """what a host caller sees (kernels + the device-to-host copy over PCIe), outside the timed region: rt_render into
+    pageable and pinned memory, and the pipelined forms (rt_render_async / rt_wait: frame k's copy runs beside frame k+1's
+    kernels) for the float4 frame and for the 8-bit image a PNG writer needs."""
+    out = {}
+    t1 = time.perf_counter()
+    for _ in range(3):
+        ctx.render(p)
+    out["host_frame_ms_incl_d2h"] = round((time.perf_counter() - t1) / 3 * 1e3, 3)
+    pin = rt.PinnedArray((H, W, 4))                                  # the same into a buffer from rt_host_alloc: the copy is one DMA
+    ctx.render(p, out=pin.array)
+    t1 = time.perf_counter()
+    for _ in range(3):
+        ctx.render(p, out=pin.array)
+    out["host_frame_ms_incl_d2h_pinned"] = round((time.perf_counter() - t1) / 3 * 1e3, 3)
+    if hasattr(ctx, "render_async"):
+        n = 12
+        pins = [pin, rt.PinnedArray((H, W, 4))]
+        for rgb8, key in ((False, "host_frame_ms_pipelined_pinned"), (True, "host_frame_ms_pipelined_rgb8")):
+            bufs = [rt.PinnedArray((H, W, 3), dtype=np.uint8) for _ in range(2)] if rgb8 else pins
+            for k in range(2):                                        # warm both slots
+                ctx.render_async(p, bufs[k].array, slot=k, rgb8=rgb8)
+                ctx.wait(k)
+            t1 = time.perf_counter()
+            ctx.render_async(p, bufs[0].array, slot=0, rgb8=rgb8)
+            for k in range(1, n):
+                ctx.render_async(p, bufs[k & 1].array, slot=k & 1, rgb8=rgb8)   # frame k starts ...
+                ctx.wait((k - 1) & 1)                                           # ... while frame k-1's copy completes
+            ctx.wait((n - 1) & 1)
+            out[key] = round((time.perf_counter() - t1) / n * 1e3, 3)
+            if rgb8:
+                for b in bufs:
+                    b.close()
+        pins[1].close()
+    pin.close()
+    return out
 
 
 if __name__ == "__main__":

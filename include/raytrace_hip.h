@@ -193,6 +193,18 @@ int rt_count_work(rt_ctx *ctx, const rt_params *p, int row_begin, int row_end, r
 
 int rt_synchronize(rt_ctx *ctx);
 int rt_get_stats(rt_ctx *ctx, rt_stats *stats);        /* waits for the last render to finish */
+/* trav_ms / trav_launches are measured only on request (on != 0): production frames record no per-launch timing events */
+int rt_stats_enable(rt_ctx *ctx, int on);
+
+/* --- pipelined frames for a host caller.  optimized.cu renders, synchronises and then copies (optimized.cu:849-856), so the
+ *     33 MB of a 1080p float frame cross PCIe strictly after the kernels.  rt_render_async renders the whole frame into one of
+ *     two device buffers (slot 0 / 1) and starts its device-to-host copy on a separate copy stream; rt_wait(slot) blocks until that
+ *     slot's frame is in out_host.  Calling rt_render_async(slot ^ 1) before rt_wait(slot) overlaps frame k's copy with frame
+ *     k+1's kernels.  out_host: width*height float4 (rgb8 == 0) or width*height*3 bytes (rgb8 != 0: the tonemapped image of
+ *     cpu:714-716); memory from rt_host_alloc makes the copy one DMA.  Re-using a slot whose frame has not been waited for is
+ *     allowed: its kernels wait for the pending copy. */
+int rt_render_async(rt_ctx *ctx, const rt_params *p, int slot, void *out_host, int rgb8);
+int rt_wait(rt_ctx *ctx, int slot);
 /* every device buffer of the context lives on the context's device (RT_ERR_INTERNAL otherwise): a context used from a thread
  * whose current device is another GPU must not allocate there (the CUDA programs of the reference only ever see device 0) */
 int rt_ctx_selfcheck(rt_ctx *ctx);

@@ -6,6 +6,7 @@ raises instead of rendering with something else.
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -24,7 +25,7 @@ EXPORTS = ["rt_abi_version", "rt_device_count", "rt_ctx_create", "rt_ctx_destroy
            "rt_progressive_frames",
            "rt_multi_create", "rt_multi_destroy", "rt_multi_last_error", "rt_multi_scene_upload", "rt_render_multi",
            "rt_render_multi_device", "rt_render_multi_rgb8", "rt_multi_get_stats",
-           "rt_mesh_rebuild", "rt_host_alloc", "rt_host_free", "rt_device_alloc", "rt_device_free", "rt_device_to_host", "rt_kat_sphere", "rt_kat_box", "rt_kat_triangle", "rt_kat_mesh"]
+           "rt_stats_enable", "rt_render_async", "rt_wait", "rt_mesh_rebuild", "rt_host_alloc", "rt_host_free", "rt_device_alloc", "rt_device_free", "rt_device_to_host", "rt_kat_sphere", "rt_kat_box", "rt_kat_triangle", "rt_kat_mesh"]
 MAX_DEVICES = 16
 
 
@@ -142,6 +143,9 @@ def load():
     L.rt_synchronize.argtypes = [vp]
     L.rt_ctx_selfcheck.argtypes = [vp]
     L.rt_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.rt_stats_enable.argtypes = [vp, C.c_int]
+    L.rt_render_async.argtypes = [vp, C.POINTER(Params), C.c_int, vp, C.c_int]
+    L.rt_wait.argtypes = [vp, C.c_int]
     fp3 = C.POINTER(C.c_float)
     L.rt_mesh_transform.argtypes = [vp, fp3, fp3]
     L.rt_mesh_set_normals.argtypes = [vp, fp3, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_int]
@@ -172,25 +176,25 @@ def load():
 
 
 class PinnedArray:
-    """A float32 / uint8 numpy array over rt_host_alloc memory (frame buffer for rt_render*: the D2H copy is one DMA)."""
+    """A float32 / uint8 numpy array over rt_host_alloc memory (frame buffer for rt_render*: the D2H copy is one DMA).
+
+    The allocation lives as long as ANY view of it: `array`, its slices and whatever a render call returned all keep the underlying
+    ctypes buffer alive, and the pinned memory is released when that buffer is collected -- close() only drops this object's own
+    reference, it never frees memory somebody still looks at."""
 
     def __init__(self, shape, dtype=np.float32):
-        self._L = load()
-        self._p = C.c_void_p()
+        L = load()
+        p = C.c_void_p()
         n = int(np.prod(shape)) * np.dtype(dtype).itemsize
-        rc = self._L.rt_host_alloc(C.byref(self._p), max(n, 16))
+        rc = L.rt_host_alloc(C.byref(p), max(n, 16))
         if rc != RT_OK:
-            raise RtError(rc, self._L.rt_last_error(None).decode())
-        buf = (C.c_uint8 * max(n, 16)).from_address(self._p.value)
+            raise RtError(rc, L.rt_last_error(None).decode())
+        buf = (C.c_uint8 * max(n, 16)).from_address(p.value)
+        weakref.finalize(buf, L.rt_host_free, C.c_void_p(p.value))    # runs when the last numpy view of `buf` is gone
         self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
     def close(self):
-        if getattr(self, "_p", None) is not None and self._p.value:
-            self.array = None
-            self._L.rt_host_free(self._p)
-            self._p = C.c_void_p()
-
-    __del__ = close
+        self.array = None
 
 
 def camera_basis(pose):
@@ -312,6 +316,20 @@ class Context:
         """Asynchronous render into device memory (e.g. a torch tensor's data_ptr())."""
         self._check(self._L.rt_render_device(self._h, C.byref(params), C.byref(rows), C.c_void_p(out_ptr),
                                              C.c_void_p(stream) if stream else None))
+
+    def render_async(self, params, out, slot=0, rgb8=False):
+        """rt_render_async: whole frame into device buffer `slot` (0 / 1), device-to-host copy into `out` on the copy stream;
+        wait(slot) returns when `out` holds the frame.  out: [H, W, 4] float32 or, rgb8, [H, W, 3] uint8 (PinnedArray: one DMA)."""
+        want = (np.uint8, 3) if rgb8 else (np.float32, 4)
+        assert out.dtype == want[0] and out.flags.c_contiguous and out.size == params.height * params.width * want[1]
+        self._check(self._L.rt_render_async(self._h, C.byref(params), int(slot), C.c_void_p(out.ctypes.data), 1 if rgb8 else 0))
+
+    def wait(self, slot=0):
+        self._check(self._L.rt_wait(self._h, int(slot)))
+
+    def stats_enable(self, on=True):
+        """trav_ms / trav_launches of stats() are measured only while enabled (production frames record no per-launch events)."""
+        self._check(self._L.rt_stats_enable(self._h, 1 if on else 0))
 
     def tonemap_device(self, rgba_ptr, n_pixels, rgb8_ptr, stream=None):
         self._check(self._L.rt_tonemap_device(self._h, C.c_void_p(rgba_ptr), n_pixels, C.c_void_p(rgb8_ptr),

@@ -116,6 +116,12 @@ struct rt_ctx {
     hipEvent_t part_ev[kMaxParts] = {};
     hipEvent_t fork_ev = nullptr;
     bool trav_attr_set = false;
+    bool stats_on = false;                                          // rt_stats_enable: bracket the traversal launches with timing events (production frames record none)
+    static constexpr int kSlots = 2;                                // rt_render_async: double-buffered device frames, one copy stream
+    DevBuf slot_rgba[kSlots], slot_rgb8[kSlots];
+    hipEvent_t slot_rendered[kSlots] = {}, slot_done[kSlots] = {};
+    bool slot_pending[kSlots] = {false, false};
+    hipStream_t copy_stream = nullptr;
     bool travq_ok = true;                                           // the uploaded tree fits wf_travq's entry formats (leaf sizes, triangle offsets)
     static constexpr int kMaxTravEvents = 2 * RT_MAX_SEGMENTS;
     hipEvent_t ev_trav[2 * kMaxTravEvents] = {};
@@ -634,7 +640,7 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
 #ifdef RT_DEBUG
                         pt.st.dbg = (dbg_env && it == dbg_it) ? static_cast<unsigned long long *>(ctx->dbgbuf.p) : nullptr;
 #endif
-                        const bool timed = j == 0 && s + chunk >= fr.spp;   // time part 0's traversal launches of the last chain
+                        const bool timed = ctx->stats_on && j == 0 && s + chunk >= fr.spp;   // on request (rt_stats_enable): time part 0's traversal launches of the last chain
                         if (timed) RT_HIP(ctx, hipEventRecord(ctx->ev_trav[2 * it], q));
                         const dim3 tg((unsigned)pt.tblocks), tbd(tb);
                         if (queue) {
@@ -924,6 +930,11 @@ int rt_ctx_create(rt_ctx **out, int device_id) {
     for (hipEvent_t &ev : ctx->part_ev) if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
     for (hipStream_t &q : ctx->part_stream) if (e == hipSuccess) e = hipStreamCreateWithFlags(&q, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
+    for (int k = 0; k < rt_ctx::kSlots; ++k) {
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->slot_rendered[k], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->slot_done[k], hipEventDisableTiming);
+    }
     if (e != hipSuccess) {
         int code = fail(nullptr, RT_ERR_HIP, "context creation: %s", hipGetErrorString(e));
         rt_ctx_destroy(ctx);
@@ -944,6 +955,12 @@ int rt_ctx_destroy(rt_ctx *ctx) {
     if (!ctx) return RT_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
+    for (int k = 0; k < rt_ctx::kSlots; ++k) {
+        ctx->slot_rgba[k].release(); ctx->slot_rgb8[k].release();
+        if (ctx->slot_rendered[k]) (void)hipEventDestroy(ctx->slot_rendered[k]);
+        if (ctx->slot_done[k]) (void)hipEventDestroy(ctx->slot_done[k]);
+    }
     ctx->node_lo.release(); ctx->node_hi.release(); ctx->nodes2.release(); ctx->nodesq.release(); ctx->nodesb.release(); ctx->q2thr.release(); ctx->left_dev.release(); ctx->lvl_nodes.release(); ctx->lvl_off.release(); ctx->nrm.release(); ctx->tri.release(); ctx->verts.release(); ctx->tidx.release();
     ctx->scratch_rgba.release(); ctx->scratch_rgb8.release(); ctx->work.release(); ctx->queue.release();
     ctx->wfM.release(); ctx->wfPR.release(); ctx->wfT.release(); ctx->wfLS.release(); ctx->wfSID.release(); ctx->wfSamp.release();
@@ -1013,6 +1030,48 @@ int rt_render(rt_ctx *ctx, const rt_params *p, int row_begin, int row_end, float
     if (rc != RT_OK) return rc;
     RT_HIP(ctx, hipMemcpyAsync(out_rgba_host, ctx->scratch_rgba.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_stats_enable(rt_ctx *ctx, int on) {
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    ctx->stats_on = on != 0;
+    return RT_OK;
+}
+
+int rt_render_async(rt_ctx *ctx, const rt_params *p, int slot, void *out_host, int rgb8) {
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    if (!p) return fail(ctx, RT_ERR_INVALID, "params is NULL");
+    if (slot < 0 || slot >= rt_ctx::kSlots) return fail(ctx, RT_ERR_INVALID, "slot %d outside [0,%d)", slot, rt_ctx::kSlots);
+    if (!out_host) return fail(ctx, RT_ERR_INVALID, "output pointer is NULL");
+    if (p->width <= 0 || p->height <= 0) return fail(ctx, RT_ERR_INVALID, "width/height must be positive");
+    const int64_t npix = (int64_t)p->width * p->height;
+    int rc = ensure(ctx, ctx->slot_rgba[slot], (size_t)npix * sizeof(float4));
+    if (rc != RT_OK) return rc;
+    if (rgb8 && (rc = ensure(ctx, ctx->slot_rgb8[slot], (size_t)npix * 3 + 16)) != RT_OK) return rc;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    // the slot's previous frame may still be on its way to the host: the kernels that overwrite its device buffer wait for that copy
+    if (ctx->slot_pending[slot]) RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->slot_done[slot], 0));
+    rt_rows rows{0, p->height, p->height, 1};
+    if ((rc = launch_render(ctx, p, &rows, ctx->slot_rgba[slot].p, ctx->stream)) != RT_OK) return rc;
+    if (rgb8 && (rc = launch_tonemap(ctx, ctx->slot_rgba[slot].p, npix, ctx->slot_rgb8[slot].p, ctx->stream)) != RT_OK) return rc;
+    RT_HIP(ctx, hipEventRecord(ctx->slot_rendered[slot], ctx->stream));
+    // the copy runs on its own stream: the next frame's kernels (other slot) do not queue behind it
+    RT_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->slot_rendered[slot], 0));
+    if (rgb8) RT_HIP(ctx, hipMemcpyAsync(out_host, ctx->slot_rgb8[slot].p, (size_t)npix * 3, hipMemcpyDeviceToHost, ctx->copy_stream));
+    else RT_HIP(ctx, hipMemcpyAsync(out_host, ctx->slot_rgba[slot].p, (size_t)npix * sizeof(float4), hipMemcpyDeviceToHost, ctx->copy_stream));
+    RT_HIP(ctx, hipEventRecord(ctx->slot_done[slot], ctx->copy_stream));
+    ctx->slot_pending[slot] = true;
+    return RT_OK;
+}
+
+int rt_wait(rt_ctx *ctx, int slot) {
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    if (slot < 0 || slot >= rt_ctx::kSlots) return fail(ctx, RT_ERR_INVALID, "slot %d outside [0,%d)", slot, rt_ctx::kSlots);
+    if (!ctx->slot_pending[slot]) return fail(ctx, RT_ERR_INVALID, "slot %d has no frame in flight", slot);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipEventSynchronize(ctx->slot_done[slot]));
+    ctx->slot_pending[slot] = false;
     return RT_OK;
 }
 

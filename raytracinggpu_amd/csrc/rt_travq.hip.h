@@ -196,12 +196,14 @@ __device__ __forceinline__ bool qtri_test(const float4 q0, const float4 q1, cons
     bool ok = trust && mbg >= kE && sum <= 1.f - 3.f * kE && valid;
     how = ok ? 1 : 0;
     if (!reject && !ok && valid) {              // undecided: the literal tests (rare)
+        asm volatile("rt_mark_trilit_begin_%=:" ::);
         how = 2;
         if (det != 0) {                         // cpu:230
             const float beta = bn / det;
             const float gamma = gn / det;
             ok = (0 <= beta && beta <= 1) && (0 <= gamma && gamma <= 1) && (beta + gamma <= 1);
         }
+        asm volatile("rt_mark_trilit_end_%=:" ::);
     }
     if (!ok) return false;
     const float t = dot(AO, N) / det;
@@ -349,6 +351,7 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
         // =============================== retire + refill ===============================
         if (top < kLow) {
             if (STATS) n_refill++;
+            WQ_MARK("refill_begin");
             if (lane < R && path >= 0) {
                 if (*pend(my_sb) == 0) {
                     st.M[path] = *best(my_sb);        // always: the emitter does not initialise M (WF_NOHIT = no triangle accepted)
@@ -363,8 +366,10 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
                 const int n_free = __popcll(freem);
                 if (n_free == 0 || (n_free < kMinFree && top >= 64)) break;
                 if (STATS) n_round++;
+                WQ_MARK("round_begin");
                 if (stage_used >= stage_n) {
                     if (drained) break;
+                    WQ_MARK("fetch_begin");
                     int base = 0;
                     if (lane == 0) base = atomicAdd(blk_cur, 64);
                     base = __builtin_amdgcn_readfirstlane(base);
@@ -382,6 +387,7 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
                     stage_used = 0;
                     if (STATS) n_fetch++;
                     if (dbg_on) d_fetch++;
+                    WQ_MARK("fetch_end");
                     if (stage_n == 0) continue;
                 }
                 const int take = n_free < stage_n - stage_used ? n_free : stage_n - stage_used;
@@ -421,6 +427,7 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
                     }
                     break;                         // at most R leaf entries per pass: the TRI steps below drain them
                 }
+                WQ_MARK("round_end");
             }
         }
         WQ_STAMP(cy_srv);

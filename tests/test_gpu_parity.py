@@ -136,6 +136,63 @@ def test_pinned_frame_buffer_gives_the_same_frame(ctx, cat_golden):
     pin.close(); part.close()
 
 
+def test_pinned_views_outlive_close(ctx, cat_golden):
+    """A view of a PinnedArray keeps the allocation alive after close() (the memory is released with the last view)."""
+    upload(ctx, "cpu", cat_golden)
+    p = rt.make_params(64, 40, 1, 1, **rt.scenes.CPU_LAUNCHER)
+    pin = rt.PinnedArray((40, 64, 4))
+    view = ctx.render(p, out=pin.array)[3:7]
+    keep = view.copy()
+    pin.close()
+    del pin
+    import gc; gc.collect()
+    other = rt.PinnedArray((40, 64, 4)); other.array[:] = -1.0          # would land on the freed block if it had been freed
+    np.testing.assert_array_equal(view.view(np.uint32), keep.view(np.uint32))
+    other.close()
+
+
+def test_async_pipelined_frames_equal_the_synchronous_ones(ctx, cat_golden):
+    """rt_render_async / rt_wait: frame k's device-to-host copy runs on the copy stream beside frame k+1's kernels (two device
+    slots); every delivered frame -- float4 and the 8-bit image -- is bitwise what rt_render / rt_render_rgb8 return, including
+    when a slot is re-used without waiting for it and when the frames differ from one another."""
+    upload(ctx, "cpu", cat_golden)
+    W, H = 400, 250
+    params = [rt.make_params(W, H, 1, b, **rt.scenes.CPU_LAUNCHER) for b in (0, 2, 1, 3, 2)]
+    ref = [ctx.render(p) for p in params]
+    ref8 = [ctx.render_rgb8(p) for p in params]
+    pins = [rt.PinnedArray((H, W, 4)) for _ in range(2)]
+    got = []
+    ctx.render_async(params[0], pins[0].array, slot=0)
+    for k in range(1, len(params)):
+        ctx.render_async(params[k], pins[k & 1].array, slot=k & 1)       # frame k is submitted ...
+        ctx.wait((k - 1) & 1)                                            # ... before frame k-1 has been collected
+        got.append(pins[(k - 1) & 1].array.copy())
+    ctx.wait((len(params) - 1) & 1)
+    got.append(pins[(len(params) - 1) & 1].array.copy())
+    for g, r in zip(got, ref):
+        np.testing.assert_array_equal(g.view(np.uint32), r.view(np.uint32))
+    pins8 = [rt.PinnedArray((H, W, 3), dtype=np.uint8) for _ in range(2)]
+    for k, p in enumerate(params):
+        ctx.render_async(p, pins8[k & 1].array, slot=k & 1, rgb8=True)
+        ctx.wait(k & 1)
+        np.testing.assert_array_equal(pins8[k & 1].array, ref8[k])
+    # a slot re-used without rt_wait: its kernels queue behind the pending copy, the second frame arrives intact
+    ctx.render_async(params[1], pins[0].array, slot=0)
+    ctx.render_async(params[3], pins[0].array, slot=0)
+    ctx.wait(0)
+    np.testing.assert_array_equal(pins[0].array.view(np.uint32), ref[3].view(np.uint32))
+    with pytest.raises(rt.RtError):
+        ctx.wait(1)                                                      # nothing in flight there
+    with pytest.raises(rt.RtError):
+        ctx.render_async(params[0], pins[0].array, slot=2)
+    # pageable memory works too (the runtime stages the copy)
+    out = np.empty((H, W, 4), np.float32)
+    ctx.render_async(params[2], out, slot=1); ctx.wait(1)
+    np.testing.assert_array_equal(out.view(np.uint32), ref[2].view(np.uint32))
+    for pn in pins + pins8:
+        pn.close()
+
+
 def test_error_paths(ctx, cat_golden):
     upload(ctx, "cpu", cat_golden)
     with pytest.raises(rt.RtError):

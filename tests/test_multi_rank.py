@@ -103,6 +103,49 @@ def test_rgb8_gather_equals_full_image_gloo_cpu(oracle, oracle_cat, tmp_path):
     np.testing.assert_array_equal(np.load(out), exp8)
 
 
+def _bench(*args, timeout=600):
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")})
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_starts_its_own_ranks_gloo_cpu(oracle, oracle_cat, tmp_path):
+    """`python bench.py --gpus 2` (the shape of the driver's command, no torch.distributed environment) starts its two ranks itself,
+    relays rank 0's ONE JSON line and the exit code.  Here with the CPU stand-in renderer over gloo: launcher, partition, gather and
+    reassembly are the ones the GPU run uses; the gathered frame equals the full oracle frame bit for bit and the line refuses to
+    carry a throughput (value null)."""
+    W, H, b = 96, 50, 2
+    out = str(tmp_path / "frame.npy")
+    r, line = _bench("--gpus", "2", "--renderer", "oracle", "--width", str(W), "--height", str(H), "--bounces", str(b), "--steps", "1", "--warmup", "0",
+                     "--large-steps", "0", "--dump-frame", out)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line["n_gpus"] == 2 and line["config"]["ranks"] == 2 and line["value"] is None and line["steps"] == 1
+    exp, _, _ = oracle.Scene.preset("cpu", oracle_cat).render(W, H, 1, b, want_rgb8=False)
+    np.testing.assert_array_equal(np.load(out).view(np.uint32), exp.view(np.uint32))
+    assert line["config"]["rays_per_frame"] == int(exp[..., 3].sum())
+
+
+def test_bench_refuses_more_ranks_than_gpus_with_a_clear_message():
+    if torch.cuda.device_count() >= 16:
+        pytest.skip("needs fewer than 16 GPUs")
+    r, line = _bench("--gpus", "16", "--steps", "1", "--warmup", "0")
+    assert r.returncode != 0 and line is None
+    assert "GPU(s) visible" in r.stderr and "--share-gpu" in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_the_one_gpu_frame_equals_single_device_frame(tmp_path):
+    """--share-gpu: both ranks render on GPU 0 through the HIP path, gloo moves the tiles; the line reports the ranks the process group
+    saw and that the gathered frame is bitwise the frame one context renders alone."""
+    r, line = _bench("--gpus", "2", "--share-gpu", "--check-frame", "--width", "640", "--height", "356", "--steps", "2", "--warmup", "1", "--large-steps", "0")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line["n_gpus"] == 2 and line["config"]["ranks"] == 2 and line["config"]["frame_equals_single_device_frame"] is True
+    assert line["value"] > 0 and "roofline" in line
+
+
 def test_assemble_is_the_inverse_of_the_partition():
     from raytracinggpu_amd import tiling
     import raytracinggpu_amd as rt
