@@ -220,6 +220,15 @@ int rt_device_alloc(rt_ctx *ctx, void **ptr, size_t bytes);
 int rt_device_free(void *ptr);
 int rt_device_to_host(rt_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);   /* synchronous copy on the context's stream */
 
+/* --- a batch of explicit rays through the PRODUCTION traversal launches.  TriangleMesh::intersect (cpu_launcher.cpp:238-313,
+ *     optimized.cu:220-285) is callable with any ray; this entry writes the caller's rays into the traversal queue exactly as the
+ *     render path's emitter does (root-box test of cpu:279 included) and runs the same kernel instantiation with the launch geometry
+ *     of a frame: variant RT_VARIANT_WAVEFRONT_QUEUE (or AUTO: wf_travq, the default traversal), RT_VARIANT_WAVEFRONT (wf_trav) or
+ *     RT_VARIANT_PATH (wf_path).  rays: n x 6 floats (O.xyz, u.xyz; u is used as given, the reference does not renormalise either);
+ *     out: n x 5 floats (hit 0 / 1, t, N.xyz normalised as cpu:308; a miss leaves t = 1e9 = INF narrowed, cpu:283).
+ *     tri_tmin: the leaf loop's t > tri_tmin (cpu:301: 1e-4; 0 = moller_trumbore's own t > 0). */
+int rt_trace_rays(rt_ctx *ctx, const float *rays, int n, float tri_tmin, int variant, float *out);
+
 /* --- known-answer entry points (test interface; same library, same device functions the render kernels inline).
  *     One lane per row.  Inputs/outputs use the layouts of tests/golden/kat.npz, which the reference's own functions
  *     produced (oracle/ref_harness.cpp):

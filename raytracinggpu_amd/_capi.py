@@ -25,7 +25,7 @@ EXPORTS = ["rt_abi_version", "rt_device_count", "rt_ctx_create", "rt_ctx_destroy
            "rt_progressive_frames",
            "rt_multi_create", "rt_multi_destroy", "rt_multi_last_error", "rt_multi_scene_upload", "rt_render_multi",
            "rt_render_multi_device", "rt_render_multi_rgb8", "rt_multi_get_stats",
-           "rt_stats_enable", "rt_render_async", "rt_wait", "rt_mesh_rebuild", "rt_host_alloc", "rt_host_free", "rt_device_alloc", "rt_device_free", "rt_device_to_host", "rt_kat_sphere", "rt_kat_box", "rt_kat_triangle", "rt_kat_mesh"]
+           "rt_stats_enable", "rt_render_async", "rt_wait", "rt_trace_rays", "rt_mesh_rebuild", "rt_host_alloc", "rt_host_free", "rt_device_alloc", "rt_device_free", "rt_device_to_host", "rt_kat_sphere", "rt_kat_box", "rt_kat_triangle", "rt_kat_mesh"]
 MAX_DEVICES = 16
 
 
@@ -146,6 +146,7 @@ def load():
     L.rt_stats_enable.argtypes = [vp, C.c_int]
     L.rt_render_async.argtypes = [vp, C.POINTER(Params), C.c_int, vp, C.c_int]
     L.rt_wait.argtypes = [vp, C.c_int]
+    L.rt_trace_rays.argtypes = [vp, C.POINTER(C.c_float), C.c_int, C.c_float, C.c_int, C.POINTER(C.c_float)]
     fp3 = C.POINTER(C.c_float)
     L.rt_mesh_transform.argtypes = [vp, fp3, fp3]
     L.rt_mesh_set_normals.argtypes = [vp, fp3, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_int]
@@ -326,6 +327,15 @@ class Context:
 
     def wait(self, slot=0):
         self._check(self._L.rt_wait(self._h, int(slot)))
+
+    def trace_rays(self, rays, tri_tmin=1e-4, variant="auto"):
+        """rt_trace_rays: rays [n, 6] (O, u) through the production traversal kernel of `variant` -> [n, 5] (hit, t, N)."""
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        out = np.empty((rays.shape[0], 5), np.float32)
+        v = VARIANTS[variant] if isinstance(variant, str) else int(variant)
+        self._check(self._L.rt_trace_rays(self._h, rays.ctypes.data_as(C.POINTER(C.c_float)), rays.shape[0], C.c_float(tri_tmin), v,
+                                          out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
 
     def stats_enable(self, on=True):
         """trav_ms / trav_launches of stats() are measured only while enabled (production frames record no per-launch events)."""

@@ -279,6 +279,40 @@ void camera_basis(float yaw, float pitch, float bx[3], float by[3], float bz[3])
     bx[0] = x.x; bx[1] = x.y; bx[2] = x.z; by[0] = y.x; by[1] = y.y; by[2] = y.z; bz[0] = z.x; bz[1] = z.y; bz[2] = z.z;
 }
 
+// Traversal-launch geometry of the wavefront pipeline for st.n_paths paths (2 ray slots each): every workgroup owns an equal,
+// spatially scrambled share of the ray slots; its waves draw from it on demand.  Fills st.n_groups, log2S, Q, Q_m, slots_per_block.
+void wf_geometry(const Knobs &kn, int n_cus, int bpc, int parts, int wpb, bool oversubscribe, rtk::WfState &st, int64_t &tblocks_out) {
+    st.n_groups = 2 * st.n_paths / 4;                         // two ray slots per path (continuation + shadow)
+    int64_t tblocks = std::max<int64_t>(1, (int64_t)n_cus * bpc / parts);   // all parts co-resident
+    // work-stack kernel: more workgroups than fit at once; the dispatcher hands a finished workgroup's CU share to
+    // the next one, which evens out the cost differences between the workgroups' shares of the rays
+    const int oversub = kn.oversub;                            // default 2, measured: 1.85 -> 1.67 ms/frame (cat, 1080p)
+    if (oversubscribe && oversub > 1) {
+        // (measured down to one GPU's share of a 1080p frame split over 8: oversubscribing pays at every size;
+        // RT_TRAVQ_OVERSUB_MIN = ray slots per wave below which a launch is not oversubscribed, for experiments)
+        const int min_slots = kn.oversub_min;
+        const int64_t slots_per_wave = (int64_t)st.n_groups * 4 / (tblocks * oversub * wpb);
+        if (slots_per_wave >= min_slots) tblocks *= oversub;
+    }
+    const int min_groups = kn.min_groups * wpb;               // default 16: >= 64 ray slots per wave on average
+    int64_t groups_per_block = (st.n_groups + tblocks - 1) / tblocks;
+    if (groups_per_block < min_groups) {                      // small launch: fewer, fuller workgroups
+        tblocks = (st.n_groups + min_groups - 1) / min_groups;
+        if (tblocks < 1) tblocks = 1;
+        groups_per_block = (st.n_groups + tblocks - 1) / tblocks;
+    }
+    // scramble: consecutive group-slots of one workgroup must land on groups spread over the WHOLE sub-frame, so
+    // the stride pattern's period S is the largest power of two not above a workgroup's number of groups
+    st.log2S = 0;
+    while ((2 << st.log2S) <= groups_per_block && st.log2S < 16) ++st.log2S;
+    if (kn.log2S >= 0 && kn.log2S < st.log2S) st.log2S = kn.log2S;   // experiment: less scrambling = more coherent rays per workgroup
+    const int S = 1 << st.log2S;
+    st.Q = (st.n_groups + S - 1) / S; st.Q_m = rtk::wf_div_magic(st.Q);
+    const int64_t total_slots = (int64_t)S * st.Q * 4;
+    st.slots_per_block = (int)(((total_slots + tblocks - 1) / tblocks + 3) / 4 * 4);
+    tblocks_out = tblocks;
+}
+
 int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *out_dev, hipStream_t stream,
                   unsigned long long *work_dev = nullptr, const rt_camera_pose *pose = nullptr) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
@@ -556,36 +590,8 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
             pt.pxbase = px_total;
             np_total += (size_t)n_paths64;
             px_total += (size_t)n_px64;
-            // every workgroup owns an equal, spatially scrambled share of the ray slots; its waves draw from it on demand
-            rtk::WfState &st = pt.st;
-            st.n_groups = 2 * st.n_paths / 4;                         // two ray slots per path (continuation + shadow)
-            int64_t tblocks = std::max<int64_t>(1, (int64_t)ctx->n_cus * bpc / parts);   // all parts co-resident
-            // work-stack kernel: more workgroups than fit at once; the dispatcher hands a finished workgroup's CU share to
-            // the next one, which evens out the cost differences between the workgroups' shares of the rays
-            const int oversub = kn.oversub;                            // default 2, measured: 1.85 -> 1.67 ms/frame (cat, 1080p)
-            if (queue && !qlds && oversub > 1) {
-                // (measured down to one GPU's share of a 1080p frame split over 8: oversubscribing pays at every size;
-                // RT_TRAVQ_OVERSUB_MIN = ray slots per wave below which a launch is not oversubscribed, for experiments)
-                const int min_slots = kn.oversub_min;
-                const int64_t slots_per_wave = (int64_t)st.n_groups * 4 / (tblocks * oversub * wpb);
-                if (slots_per_wave >= min_slots) tblocks *= oversub;
-            }
-            const int min_groups = kn.min_groups * wpb;               // default 16: >= 64 ray slots per wave on average
-            int64_t groups_per_block = (st.n_groups + tblocks - 1) / tblocks;
-            if (groups_per_block < min_groups) {                      // small launch: fewer, fuller workgroups
-                tblocks = (st.n_groups + min_groups - 1) / min_groups;
-                if (tblocks < 1) tblocks = 1;
-                groups_per_block = (st.n_groups + tblocks - 1) / tblocks;
-            }
-            // scramble: consecutive group-slots of one workgroup must land on groups spread over the WHOLE sub-frame, so
-            // the stride pattern's period S is the largest power of two not above a workgroup's number of groups
-            st.log2S = 0;
-            while ((2 << st.log2S) <= groups_per_block && st.log2S < 16) ++st.log2S;
-            if (kn.log2S >= 0 && kn.log2S < st.log2S) st.log2S = kn.log2S;   // experiment: less scrambling = more coherent rays per workgroup
-            const int S = 1 << st.log2S;
-            st.Q = (st.n_groups + S - 1) / S; st.Q_m = rtk::wf_div_magic(st.Q);
-            const int64_t total_slots = (int64_t)S * st.Q * 4;
-            st.slots_per_block = (int)(((total_slots + tblocks - 1) / tblocks + 3) / 4 * 4);
+            int64_t tblocks = 0;
+            wf_geometry(kn, ctx->n_cus, bpc, parts, wpb, queue && !qlds, pt.st, tblocks);
             pt.tblocks = tblocks;
             pt.pblocks = (unsigned)((n_paths64 + 255) / 256);
         }
@@ -1452,3 +1458,4 @@ int rt_get_stats(rt_ctx *ctx, rt_stats *stats) {
 
 #include "rt_multi.hip.h"
 #include "rt_kat.hip.h"
+#include "rt_trace.hip.h"

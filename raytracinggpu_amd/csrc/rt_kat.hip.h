@@ -37,7 +37,8 @@ __global__ __launch_bounds__(256) void kat_sphere_kernel(const float *__restrict
 }
 
 // in: mn[3] mx[3] O[3] u[3]; out: hit.  route 0: literal slab; 1: slab_filtered (RayInv: root-box pre-test, stackless
-// walks); 2: qbox_filter with the per-ray table entry of the work-stack kernels, literal slab when undecided
+// walks); 2: qbox_filter with the per-ray table entry of wf_path, literal slab when undecided; 3: wf_travq's centre / half-extent
+// filter (cbox_filter: the box as rt_scene_upload stores it, the per-ray constants of the refill), literal slab when undecided
 __global__ __launch_bounds__(256) void kat_box_kernel(const float *__restrict__ in, int n, int route, float *__restrict__ out, unsigned long long *cnt) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = i < n;
@@ -50,11 +51,24 @@ __global__ __launch_bounds__(256) void kat_box_kernel(const float *__restrict__ 
             hit = slab(lo, hi, O, u);
         } else if (route == 1) {
             hit = slab_filtered(lo, hi, O, u, ray_inv(u), decided);
-        } else {
+        } else if (route == 2) {
             const RayBox rb = ray_box(O, u);
             const float4 A = make_float4(rb.rx, rb.ry, rb.rz, rb.safe ? rb.c0 : __builtin_inff());
             const float4 C = make_float4(O.x, O.y, O.z, u.x);
             decided = qbox_filter(lo, hi, A, C, hit);
+            if (!decided) hit = slab(lo, hi, O, u);
+        } else {
+            // the scene-wide quantities of install_scene, for this one box: magnitudes, and whether the fast filter may run at all
+            const float v[6] = {lo.x, lo.y, lo.z, hi.x, hi.y, hi.z};
+            bool fast = true;
+            for (int a = 0; a < 3; ++a) fast = fast && v[a] <= v[a + 3] && fabsf(v[a]) < 1e8f && fabsf(v[a + 3]) < 1e8f;
+            const f3 bm = mk(fmaxf(fabsf(lo.x), fabsf(hi.x)), fmaxf(fabsf(lo.y), fabsf(hi.y)), fmaxf(fabsf(lo.z), fabsf(hi.z)));
+            const RayBoxC rb = ray_box_c(O, u, bm, fast);
+            const float4 n0 = make_float4(box_centre(lo.x, hi.x), box_centre(lo.y, hi.y), box_centre(lo.z, hi.z), 0.f);
+            const float4 n1 = make_float4(box_half(lo.x, hi.x), box_half(lo.y, hi.y), box_half(lo.z, hi.z), 0.f);
+            bool miss;
+            cbox_filter(n0, n1, make_float4(rb.rx, rb.ry, rb.rz, rb.c0), make_float4(rb.ox, rb.oy, rb.oz, 0.f), hit, miss);
+            decided = hit || miss;
             if (!decided) hit = slab(lo, hi, O, u);
         }
         out[i] = hit ? 1.f : 0.f;
@@ -195,7 +209,7 @@ int rt_kat_sphere(rt_ctx *ctx, const float *in, int n, float *out) {
 }
 
 int rt_kat_box(rt_ctx *ctx, const float *in, int n, int route, float *out, rt_kat_counts *counts) {
-    if (route < 0 || route > 2) return fail(ctx, RT_ERR_INVALID, "route must be 0 (literal), 1 (slab_filtered) or 2 (qbox_filter)");
+    if (route < 0 || route > 3) return fail(ctx, RT_ERR_INVALID, "route must be 0 (literal), 1 (slab_filtered), 2 (qbox_filter) or 3 (cbox_filter)");
     return kat_run(ctx, in, n, 12, out, 1, counts, [&](const float *di, float *dres, unsigned long long *dc, dim3 g, dim3 b) {
         hipLaunchKernelGGL(rtk::kat_box_kernel, g, b, 0, ctx->stream, di, n, route, dres, dc);
     });

@@ -45,6 +45,11 @@ struct PathState {
     int log2S, Q, n_groups;   // scrambled static shares: item slot q -> item 4 g + (q & 3), g = ((q >> 2) & (S - 1)) * Q + ((q >> 2) >> log2S)
     int slots_per_block;      // item slots owned by one workgroup (multiple of 4)
     float4 *samp_out;     // [n_samp][n_paths] (colour of the sample, rays traced) when the frame has more than one sample; else nullptr
+    // rt_trace_rays: the items are n_ext EXPLICIT rays (6 floats each: O, u) instead of camera rays; a path is one ray, and what leaves
+    // the CU is its traversal result ext_out[item] = bits(t) << 32 | triangle (WF_NOHIT if none) instead of a colour
+    const float *ext_rays;
+    unsigned long long *ext_out;
+    int n_ext;
 };
 
 struct PCarve {
@@ -188,7 +193,13 @@ __global__ __launch_bounds__(kQBlock, 2) void wf_path(const Scene sc, const Fram
                         fr.out[out_index(fr, lrow, px)] = make_float4(tx / n, ty / n, tz / n, rays);
                     }
                 };
-                if (ready && alive) {
+                if (ready && alive && ps.ext_rays != nullptr) {               // rt_trace_rays: the ray's traversal result is the path's result
+                    item = pI[lane];
+                    PQ_CHECK(item >= 0 && item < ps.n_ext, 1, item = 0);
+                    ps.ext_out[item] = (F.x & PF_MESHY) ? best[lane] : WF_NOHIT;
+                    alive = false;
+                    F = make_int4(0, 0, 0, 0);
+                } else if (ready && alive) {
                     S = pS[lane];
                     item = pI[lane];
                     decode_item(item);
@@ -344,7 +355,17 @@ __global__ __launch_bounds__(kQBlock, 2) void wf_path(const Scene sc, const Fram
                     if (want) {
                         const int qo = base + lanes_below(wm);
                         item = qo < blk_n ? path_slot_to_item(ps, (int)blk_base + qo) : -1;
-                        if (item >= 0) {
+                        if (item >= 0 && ps.ext_rays != nullptr) {            // rt_trace_rays: item = ray index, the ray as given (not normalised)
+                            if (item < ps.n_ext) {
+                                const float *er = ps.ext_rays + 6 * (size_t)item;
+                                Oy = mk(er[0], er[1], er[2]);
+                                uy = mk(er[3], er[4], er[5]);
+                                emitY = true;
+                                alive = true;
+                                F = make_int4(PF_ALIVE | PF_HASY | (1 << PF_RAYS_SHIFT), 0, 0, 0);
+                                S = make_float4(0, 0, 0, 1.f);
+                            }
+                        } else if (item >= 0) {
                             decode_item(item);
                             const bool valid = px < fr.W && lrow < fr.n_rows;
                             if (valid && fr.segs <= 0) {                       // optimized.cu convention with num_bounce 0: black

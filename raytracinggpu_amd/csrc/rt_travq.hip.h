@@ -135,15 +135,15 @@ __device__ __forceinline__ bool qbox_filter(const float4 lo, const float4 hi, co
 // huge / NaN component, scenes whose boxes are not finite, ordered and below 1e8 in magnitude: Scene::fast_box) makes both
 // comparisons false, and so does any NaN.  Within those guards no intermediate overflows: |c r|, |h r| < 1e8 * 1e30.
 struct RayBoxC { float rx, ry, rz, ox, oy, oz, c0; };
-__device__ __forceinline__ RayBoxC ray_box_c(const Scene &sc, f3 O, f3 u) {
+__device__ __forceinline__ RayBoxC ray_box_c(f3 O, f3 u, f3 bm, bool fast_box) {   // bm: per axis max |bound| over the boxes the ray will meet
     RayBoxC b;
     b.rx = __builtin_amdgcn_rcpf(u.x); b.ry = __builtin_amdgcn_rcpf(u.y); b.rz = __builtin_amdgcn_rcpf(u.z);
     b.ox = O.x * b.rx; b.oy = O.y * b.ry; b.oz = O.z * b.rz;
     const float omax = vmax3abs(b.ox, b.oy, b.oz);
-    const float wx = fabsf(b.rx) * fmaf(3.f, sc.bmx, 2.f * fabsf(O.x)), wy = fabsf(b.ry) * fmaf(3.f, sc.bmy, 2.f * fabsf(O.y)), wz = fabsf(b.rz) * fmaf(3.f, sc.bmz, 2.f * fabsf(O.z));
+    const float wx = fabsf(b.rx) * fmaf(3.f, bm.x, 2.f * fabsf(O.x)), wy = fabsf(b.ry) * fmaf(3.f, bm.y, 2.f * fabsf(O.y)), wz = fabsf(b.rz) * fmaf(3.f, bm.z, 2.f * fabsf(O.z));
     const float w = vmax3(wx, wy, wz);
     const float umin = fminf(fminf(fabsf(u.x), fabsf(u.y)), fabsf(u.z)), umax = fmaxf(fmaxf(fabsf(u.x), fabsf(u.y)), fabsf(u.z));
-    const bool safe = sc.fast_box != 0 && umin > kTiny && umax < kBig && omax < kBig && w < kBig;      // false for 0, denormal, inf, NaN anywhere
+    const bool safe = fast_box && umin > kTiny && umax < kBig && omax < kBig && w < kBig;      // false for 0, denormal, inf, NaN anywhere
     b.c0 = safe ? fmaf(w, 0x1.2p-23f, 2e-35f) : __builtin_inff();
     return b;
 }
@@ -403,7 +403,7 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
                 const bool work = root_hiw < 0 || cnt > 0;
                 if (got) {
                     const f3 O = mk(r0.x, r0.y, r0.z), u = mk(r0.w, r1.x, r1.y);
-                    const RayBoxC rb = ray_box_c(sc, O, u);
+                    const RayBoxC rb = ray_box_c(O, u, mk(sc.bmx, sc.bmy, sc.bmz), sc.fast_box != 0);
                     rowA(my_sb) = make_float4(rb.rx, rb.ry, rb.rz, rb.c0);
                     rowO(my_sb) = make_float4(rb.ox, rb.oy, rb.oz, __int_as_float(work ? 1 : 0));      // .w: one outstanding entry
                     rowC(my_sb) = r0;

@@ -38,6 +38,14 @@ def test_device_tree_equals_host_tree(ctx, cat_golden, kind):
         v, t = _synthetic_mesh(kind, rng)
     first = hostlib.build_mesh(v, t, albedo=rt.scenes.CAT_ALBEDO, object_slot=6)        # host tree from OBJ order: what a caller uploads
     ctx.scene_upload(rt.scenes.spheres("cpu"), first)
+    if kind == "cat":
+        # the device tree against the REFERENCE's own tree (tests/golden/cat_mesh.npz: TriangleMesh::buildBVH + bvhTreeToArray of the
+        # reference program, oracle/ref_harness.cpp), not only against this repo's host builder: built from OBJ order, bit for bit
+        ctx.scene_upload(rt.scenes.spheres("cpu"), dict(vertices=v, indices=t, bvh_arr10=first["bvh_arr10"], albedo=rt.scenes.CAT_ALBEDO, object_slot=6))
+        arr, order = ctx.mesh_rebuild(len(t))
+        np.testing.assert_array_equal(arr.view(np.uint32), np.ascontiguousarray(cat_golden["bvh_arr10"], np.float32).view(np.uint32))
+        np.testing.assert_array_equal(t[order], np.asarray(cat_golden["tri_bvh_order"])[:, :3])
+        ctx.scene_upload(rt.scenes.spheres("cpu"), first)
     p = rt.make_params(320, 200, 1, 1, **rt.scenes.CPU_LAUNCHER)
     exp = _check_rebuild(ctx, v, first["indices"][:, :3])
     got = ctx.render(p)

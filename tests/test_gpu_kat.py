@@ -39,9 +39,10 @@ def test_kat_sphere_on_device(ctx):
     assert 0.05 < hit.mean() < 0.95
 
 
-@pytest.mark.parametrize("route", [0, 1, 2])
+@pytest.mark.parametrize("route", [0, 1, 2, 3])
 def test_kat_box_on_device(ctx, route):
-    """BoundingBox::intersect incl. u_k = 0 (+-inf / NaN slabs, SURVEY H7): literal code, slab_filtered, qbox_filter + fall-back."""
+    """BoundingBox::intersect incl. u_k = 0 (+-inf / NaN slabs, SURVEY H7): literal code, slab_filtered, qbox_filter + fall-back,
+    and wf_travq's centre / half-extent filter (cbox_filter) + fall-back."""
     g = load_golden("kat.npz")
     rows = g["box_in"]
     got, cnt = ctx.kat_box(rows, route)
@@ -89,6 +90,86 @@ def test_kat_mesh_on_device(ctx, route):
     if route == 0:
         assert cnt["box_decided"] > 0 and cnt["tri_decided"] > 0
         print(f"mesh: box decided/literal {cnt['box_decided']}/{cnt['box_literal']}, triangle {cnt['tri_decided']}/{cnt['tri_literal']}")
+
+
+def _check_mesh_rows(got, exp):
+    np.testing.assert_array_equal(got[:, 0], exp[:, 0])
+    hit = exp[:, 0] != 0
+    np.testing.assert_array_equal(bits(got[hit, 1:5]), bits(exp[hit, 1:5]))
+    return hit
+
+
+@pytest.mark.parametrize("variant", ["wavefront_queue", "path", "wavefront"])
+def test_reference_mesh_vectors_through_the_production_traversal_kernels(ctx, variant):
+    """rt_trace_rays: the reference's own TriangleMesh::intersect vectors (tests/golden/kat.npz, 6 600 rays incl. origins inside the
+    mesh and grazing rays) written into the traversal queue and traced by the PRODUCTION launches -- wf_travq (stack, leaf queue,
+    refill), wf_path, wf_trav (work splitting) -- not by a test kernel's own loop: nearest t and normal bit-exact."""
+    g = load_golden("kat.npz")
+    got = ctx.trace_rays(g["mesh_in"], 1e-4, variant)
+    hit = _check_mesh_rows(got, g["mesh_out"])
+    assert hit.sum() > 1500
+
+
+def test_reference_mesh_vectors_through_the_serial_drain(cat_golden, monkeypatch):
+    """The same under RT_TRAVQ_CAP=128 (a context reads its knobs once): the work stack overflows and wf_travq drains popped pairs by
+    the serial skip-pointer walk."""
+    monkeypatch.setenv("RT_TRAVQ_CAP", "128")
+    c = rt.Context(0)
+    monkeypatch.delenv("RT_TRAVQ_CAP")
+    mesh = dict(vertices=cat_golden["vertices"], indices=cat_golden["tri_bvh_order"], bvh_arr10=cat_golden["bvh_arr10"], albedo=rt.scenes.CAT_ALBEDO, object_slot=6)
+    c.scene_upload(rt.scenes.spheres("cpu"), mesh)
+    g = load_golden("kat.npz")
+    for variant in ("wavefront_queue", "path"):
+        _check_mesh_rows(c.trace_rays(g["mesh_in"], 1e-4, variant), g["mesh_out"])
+    drains = c.count_work(rt.make_params(640, 360, 1, 2, **rt.scenes.CPU_LAUNCHER), detail=True)["steps"]["serial_drains"]
+    assert drains > 0                                                  # the capacity really forces the drain on this mesh
+    c.close()
+
+
+@pytest.mark.parametrize("variant", ["wavefront_queue", "path", "wavefront"])
+def test_degenerate_rays_through_the_production_traversal_kernels(ctx, oracle, oracle_cat, variant):
+    """Rays a camera or a bounce never produces -- zero, denormal, huge and axis-parallel direction components, origins inside the
+    mesh and on its box faces, unnormalised directions -- against the oracle's TriangleMesh::intersect (pinned to the reference by
+    tests/test_oracle_pinned.py): hit flag, t and normal bit-exact through every production traversal kernel.  These rays reach
+    wf_travq's c0 = +inf route (literal box tests for every pair) and, with tri_tmin = 0, moller_trumbore's own t > 0."""
+    rng = np.random.default_rng(20260410)
+    n = 1200
+    O = rng.uniform(-30, 30, (n, 3)).astype(np.float32)
+    O[:300] = rng.uniform(-8, 8, (300, 3)).astype(np.float32) + np.float32([0, 5, 0])       # inside / near the cat
+    u = rng.normal(size=(n, 3)).astype(np.float32)
+    k = rng.integers(0, 3, n)
+    u[np.arange(600), k[:600]] = 0.0                                   # one zero component
+    u[np.arange(600, 700), k[600:700]] = np.float32(1e-42)             # denormal
+    u[np.arange(700, 760), k[700:760]] = np.float32(-0.0)
+    u[760:800] = 0.0; u[np.arange(760, 800), k[760:800]] = rng.choice([-1.0, 1.0], 40)      # axis-parallel
+    u[800:840] *= np.float32(1e20)                                     # huge, unnormalised
+    u[840:880] *= np.float32(1e-20)
+    bb = oracle_cat.bvh_array()[0]
+    O[880:940, 0] = bb[2]; O[940:1000, 1] = bb[6]                     # on the root box's faces
+    rays = np.concatenate([O, u], axis=1)
+    for tmin in (1e-4, 0.0):
+        exp = np.zeros((n, 5), np.float32)
+        for i in range(n):
+            h, t, N = oracle_cat.intersect(O[i], u[i], tmin)
+            exp[i, 0] = 1.0 if h else 0.0
+            exp[i, 1] = t; exp[i, 2:5] = N
+        got = ctx.trace_rays(rays, tmin, variant)
+        hit = _check_mesh_rows(got, exp)
+        assert hit.sum() > 50 and (~hit).sum() > 50
+    assert ((rays[:, 3:6] == 0).any(axis=1)).sum() >= 500
+
+
+def test_trace_rays_error_paths_and_empty_scene(ctx):
+    assert ctx.trace_rays(np.zeros((0, 6), np.float32)).shape == (0, 5)
+    with pytest.raises(rt.RtError):
+        ctx.trace_rays(np.zeros((4, 6), np.float32), variant="lockstep")
+    fresh = rt.Context(0)
+    with pytest.raises(rt.RtError):
+        fresh.trace_rays(np.zeros((4, 6), np.float32))
+    fresh.scene_upload(rt.scenes.spheres("cpu"), None)                 # no mesh: every ray misses it
+    out = fresh.trace_rays(np.ones((5, 6), np.float32))
+    assert (out[:, 0] == 0).all()
+    fresh.close()
 
 
 def test_kat_error_paths(ctx):

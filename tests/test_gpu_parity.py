@@ -1,9 +1,10 @@
 """HIP render path (through the C-ABI) vs the CPU oracle on the same inputs.  -m gpu.
 
 Tolerance (BASELINE.json / SURVEY 8d): per-channel L-inf <= 1e-4 on g = min(pow(c,1/2.2),255)/255.
-For sigma == 0 the linear float colour is expected to be bit-identical (same single IEEE roundings);
-where it is not (binary64 sin/cos of the ROCm device library vs glibc on the bounce directions), the
-test states the measured fraction and still enforces the 1e-4 bound.
+For sigma == 0 the linear float colour IS bit-identical -- same single IEEE roundings everywhere, and the binary64
+sin / cos of the bounce direction (rt_sincos.h) gives the same binary32 products as glibc over all 2^24 arguments
+(tools/check_sincos.cpp) -- so every such comparison asserts exact equality of every channel.  Only frames with
+pixel jitter (sigma != 0: device logf vs glibc) are held to the 1e-4 bound with a stated identical fraction.
 """
 import numpy as np
 import pytest
@@ -84,7 +85,7 @@ def test_bounces_within_tolerance(ctx, oracle, oracle_cat, cat_golden, scene, W,
     err = linf(oracle, got, exp)
     print(f"{scene} {W}x{H} spp={spp} b={b}: bit-identical channels {same:.6f}, Linf(gamma) {err:.3g}")
     assert err <= TOL
-    assert same > 0.999
+    assert values_equal(got[..., :3], exp[..., :3]).all()              # sigma == 0: every channel bit-identical
     np.testing.assert_array_equal(got[..., 3], exp[..., 3])
 
 
@@ -275,7 +276,7 @@ def test_product_builder_feeds_the_kernel(ctx, oracle, oracle_cat, cat_golden):
     got = ctx.render(rt.make_params(640, 360, 1, 1, **rt.scenes.CPU_LAUNCHER))
     exp, _, _ = oracle.Scene.preset("cpu", oracle_cat).render(640, 360, 1, 1, want_rgb8=False)
     assert linf(oracle, got, exp) <= TOL
-    assert values_equal(got[..., :3], exp[..., :3]).mean() > 0.999
+    assert values_equal(got[..., :3], exp[..., :3]).all()
 
 
 def test_work_counters_equal_oracle_counters(ctx, oracle, oracle_cat, cat_golden):
@@ -309,7 +310,7 @@ def test_headline_config_full_frame_against_the_oracle(ctx, oracle, oracle_cat, 
     same = values_equal(ref[..., :3], exp[..., :3]).mean()
     err = linf(oracle, ref, exp)
     print(f"cat 1920x1080 b=3: rays {cnt['rays']}, bit-identical channels {same:.6f}, Linf(gamma) {err:.3g}")
-    assert err <= TOL and same > 0.999
+    assert err <= TOL and values_equal(ref[..., :3], exp[..., :3]).all()
     assert ctx.count_work(rt.make_params(W, H, 1, 3, **rt.scenes.CPU_LAUNCHER)) == {k: cnt[k] for k in ("rays", "box_tests", "nodes", "tri_tests")}
 
 
@@ -323,7 +324,7 @@ def test_config2_spheres_only_full_size(ctx, oracle, cat_golden):
         got = ctx.render(rt.make_params(W, H, 1, 3, variant=variant, **rt.scenes.CPU_LAUNCHER))
         np.testing.assert_array_equal(got[..., 3], exp[..., 3])
         assert linf(oracle, got, exp) <= TOL
-        assert values_equal(got[..., :3], exp[..., :3]).mean() > 0.999
+        assert values_equal(got[..., :3], exp[..., :3]).all()
     assert int(got[..., 3].astype(np.float64).sum()) == cnt["rays"]
 
 
