@@ -312,6 +312,8 @@ typedef struct rt_multi_stats {
     uint64_t gather_bytes;                /* bytes the peers moved into the root device for the last frame   */
     int32_t  peer_access[RT_MAX_DEVICES]; /* 1: device k writes the root's memory directly (peer access over xGMI),
                                              0: no peer path, the runtime stages the copy; -1: same device as the root */
+    float    submit_ms;                   /* host: call entry -> every device's launches, events and peer copy issued (one submit
+                                             thread per device; frame_ms - submit_ms is spent waiting for the devices)          */
 } rt_multi_stats;
 int rt_multi_create(rt_multi **m, const int *device_ids, int n_devices);
 int rt_multi_destroy(rt_multi *m);

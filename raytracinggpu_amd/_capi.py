@@ -96,7 +96,7 @@ def make_pose(position=(0.0, 0.0, 55.0), yaw=0.0, pitch=0.3, fov=None):
 class MultiStats(C.Structure):
     _fields_ = [("n_devices", C.c_int32), ("device_id", C.c_int32 * MAX_DEVICES), ("kernel_ms", C.c_float * MAX_DEVICES),
                 ("gather_ms", C.c_float), ("frame_ms", C.c_float), ("rays", C.c_uint64), ("gather_bytes", C.c_uint64),
-                ("peer_access", C.c_int32 * MAX_DEVICES)]
+                ("peer_access", C.c_int32 * MAX_DEVICES), ("submit_ms", C.c_float)]
 
 
 _lib = None
@@ -488,4 +488,4 @@ class MultiContext:
         n = s.n_devices
         return {"n_devices": n, "device_id": list(s.device_id)[:n], "kernel_ms": list(s.kernel_ms)[:n],
                 "gather_ms": s.gather_ms, "frame_ms": s.frame_ms, "rays": int(s.rays), "gather_bytes": int(s.gather_bytes),
-                "peer_access": list(s.peer_access)[:n]}
+                "peer_access": list(s.peer_access)[:n], "submit_ms": s.submit_ms}

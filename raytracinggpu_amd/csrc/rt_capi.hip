@@ -54,6 +54,8 @@ struct Knobs {
     long long path_samp_bytes = 400ll << 20; // RT_PATH_SAMP_MB: state of the samples traced together (frames with num_rays > 1; ~130 B per sample and pixel slot).
                                              // Measured: a chain is fastest while its state stays near the 256 MB Infinity Cache -- 512x512, 64 samples: 23.5 / 8.8 / 8.0 /
                                              // 8.8 ms for 30 / 192 / 400 / 4096 MB; 1920x1080 (277 MB per sample): one sample per chain is best (71.5 vs 76.9 ms at 13)
+    int copy_split = 0;        // RT_COPY_SPLIT=1: rt_render_async sends the two halves of a big frame through two copy streams (measured SLOWER: 1.62 vs 1.48 ms per
+                               // pipelined 1080p float4 frame -- one DMA already runs at the rate the PCIe link gives, two share it and add an event hop)
     int debug_trav = -2;       // RT_DEBUG_TRAV: traversal launch whose per-wave records are dumped (-DRT_DEBUG builds only)
 };
 
@@ -78,6 +80,7 @@ static Knobs read_knobs() {
     if (geti("RT_PATH_OVERSUB", v) && v >= 1 && v <= 64) k.path_oversub = v;
     if (geti("RT_PATH_BPC", v) && v >= 1 && v <= 8) k.path_bpc = v;
     if (geti("RT_PATH_PARTS", v) && v >= 1 && v <= 8) k.path_parts = v;
+    if (geti("RT_COPY_SPLIT", v)) k.copy_split = v != 0;
     if (geti("RT_PATH_SAMP_MB", v) && v >= 1) k.path_samp_bytes = (long long)v << 20;
 #ifdef RT_DEBUG
     if (geti("RT_DEBUG_TRAV", v)) k.debug_trav = v;
@@ -121,7 +124,8 @@ struct rt_ctx {
     DevBuf slot_rgba[kSlots], slot_rgb8[kSlots];
     hipEvent_t slot_rendered[kSlots] = {}, slot_done[kSlots] = {};
     bool slot_pending[kSlots] = {false, false};
-    hipStream_t copy_stream = nullptr;
+    hipStream_t copy_stream = nullptr, copy_stream2 = nullptr;      // two copy streams: the halves of a frame go out through two DMA engines
+    hipEvent_t slot_half[kSlots] = {};
     bool travq_ok = true;                                           // the uploaded tree fits wf_travq's entry formats (leaf sizes, triangle offsets)
     static constexpr int kMaxTravEvents = 2 * RT_MAX_SEGMENTS;
     hipEvent_t ev_trav[2 * kMaxTravEvents] = {};
@@ -937,6 +941,8 @@ int rt_ctx_create(rt_ctx **out, int device_id) {
     for (hipStream_t &q : ctx->part_stream) if (e == hipSuccess) e = hipStreamCreateWithFlags(&q, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_stream2, hipStreamNonBlocking);
+    for (int k = 0; k < rt_ctx::kSlots; ++k) if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->slot_half[k], hipEventDisableTiming);
     for (int k = 0; k < rt_ctx::kSlots; ++k) {
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->slot_rendered[k], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->slot_done[k], hipEventDisableTiming);
@@ -962,6 +968,8 @@ int rt_ctx_destroy(rt_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
+    if (ctx->copy_stream2) { (void)hipStreamSynchronize(ctx->copy_stream2); (void)hipStreamDestroy(ctx->copy_stream2); }
+    for (int k = 0; k < rt_ctx::kSlots; ++k) if (ctx->slot_half[k]) (void)hipEventDestroy(ctx->slot_half[k]);
     for (int k = 0; k < rt_ctx::kSlots; ++k) {
         ctx->slot_rgba[k].release(); ctx->slot_rgb8[k].release();
         if (ctx->slot_rendered[k]) (void)hipEventDestroy(ctx->slot_rendered[k]);
@@ -1064,8 +1072,16 @@ int rt_render_async(rt_ctx *ctx, const rt_params *p, int slot, void *out_host, i
     RT_HIP(ctx, hipEventRecord(ctx->slot_rendered[slot], ctx->stream));
     // the copy runs on its own stream: the next frame's kernels (other slot) do not queue behind it
     RT_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->slot_rendered[slot], 0));
-    if (rgb8) RT_HIP(ctx, hipMemcpyAsync(out_host, ctx->slot_rgb8[slot].p, (size_t)npix * 3, hipMemcpyDeviceToHost, ctx->copy_stream));
-    else RT_HIP(ctx, hipMemcpyAsync(out_host, ctx->slot_rgba[slot].p, (size_t)npix * sizeof(float4), hipMemcpyDeviceToHost, ctx->copy_stream));
+    const size_t bytes = rgb8 ? (size_t)npix * 3 : (size_t)npix * sizeof(float4);
+    const uint8_t *src = static_cast<const uint8_t *>(rgb8 ? ctx->slot_rgb8[slot].p : ctx->slot_rgba[slot].p);
+    const size_t half = ctx->knobs.copy_split && bytes >= (4u << 20) ? (bytes / 2 + 4095) / 4096 * 4096 : bytes;   // big frames: two halves on two copy streams
+    RT_HIP(ctx, hipMemcpyAsync(out_host, src, half, hipMemcpyDeviceToHost, ctx->copy_stream));
+    if (half < bytes) {
+        RT_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream2, ctx->slot_rendered[slot], 0));
+        RT_HIP(ctx, hipMemcpyAsync(static_cast<uint8_t *>(out_host) + half, src + half, bytes - half, hipMemcpyDeviceToHost, ctx->copy_stream2));
+        RT_HIP(ctx, hipEventRecord(ctx->slot_half[slot], ctx->copy_stream2));
+        RT_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->slot_half[slot], 0));
+    }
     RT_HIP(ctx, hipEventRecord(ctx->slot_done[slot], ctx->copy_stream));
     ctx->slot_pending[slot] = true;
     return RT_OK;

@@ -8,6 +8,11 @@
 // restores row order.  The one-process-per-GPU path (bench.py, torch.distributed) does the same exchange with one
 // RCCL gather instead; results are bitwise the single-device frame either way.
 
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+
 namespace rtk {
 
 struct MultiSrc { const float4 *base[RT_MAX_DEVICES]; };
@@ -56,8 +61,50 @@ __global__ __launch_bounds__(256) void sum_rays_kernel(const float4 *__restrict_
 
 }  // namespace rtk
 
+// One submit thread per peer device (device 0 is driven by the calling thread): a frame's ~25 runtime calls per device -- launches,
+// event records, the peer copy -- are issued by all devices' threads at once instead of one device after the other (with eight
+// devices the last one used to start ~300 runtime calls late).  The threads live as long as the multi context.
+struct MultiWorker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool has_job = false, busy = false, quit = false;
+    void start() {
+        th = std::thread([this] {
+            std::unique_lock<std::mutex> lk(mu);
+            for (;;) {
+                cv.wait(lk, [this] { return has_job || quit; });
+                if (quit) return;
+                std::function<void()> j = std::move(job);
+                has_job = false;
+                lk.unlock();
+                j();
+                lk.lock();
+                busy = false;
+                cv.notify_all();
+            }
+        });
+    }
+    void submit(std::function<void()> j) {
+        std::lock_guard<std::mutex> lk(mu);
+        job = std::move(j); has_job = true; busy = true;
+        cv.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [this] { return !busy; });
+    }
+    void stop() {
+        if (!th.joinable()) return;
+        { std::lock_guard<std::mutex> lk(mu); quit = true; cv.notify_all(); }
+        th.join();
+    }
+};
+
 struct rt_multi {
     int n = 0;
+    MultiWorker *worker[RT_MAX_DEVICES] = {};   // worker[k] submits device k's work (k >= 1)
     rt_ctx *ctx[RT_MAX_DEVICES] = {};
     DevBuf local[RT_MAX_DEVICES];           // dense tiles of device k (on device k)
     DevBuf local8[RT_MAX_DEVICES], rays_k[RT_MAX_DEVICES];   // RGB8 gather: tonemapped tiles and ray count of device k (on device k)
@@ -118,31 +165,46 @@ int multi_render(rt_multi *m, const rt_params *p, void *out_dev_on_root, void *o
         for (int j = 0; j < launched; ++j) { (void)hipSetDevice(m->ctx[j]->device); (void)hipStreamSynchronize(m->ctx[j]->stream); }
         (void)hipSetDevice(root->device);
     };
-    for (int k = 0; k < n; ++k) {
+    // each device's submission: returns a status, leaves its text in err_k[k] (the submit threads have their own thread-local error)
+    int rc_k[RT_MAX_DEVICES] = {};
+    std::string err_k[RT_MAX_DEVICES];
+    auto submit = [&](int k) -> int {
         rt_ctx *c = m->ctx[k];
+        int r;
         hipError_t e = hipSetDevice(c->device);
-        if (e != hipSuccess) { drain(k); return mfail(m, RT_ERR_HIP, "hipSetDevice(%d): %s", c->device, hipGetErrorString(e)); }
-        if ((rc = ensure(c, m->local[k], std::max<size_t>((size_t)nrows[k] * W, 1) * sizeof(float4))) != RT_OK) { m->err = c->err; drain(k); return rc; }
+        if (e != hipSuccess) { err_k[k] = std::string("hipSetDevice: ") + hipGetErrorString(e); return RT_ERR_HIP; }
+        if ((r = ensure(c, m->local[k], std::max<size_t>((size_t)nrows[k] * W, 1) * sizeof(float4))) != RT_OK) { err_k[k] = c->err; return r; }
         rt_rows rows{k * R, nrows[k], R, n};
-        if ((rc = launch_render(c, p, &rows, m->local[k].p, c->stream)) != RT_OK) { m->err = c->err; drain(k + 1); return rc; }
+        if ((r = launch_render(c, p, &rows, m->local[k].p, c->stream)) != RT_OK) { err_k[k] = c->err; return r; }
         const int64_t npix_k = (int64_t)nrows[k] * W;
         const void *piece = m->local[k].p;
         if (rgb8) {
-            if ((rc = ensure(c, m->local8[k], (size_t)std::max<int64_t>(npix_k, 1) * 3 + 16)) != RT_OK || (rc = ensure(c, m->rays_k[k], 8)) != RT_OK) { m->err = c->err; drain(k + 1); return rc; }
+            if ((r = ensure(c, m->local8[k], (size_t)std::max<int64_t>(npix_k, 1) * 3 + 16)) != RT_OK || (r = ensure(c, m->rays_k[k], 8)) != RT_OK) { err_k[k] = c->err; return r; }
             e = hipMemsetAsync(m->rays_k[k].p, 0, 8, c->stream);
             if (e == hipSuccess && npix_k > 0) {
                 hipLaunchKernelGGL(rtk::sum_rays_kernel, dim3((unsigned)((npix_k + 255) / 256)), dim3(256), 0, c->stream,
                                    static_cast<const float4 *>(m->local[k].p), npix_k, static_cast<unsigned long long *>(m->rays_k[k].p));
-                if ((rc = launch_tonemap(c, m->local[k].p, npix_k, m->local8[k].p, c->stream)) != RT_OK) { m->err = c->err; drain(k + 1); return rc; }
+                if ((r = launch_tonemap(c, m->local[k].p, npix_k, m->local8[k].p, c->stream)) != RT_OK) { err_k[k] = c->err; return r; }
             }
-            if (e != hipSuccess) { drain(k + 1); return mfail(m, RT_ERR_HIP, "tonemap of device %d: %s", c->device, hipGetErrorString(e)); }
+            if (e != hipSuccess) { err_k[k] = std::string("tonemap: ") + hipGetErrorString(e); return RT_ERR_HIP; }
             piece = m->local8[k].p;
         }
         if (k > 0) {
             if (nrows[k] > 0) e = hipMemcpyPeerAsync(static_cast<uint8_t *>(m->stage.p) + stage_off(k), root->device, piece, c->device,
                                                      (size_t)npix_k * px_bytes, c->stream);
             if (e == hipSuccess) e = hipEventRecord(m->done[k], c->stream);
-            if (e != hipSuccess) { drain(k + 1); return mfail(m, RT_ERR_HIP, "tile exchange of device %d: %s", c->device, hipGetErrorString(e)); }
+            if (e != hipSuccess) { err_k[k] = std::string("tile exchange: ") + hipGetErrorString(e); return RT_ERR_HIP; }
+        }
+        return RT_OK;
+    };
+    for (int k = 1; k < n; ++k) m->worker[k]->submit([&, k] { rc_k[k] = submit(k); });
+    rc_k[0] = submit(0);
+    for (int k = 1; k < n; ++k) m->worker[k]->wait();
+    m->stats.submit_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    for (int k = 0; k < n; ++k) {
+        if (rc_k[k] != RT_OK) {
+            drain(n);
+            return mfail(m, rc_k[k], "device %d: %s", m->ctx[k]->device, err_k[k].c_str());
         }
     }
     // 2. root: wait for the peers, restore row order
@@ -212,6 +274,7 @@ int rt_multi_create(rt_multi **out, const int *device_ids, int n_devices) {
         const int rc = rt_ctx_create(&m->ctx[k], device_ids[k]);
         if (rc != RT_OK) { rt_multi_destroy(m); return rc; }
     }
+    for (int k = 1; k < n_devices; ++k) { m->worker[k] = new MultiWorker(); m->worker[k]->start(); }
     m->peer_access[0] = -1;                                               // the root itself
     hipError_t e = hipSetDevice(m->ctx[0]->device);
     if (e == hipSuccess) e = hipEventCreate(&m->g0);
@@ -237,6 +300,7 @@ int rt_multi_create(rt_multi **out, const int *device_ids, int n_devices) {
 
 int rt_multi_destroy(rt_multi *m) {
     if (!m) return RT_OK;
+    for (int k = 1; k < RT_MAX_DEVICES; ++k) if (m->worker[k]) { m->worker[k]->stop(); delete m->worker[k]; m->worker[k] = nullptr; }
     if (m->ctx[0]) {
         (void)hipSetDevice(m->ctx[0]->device);
         if (m->ctx[0]->stream) (void)hipStreamSynchronize(m->ctx[0]->stream);
