@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "rt_sincos.h"
+#include "rt_div.h"
 
 namespace rtk {
 
@@ -103,9 +104,32 @@ __device__ __forceinline__ f3 cross(f3 a, f3 b) {
 // (1-ulp) v_sqrt_f32; sqrtf under -fhip-fp32-correctly-rounded-divide-sqrt gets the fix-up sequence.
 __device__ __forceinline__ float rt_sqrtf(float x) { return __builtin_sqrtf(x); }
 __device__ __forceinline__ float norm2(f3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
-__device__ __forceinline__ f3 normalize(f3 a) {   // cpu:58-63: three divisions by sqrt(norm2)
-    float n = rt_sqrtf(norm2(a));
-    return mk(a.x / n, a.y / n, a.z / n);
+// cpu:58-63: three divisions by sqrt(norm2).  The three quotients share one reciprocal (rt_div.h: the compiler's own correctly rounded
+// sequence with its denominator part done once); lanes with a component or a norm outside [2^-60, 2^60] -- zero, denormal, overflowed,
+// NaN -- take the literal divisions behind a wave-uniform branch.
+__device__ __forceinline__ f3 normalize(f3 a) {
+    const float n = rt_sqrtf(norm2(a));
+    float mn, mx;
+    asm("v_min3_f32 %0, |%1|, |%2|, |%3|" : "=v"(mn) : "v"(a.x), "v"(a.y), "v"(a.z));
+    const bool fast = mn >= kDivLo && n <= kDivHi;                     // n >= every |component| >= 2^-60 then; false for NaN
+    (void)mx;
+    const float r1 = div_refine(n, __builtin_amdgcn_rcpf(n));
+    f3 q = mk(div_by(a.x, n, r1), div_by(a.y, n, r1), div_by(a.z, n, r1));
+    if (__builtin_expect(__ballot(!fast) != 0ull, 0)) {
+        if (!fast) q = mk(a.x / n, a.y / n, a.z / n);
+    }
+    return q;
+}
+// the same for a vector whose THIRD listed component is the literal +0 (T1 of cpu:634-636: (-Ny, Nx, 0) or (-Nz, 0, Nx)): +0 / n = +0
+// for every n the fast range admits, so only two quotients are formed; (p, q) are the other two components
+__device__ __forceinline__ void normalize_pq0(float p, float q, float &op, float &oq, float &ozero) {
+    const float n = rt_sqrtf(p * p + q * q + 0.f * 0.f);
+    const bool fast = fminf(fabsf(p), fabsf(q)) >= kDivLo && n <= kDivHi;
+    const float r1 = div_refine(n, __builtin_amdgcn_rcpf(n));
+    op = div_by(p, n, r1); oq = div_by(q, n, r1); ozero = 0.f;
+    if (__builtin_expect(__ballot(!fast) != 0ull, 0)) {
+        if (!fast) { op = p / n; oq = q / n; ozero = 0.f / n; }
+    }
 }
 
 // counter RNG, DESIGN.md "RNG" (same definition as the oracle's or_uniform)
@@ -358,7 +382,7 @@ __device__ __forceinline__ f3 get_color(const Scene &sc, const Frame &fr, f3 O, 
         } else {                                                    // cpu:605-645
             const f3 Pa = P + fr.eps * N;
             const f3 toL = L - Pa;
-            const f3 sdir = toL / rt_sqrtf(norm2(toL));           // NORMED_VEC, cpu:30,614
+            const f3 sdir = normalize(toL);   // = toL / sqrt(norm2(toL))           // NORMED_VEC, cpu:30,614
             f3 Pp, Np; int ids_;
             rays += 1.f;
             (void)intersect_all<STATS>(sc, Pa, sdir, fr.tri_tmin, Pp, Np, ids_, wk);
@@ -380,10 +404,11 @@ __device__ __forceinline__ f3 get_color(const Scene &sc, const Frame &fr, f3 O, 
             const float x = (float)(cs * (double)s1);               // cpu:630
             const float y = (float)(sn * (double)s1);               // cpu:631
             const float zz = rt_sqrtf(r2);                        // cpu:632
-            f3 T1;
-            if (N.y != 0 && N.x != 0) T1 = mk(-N.y, N.x, 0);        // cpu:634-638
-            else T1 = mk(-N.z, 0, N.x);
-            T1 = normalize(T1);
+            // T1 = normalize((-Ny, Nx, 0)) if Nx != 0 && Ny != 0 else normalize((-Nz, 0, Nx)) (cpu:634-638): two quotients, the third component is +0 / n
+            const bool t1a = N.y != 0 && N.x != 0;
+            float t1p, t1q, t1z;
+            normalize_pq0(t1a ? -N.y : -N.z, N.x, t1p, t1q, t1z);
+            const f3 T1 = t1a ? mk(t1p, t1q, t1z) : mk(t1p, t1z, t1q);
             const f3 T2 = cross(N, T1);
             u = x * T1 + y * T2 + zz * N;                           // cpu:641
             O = Pa;

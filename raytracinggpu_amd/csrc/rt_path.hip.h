@@ -282,7 +282,7 @@ __global__ __launch_bounds__(kQBlock, 2) void wf_path(const Scene sc, const Fram
                             } else {                                          // cpu:605-642: diffuse
                                 const f3 Pa = Pt + fr.eps * N;
                                 const f3 toL = L - Pa;
-                                Ox = Pa; ux = toL / rt_sqrtf(norm2(toL));     // NORMED_VEC, cpu:614: the shadow ray of segment d
+                                Ox = Pa; ux = normalize(toL);   // = toL / sqrt(norm2(toL))     // NORMED_VEC, cpu:614: the shadow ray of segment d
                                 emitX = true;
                                 nrays += 1;
                                 // its direct term if the light turns out to be visible (cpu:620-623), kept until the shadow ray is back
@@ -305,10 +305,11 @@ __global__ __launch_bounds__(kQBlock, 2) void wf_path(const Scene sc, const Fram
                                     const float x = (float)(cs * (double)s1f);
                                     const float y = (float)(sn * (double)s1f);
                                     const float zz = rt_sqrtf(r2u);
-                                    f3 T1;
-                                    if (N.y != 0 && N.x != 0) T1 = mk(-N.y, N.x, 0);
-                                    else T1 = mk(-N.z, 0, N.x);
-                                    T1 = normalize(T1);
+                                    // T1 = normalize((-Ny, Nx, 0)) if Nx != 0 && Ny != 0 else normalize((-Nz, 0, Nx)) (cpu:634-638): two quotients, the third component is +0 / n
+                                    const bool t1a = N.y != 0 && N.x != 0;
+                                    float t1p, t1q, t1z;
+                                    normalize_pq0(t1a ? -N.y : -N.z, N.x, t1p, t1q, t1z);
+                                    const f3 T1 = t1a ? mk(t1p, t1q, t1z) : mk(t1p, t1z, t1q);
                                     const f3 T2 = cross(N, T1);
                                     u = x * T1 + y * T2 + zz * N;
                                     O = Pa;

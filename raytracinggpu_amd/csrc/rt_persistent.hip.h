@@ -206,7 +206,7 @@ __global__ __launch_bounds__(kPBlock) void render_persistent(const Scene sc, con
                         Ps = P; Ns = N; sid = win;
                         const f3 Pa = P + fr.eps * N;
                         const f3 toL = L - Pa;
-                        u = toL / rt_sqrtf(norm2(toL));                  // NORMED_VEC
+                        u = normalize(toL);   // = toL / sqrt(norm2(toL))                  // NORMED_VEC
                         O = Pa;
                         shadow = true;
                         next_segment = false;
@@ -243,10 +243,11 @@ __global__ __launch_bounds__(kPBlock) void render_persistent(const Scene sc, con
                     const float x = (float)(cs * (double)s1);
                     const float y = (float)(sn * (double)s1);
                     const float zz = rt_sqrtf(r2);
-                    f3 T1;
-                    if (Ns.y != 0 && Ns.x != 0) T1 = mk(-Ns.y, Ns.x, 0);
-                    else T1 = mk(-Ns.z, 0, Ns.x);
-                    T1 = normalize(T1);
+                    // T1 = normalize((-Ny, Nx, 0)) if Nx != 0 && Ny != 0 else normalize((-Nz, 0, Nx)) (cpu:634-638): two quotients, the third component is +0 / n
+                    const bool t1a = Ns.y != 0 && Ns.x != 0;
+                    float t1p, t1q, t1z;
+                    normalize_pq0(t1a ? -Ns.y : -Ns.z, Ns.x, t1p, t1q, t1z);
+                    const f3 T1 = t1a ? mk(t1p, t1q, t1z) : mk(t1p, t1z, t1q);
                     const f3 T2 = cross(Ns, T1);
                     u = x * T1 + y * T2 + zz * Ns;
                     refr = 1.f;                                          // O stays P_adjusted

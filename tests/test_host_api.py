@@ -111,3 +111,15 @@ def test_device_sincos_matches_glibc_on_every_argument(tmp_path):
     assert r.returncode == 0, r.stdout
     assert "(max 1 ulp)" in r.stdout or "(max 0 ulp)" in r.stdout
     assert r.stdout.rstrip().endswith("differing 0"), r.stdout
+
+
+def test_shared_reciprocal_quotients_equal_the_compilers_division(tmp_path):
+    """raytracinggpu_amd/csrc/rt_div.h (normalize's three quotients through one reciprocal) built for the host: over 10^8 operand
+    pairs of the guarded range, with the reciprocal at -1 / 0 / +1 ulp (v_rcp_f32 is a 1-ulp instruction), the sequence returns the
+    correctly rounded quotient bit for bit."""
+    import subprocess
+    exe = str(tmp_path / "check_div")
+    subprocess.run(["g++", "-O2", "-ffp-contract=off", "-o", exe, os.path.join(ROOT, "tools", "check_div.cpp")], check=True)
+    r = subprocess.run([exe], stdout=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stdout
+    assert r.stdout.rstrip().endswith(": 0 differ from the compiler's division"), r.stdout
