@@ -60,6 +60,8 @@ def parse():
                     help="TEST: every rank renders on GPU 0 and the exchange runs over gloo (RCCL refuses several ranks on one device); rehearses the N-rank path on a one-GPU box")
     ap.add_argument("--renderer", default="hip", choices=["hip", "oracle"],
                     help="TEST: 'oracle' renders every rank's tiles with the CPU restatement over gloo (launcher / partition / gather plumbing without a GPU); its line carries value = null")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="whole frames kept in flight, one context each (0 = auto: 1 on one GPU, 2 when the frame is shared by several ranks)")
     ap.add_argument("--dump-frame", default="", help="rank 0 saves the (gathered) float4 frame of the first step as .npy (tests)")
     ap.add_argument("--check-frame", action="store_true", help="rank 0 renders the whole frame alone as well and reports whether the gathered frame equals it bit for bit")
     return ap.parse_args()
@@ -365,53 +367,86 @@ def main():
     xdev = torch.device("cpu") if gloo else dev                       # where the exchange runs (gloo moves host tensors)
 
     W, H = args.width, args.height
+    # Frames in flight.  One GPU renders a whole 1080p frame as two concurrent sub-frames (the library's default) and a second frame
+    # would only queue behind it.  A 1/N share of the frame no longer fills the chip with its eleven dependent launches; there the
+    # bench keeps `lanes` whole frames in flight instead -- one context per lane (own streams, own path state, sub-frames off),
+    # frames dealt round-robin, every frame still rendered, gathered and assembled in full.  Measured on one MI355X for rank 0's share
+    # of 1080p (tools/share8_pipelined.py): world 8: 0.330 ms (1 frame, 2 sub-frames) -> 0.243 ms (2 frames in flight).
+    lanes_n = args.frames_in_flight if args.frames_in_flight > 0 else (2 if (world > 1 and not cpu_only) else 1)
     ctx = None
+    ctxs, tstreams = [], []
     if cpu_only:
         oren = OracleRenderer(args)
-        stream = None
+        lanes_n = 1
     else:
-        ctx = rt.Context(dev_index)
-        build_scene(rt, ctx, args.scene)
-        # a non-default torch stream: its handle is non-NULL (NULL means "the context's own stream" in the C-ABI),
-        # so the render kernel, torch's timing events and the RCCL gather are all ordered on ONE stream
-        side = torch.cuda.Stream(device=dev)
-        torch.cuda.set_stream(side)
-        stream = side.cuda_stream
-        assert stream != 0
+        old_parts = os.environ.get("RT_PARTS")
+        if lanes_n > 1 and old_parts is None:
+            os.environ["RT_PARTS"] = "1"                              # knobs are read when a context is created
+        for _ in range(lanes_n):
+            c = rt.Context(dev_index)
+            build_scene(rt, c, args.scene)
+            ctxs.append(c)
+            # a non-default torch stream per lane: its handle is non-NULL (NULL means "the context's own stream" in the C-ABI),
+            # so the lane's render kernels, torch's timing events and its gather are all ordered on ONE stream
+            tstreams.append(torch.cuda.Stream(device=dev))
+        if lanes_n > 1 and old_parts is None:
+            del os.environ["RT_PARTS"]
+        ctx = ctxs[0]
+        torch.cuda.set_stream(tstreams[0])
+        assert tstreams[0].cuda_stream != 0
+    stream = tstreams[0].cuda_stream if tstreams else None
     rgb8 = args.gather == "rgb8" and world > 1 and not cpu_only
 
-    class Point:
-        """One timed workload: its parameters, this rank's tiles and the buffers of the exchange."""
-        def __init__(self, W, H):
-            self.W, self.H = W, H
-            self.p = rt.make_params(W, H, args.spp, args.bounces, variant=args.variant, **rt.scenes.CPU_LAUNCHER)
-            self.rows, self.idx = rt.interleaved_rows(H, TILE_ROWS, rank, world)
+    class Lane:
+        """One frame in flight: this rank's tile buffer and the buffers of its exchange."""
+        def __init__(self, k, W, H):
+            self.k = k
             self.local = tiling.local_buffer(H, W, world, dev)
             self.local8 = tiling.local_buffer(H, W, world, dev, rgb8=True) if rgb8 else None
             src = self.local8 if rgb8 else self.local
             self.xlocal = torch.empty(src.shape, dtype=src.dtype, device=xdev, pin_memory=not cpu_only) if (gloo and world > 1 and not cpu_only) else src
             self.gathered = tiling.gather_buffer(self.xlocal, world) if (world > 1 and rank == 0) else None
+
+    class Point:
+        """One timed workload: its parameters, this rank's tiles, and one Lane per frame in flight."""
+        def __init__(self, W, H):
+            self.W, self.H = W, H
+            self.p = rt.make_params(W, H, args.spp, args.bounces, variant=args.variant, **rt.scenes.CPU_LAUNCHER)
+            self.rows, self.idx = rt.interleaved_rows(H, TILE_ROWS, rank, world)
+            self.lanes = [Lane(k, W, H) for k in range(lanes_n)]
+            self.local = self.lanes[0].local
             self.frame = None
+            self.n = 0
 
-        def render(self):
+        def render(self, ln):
             if cpu_only:
-                oren.render(self.W, self.H, args.spp, args.bounces, rank, world, self.local)
+                oren.render(self.W, self.H, args.spp, args.bounces, rank, world, ln.local)
             else:
-                ctx.render_device(self.p, self.rows, self.local.data_ptr(), stream)
+                ctxs[ln.k].render_device(self.p, self.rows, ln.local.data_ptr(), tstreams[ln.k].cuda_stream)
 
-        def exchange(self):
-            src = self.local
+        def exchange(self, ln):
+            src = ln.local
             if rgb8:                                                  # tonemap this rank's tiles (cpu:714-716), gather 3 bytes per pixel
-                ctx.tonemap_device(self.local.data_ptr(), self.rows.n_rows * self.W, self.local8.data_ptr(), stream)
-                src = self.local8
-            if self.xlocal is not src:                                # --share-gpu: the exchange runs over gloo on host tensors
-                self.xlocal.copy_(src, non_blocking=True)
+                ctxs[ln.k].tonemap_device(ln.local.data_ptr(), self.rows.n_rows * self.W, ln.local8.data_ptr(), tstreams[ln.k].cuda_stream)
+                src = ln.local8
+            if ln.xlocal is not src:                                  # --share-gpu: the exchange runs over gloo on host tensors
+                ln.xlocal.copy_(src, non_blocking=True)
                 torch.cuda.current_stream().synchronize()
-            self.frame = tiling.gather_frame(self.xlocal, self.H, world, rank, self.gathered)
+            self.frame = tiling.gather_frame(ln.xlocal, self.H, world, rank, ln.gathered)
 
-        def step(self):
-            self.render()
-            self.exchange()
+        def step(self, ev=None):
+            ln = self.lanes[self.n % lanes_n]
+            self.n += 1
+            if cpu_only:
+                self.render(ln); self.exchange(ln)
+                return
+            with torch.cuda.stream(tstreams[ln.k]):
+                if ev:
+                    ev[0].record()
+                self.render(ln)
+                if ev:
+                    ev[1].record()
+                self.exchange(ln)
 
     def sync():
         if not cpu_only:
@@ -427,12 +462,7 @@ def main():
         sync()
         t0 = time.perf_counter()
         for k in range(steps):
-            if ev:
-                ev[k][0].record()
-            pt.render()
-            if ev:
-                ev[k][1].record()
-            pt.exchange()
+            pt.step(ev[k] if ev else None)
         sync()
         if world > 1:
             dist.barrier()
@@ -489,6 +519,7 @@ def main():
                "config": {"workload": workload, "scene": "cpu_launcher.cpp walls + cat.obj (3954 tris, 2019-node array BVH)",
                           "num_rays": args.spp, "num_bounce": args.bounces, "depth_convention": "cpu_launcher (b+1 segments)",
                           "rays_per_frame": rays_per_frame, "ranks": dist.get_world_size() if world > 1 else 1,
+                          "frames_in_flight": lanes_n,
                           "tiling": f"{TILE_ROWS}-row tiles interleaved over {world} rank(s)"
                           + (f", one gather ({backend}) of the {'RGB8' if rgb8 else 'float4'} tiles to rank 0 per frame" if world > 1 else ""),
                           "variant": ctx.stats()["variant"] if ctx else None, "device": ctx.device_name if ctx else "cpu (oracle stand-in: not a measurement)",

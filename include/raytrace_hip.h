@@ -66,9 +66,10 @@ typedef enum rt_variant {
                                   workgroup per CU shares the copy); RT_ERR_UNSUPPORTED when the
                                   nodes do not fit the 160 KB                                       */
     RT_VARIANT_WAVEFRONT_QUEUE = 8, /* wavefront pipeline whose traversal kernel keeps a per-wave LDS
-                                  work stack of (ray, node) pairs: every lane tests one box or one
-                                  triangle per step, no per-lane walk (rt_travq.hip.h)              */
-    RT_VARIANT_PATH = 9        /* the whole render in ONE persistent launch: a wave owns 32 paths from
+                                  work stack of (ray slot, sibling pair) entries: every lane tests the two
+                                  boxes of a pair, or two triangles, per step; no per-lane walk
+                                  (rt_travq.hip.h).  The default (RT_VARIANT_AUTO)                  */
+    RT_VARIANT_PATH = 9        /* the whole render in ONE persistent launch: a wave owns 64 paths (one per lane) from
                                   camera ray to framebuffer store; the work-stack traversal and the
                                   shading of ready paths alternate inside the wave, path state lives
                                   in LDS, nothing but the pixel leaves the CU (rt_path.hip.h)       */
@@ -265,7 +266,11 @@ int rt_mesh_transform(rt_ctx *ctx, const float rotation[9], const float translat
  *     order the partition leaves the triangles in.  The library then re-lays the mesh out for its kernels as rt_scene_upload
  *     does; the uploaded order becomes the new BVH order (the reference partitions `indices` in place too).
  *     Optional outputs: bvh_arr10_out (capacity (2 * n_triangles + 2) * 10 floats), tri_order_out[n_triangles] (position ->
- *     index of the triangle in the order before this call), n_nodes_out. ----------------------------------------------- */
+ *     index of the triangle in the order before this call), n_nodes_out.
+ *     Failure: an error during the BUILD leaves the scene in use untouched.  An allocation failure during the re-layout that
+ *     follows (RT_ERR_HIP: out of device memory) leaves the context WITHOUT a scene (RT_ERR_NO_SCENE from the render calls):
+ *     upload again.  Cost model: one workgroup per node and one blocking read-back per level, so the top levels of a mesh far
+ *     larger than the cat's 3 954 triangles run on a single CU each (the build is a step before the hot path, not part of it). */
 int rt_mesh_rebuild(rt_ctx *ctx, float *bvh_arr10_out, int32_t *tri_order_out, int32_t *n_nodes_out);
 
 /* --- smooth (interpolated) normals: get_smooth_normal of realtime_render.cu:221-245 / global_launcher.cu:207-231

@@ -31,6 +31,7 @@ struct BuildArgs {
     float4 *n_mn, *n_mx;
     int *counter;              // nodes allocated so far
     int n_tris;
+    int cap;                   // node capacity of the n_* arrays: a split that would pass it is refused (the node stays a leaf, counter[1] is raised)
 };
 
 struct VP { float v; int p; };
@@ -147,7 +148,8 @@ __global__ __launch_bounds__(kBuildThreads) void bvh_level_kernel(const BuildArg
         int l = -1, r = -1;
         if (!(pivot <= s || pivot >= e - 1 || e - s < 5)) {
             l = atomicAdd(a.counter, 2); r = l + 1;
-            a.n_start[l] = s; a.n_end[l] = pivot; a.n_start[r] = pivot; a.n_end[r] = e;
+            if (r >= a.cap) { a.counter[1] = 1; l = -1; r = -1; }          // cannot happen for a tree of n triangles (<= 2 n - 1 nodes): refuse rather than write past the arrays
+            else { a.n_start[l] = s; a.n_end[l] = pivot; a.n_start[r] = pivot; a.n_end[r] = e; }
         }
         a.n_left[node] = l; a.n_right[node] = r;
     }

@@ -54,6 +54,7 @@ struct Knobs {
     long long path_samp_bytes = 400ll << 20; // RT_PATH_SAMP_MB: state of the samples traced together (frames with num_rays > 1; ~130 B per sample and pixel slot).
                                              // Measured: a chain is fastest while its state stays near the 256 MB Infinity Cache -- 512x512, 64 samples: 23.5 / 8.8 / 8.0 /
                                              // 8.8 ms for 30 / 192 / 400 / 4096 MB; 1920x1080 (277 MB per sample): one sample per chain is best (71.5 vs 76.9 ms at 13)
+    int top_lds = 0;           // RT_TRAVQ_TOPLDS: nodes of the breadth-first top of the tree every ordinary (4-wave) workgroup of wf_travq stages in LDS
     int copy_split = 0;        // RT_COPY_SPLIT=1: rt_render_async sends the two halves of a big frame through two copy streams (measured SLOWER: 1.62 vs 1.48 ms per
                                // pipelined 1080p float4 frame -- one DMA already runs at the rate the PCIe link gives, two share it and add an event hop)
     int debug_trav = -2;       // RT_DEBUG_TRAV: traversal launch whose per-wave records are dumped (-DRT_DEBUG builds only)
@@ -81,6 +82,7 @@ static Knobs read_knobs() {
     if (geti("RT_PATH_BPC", v) && v >= 1 && v <= 8) k.path_bpc = v;
     if (geti("RT_PATH_PARTS", v) && v >= 1 && v <= 8) k.path_parts = v;
     if (geti("RT_COPY_SPLIT", v)) k.copy_split = v != 0;
+    if (geti("RT_TRAVQ_TOPLDS", v) && v >= 0 && v <= 1024) k.top_lds = v & ~1;
     if (geti("RT_PATH_SAMP_MB", v) && v >= 1) k.path_samp_bytes = (long long)v << 20;
 #ifdef RT_DEBUG
     if (geti("RT_DEBUG_TRAV", v)) k.debug_trav = v;
@@ -387,7 +389,7 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
     const int nseg = segs > 0 ? segs : 1;
     ctx->n_trav_events = 0;
     if (variant == RT_VARIANT_PATH) {
-        // ONE persistent launch per sub-frame and sample chunk (rt_path.hip.h): a wave owns 32 paths from camera ray to framebuffer store
+        // ONE persistent launch per sub-frame and sample chunk (rt_path.hip.h): a wave owns 64 paths (one per lane) from camera ray to framebuffer store
         const Knobs &kn = ctx->knobs;
         constexpr int wpb = rtk::kQBlock / 64;
         const size_t lds = (size_t)wpb * rtk::PCarve::bytes(segs) + 16;
@@ -504,7 +506,10 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
             qW = 0;
         }
         const bool qlds = queue && qW > 0;                            // ONE workgroup of qW waves per CU
-        const bool qldsn = qlds && q_nlds > 0;
+        // RT_TRAVQ_TOPLDS: the ordinary launch (4-wave workgroups, 4 per CU) with the first levels of the tree staged per workgroup
+        if (queue && !qlds && mesh_here && kn.top_lds > 0) q_nlds = std::min(kn.top_lds, (ctx->scene.n_nodes + 1) & ~1);
+        const bool qtop = queue && !qlds && q_nlds > 0;
+        const bool qldsn = (qlds || qtop) && q_nlds > 0;
         const int q_low = kn.q_low;                                   // refill thresholds of the work-stack kernel (stack entries are sibling pairs)
         const int q_minfree = (kn.q_minfree >= 1 && kn.q_minfree <= qR) ? kn.q_minfree : qR / 4;
         // begin, (trav, advance) x 2*segments per sample; path state SoA in HBM, tile-order path index.
@@ -543,9 +548,9 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
                 bpc = 1;
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(travq_fn(work_dev != nullptr, qR, qldsn, ldsv)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             } else {
-                if (ctx->travq_blocks_per_cu[qi] == 0) {
+                if (ctx->travq_blocks_per_cu[qi] == 0 || qtop) {
                     int nb = 0;
-                    RT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, travq_fn(work_dev != nullptr, qR, false, false), rtk::kQBlock, trav_lds));
+                    RT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, travq_fn(work_dev != nullptr, qR, qtop, false), rtk::kQBlock, trav_lds));
                     ctx->travq_blocks_per_cu[qi] = nb > 0 ? nb : 1;
                 }
                 bpc = std::min(ctx->travq_blocks_per_cu[qi], (kn.bpc5 ? 20 : 16) / (rtk::kQBlock / 64));    // a fifth workgroup per CU fits but does not pay (measured)
@@ -1230,7 +1235,7 @@ int rt_mesh_rebuild(rt_ctx *ctx, float *bvh_arr10_out, int32_t *tri_order_out, i
     if ((rc = ensure(ctx, ctx->bb_idx, nt * sizeof(int))) != RT_OK || (rc = ensure(ctx, ctx->bb_cnt, nt * sizeof(int))) != RT_OK ||
         (rc = ensure(ctx, ctx->bb_pa, nt * sizeof(int))) != RT_OK || (rc = ensure(ctx, ctx->bb_pb, nt * sizeof(int))) != RT_OK ||
         (rc = ensure(ctx, ctx->bb_tmp, nt * sizeof(int))) != RT_OK || (rc = ensure(ctx, ctx->bb_nodes_i, 4 * cap * sizeof(int))) != RT_OK ||
-        (rc = ensure(ctx, ctx->bb_nodes_f, 2 * cap * sizeof(float4))) != RT_OK || (rc = ensure(ctx, ctx->bb_counter, sizeof(int))) != RT_OK ||
+        (rc = ensure(ctx, ctx->bb_nodes_f, 2 * cap * sizeof(float4))) != RT_OK || (rc = ensure(ctx, ctx->bb_counter, 2 * sizeof(int))) != RT_OK ||
         (rc = ensure(ctx, ctx->bb_lvl, (cap + 1) * sizeof(int))) != RT_OK || (rc = ensure(ctx, ctx->bb_size, cap * sizeof(int))) != RT_OK ||
         (rc = ensure(ctx, ctx->bb_pre, cap * sizeof(int))) != RT_OK || (rc = ensure(ctx, ctx->bb_arr, cap * 10 * sizeof(float))) != RT_OK)
         return rc;
@@ -1241,27 +1246,29 @@ int rt_mesh_rebuild(rt_ctx *ctx, float *bvh_arr10_out, int32_t *tri_order_out, i
     int *ni = static_cast<int *>(ctx->bb_nodes_i.p);
     a.n_start = ni; a.n_end = ni + cap; a.n_left = ni + 2 * cap; a.n_right = ni + 3 * cap;
     a.n_mn = static_cast<float4 *>(ctx->bb_nodes_f.p); a.n_mx = a.n_mn + cap;
-    a.counter = static_cast<int *>(ctx->bb_counter.p); a.n_tris = nt;
+    a.counter = static_cast<int *>(ctx->bb_counter.p); a.n_tris = nt; a.cap = (int)cap;
     hipStream_t q = ctx->stream;
     // root = node 0 over all triangles (buildBVH(&bvh, 0, T), cpu:684); the permutation starts as the identity
     hipLaunchKernelGGL(rtk::iota_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, q, a.idx, nt);
-    const int root_range[2] = {0, nt}, one = 1;
+    const int root_range[2] = {0, nt}, one[2] = {1, 0};              // counter[0] = nodes allocated, counter[1] = a split was refused for lack of capacity
     RT_HIP(ctx, hipMemcpyAsync(a.n_start, &root_range[0], sizeof(int), hipMemcpyHostToDevice, q));
     RT_HIP(ctx, hipMemcpyAsync(a.n_end, &root_range[1], sizeof(int), hipMemcpyHostToDevice, q));
-    RT_HIP(ctx, hipMemcpyAsync(a.counter, &one, sizeof(int), hipMemcpyHostToDevice, q));
+    RT_HIP(ctx, hipMemcpyAsync(a.counter, one, 2 * sizeof(int), hipMemcpyHostToDevice, q));
     RT_HIP(ctx, hipStreamSynchronize(q));                                           // the three sources above live on this stack frame
     std::vector<int> lvl_first{0};
     int first = 0, count = 1;
     while (count > 0) {                                                             // one launch per level, one workgroup per node
         hipLaunchKernelGGL(rtk::bvh_level_kernel, dim3((unsigned)count), dim3(rtk::kBuildThreads), 0, q, a, first);
         RT_HIP(ctx, hipGetLastError());
-        int total = 0;
-        RT_HIP(ctx, hipMemcpyAsync(&total, a.counter, sizeof(int), hipMemcpyDeviceToHost, q));
+        int tot[2] = {0, 0};
+        RT_HIP(ctx, hipMemcpyAsync(tot, a.counter, 2 * sizeof(int), hipMemcpyDeviceToHost, q));
         RT_HIP(ctx, hipStreamSynchronize(q));
+        const int total = tot[0];
+        // the kernel refuses a split that would pass the arrays' capacity (it cannot for a tree over nt triangles); the scene in use is untouched so far
+        if (tot[1] != 0 || (size_t)total > cap) return fail(ctx, RT_ERR_INTERNAL, "BVH build needed more than %zu nodes for %d triangles (scene unchanged)", cap, nt);
         first += count;
         lvl_first.push_back(first);
         count = total - first;
-        if ((size_t)total > cap) return fail(ctx, RT_ERR_INTERNAL, "BVH build allocated %d nodes for %d triangles", total, nt);
     }
     const int n_nodes = first, n_levels = (int)lvl_first.size() - 1;
     if (n_nodes >= (1 << 24)) return fail(ctx, RT_ERR_INVALID, "node indices are stored as floats: < 2^24 nodes");
@@ -1402,7 +1409,9 @@ int rt_ctx_selfcheck(rt_ctx *ctx) {
     RT_HIP(ctx, hipSetDevice(ctx->device));
     const DevBuf *bufs[] = {&ctx->node_lo, &ctx->node_hi, &ctx->nodes2, &ctx->nodesq, &ctx->nodesb, &ctx->q2thr, &ctx->tri, &ctx->verts, &ctx->tidx, &ctx->tidx_up, &ctx->nrm,
                             &ctx->scratch_rgba, &ctx->scratch_rgb8, &ctx->work, &ctx->queue, &ctx->wfM, &ctx->wfPR, &ctx->wfT, &ctx->wfLS, &ctx->wfSID, &ctx->wfSamp,
-                            &ctx->wfQR, &ctx->pathSamp, &ctx->pathT, &ctx->accum, &ctx->left_dev, &ctx->lvl_nodes, &ctx->lvl_off, &ctx->bb_idx, &ctx->bb_arr};
+                            &ctx->wfQR, &ctx->pathSamp, &ctx->pathT, &ctx->accum, &ctx->left_dev, &ctx->lvl_nodes, &ctx->lvl_off, &ctx->bb_idx, &ctx->bb_cnt, &ctx->bb_pa, &ctx->bb_pb, &ctx->bb_tmp,
+                            &ctx->bb_nodes_i, &ctx->bb_nodes_f, &ctx->bb_counter, &ctx->bb_lvl, &ctx->bb_size, &ctx->bb_pre, &ctx->bb_arr,
+                            &ctx->slot_rgba[0], &ctx->slot_rgba[1], &ctx->slot_rgb8[0], &ctx->slot_rgb8[1]};
     for (const DevBuf *b : bufs) {
         if (!b->p) continue;
         hipPointerAttribute_t at{};

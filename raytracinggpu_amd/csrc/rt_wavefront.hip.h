@@ -5,9 +5,11 @@
 //
 //   wf_advance<FIRST>  one lane per pixel, uniform: camera ray of sample s (cpu:699-709), its ray/sphere tests
 //              (cpu:512-527) and the mesh's root-box test (cpu:279); path record initialised
-//   wf_trav    persistent lanes, one RAY (or a sub-range of one ray's traversal) per lane: stackless BVH walk
-//              (BoundingBox::intersect cpu:146-157, moller_trumbore cpu:226-236, traversal cpu:277-311).
-//              Two micro-ops (BOX, TRI) chosen by wave vote; lanes refill from the wave's own, spatially
+//   wf_travq   (rt_travq.hip.h; the pipeline's traversal kernel by default) the BVH traversal as a per-wave work stack of
+//              (ray slot, sibling pair) entries: BoundingBox::intersect cpu:146-157, moller_trumbore cpu:226-236, traversal
+//              cpu:277-311
+//   wf_trav    (variants wavefront / wavefront_lds) persistent lanes, one RAY (or a sub-range of one ray's traversal) per lane:
+//              stackless BVH walk.  Two micro-ops (BOX, TRI) chosen by wave vote; lanes refill from the wave's own, spatially
 //              scrambled, share of the rays; when that runs out busy lanes hand parts of their traversal
 //              to idle lanes (see "work splitting" below).
 //   wf_advance one lane per pixel, uniform: closes the query (Scene::intersect_all cpu:545-564), then
@@ -19,8 +21,8 @@
 // A shadow ray and the continuation (bounce / mirror / refraction) ray that leave the same hit point do not
 // depend on each other, so both are traced by the SAME traversal launch: per sample the sequence is
 //     advance<FIRST>, (trav, advance) x (segments + 1)
-// with launch j tracing the shadow rays of segment j-1 and the continuation rays of segment j.  The path records (32 bytes)
-// live in HBM as float4 / int4 SoA indexed by a TILE-ORDER path index (8x8 pixel tiles: a wave's 64 consecutive paths are one
+// with launch j tracing the shadow rays of segment j-1 and the continuation rays of segment j.  The path records (16 bytes)
+// live in HBM as float4 indexed by a TILE-ORDER path index (8x8 pixel tiles: a wave's 64 consecutive paths are one
 // tile, every record access is a fully coalesced 1 KiB wave transaction); the rays themselves live only in the traversal queue
 // (slot order), see WfState.
 //
