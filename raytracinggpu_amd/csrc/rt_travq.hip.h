@@ -343,7 +343,6 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
         top = __builtin_amdgcn_readfirstlane(top);
         lhead = (unsigned int)__builtin_amdgcn_readfirstlane((int)lhead);
         ltail = (unsigned int)__builtin_amdgcn_readfirstlane((int)ltail);
-        drained = __builtin_amdgcn_readfirstlane((int)drained) != 0;
         stage_n = __builtin_amdgcn_readfirstlane(stage_n);
         stage_used = __builtin_amdgcn_readfirstlane(stage_used);
         if (STATS) n_iter++;
