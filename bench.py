@@ -229,9 +229,13 @@ def travq_instructions(counts, sc):
     """Vector / scalar wave-instructions of the frame's wf_travq launches: the step counters of the counting instantiation (this run)
     x the static per-region counts of the production code object (tools/static_counts.py)."""
     st, t = counts["steps"], sc["wf_travq"]
-    weights = (("loop_head", st["iterations"]), ("dispatch", st["iterations"]), ("retire", st["refill_passes"]), ("round", st["refill_rounds"]),
-               ("fetch", st["fetches"]), ("tri", st["tri_steps"]), ("box", st["box_steps"]))
+    weights = (("loop_head", st["iterations"]), ("retire", st["refill_passes"]), ("round", st["refill_rounds"]),
+               ("fetch", st["fetches"]), ("tri", st["tri_steps"]), ("tdiv", st["tdiv_blocks"]), ("box", st["box_steps"]),
+               ("lpush", st["leaf_push_blocks"]), ("lpush2", st["leaf_push2_blocks"]))
     out = {k: int(sum(t[r][k] * n for r, n in weights)) for k in ("valu", "valu_weight", "salu")}
+    # the step dispatch between the refill and the steps: scalar instructions every iteration, its vector ones only in front of a TRI step
+    out["salu"] += int(t["dispatch"]["salu"] * st["iterations"])
+    out["valu"] += int(t["dispatch"]["valu"] * st["tri_steps"]); out["valu_weight"] += int(t["dispatch"]["valu_weight"] * st["tri_steps"])
     out["by_region_valu"] = {r: int(t[r]["valu"] * n) for r, n in weights}
     return out
 

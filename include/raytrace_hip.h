@@ -186,9 +186,11 @@ typedef struct rt_work {
     uint64_t tri_tests;            /* moller_trumbore calls                                   */
     uint64_t box_literal;          /* of box_tests: decided by the literal divisions of cpu:147-152 (the error-bounded filter deferred) */
     uint64_t tri_literal;          /* of tri_tests: barycentrics by the literal divisions of cpu:232-233                                */
-    uint64_t steps[8];             /* work-stack traversal kernel, summed over its waves and launches: loop iterations, refill passes,
+    uint64_t steps[12];            /* work-stack traversal kernel, summed over its waves and launches: loop iterations, refill passes,
                                     * refill rounds, queue fetches, TRI steps (128 triangle tests), BOX steps (64 sibling pairs),
-                                    * literal-box fall-backs, serial drains.  bench.py prices the vector-issue roofline with them. */
+                                    * literal-box fall-backs, serial drains; then blocks a step enters only when some lane needs them:
+                                    * t-division blocks of the triangle tests (2 per TRI step at most), first and second leaf-queue
+                                    * push of a BOX step; one reserved.  bench.py prices the vector-issue roofline with them. */
 } rt_work;
 int rt_count_work(rt_ctx *ctx, const rt_params *p, int row_begin, int row_end, rt_work *out);
 

@@ -67,7 +67,7 @@ class Rows(C.Structure):
 
 class Work(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("box_tests", C.c_uint64), ("nodes", C.c_uint64), ("tri_tests", C.c_uint64),
-                ("box_literal", C.c_uint64), ("tri_literal", C.c_uint64), ("steps", C.c_uint64 * 8)]
+                ("box_literal", C.c_uint64), ("tri_literal", C.c_uint64), ("steps", C.c_uint64 * 12)]
 
 
 class Stats(C.Structure):
@@ -356,7 +356,8 @@ class Context:
         if not detail:
             return out
         out.update(box_literal=int(w.box_literal), tri_literal=int(w.tri_literal))
-        out["steps"] = dict(zip(("iterations", "refill_passes", "refill_rounds", "fetches", "tri_steps", "box_steps", "literal_box_fallbacks", "serial_drains"),
+        out["steps"] = dict(zip(("iterations", "refill_passes", "refill_rounds", "fetches", "tri_steps", "box_steps", "literal_box_fallbacks", "serial_drains",
+                                 "tdiv_blocks", "leaf_push_blocks", "leaf_push2_blocks", "reserved"),
                                 (int(v) for v in w.steps)))
         return out
 

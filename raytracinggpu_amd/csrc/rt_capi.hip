@@ -1132,13 +1132,13 @@ int rt_count_work(rt_ctx *ctx, const rt_params *p, int row_begin, int row_end, r
     const int n = row_end - row_begin;
     int rc = ensure(ctx, ctx->scratch_rgba, (size_t)n * (p->width > 0 ? p->width : 0) * sizeof(float4));
     if (rc != RT_OK) return rc;
-    if ((rc = ensure(ctx, ctx->work, 16 * sizeof(unsigned long long))) != RT_OK) return rc;
+    if ((rc = ensure(ctx, ctx->work, 24 * sizeof(unsigned long long))) != RT_OK) return rc;
     RT_HIP(ctx, hipSetDevice(ctx->device));
-    RT_HIP(ctx, hipMemsetAsync(ctx->work.p, 0, 16 * sizeof(unsigned long long), ctx->stream));
+    RT_HIP(ctx, hipMemsetAsync(ctx->work.p, 0, 24 * sizeof(unsigned long long), ctx->stream));
     rt_rows rows{row_begin, n, n > 0 ? n : 1, 1};
     rc = launch_render(ctx, p, &rows, ctx->scratch_rgba.p, ctx->stream, static_cast<unsigned long long *>(ctx->work.p));
     if (rc != RT_OK) return rc;
-    unsigned long long h[16];
+    unsigned long long h[24];
     RT_HIP(ctx, hipMemcpyAsync(h, ctx->work.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     std::vector<float> fb((size_t)n * (size_t)p->width * 4);
     RT_HIP(ctx, hipMemcpyAsync(fb.data(), ctx->scratch_rgba.p, fb.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
@@ -1147,7 +1147,7 @@ int rt_count_work(rt_ctx *ctx, const rt_params *p, int row_begin, int row_end, r
     for (size_t k = 3; k < fb.size(); k += 4) rays += fb[k];
     out->rays = (uint64_t)rays; out->box_tests = h[1]; out->nodes = h[2]; out->tri_tests = h[3];
     out->box_literal = h[5]; out->tri_literal = h[6];
-    for (int k = 0; k < 8; ++k) out->steps[k] = h[8 + k];
+    for (int k = 0; k < 12; ++k) out->steps[k] = h[8 + k];
     // the counting instantiation checks every index that reaches an address (rt_travq.hip.h WQ_CHECK, rt_path.hip.h)
     if (h[4] != 0) return fail(ctx, RT_ERR_INTERNAL, "traversal invariant violated (mask 0x%llx: 1 path, 2 triangle, 4 node, 8 stack, 16 leaf queue, 32 staging)", h[4]);
     return RT_OK;

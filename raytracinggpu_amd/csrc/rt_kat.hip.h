@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void kat_tri_kernel(const float *__restrict__ 
         float *o = out + 5 * (size_t)i;
         o[0] = hit ? 1.f : 0.f; o[1] = t; o[2] = N.x; o[3] = N.y; o[4] = N.z;
     }
-    kat_count(cnt, how != 2, active);
+    kat_count(cnt, (how & 3) != 2, active);
 }
 
 // in: O[3] u[3]; out: hit t N[3] (N normalised, cpu:308) against the uploaded mesh.  route 0: the work-stack kernels'
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void kat_mesh_kernel(const Scene sc, const flo
                             const unsigned long long key = (unsigned long long)__float_as_uint(tt) << 32 | (unsigned int)k;
                             if (key < best) best = key;
                         }
-                        if (how == 2) tl++; else td++;
+                        if ((how & 3) == 2) tl++; else td++;
                     }
                 };
                 if (root_hiw >= 0) {

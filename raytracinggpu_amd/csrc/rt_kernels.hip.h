@@ -71,8 +71,9 @@ struct Frame {
     uint32_t seed;
     int row0, n_rows, tile_rows, tile_step;
     float4 *out;
-    unsigned long long *work;   // STATS kernels only: [16] {rays, box_tests, nodes, tri_tests, invariant mask, literal box tests, literal triangle tests, -,
-                                // wf_travq step counters: loop iterations, refill passes, refill rounds, queue fetches, TRI steps, BOX steps, literal-box fall-backs, serial drains}
+    unsigned long long *work;   // STATS kernels only: [24] {rays, box_tests, nodes, tri_tests, invariant mask, literal box tests, literal triangle tests, -,
+                                // wf_travq step counters [8..19]: loop iterations, refill passes, refill rounds, queue fetches, TRI steps, BOX steps, literal-box fall-backs,
+                                // serial drains, t-division blocks, first / second leaf pushes, -}
     int out_tile0, out_tile_step;   // local row r is stored at output row ((r / tile_rows) * out_tile_step + out_tile0) * tile_rows + r % tile_rows
     // cam_mode 1 = realtime_render.cu's camera and sample averaging (KernelLaunch realtime:1100-1134; wavefront variants only):
     // u_center = C + bz * z + bx * X + by * Y, every sample weighted by inv_n = (float)(1. / num_rays) as it is added

@@ -495,7 +495,7 @@ __global__ __launch_bounds__(kQBlock, 2) void wf_path(const Scene sc, const Fram
             int how0, how1;
             const bool ok0 = qtri_test(a0, a1, a2, mk(C0.x, C0.y, C0.z), mk(C0.w, D0.x, D0.y), fr.tri_tmin, ta, how0) && t0;
             const bool ok1 = qtri_test(b0, b1, b2, mk(C1.x, C1.y, C1.z), mk(C1.w, D1.x, D1.y), fr.tri_tmin, tb, how1) && t1;
-            if (STATS) wk.lit_tri += ((t0 && how0 == 2) ? 1u : 0u) + ((t1 && how1 == 2) ? 1u : 0u);
+            if (STATS) wk.lit_tri += ((t0 && (how0 & 3) == 2) ? 1u : 0u) + ((t1 && (how1 & 3) == 2) ? 1u : 0u);
             if (ok0) atomicMin(&best[o0], (unsigned long long)__float_as_uint(ta) << 32 | (unsigned int)i0);
             if (ok1) atomicMin(&best[o1], (unsigned long long)__float_as_uint(tb) << 32 | (unsigned int)i1);
             const bool full = part && Pq + c <= 128u;

@@ -163,7 +163,8 @@ __host__ __device__ inline float box_half(float lo, float hi) { return (float)((
 
 // moller_trumbore (cpu:226-236) + the acceptance test of the leaf loop (cpu:301): beta/gamma through the filter,
 // undecided lanes by the literal divisions, t always by the exact division.
-// `how` reports the route (callers that do not look at it pay nothing): 0 filter rejected, 1 filter accepted, 2 literal divisions.
+// `how` reports the route (callers that do not look at it pay nothing): 0 filter rejected, 1 filter accepted, 2 literal divisions;
+// + 4 when the barycentrics were accepted and t was computed.
 //
 // Filter.  b = bn * rcp(det), g = gn * rcp(det) differ from the reference's beta' = RN(bn / det), gamma' by at most 2^-22 of their
 // magnitude (+ denormal slack) whenever rd = rcp(det) is a NORMAL number (one v_cmp_class: excludes det = 0, denormal or beyond
@@ -206,9 +207,15 @@ __device__ __forceinline__ bool qtri_test(const float4 q0, const float4 q1, cons
         asm volatile("rt_mark_trilit_end_%=:" ::);
     }
     if (!ok) return false;
-    const float t = dot(AO, N) / det;
+    how |= 4;                                                       // the lane reaches the division (callers that do not look at `how` pay nothing)
+    // (code-object markers: tools/static_counts.py prices this block by how often a step enters it; the operands tie the labels to
+    // the computation -- no instruction is emitted for them)
+    float dd = det;
+    asm volatile("rt_mark_tdiv_begin_%=:" : "+v"(dd));
+    float t = dot(AO, N) / dd;
+    asm volatile("rt_mark_tdiv_end_%=:" : "+v"(t));
     t_out = t;
-    return t > (tri_tmin > 0.f ? tri_tmin : 0.f) && t < 1e9f;   // cpu:235 (t > 0) and cpu:301 (t > 1e-4); 1e9f = INF narrowed (cpu:283)
+    return t > (tri_tmin > 0.f ? tri_tmin : 0.f) && t < 1e9f;       // cpu:235 (t > 0) and cpu:301 (t > 1e-4); 1e9f = INF narrowed (cpu:283)
 }
 __device__ __forceinline__ bool qtri_test(const float4 q0, const float4 q1, const float4 q2, const f3 Oo, const f3 uo,
                                           const float tri_tmin, float &t_out) {
@@ -225,7 +232,9 @@ __device__ __forceinline__ bool qtri_test(const float4 q0, const float4 q1, cons
 //
 // Step counters of the counting (STATS) instantiation, fr.work[8..15] (bench.py prices the vector-issue roofline with them and the
 // static per-step instruction counts of the production code object, tools/static_counts.py): loop iterations, refill passes
-// entered, refill rounds, queue fetches, TRI steps, BOX steps, literal-box fall-backs taken, serial drains.
+// entered, refill rounds, queue fetches, TRI steps, BOX steps, literal-box fall-backs taken, serial drains; then the conditionally
+// executed blocks of the steps, counted per entry: the t-division block of a triangle test (some lane accepted the barycentrics), the
+// first and the second leaf-queue push of a BOX step.
 template <bool STATS, int R, bool LDSN, bool LDSV>
 __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || kQBlock != 256 || RT_TRAVQ_KP > 1) ? 4 : 5) void wf_travq(const Scene sc, const Frame fr, const WfState st, const int cap, const int n_lds, const int kLow, const int kMinFree) {
     // kLow: refill while the stack holds fewer entries (sibling pairs) than this (default 48); kMinFree: ... and at least this
@@ -278,6 +287,7 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
     bool drained = false;
     Work wk;
     unsigned int n_iter = 0, n_refill = 0, n_round = 0, n_fetch = 0, n_tri = 0, n_box = 0, n_lit = 0, n_serial = 0;   // STATS: step counters (wave-uniform)
+    unsigned int n_tdiv = 0, n_lpush = 0, n_lpush2 = 0;             // STATS: conditionally executed blocks of the steps (entered when any lane needs them)
     // optional per-wave record (-DRT_DEBUG builds with RT_DEBUG_TRAV set; tools/dbg_travq.py): st.dbg[16 * wave + k]
 #ifdef RT_DEBUG
     const bool dbg_on = st.dbg != nullptr;
@@ -364,8 +374,6 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
                 const unsigned long long freem = __ballot(lane < R && path < 0);
                 const int n_free = __popcll(freem);
                 if (n_free == 0 || (n_free < kMinFree && top >= 64)) break;
-                if (STATS) n_round++;
-                WQ_MARK("round_begin");
                 if (stage_used >= stage_n) {
                     if (drained) break;
                     WQ_MARK("fetch_begin");
@@ -389,6 +397,8 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
                     WQ_MARK("fetch_end");
                     if (stage_n == 0) continue;
                 }
+                if (STATS) n_round++;                                  // hand-off rounds: staged rays go to free slots
+                WQ_MARK("round_begin");
                 const int take = n_free < stage_n - stage_used ? n_free : stage_n - stage_used;
                 const int rank = lanes_below(freem);
                 const bool got = lane < R && path < 0 && rank < take;
@@ -486,7 +496,10 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
             int how0, how1;
             const bool ok0 = qtri_test(a0, a1, a2, mk(C0.x, C0.y, C0.z), mk(C0.w, D0.x, D0.y), fr.tri_tmin, ta, how0, t0);
             const bool ok1 = qtri_test(b0, b1, b2, mk(C1.x, C1.y, C1.z), mk(C1.w, D1.x, D1.y), fr.tri_tmin, tb_, how1, t1);
-            if (STATS) wk.lit_tri += ((t0 && how0 == 2) ? 1u : 0u) + ((t1 && how1 == 2) ? 1u : 0u);
+            if (STATS) {
+                wk.lit_tri += ((t0 && (how0 & 3) == 2) ? 1u : 0u) + ((t1 && (how1 & 3) == 2) ? 1u : 0u);
+                n_tdiv += (__ballot((how0 & 4) != 0) != 0ull ? 1u : 0u) + (__ballot((how1 & 4) != 0) != 0ull ? 1u : 0u);   // division blocks some lane entered
+            }
             if (ok0) atomicMin(best(o0), (unsigned long long)__float_as_uint(ta) << 32 | (unsigned int)i0);
             if (ok1) atomicMin(best(o1), (unsigned long long)__float_as_uint(tb_) << 32 | (unsigned int)i1);
             const bool full = part && P + c <= 128u;
@@ -610,8 +623,12 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
                 if (__builtin_amdgcn_inverse_ballot_w64(mI0 & mI1)) sp[1] = p1 | sb;
                 top += __popcll(mI0) + __popcll(mI1);
                 const unsigned int oL = ltail + (unsigned int)lanes_below2(mL0, mL1);
+                if (STATS) { n_lpush += (mL0 | mL1) != 0ull ? 1u : 0u; n_lpush2 += (mL0 & mL1) != 0ull ? 1u : 0u; }
+                WQ_MARK("lpush_begin");
                 if (__builtin_amdgcn_inverse_ballot_w64(mL0 | mL1)) leafq[oL & (LCAP - 1)] = make_uint2(sL0 ? p0 : p1, (unsigned int)(sL0 ? k0 : k1) | sb);
+                WQ_MARK("lpush2_begin");
                 if (__builtin_amdgcn_inverse_ballot_w64(mL0 & mL1)) leafq[(oL + 1u) & (LCAP - 1)] = make_uint2(p1, (unsigned int)k1 | sb);
+                WQ_MARK("lpush_end");
                 ltail += (unsigned int)(__popcll(mL0) + __popcll(mL1));
                 // outstanding entries of the ray: this pair is gone (-1), every pushed pair and leaf entry counts +1: one LDS add per lane
                 const int delta = lane_count4_minus(mI0, mI1, mL0, mL1, mact);
@@ -633,8 +650,8 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
         d[14] = d_fetch; d[15] = d_maxtop;
     }
     if (STATS && lane == 0) {
-        const unsigned int v[8] = {n_iter, n_refill, n_round, n_fetch, n_tri, n_box, n_lit, n_serial};
-        for (int k = 0; k < 8; ++k) if (v[k]) atomicAdd(&fr.work[8 + k], (unsigned long long)v[k]);
+        const unsigned int v[11] = {n_iter, n_refill, n_round, n_fetch, n_tri, n_box, n_lit, n_serial, n_tdiv, n_lpush, n_lpush2};
+        for (int k = 0; k < 11; ++k) if (v[k]) atomicAdd(&fr.work[8 + k], (unsigned long long)v[k]);
     }
     wf_flush_work<STATS>(fr, wk);
 }

@@ -34,8 +34,8 @@ def test_struct_sizes_match_header():
     assert ctypes.sizeof(_capi.Params) == 40
     assert ctypes.sizeof(_capi.Rows) == 16
     assert ctypes.sizeof(_capi.Light) == 16 and ctypes.sizeof(_capi.Camera) == 16
-    assert ctypes.sizeof(_capi.Stats) == 48 and ctypes.sizeof(_capi.Work) == 32 and ctypes.sizeof(_capi.CameraPose) == 24 and ctypes.sizeof(_capi.KatCounts) == 40
-    assert ctypes.sizeof(_capi.MultiStats) == 4 + 64 + 64 + 4 + 4 + 4 + 8 + 8 + 64     # incl. 4 bytes of padding before `rays`
+    assert ctypes.sizeof(_capi.Stats) == 48 and ctypes.sizeof(_capi.Work) == 32 + 16 + 12 * 8 and ctypes.sizeof(_capi.CameraPose) == 24 and ctypes.sizeof(_capi.KatCounts) == 40
+    assert ctypes.sizeof(_capi.MultiStats) == 4 + 64 + 64 + 4 + 4 + 4 + 8 + 8 + 64 + 4 + 4     # incl. 4 bytes of padding before `rays`, submit_ms + tail padding
 
 
 def test_no_cpu_fallback_without_a_gpu():

@@ -41,5 +41,20 @@ for key, pat in (("wf_travq", "wf_travq<false"), ("wf_advance", "wf_advance<fals
         "wave_cycles_waiting_frac": round(dv.get("SQ_WAIT_ANY/WAVE_CYCLES", 0), 4), "wave_cycles_issue_stalled_frac": round(dv.get("SQ_WAIT_INST_ANY/WAVE_CYCLES", 0), 4),
         "waves_per_launch": int(c.get("SQ_WAVES", 0)), "vgprs": c.get("_VGPR_Count"), "sgprs": c.get("_SGPR_Count"),
     }
+# the code the counters were taken from (bench.py quotes `traffic` only when its own sources hash to the same value) and the check of
+# bench.py's in-run instruction estimate (step counters x static per-step counts) against the hardware counter
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+res["code_hash"] = bench.code_hash()
+try:
+    line = json.loads([l for l in open(os.path.join(d, "bench_n1.json")) if l.startswith("{")][-1])
+    r = line["roofline"]
+    est, pmc = r["valu_wave_insts_per_launch"], res["kernels"]["wf_travq"]["valu_wave_insts_per_launch"]
+    ests, pmcs = r["salu_wave_insts_per_launch"], res["kernels"]["wf_travq"]["salu_wave_insts_per_launch"]
+    res["instruction_estimate_check"] = {"bench_estimate_valu_per_launch": est, "pmc_SQ_INSTS_VALU_per_launch": pmc, "ratio": round(est / pmc, 4),
+                                         "bench_estimate_salu_per_launch": ests, "pmc_SQ_INSTS_SALU_per_launch": pmcs, "salu_ratio": round(ests / pmcs, 4),
+                                         "bench_frac": r["frac"], "driver_style_ms_per_step": line["ms_per_step"]}
+except Exception as e:
+    res["instruction_estimate_check"] = {"skipped": str(e)}
 json.dump(res, open(os.path.join(d, "summary.json"), "w"), indent=1)
 print(json.dumps(res["kernels"], indent=1))

@@ -92,18 +92,32 @@ def travq_counts(lines):
         raise SystemExit(f"static_counts: markers missing from the code object: {missing}")
     one = {n: pos[n][0] for n in need}
     reg = lambda a, b: count(lines[one[a]:one[b]])
-    trilit = count([l for b, e in zip(pos.get("trilit_begin", []), pos.get("trilit_end", [])) if one["tri_begin"] < b < one["tri_end"] for l in lines[b:e]])
+    inside = lambda name, a, b_: [(x, y) for x, y in zip(pos.get(name + "_begin", []), pos.get(name + "_end", [])) if one[a] < x < one[b_]]
+    span = lambda pairs: count([l for x, y in pairs for l in lines[x:y]])
+    trilit = span(inside("trilit", "tri_begin", "tri_end"))
+    tdivs = inside("tdiv", "tri_begin", "tri_end")                   # the two inlined triangle tests of a TRI step: t = dot(AO, N) / det, entered when some lane accepted
+    tdiv = span(tdivs)
+    n_tdiv = max(len(tdivs), 1)
+    lp = [x for x in pos.get("lpush_begin", []) if one["box_begin"] < x < one["box_end"]]
+    lp2 = [x for x in pos.get("lpush2_begin", []) if one["box_begin"] < x < one["box_end"]]
+    lpe = [x for x in pos.get("lpush_end", []) if one["box_begin"] < x < one["box_end"]]
+    if not (lp and lp2 and lpe):
+        raise SystemExit("static_counts: leaf-push markers missing")
+    lpush1, lpush2 = count(lines[lp[0]:lp2[0]]), count(lines[lp2[0]:lpe[0]])
     loop_first = one["head"]
     loop_last = max(one["box_end"], one["tri_end"], one["refill_end"])
     out = {
         "loop_head": reg("head", "refill_begin"),                      # per loop iteration: the step dispatch up to the refill test
-        "retire": reg("refill_begin", "round_begin"),                   # per refill pass
-        "round": sub(reg("round_begin", "round_end"), reg("fetch_begin", "fetch_end")),   # per refill round (hand-off of staged rays)
+        "retire": sub(reg("refill_begin", "round_begin"), reg("fetch_begin", "fetch_end")),   # per refill pass: retire finished rays, look for free slots
+        "round": reg("round_begin", "round_end"),                       # per hand-off round (staged rays -> free slots)
         "fetch": reg("fetch_begin", "fetch_end"),                       # per queue fetch (64 slots)
-        "dispatch": reg("refill_end", "tri_begin"),                     # per loop iteration: which step runs next
-        "tri": sub(reg("tri_begin", "tri_end"), trilit),                # per TRI step (128 triangle tests); literal beta / gamma blocks excluded (rare)
-        "tri_literal_blocks": trilit,
-        "box": reg("box_begin", "box_end"),                             # per BOX step (64 sibling pairs)
+        "dispatch": reg("refill_end", "tri_begin"),                     # which step runs next: scalar, per loop iteration; its few vector instructions are the TRI
+                                                                        # step's first ones, placed in front of the label (priced per TRI step)
+        "tri": sub(sub(reg("tri_begin", "tri_end"), trilit), tdiv),     # per TRI step (128 triangle tests) without the blocks below
+        "tri_literal_blocks": trilit,                                   # literal beta / gamma divisions: rare, not priced
+        "tdiv": {k: v / n_tdiv for k, v in tdiv.items()},               # per t-division block entered (a TRI step has two)
+        "box": sub(sub(reg("box_begin", "box_end"), lpush1), lpush2),   # per BOX step (64 sibling pairs) without the leaf-queue pushes
+        "lpush": lpush1, "lpush2": lpush2,                              # per first / second leaf-queue push entered
         "whole_kernel": count(lines),
         "prologue_epilogue": sub(count(lines), count(lines[loop_first:loop_last])),
     }
@@ -131,8 +145,8 @@ def main():
     with open(OUT, "w") as f:
         json.dump(res, f, indent=1)
     t = res["wf_travq"]
-    print("static_counts: wf_travq per step: BOX %d valu (weight %d) %d salu | TRI %d (%d) %d | round %d (%d) %d | fetch %d | retire %d | head+dispatch %d" % (
-        t["box"]["valu"], t["box"]["valu_weight"], t["box"]["salu"], t["tri"]["valu"], t["tri"]["valu_weight"], t["tri"]["salu"],
+    print("static_counts: wf_travq per step: BOX %d valu (weight %d) %d salu + leaf pushes %d / %d | TRI %d (%d) %d + %.0f per t-division block | round %d (%d) %d | fetch %d | retire %d | head+dispatch %d" % (
+        t["box"]["valu"], t["box"]["valu_weight"], t["box"]["salu"], t["lpush"]["valu"], t["lpush2"]["valu"], t["tri"]["valu"], t["tri"]["valu_weight"], t["tri"]["salu"], t["tdiv"]["valu"],
         t["round"]["valu"], t["round"]["valu_weight"], t["round"]["salu"], t["fetch"]["valu"], t["retire"]["valu"], t["loop_head"]["valu"] + t["dispatch"]["valu"]))
 
 
