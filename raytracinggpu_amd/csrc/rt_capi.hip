@@ -54,6 +54,7 @@ struct Knobs {
     long long path_samp_bytes = 400ll << 20; // RT_PATH_SAMP_MB: state of the samples traced together (frames with num_rays > 1; ~130 B per sample and pixel slot).
                                              // Measured: a chain is fastest while its state stays near the 256 MB Infinity Cache -- 512x512, 64 samples: 23.5 / 8.8 / 8.0 /
                                              // 8.8 ms for 30 / 192 / 400 / 4096 MB; 1920x1080 (277 MB per sample): one sample per chain is best (71.5 vs 76.9 ms at 13)
+    double chunk_mpx = 2.3;    // RT_CHUNK_MPX: pixels (millions) of one sequential chunk of a big frame in the wavefront pipeline; 0 = never cut
     int top_lds = 0;           // RT_TRAVQ_TOPLDS: nodes of the breadth-first top of the tree every ordinary (4-wave) workgroup of wf_travq stages in LDS
     int copy_split = 0;        // RT_COPY_SPLIT=1: rt_render_async sends the two halves of a big frame through two copy streams (measured SLOWER: 1.62 vs 1.48 ms per
                                // pipelined 1080p float4 frame -- one DMA already runs at the rate the PCIe link gives, two share it and add an event hop)
@@ -82,6 +83,7 @@ static Knobs read_knobs() {
     if (geti("RT_PATH_BPC", v) && v >= 1 && v <= 8) k.path_bpc = v;
     if (geti("RT_PATH_PARTS", v) && v >= 1 && v <= 8) k.path_parts = v;
     if (geti("RT_COPY_SPLIT", v)) k.copy_split = v != 0;
+    { const char *e = getenv("RT_CHUNK_MPX"); if (e && *e) { const double d = atof(e); if (d >= 0 && d < 1e4) k.chunk_mpx = d; } }
     if (geti("RT_TRAVQ_TOPLDS", v) && v >= 0 && v <= 1024) k.top_lds = v & ~1;
     if (geti("RT_PATH_SAMP_MB", v) && v >= 1) k.path_samp_bytes = (long long)v << 20;
 #ifdef RT_DEBUG
@@ -319,8 +321,10 @@ void wf_geometry(const Knobs &kn, int n_cus, int bpc, int parts, int wpb, bool o
     tblocks_out = tblocks;
 }
 
-int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *out_dev, hipStream_t stream,
-                  unsigned long long *work_dev = nullptr, const rt_camera_pose *pose = nullptr) {
+// One chunk of rows (launch_render below cuts big frames into cache-sized chunks).  rec_begin / rec_end: this chunk opens / closes the
+// call's kernel-time bracket (ev_k0 / ev_k1).
+int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *out_dev, hipStream_t stream,
+                        unsigned long long *work_dev, const rt_camera_pose *pose, bool rec_begin, bool rec_end) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
     if (!ctx->have_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_scene_upload has not been called");
     int segs = 0;
@@ -438,7 +442,7 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
         ctx->stats.lds_bytes = (int)lds;
         ctx->stats.block_threads = rtk::kQBlock;
         ctx->stats.parts = parts;
-        RT_HIP(ctx, hipEventRecord(ctx->ev_k0, stream));
+        if (rec_begin) RT_HIP(ctx, hipEventRecord(ctx->ev_k0, stream));
         if (parts > 1) RT_HIP(ctx, hipEventRecord(ctx->fork_ev, stream));
         for (int j = 0; j < parts; ++j) {
             hipStream_t q = j == 0 ? stream : ctx->part_stream[j];
@@ -639,7 +643,7 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
         ctx->stats.block_threads = tb;
         ctx->stats.grid_blocks = (int)pv[0].tblocks;
         ctx->stats.parts = parts;
-        RT_HIP(ctx, hipEventRecord(ctx->ev_k0, stream));
+        if (rec_begin) RT_HIP(ctx, hipEventRecord(ctx->ev_k0, stream));
         if (parts > 1) RT_HIP(ctx, hipEventRecord(ctx->fork_ev, stream));
         for (int j = 0; j < parts; ++j) {
             Part &pt = pv[j];
@@ -695,7 +699,7 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
         ctx->stats.lds_bytes = (int)lds;
         ctx->stats.block_threads = rtk::kBlockThreads;
         ctx->stats.grid_blocks = (int)(grid.x * grid.y);
-        RT_HIP(ctx, hipEventRecord(ctx->ev_k0, stream));
+        if (rec_begin) RT_HIP(ctx, hipEventRecord(ctx->ev_k0, stream));
         if (work_dev) hipLaunchKernelGGL(rtk::render_kernel<true>, grid, dim3(rtk::kBlockThreads), lds, stream, scn, fr);
         else hipLaunchKernelGGL(rtk::render_kernel<false>, grid, dim3(rtk::kBlockThreads), lds, stream, scn, fr);
     } else {
@@ -724,13 +728,45 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
         ctx->stats.block_threads = rtk::kPBlock;
         ctx->stats.grid_blocks = (int)blocks;
         RT_HIP(ctx, hipMemsetAsync(pf.queue, 0, sizeof(unsigned int), stream));
-        RT_HIP(ctx, hipEventRecord(ctx->ev_k0, stream));
+        if (rec_begin) RT_HIP(ctx, hipEventRecord(ctx->ev_k0, stream));
         if (work_dev) hipLaunchKernelGGL(rtk::render_persistent<true>, dim3((unsigned)blocks), dim3(rtk::kPBlock), lds, stream, scn, pf);
         else hipLaunchKernelGGL(rtk::render_persistent<false>, dim3((unsigned)blocks), dim3(rtk::kPBlock), lds, stream, scn, pf);
     }
     RT_HIP(ctx, hipGetLastError());
-    RT_HIP(ctx, hipEventRecord(ctx->ev_k1, stream));
-    ctx->have_kernel_time = true;
+    if (rec_end) { RT_HIP(ctx, hipEventRecord(ctx->ev_k1, stream)); ctx->have_kernel_time = true; }
+    return RT_OK;
+}
+
+// The wavefront pipeline streams ~150 bytes of path state per pixel and launch through the memory system.  While a (sub-)frame's state
+// fits the 256 MB Infinity Cache the uniform kernel runs at the rate the headline 1080p frame shows; a 3840x2160 frame (1 GB of
+// state) does not, and ran 8 % slower per ray.  So a call is cut into sequential chunks of about RT_CHUNK_MPX million pixels
+// (default 2.3: a 1080p frame is ONE chunk) of whole tiles; every chunk is the same pipeline on the same streams and buffers.
+int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *out_dev, hipStream_t stream,
+                  unsigned long long *work_dev = nullptr, const rt_camera_pose *pose = nullptr) {
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    const int v = p ? p->variant : 0;
+    const bool wf = v == RT_VARIANT_AUTO || v == RT_VARIANT_WAVEFRONT || v == RT_VARIANT_WAVEFRONT_LDS || v == RT_VARIANT_WAVEFRONT_QUEUE ||
+                    v == RT_VARIANT_LDS_VERTS || v == RT_VARIANT_LDS_TOP || v == RT_VARIANT_LDS_ALL;
+    const int64_t chunk_px = (int64_t)(ctx->knobs.chunk_mpx * 1e6);
+    if (!p || !rows || !wf || chunk_px <= 0 || p->width <= 0 || rows->tile_rows <= 0 || (int64_t)rows->n_rows * p->width <= chunk_px * 5 / 4)
+        return launch_render_chunk(ctx, p, rows, out_dev, stream, work_dev, pose, true, true);
+    // rows per chunk: whole tiles (and whole 8-row wave tiles for contiguous rows), two sub-frames' worth at least
+    int unit = rows->tile_step == 1 ? 16 : rows->tile_rows * 2;
+    if (unit % rows->tile_rows != 0) unit *= rows->tile_rows;
+    const int64_t n_chunks = ((int64_t)rows->n_rows * p->width + chunk_px - 1) / chunk_px;
+    int per = (int)(((int64_t)rows->n_rows + n_chunks - 1) / n_chunks);
+    per = (per + unit - 1) / unit * unit;
+    uint64_t pixels = 0;
+    for (int a = 0; a < rows->n_rows; a += per) {
+        const int nr = std::min(per, rows->n_rows - a);
+        rt_rows rc{rows->row0 + (a / rows->tile_rows) * rows->tile_rows * rows->tile_step, nr, rows->tile_rows, rows->tile_step};
+        if (rows->tile_step == 1) { rc.row0 = rows->row0 + a; rc.tile_rows = nr; }      // contiguous rows: one tile of any height describes them
+        const int r = launch_render_chunk(ctx, p, &rc, static_cast<uint8_t *>(out_dev) + (size_t)a * p->width * sizeof(float4), stream, work_dev, pose,
+                                          a == 0, a + per >= rows->n_rows);
+        if (r != RT_OK) return r;
+        pixels += ctx->stats.pixels;
+    }
+    ctx->stats.pixels = pixels;
     return RT_OK;
 }
 
