@@ -372,33 +372,41 @@ def main():
 
     W, H = args.width, args.height
     # Frames in flight.  One GPU renders a whole 1080p frame as two concurrent sub-frames (the library's default) and a second frame
-    # would only queue behind it.  A 1/N share of the frame no longer fills the chip with its eleven dependent launches; there the
-    # bench keeps `lanes` whole frames in flight instead -- one context per lane (own streams, own path state, sub-frames off),
-    # frames dealt round-robin, every frame still rendered, gathered and assembled in full.  Measured on one MI355X for rank 0's share
-    # of 1080p (tools/share8_pipelined.py): world 8: 0.330 ms (1 frame, 2 sub-frames) -> 0.243 ms (2 frames in flight).
-    lanes_n = args.frames_in_flight if args.frames_in_flight > 0 else (2 if (world > 1 and not cpu_only) else 1)
+    # would only queue behind it.  A small share of a frame no longer fills the chip with its eleven dependent launches; there the
+    # bench keeps two whole frames in flight instead -- one context per lane (own streams, own path state, sub-frames off), frames
+    # dealt round-robin, every frame still rendered, gathered and assembled in full.  Measured on one MI355X for rank 0's share
+    # (tools/share_scaling.py, profiles/round3/share_scaling.txt): 1/8 of 1080p 0.323 -> 0.234 ms, 1/8 of 3840x2160 0.620 -> 0.538 ms;
+    # a share above ~1.3 Mpixel is faster as ONE frame with two sub-frames (two frames' path state would overflow the Infinity Cache).
+    SMALL_SHARE_PX = 1.3e6
     ctx = None
-    ctxs, tstreams = [], []
+    pools = {}                                                         # "full": [context with the default knobs]; "lanes": contexts with sub-frames off
+
+    def pool(kind, n):
+        if kind not in pools:
+            old_parts = os.environ.get("RT_PARTS")
+            if kind == "lanes" and old_parts is None:
+                os.environ["RT_PARTS"] = "1"                          # knobs are read when a context is created
+            cs, ts = [], []
+            for _ in range(n):
+                c = rt.Context(dev_index)
+                build_scene(rt, c, args.scene)
+                cs.append(c)
+                # a non-default torch stream per lane: its handle is non-NULL (NULL means "the context's own stream" in the C-ABI),
+                # so the lane's render kernels, torch's timing events and its gather are all ordered on ONE stream
+                ts.append(torch.cuda.Stream(device=dev))
+            if kind == "lanes" and old_parts is None:
+                del os.environ["RT_PARTS"]
+            pools[kind] = (cs, ts)
+        return pools[kind]
+
     if cpu_only:
         oren = OracleRenderer(args)
-        lanes_n = 1
+        stream = None
     else:
-        old_parts = os.environ.get("RT_PARTS")
-        if lanes_n > 1 and old_parts is None:
-            os.environ["RT_PARTS"] = "1"                              # knobs are read when a context is created
-        for _ in range(lanes_n):
-            c = rt.Context(dev_index)
-            build_scene(rt, c, args.scene)
-            ctxs.append(c)
-            # a non-default torch stream per lane: its handle is non-NULL (NULL means "the context's own stream" in the C-ABI),
-            # so the lane's render kernels, torch's timing events and its gather are all ordered on ONE stream
-            tstreams.append(torch.cuda.Stream(device=dev))
-        if lanes_n > 1 and old_parts is None:
-            del os.environ["RT_PARTS"]
-        ctx = ctxs[0]
-        torch.cuda.set_stream(tstreams[0])
-        assert tstreams[0].cuda_stream != 0
-    stream = tstreams[0].cuda_stream if tstreams else None
+        ctx = pool("full", 1)[0][0]
+        torch.cuda.set_stream(pool("full", 1)[1][0])
+        stream = pool("full", 1)[1][0].cuda_stream
+        assert stream != 0
     rgb8 = args.gather == "rgb8" and world > 1 and not cpu_only
 
     class Lane:
@@ -417,7 +425,11 @@ def main():
             self.W, self.H = W, H
             self.p = rt.make_params(W, H, args.spp, args.bounces, variant=args.variant, **rt.scenes.CPU_LAUNCHER)
             self.rows, self.idx = rt.interleaved_rows(H, TILE_ROWS, rank, world)
-            self.lanes = [Lane(k, W, H) for k in range(lanes_n)]
+            want = args.frames_in_flight if args.frames_in_flight > 0 else (2 if (world > 1 and self.rows.n_rows * W <= SMALL_SHARE_PX) else 1)
+            self.n_lanes = 1 if cpu_only else want
+            if not cpu_only:
+                self.ctxs, self.tstreams = pool("lanes", self.n_lanes) if self.n_lanes > 1 else pool("full", 1)
+            self.lanes = [Lane(k, W, H) for k in range(self.n_lanes)]
             self.local = self.lanes[0].local
             self.frame = None
             self.n = 0
@@ -426,12 +438,12 @@ def main():
             if cpu_only:
                 oren.render(self.W, self.H, args.spp, args.bounces, rank, world, ln.local)
             else:
-                ctxs[ln.k].render_device(self.p, self.rows, ln.local.data_ptr(), tstreams[ln.k].cuda_stream)
+                self.ctxs[ln.k].render_device(self.p, self.rows, ln.local.data_ptr(), self.tstreams[ln.k].cuda_stream)
 
         def exchange(self, ln):
             src = ln.local
             if rgb8:                                                  # tonemap this rank's tiles (cpu:714-716), gather 3 bytes per pixel
-                ctxs[ln.k].tonemap_device(ln.local.data_ptr(), self.rows.n_rows * self.W, ln.local8.data_ptr(), tstreams[ln.k].cuda_stream)
+                self.ctxs[ln.k].tonemap_device(ln.local.data_ptr(), self.rows.n_rows * self.W, ln.local8.data_ptr(), self.tstreams[ln.k].cuda_stream)
                 src = ln.local8
             if ln.xlocal is not src:                                  # --share-gpu: the exchange runs over gloo on host tensors
                 ln.xlocal.copy_(src, non_blocking=True)
@@ -439,12 +451,12 @@ def main():
             self.frame = tiling.gather_frame(ln.xlocal, self.H, world, rank, ln.gathered)
 
         def step(self, ev=None):
-            ln = self.lanes[self.n % lanes_n]
+            ln = self.lanes[self.n % self.n_lanes]
             self.n += 1
             if cpu_only:
                 self.render(ln); self.exchange(ln)
                 return
-            with torch.cuda.stream(tstreams[ln.k]):
+            with torch.cuda.stream(self.tstreams[ln.k]):
                 if ev:
                     ev[0].record()
                 self.render(ln)
@@ -509,7 +521,8 @@ def main():
         lrays = rays_of(lp)
         lel, lk = timed(lp, args.large_steps, 1)
         large = {"workload": f"cat_7680x4320_spp{args.spp}_b{args.bounces}", "steps": args.large_steps, "ms_per_step": round(1e3 * lel / args.large_steps, 4),
-                 "value": round(lrays / (lel / args.large_steps) / 1e6, 2), "unit": "Mrays/s", "rays_per_frame": lrays, "kernels_ms_max_over_ranks": round(lk, 4)}
+                 "value": round(lrays / (lel / args.large_steps) / 1e6, 2), "unit": "Mrays/s", "rays_per_frame": lrays, "kernels_ms_max_over_ranks": round(lk, 4),
+                 "frames_in_flight": lp.n_lanes}
         del lp
 
     if rank == 0:
@@ -523,7 +536,7 @@ def main():
                "config": {"workload": workload, "scene": "cpu_launcher.cpp walls + cat.obj (3954 tris, 2019-node array BVH)",
                           "num_rays": args.spp, "num_bounce": args.bounces, "depth_convention": "cpu_launcher (b+1 segments)",
                           "rays_per_frame": rays_per_frame, "ranks": dist.get_world_size() if world > 1 else 1,
-                          "frames_in_flight": lanes_n,
+                          "frames_in_flight": main_pt.n_lanes,
                           "tiling": f"{TILE_ROWS}-row tiles interleaved over {world} rank(s)"
                           + (f", one gather ({backend}) of the {'RGB8' if rgb8 else 'float4'} tiles to rank 0 per frame" if world > 1 else ""),
                           "variant": ctx.stats()["variant"] if ctx else None, "device": ctx.device_name if ctx else "cpu (oracle stand-in: not a measurement)",

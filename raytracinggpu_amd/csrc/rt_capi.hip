@@ -745,8 +745,9 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
                   unsigned long long *work_dev = nullptr, const rt_camera_pose *pose = nullptr) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
     const int v = p ? p->variant : 0;
-    const bool wf = v == RT_VARIANT_AUTO || v == RT_VARIANT_WAVEFRONT || v == RT_VARIANT_WAVEFRONT_LDS || v == RT_VARIANT_WAVEFRONT_QUEUE ||
-                    v == RT_VARIANT_LDS_VERTS || v == RT_VARIANT_LDS_TOP || v == RT_VARIANT_LDS_ALL;
+    // (the work-stack pipeline and its LDS-staged variants; the per-lane-walk variants with one big workgroup per CU lose more to the
+    // smaller launches than the cache gives back: wavefront_lds 7.9 -> 9.1 ms at 3840x2160)
+    const bool wf = v == RT_VARIANT_AUTO || v == RT_VARIANT_WAVEFRONT_QUEUE || v == RT_VARIANT_LDS_VERTS || v == RT_VARIANT_LDS_TOP || v == RT_VARIANT_LDS_ALL;
     const int64_t chunk_px = (int64_t)(ctx->knobs.chunk_mpx * 1e6);
     if (!p || !rows || !wf || chunk_px <= 0 || p->width <= 0 || rows->tile_rows <= 0 || (int64_t)rows->n_rows * p->width <= chunk_px * 5 / 4)
         return launch_render_chunk(ctx, p, rows, out_dev, stream, work_dev, pose, true, true);
