@@ -381,6 +381,9 @@ def main():
     ctx = None
     pools = {}                                                         # "full": [context with the default knobs]; "lanes": contexts with sub-frames off
 
+    if world > 1:
+        os.environ.setdefault("RT_PART_PRIO", "1")                    # this process will hold several contexts: keep their sub-frame streams off each other's hardware queues
+
     def pool(kind, n):
         if kind not in pools:
             old_parts = os.environ.get("RT_PARTS")

@@ -55,6 +55,10 @@ struct Knobs {
                                              // Measured: a chain is fastest while its state stays near the 256 MB Infinity Cache -- 512x512, 64 samples: 23.5 / 8.8 / 8.0 /
                                              // 8.8 ms for 30 / 192 / 400 / 4096 MB; 1920x1080 (277 MB per sample): one sample per chain is best (71.5 vs 76.9 ms at 13)
     double chunk_mpx = 2.3;    // RT_CHUNK_MPX: pixels (millions) of one sequential chunk of a big frame in the wavefront pipeline; 0 = never cut
+    int part_prio = 0;         // RT_PART_PRIO=1: the second sub-frame's stream in the high-priority class, which has its own pool of hardware queues.  A process
+                               // that holds SEVERAL contexts (rt_multi does this itself; bench.py with N > 1) should set it: with more streams than the runtime has
+                               // hardware queues (four) two active streams may share one and a context's sub-frames then run one after the other (1/8 of
+                               // 7680x4320: 2.7 instead of 2.0 ms).  Off by default: a lone context is 1 % faster with both sub-frames at equal priority.
     int top_lds = 0;           // RT_TRAVQ_TOPLDS: nodes of the breadth-first top of the tree every ordinary (4-wave) workgroup of wf_travq stages in LDS
     int copy_split = 0;        // RT_COPY_SPLIT=1: rt_render_async sends the two halves of a big frame through two copy streams (measured SLOWER: 1.62 vs 1.48 ms per
                                // pipelined 1080p float4 frame -- one DMA already runs at the rate the PCIe link gives, two share it and add an event hop)
@@ -83,6 +87,7 @@ static Knobs read_knobs() {
     if (geti("RT_PATH_BPC", v) && v >= 1 && v <= 8) k.path_bpc = v;
     if (geti("RT_PATH_PARTS", v) && v >= 1 && v <= 8) k.path_parts = v;
     if (geti("RT_COPY_SPLIT", v)) k.copy_split = v != 0;
+    if (geti("RT_PART_PRIO", v)) k.part_prio = v != 0;
     { const char *e = getenv("RT_CHUNK_MPX"); if (e && *e) { const double d = atof(e); if (d >= 0 && d < 1e4) k.chunk_mpx = d; } }
     if (geti("RT_TRAVQ_TOPLDS", v) && v >= 0 && v <= 1024) k.top_lds = v & ~1;
     if (geti("RT_PATH_SAMP_MB", v) && v >= 1) k.path_samp_bytes = (long long)v << 20;
@@ -95,7 +100,7 @@ static Knobs read_knobs() {
 struct rt_ctx {
     int device = 0;
     Knobs knobs;
-    hipStream_t stream = nullptr;
+    hipStream_t stream_ = nullptr;                                   // the context's own stream: created when first needed (own_stream)
     hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
     bool have_scene = false, have_kernel_time = false, have_tonemap_time = false;
     rtk::Scene scene{};
@@ -141,6 +146,17 @@ struct rt_ctx {
 };
 
 namespace {
+
+// The stream a call runs on when the caller passes none.  Created on first use: a context driven on the caller's streams (bench.py,
+// rt_render_device with a stream) owns no stream of its own -- idle streams still take part in the runtime's mapping of streams onto
+// its few hardware queues.
+hipStream_t own_stream(rt_ctx *ctx) {
+    if (!ctx->stream_) {
+        (void)hipSetDevice(ctx->device);
+        if (hipStreamCreateWithFlags(&ctx->stream_, hipStreamNonBlocking) != hipSuccess) { ctx->stream_ = nullptr; (void)hipGetLastError(); }
+    }
+    return ctx->stream_;
+}
 
 int fail(rt_ctx *ctx, int code, const char *fmt, ...) {
     char buf[512];
@@ -323,6 +339,30 @@ void wf_geometry(const Knobs &kn, int n_cus, int bpc, int parts, int wpb, bool o
 
 // One chunk of rows (launch_render below cuts big frames into cache-sized chunks).  rec_begin / rec_end: this chunk opens / closes the
 // call's kernel-time bracket (ev_k0 / ev_k1).
+// Streams are created when first needed: a context that renders one frame in two sub-frames owns two streams, not eleven.  The runtime
+// maps a process's streams onto a handful of hardware queues (four by default); with three contexts' worth of idle streams in one process
+// the two ACTIVE streams of a context could land on the same queue and its sub-frames ran one after the other (a 1/8 share of
+// 7680x4320 took 2.7 instead of 2.0 ms next to two other contexts).
+int need_part_streams(rt_ctx *ctx, int parts) {
+    for (int j = 1; j < parts && j < rt_ctx::kMaxParts; ++j) {
+        if (!ctx->part_stream[j]) {
+            // the second sub-frame's stream in the HIGH-priority class: the runtime keeps a separate pool of hardware queues per priority, so
+            // this stream can never be mapped onto the queue of the caller's (normal-priority) stream, whatever else the process has created
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            const int pr = ctx->knobs.part_prio ? ((j & 1) ? hi : lo) : 0;
+            RT_HIP(ctx, hipStreamCreateWithPriority(&ctx->part_stream[j], hipStreamNonBlocking, pr));
+        }
+        if (!ctx->part_ev[j]) RT_HIP(ctx, hipEventCreateWithFlags(&ctx->part_ev[j], hipEventDisableTiming));
+    }
+    return RT_OK;
+}
+int need_copy_streams(rt_ctx *ctx, bool second) {
+    if (!ctx->copy_stream) RT_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    if (second && !ctx->copy_stream2) RT_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream2, hipStreamNonBlocking));
+    return RT_OK;
+}
+
 int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *out_dev, hipStream_t stream,
                         unsigned long long *work_dev, const rt_camera_pose *pose, bool rec_begin, bool rec_end) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
@@ -442,6 +482,7 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
         ctx->stats.lds_bytes = (int)lds;
         ctx->stats.block_threads = rtk::kQBlock;
         ctx->stats.parts = parts;
+        if (int rs = need_part_streams(ctx, parts); rs != RT_OK) return rs;
         if (rec_begin) RT_HIP(ctx, hipEventRecord(ctx->ev_k0, stream));
         if (parts > 1) RT_HIP(ctx, hipEventRecord(ctx->fork_ev, stream));
         for (int j = 0; j < parts; ++j) {
@@ -643,6 +684,7 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
         ctx->stats.block_threads = tb;
         ctx->stats.grid_blocks = (int)pv[0].tblocks;
         ctx->stats.parts = parts;
+        if (int rs = need_part_streams(ctx, parts); rs != RT_OK) return rs;
         if (rec_begin) RT_HIP(ctx, hipEventRecord(ctx->ev_k0, stream));
         if (parts > 1) RT_HIP(ctx, hipEventRecord(ctx->fork_ev, stream));
         for (int j = 0; j < parts; ++j) {
@@ -791,7 +833,7 @@ int launch_tonemap(rt_ctx *ctx, const void *rgba_dev, int64_t npix, void *rgb8_d
 // the uploads.  `sc` carries the spheres, light and camera; rt_mesh_rebuild re-enters here with the tree it built on the device.
 int install_scene(rt_ctx *ctx, rtk::Scene sc, const rt_mesh *mesh) {
     RT_HIP(ctx, hipSetDevice(ctx->device));
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->stream_) RT_HIP(ctx, hipStreamSynchronize(ctx->stream_));   // (renders issued on a caller's stream are the caller's to order)
     ctx->have_scene = false;
     ctx->tri_perm.clear();
     std::vector<float4> lo, hi, tri, verts;
@@ -973,17 +1015,12 @@ int rt_ctx_create(rt_ctx **out, int device_id) {
     hipDeviceProp_t prop;
     hipError_t e = hipSetDevice(device_id);
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device_id);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_k0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_k1);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_t0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_t1);
     for (hipEvent_t &ev : ctx->ev_trav) if (e == hipSuccess) e = hipEventCreate(&ev);
-    for (hipEvent_t &ev : ctx->part_ev) if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-    for (hipStream_t &q : ctx->part_stream) if (e == hipSuccess) e = hipStreamCreateWithFlags(&q, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_stream2, hipStreamNonBlocking);
     for (int k = 0; k < rt_ctx::kSlots; ++k) if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->slot_half[k], hipEventDisableTiming);
     for (int k = 0; k < rt_ctx::kSlots; ++k) {
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->slot_rendered[k], hipEventDisableTiming);
@@ -1008,7 +1045,7 @@ int rt_ctx_create(rt_ctx **out, int device_id) {
 int rt_ctx_destroy(rt_ctx *ctx) {
     if (!ctx) return RT_OK;
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream_) (void)hipStreamSynchronize(ctx->stream_);
     if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
     if (ctx->copy_stream2) { (void)hipStreamSynchronize(ctx->copy_stream2); (void)hipStreamDestroy(ctx->copy_stream2); }
     for (int k = 0; k < rt_ctx::kSlots; ++k) if (ctx->slot_half[k]) (void)hipEventDestroy(ctx->slot_half[k]);
@@ -1031,7 +1068,7 @@ int rt_ctx_destroy(rt_ctx *ctx) {
     if (ctx->ev_k1) (void)hipEventDestroy(ctx->ev_k1);
     if (ctx->ev_t0) (void)hipEventDestroy(ctx->ev_t0);
     if (ctx->ev_t1) (void)hipEventDestroy(ctx->ev_t1);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->stream_) (void)hipStreamDestroy(ctx->stream_);
     delete ctx;
     return RT_OK;
 }
@@ -1069,7 +1106,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_sphere *spheres, int n_spheres, const 
 
 int rt_render_device(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *out_rgba_dev, void *stream) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
-    return launch_render(ctx, p, rows, out_rgba_dev, stream ? static_cast<hipStream_t>(stream) : ctx->stream);
+    return launch_render(ctx, p, rows, out_rgba_dev, stream ? static_cast<hipStream_t>(stream) : own_stream(ctx));
 }
 
 int rt_render(rt_ctx *ctx, const rt_params *p, int row_begin, int row_end, float *out_rgba_host) {
@@ -1082,10 +1119,10 @@ int rt_render(rt_ctx *ctx, const rt_params *p, int row_begin, int row_end, float
     int rc = ensure(ctx, ctx->scratch_rgba, bytes);
     if (rc != RT_OK) return rc;
     rt_rows rows{row_begin, n, n > 0 ? n : 1, 1};
-    rc = launch_render(ctx, p, &rows, ctx->scratch_rgba.p, ctx->stream);
+    rc = launch_render(ctx, p, &rows, ctx->scratch_rgba.p, own_stream(ctx));
     if (rc != RT_OK) return rc;
-    RT_HIP(ctx, hipMemcpyAsync(out_rgba_host, ctx->scratch_rgba.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RT_HIP(ctx, hipMemcpyAsync(out_rgba_host, ctx->scratch_rgba.p, bytes, hipMemcpyDeviceToHost, own_stream(ctx)));
+    RT_HIP(ctx, hipStreamSynchronize(own_stream(ctx)));
     return RT_OK;
 }
 
@@ -1107,11 +1144,12 @@ int rt_render_async(rt_ctx *ctx, const rt_params *p, int slot, void *out_host, i
     if (rgb8 && (rc = ensure(ctx, ctx->slot_rgb8[slot], (size_t)npix * 3 + 16)) != RT_OK) return rc;
     RT_HIP(ctx, hipSetDevice(ctx->device));
     // the slot's previous frame may still be on its way to the host: the kernels that overwrite its device buffer wait for that copy
-    if (ctx->slot_pending[slot]) RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->slot_done[slot], 0));
+    if (ctx->slot_pending[slot]) RT_HIP(ctx, hipStreamWaitEvent(own_stream(ctx), ctx->slot_done[slot], 0));
     rt_rows rows{0, p->height, p->height, 1};
-    if ((rc = launch_render(ctx, p, &rows, ctx->slot_rgba[slot].p, ctx->stream)) != RT_OK) return rc;
-    if (rgb8 && (rc = launch_tonemap(ctx, ctx->slot_rgba[slot].p, npix, ctx->slot_rgb8[slot].p, ctx->stream)) != RT_OK) return rc;
-    RT_HIP(ctx, hipEventRecord(ctx->slot_rendered[slot], ctx->stream));
+    if ((rc = launch_render(ctx, p, &rows, ctx->slot_rgba[slot].p, own_stream(ctx))) != RT_OK) return rc;
+    if (rgb8 && (rc = launch_tonemap(ctx, ctx->slot_rgba[slot].p, npix, ctx->slot_rgb8[slot].p, own_stream(ctx))) != RT_OK) return rc;
+    RT_HIP(ctx, hipEventRecord(ctx->slot_rendered[slot], own_stream(ctx)));
+    if ((rc = need_copy_streams(ctx, ctx->knobs.copy_split != 0)) != RT_OK) return rc;
     // the copy runs on its own stream: the next frame's kernels (other slot) do not queue behind it
     RT_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->slot_rendered[slot], 0));
     const size_t bytes = rgb8 ? (size_t)npix * 3 : (size_t)npix * sizeof(float4);
@@ -1141,7 +1179,7 @@ int rt_wait(rt_ctx *ctx, int slot) {
 
 int rt_tonemap_device(rt_ctx *ctx, const void *rgba_dev, int64_t n_pixels, void *rgb8_dev, void *stream) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
-    return launch_tonemap(ctx, rgba_dev, n_pixels, rgb8_dev, stream ? static_cast<hipStream_t>(stream) : ctx->stream);
+    return launch_tonemap(ctx, rgba_dev, n_pixels, rgb8_dev, stream ? static_cast<hipStream_t>(stream) : own_stream(ctx));
 }
 
 int rt_render_rgb8(rt_ctx *ctx, const rt_params *p, int row_begin, int row_end, uint8_t *out_rgb8_host) {
@@ -1155,10 +1193,10 @@ int rt_render_rgb8(rt_ctx *ctx, const rt_params *p, int row_begin, int row_end, 
     if (rc != RT_OK) return rc;
     if ((rc = ensure(ctx, ctx->scratch_rgb8, (size_t)npix * 3 + 16)) != RT_OK) return rc;
     rt_rows rows{row_begin, n, n > 0 ? n : 1, 1};
-    if ((rc = launch_render(ctx, p, &rows, ctx->scratch_rgba.p, ctx->stream)) != RT_OK) return rc;
-    if ((rc = launch_tonemap(ctx, ctx->scratch_rgba.p, npix, ctx->scratch_rgb8.p, ctx->stream)) != RT_OK) return rc;
-    RT_HIP(ctx, hipMemcpyAsync(out_rgb8_host, ctx->scratch_rgb8.p, (size_t)npix * 3, hipMemcpyDeviceToHost, ctx->stream));
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = launch_render(ctx, p, &rows, ctx->scratch_rgba.p, own_stream(ctx))) != RT_OK) return rc;
+    if ((rc = launch_tonemap(ctx, ctx->scratch_rgba.p, npix, ctx->scratch_rgb8.p, own_stream(ctx))) != RT_OK) return rc;
+    RT_HIP(ctx, hipMemcpyAsync(out_rgb8_host, ctx->scratch_rgb8.p, (size_t)npix * 3, hipMemcpyDeviceToHost, own_stream(ctx)));
+    RT_HIP(ctx, hipStreamSynchronize(own_stream(ctx)));
     return RT_OK;
 }
 
@@ -1171,15 +1209,15 @@ int rt_count_work(rt_ctx *ctx, const rt_params *p, int row_begin, int row_end, r
     if (rc != RT_OK) return rc;
     if ((rc = ensure(ctx, ctx->work, 24 * sizeof(unsigned long long))) != RT_OK) return rc;
     RT_HIP(ctx, hipSetDevice(ctx->device));
-    RT_HIP(ctx, hipMemsetAsync(ctx->work.p, 0, 24 * sizeof(unsigned long long), ctx->stream));
+    RT_HIP(ctx, hipMemsetAsync(ctx->work.p, 0, 24 * sizeof(unsigned long long), own_stream(ctx)));
     rt_rows rows{row_begin, n, n > 0 ? n : 1, 1};
-    rc = launch_render(ctx, p, &rows, ctx->scratch_rgba.p, ctx->stream, static_cast<unsigned long long *>(ctx->work.p));
+    rc = launch_render(ctx, p, &rows, ctx->scratch_rgba.p, own_stream(ctx), static_cast<unsigned long long *>(ctx->work.p));
     if (rc != RT_OK) return rc;
     unsigned long long h[24];
-    RT_HIP(ctx, hipMemcpyAsync(h, ctx->work.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipMemcpyAsync(h, ctx->work.p, sizeof(h), hipMemcpyDeviceToHost, own_stream(ctx)));
     std::vector<float> fb((size_t)n * (size_t)p->width * 4);
-    RT_HIP(ctx, hipMemcpyAsync(fb.data(), ctx->scratch_rgba.p, fb.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RT_HIP(ctx, hipMemcpyAsync(fb.data(), ctx->scratch_rgba.p, fb.size() * sizeof(float), hipMemcpyDeviceToHost, own_stream(ctx)));
+    RT_HIP(ctx, hipStreamSynchronize(own_stream(ctx)));
     double rays = 0;                                  // .w of every pixel = rays traced for it (exact in binary32)
     for (size_t k = 3; k < fb.size(); k += 4) rays += fb[k];
     out->rays = (uint64_t)rays; out->box_tests = h[1]; out->nodes = h[2]; out->tri_tests = h[3];
@@ -1194,7 +1232,7 @@ int rt_mesh_set_normals(rt_ctx *ctx, const float *normals_xyz, int n_normals, co
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
     if (!ctx->have_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_scene_upload has not been called");
     RT_HIP(ctx, hipSetDevice(ctx->device));
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(own_stream(ctx)));
     if (!normals_xyz || !nidx) { ctx->scene.nrm = nullptr; return RT_OK; }          // back to flat shading
     if (ctx->scene.mesh_slot < 0) return fail(ctx, RT_ERR_INVALID, "the scene has no mesh");
     if (n_normals <= 0 || index_stride < 3) return fail(ctx, RT_ERR_INVALID, "bad normal array sizes");
@@ -1224,12 +1262,12 @@ int rt_mesh_transform(rt_ctx *ctx, const float rotation[9], const float translat
     rtk::Mat3 m;
     for (int k = 0; k < 9; ++k) m.r[k] = rotation[k];
     for (int k = 0; k < 3; ++k) m.t[k] = translation[k];
-    hipLaunchKernelGGL(rtk::transform_kernel, dim3((unsigned)((sc.n_verts + 255) / 256)), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(rtk::transform_kernel, dim3((unsigned)((sc.n_verts + 255) / 256)), dim3(256), 0, own_stream(ctx),
                        static_cast<float4 *>(ctx->verts.p), sc.n_verts, m);
     if (sc.nrm != nullptr)      // the reference's kernel rotates the normals and ADDS the translation to them as well (global_launcher.cu:357-363)
-        hipLaunchKernelGGL(rtk::transform_kernel, dim3((unsigned)((3 * sc.n_tris + 255) / 256)), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(rtk::transform_kernel, dim3((unsigned)((3 * sc.n_tris + 255) / 256)), dim3(256), 0, own_stream(ctx),
                            static_cast<float4 *>(ctx->nrm.p), 3 * sc.n_tris, m);
-    hipLaunchKernelGGL(rtk::retri_kernel, dim3((unsigned)((sc.n_tris + 255) / 256)), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(rtk::retri_kernel, dim3((unsigned)((sc.n_tris + 255) / 256)), dim3(256), 0, own_stream(ctx),
                        static_cast<const int4 *>(ctx->tidx.p), static_cast<const float4 *>(ctx->verts.p), static_cast<float4 *>(ctx->tri.p), sc.n_tris);
     rtk::RefitArgs a{};
     a.node_lo = static_cast<float4 *>(ctx->node_lo.p); a.node_hi = static_cast<float4 *>(ctx->node_hi.p);
@@ -1238,13 +1276,13 @@ int rt_mesh_transform(rt_ctx *ctx, const float rotation[9], const float translat
     a.lvl_nodes = static_cast<const int *>(ctx->lvl_nodes.p); a.lvl_off = static_cast<const int *>(ctx->lvl_off.p);
     a.tidx = static_cast<const int4 *>(ctx->tidx.p); a.verts = static_cast<const float4 *>(ctx->verts.p);
     a.n_nodes = sc.n_nodes; a.n_levels = ctx->n_levels;
-    hipLaunchKernelGGL(rtk::refit_kernel, dim3(1), dim3(1024), 0, ctx->stream, a);
+    hipLaunchKernelGGL(rtk::refit_kernel, dim3(1), dim3(1024), 0, own_stream(ctx), a);
     RT_HIP(ctx, hipGetLastError());
     // the root box travels as a kernel argument (uniform root-box pre-test): fetch the refitted one
     float4 root[2];
-    RT_HIP(ctx, hipMemcpyAsync(&root[0], ctx->node_lo.p, sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
-    RT_HIP(ctx, hipMemcpyAsync(&root[1], ctx->node_hi.p, sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RT_HIP(ctx, hipMemcpyAsync(&root[0], ctx->node_lo.p, sizeof(float4), hipMemcpyDeviceToHost, own_stream(ctx)));
+    RT_HIP(ctx, hipMemcpyAsync(&root[1], ctx->node_hi.p, sizeof(float4), hipMemcpyDeviceToHost, own_stream(ctx)));
+    RT_HIP(ctx, hipStreamSynchronize(own_stream(ctx)));
     sc.root_lo = root[0]; sc.root_hi = root[1];
     // the refitted root box contains every node's (unions, bottom-up): it bounds the magnitudes wf_travq's box filter needs
     const float rv[6] = {root[0].x, root[0].y, root[0].z, root[1].x, root[1].y, root[1].z};
@@ -1284,7 +1322,7 @@ int rt_mesh_rebuild(rt_ctx *ctx, float *bvh_arr10_out, int32_t *tri_order_out, i
     a.n_start = ni; a.n_end = ni + cap; a.n_left = ni + 2 * cap; a.n_right = ni + 3 * cap;
     a.n_mn = static_cast<float4 *>(ctx->bb_nodes_f.p); a.n_mx = a.n_mn + cap;
     a.counter = static_cast<int *>(ctx->bb_counter.p); a.n_tris = nt; a.cap = (int)cap;
-    hipStream_t q = ctx->stream;
+    hipStream_t q = own_stream(ctx);
     // root = node 0 over all triangles (buildBVH(&bvh, 0, T), cpu:684); the permutation starts as the identity
     hipLaunchKernelGGL(rtk::iota_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, q, a.idx, nt);
     const int root_range[2] = {0, nt}, one[2] = {1, 0};              // counter[0] = nodes allocated, counter[1] = a split was refused for lack of capacity
@@ -1369,16 +1407,16 @@ int rt_render_pose(rt_ctx *ctx, const rt_params *p, const rt_camera_pose *pose, 
     int rc = ensure(ctx, ctx->scratch_rgba, bytes);
     if (rc != RT_OK) return rc;
     rt_rows rows{0, p->height, p->height > 0 ? p->height : 1, 1};
-    if ((rc = launch_render(ctx, p, &rows, ctx->scratch_rgba.p, ctx->stream, nullptr, pose)) != RT_OK) return rc;
-    RT_HIP(ctx, hipMemcpyAsync(out_rgba_host, ctx->scratch_rgba.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = launch_render(ctx, p, &rows, ctx->scratch_rgba.p, own_stream(ctx), nullptr, pose)) != RT_OK) return rc;
+    RT_HIP(ctx, hipMemcpyAsync(out_rgba_host, ctx->scratch_rgba.p, bytes, hipMemcpyDeviceToHost, own_stream(ctx)));
+    RT_HIP(ctx, hipStreamSynchronize(own_stream(ctx)));
     return RT_OK;
 }
 
 int rt_render_pose_device(rt_ctx *ctx, const rt_params *p, const rt_camera_pose *pose, const rt_rows *rows, void *out_rgba_dev, void *stream) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
     if (!pose) return fail(ctx, RT_ERR_INVALID, "pose is NULL");
-    return launch_render(ctx, p, rows, out_rgba_dev, stream ? static_cast<hipStream_t>(stream) : ctx->stream, nullptr, pose);
+    return launch_render(ctx, p, rows, out_rgba_dev, stream ? static_cast<hipStream_t>(stream) : own_stream(ctx), nullptr, pose);
 }
 
 int rt_progressive_reset(rt_ctx *ctx) {
@@ -1405,7 +1443,7 @@ int rt_progressive_frame(rt_ctx *ctx, const rt_params *p, const rt_camera_pose *
         return rc;
     RT_HIP(ctx, hipSetDevice(ctx->device));
     if (ctx->prog_frames == 0 || ctx->prog_w != p->width || ctx->prog_h != p->height) {   // realtime:1246-1251 (a new size also resets)
-        RT_HIP(ctx, hipMemsetAsync(ctx->accum.p, 0, bytes, ctx->stream));
+        RT_HIP(ctx, hipMemsetAsync(ctx->accum.p, 0, bytes, own_stream(ctx)));
         ctx->prog_frames = 0; ctx->prog_w = p->width; ctx->prog_h = p->height;
     }
     const int frame_no = ctx->prog_frames + 1;                        // frames++, realtime:1253
@@ -1414,15 +1452,15 @@ int rt_progressive_frame(rt_ctx *ctx, const rt_params *p, const rt_camera_pose *
     a = (a ^ 61u) ^ (a >> 16); a = a + (a << 3); a = a ^ (a >> 4); a = a * 0x27d4eb2du; a = a ^ (a >> 15);
     q.seed = a;
     rt_rows rows{0, p->height, p->height, 1};
-    if ((rc = launch_render(ctx, &q, &rows, ctx->scratch_rgba.p, ctx->stream, nullptr, pose)) != RT_OK) return rc;
+    if ((rc = launch_render(ctx, &q, &rows, ctx->scratch_rgba.p, own_stream(ctx), nullptr, pose)) != RT_OK) return rc;
     float4 *accum = static_cast<float4 *>(ctx->accum.p), *display = accum + npix;
-    hipLaunchKernelGGL(rtk::accumulate_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(rtk::accumulate_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, own_stream(ctx),
                        static_cast<const float4 *>(ctx->scratch_rgba.p), accum, display, static_cast<uint8_t *>(ctx->scratch_rgb8.p), npix, frame_no);
     RT_HIP(ctx, hipGetLastError());
     ctx->prog_frames = frame_no;
-    if (display_rgba_host) RT_HIP(ctx, hipMemcpyAsync(display_rgba_host, display, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    if (rgb8_host) RT_HIP(ctx, hipMemcpyAsync(rgb8_host, ctx->scratch_rgb8.p, (size_t)npix * 3, hipMemcpyDeviceToHost, ctx->stream));
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (display_rgba_host) RT_HIP(ctx, hipMemcpyAsync(display_rgba_host, display, bytes, hipMemcpyDeviceToHost, own_stream(ctx)));
+    if (rgb8_host) RT_HIP(ctx, hipMemcpyAsync(rgb8_host, ctx->scratch_rgb8.p, (size_t)npix * 3, hipMemcpyDeviceToHost, own_stream(ctx)));
+    RT_HIP(ctx, hipStreamSynchronize(own_stream(ctx)));
     return RT_OK;
 }
 
@@ -1479,15 +1517,15 @@ int rt_device_to_host(rt_ctx *ctx, void *dst_host, const void *src_dev, size_t b
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
     if (bytes && (!dst_host || !src_dev)) return fail(ctx, RT_ERR_INVALID, "bad copy arguments");
     RT_HIP(ctx, hipSetDevice(ctx->device));
-    if (bytes) RT_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (bytes) RT_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, own_stream(ctx)));
+    RT_HIP(ctx, hipStreamSynchronize(own_stream(ctx)));
     return RT_OK;
 }
 
 int rt_synchronize(rt_ctx *ctx) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
     RT_HIP(ctx, hipSetDevice(ctx->device));
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(own_stream(ctx)));
     return RT_OK;
 }
 

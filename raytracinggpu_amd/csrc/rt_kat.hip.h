@@ -183,15 +183,15 @@ int kat_run(rt_ctx *ctx, const float *in, int n, int width, float *out, int owid
     int rc;
     if ((rc = upload(ctx, din, in, (size_t)n * width * sizeof(float))) != RT_OK || (rc = ensure(ctx, dout, (size_t)n * owidth * sizeof(float))) != RT_OK ||
         (rc = ensure(ctx, dcnt, 4 * sizeof(unsigned long long))) != RT_OK) { din.release(); dout.release(); dcnt.release(); return rc; }
-    hipError_t e = hipMemsetAsync(dcnt.p, 0, 4 * sizeof(unsigned long long), ctx->stream);
+    hipError_t e = hipMemsetAsync(dcnt.p, 0, 4 * sizeof(unsigned long long), own_stream(ctx));
     if (e == hipSuccess) {
         launch(static_cast<const float *>(din.p), static_cast<float *>(dout.p), static_cast<unsigned long long *>(dcnt.p), dim3((unsigned)((n + 255) / 256)), dim3(256));
         e = hipGetLastError();
     }
     unsigned long long h[4] = {0, 0, 0, 0};
-    if (e == hipSuccess) e = hipMemcpyAsync(out, dout.p, (size_t)n * owidth * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(h, dcnt.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, dout.p, (size_t)n * owidth * sizeof(float), hipMemcpyDeviceToHost, own_stream(ctx));
+    if (e == hipSuccess) e = hipMemcpyAsync(h, dcnt.p, sizeof(h), hipMemcpyDeviceToHost, own_stream(ctx));
+    if (e == hipSuccess) e = hipStreamSynchronize(own_stream(ctx));
     din.release(); dout.release(); dcnt.release();
     if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, "KAT launch: %s", hipGetErrorString(e));
     if (counts) { counts->n = (uint64_t)n; counts->box_decided = h[0]; counts->box_literal = h[1]; counts->tri_decided = h[2]; counts->tri_literal = h[3]; }
@@ -204,20 +204,20 @@ extern "C" {
 
 int rt_kat_sphere(rt_ctx *ctx, const float *in, int n, float *out) {
     return kat_run(ctx, in, n, 10, out, 5, nullptr, [&](const float *di, float *dres, unsigned long long *, dim3 g, dim3 b) {
-        hipLaunchKernelGGL(rtk::kat_sphere_kernel, g, b, 0, ctx->stream, di, n, dres);
+        hipLaunchKernelGGL(rtk::kat_sphere_kernel, g, b, 0, own_stream(ctx), di, n, dres);
     });
 }
 
 int rt_kat_box(rt_ctx *ctx, const float *in, int n, int route, float *out, rt_kat_counts *counts) {
     if (route < 0 || route > 3) return fail(ctx, RT_ERR_INVALID, "route must be 0 (literal), 1 (slab_filtered), 2 (qbox_filter) or 3 (cbox_filter)");
     return kat_run(ctx, in, n, 12, out, 1, counts, [&](const float *di, float *dres, unsigned long long *dc, dim3 g, dim3 b) {
-        hipLaunchKernelGGL(rtk::kat_box_kernel, g, b, 0, ctx->stream, di, n, route, dres, dc);
+        hipLaunchKernelGGL(rtk::kat_box_kernel, g, b, 0, own_stream(ctx), di, n, route, dres, dc);
     });
 }
 
 int rt_kat_triangle(rt_ctx *ctx, const float *in, int n, float *out, rt_kat_counts *counts) {
     const int rc = kat_run(ctx, in, n, 15, out, 5, counts, [&](const float *di, float *dres, unsigned long long *dc, dim3 g, dim3 b) {
-        hipLaunchKernelGGL(rtk::kat_tri_kernel, g, b, 0, ctx->stream, di, n, dres, dc);
+        hipLaunchKernelGGL(rtk::kat_tri_kernel, g, b, 0, own_stream(ctx), di, n, dres, dc);
     });
     if (rc == RT_OK && counts) { counts->tri_decided = counts->box_decided; counts->tri_literal = counts->box_literal; counts->box_decided = counts->box_literal = 0; }
     return rc;
@@ -227,7 +227,7 @@ int rt_kat_mesh(rt_ctx *ctx, const float *in, int n, float tri_tmin, int route, 
     if (ctx && !ctx->have_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_scene_upload has not been called");
     if (route < 0 || route > 1) return fail(ctx, RT_ERR_INVALID, "route must be 0 (work-stack primitives) or 1 (stackless mesh_intersect)");
     return kat_run(ctx, in, n, 6, out, 5, counts, [&](const float *di, float *dres, unsigned long long *dc, dim3 g, dim3 b) {
-        hipLaunchKernelGGL(rtk::kat_mesh_kernel, g, b, 0, ctx->stream, ctx->scene, di, n, tri_tmin, route, dres, dc);
+        hipLaunchKernelGGL(rtk::kat_mesh_kernel, g, b, 0, own_stream(ctx), ctx->scene, di, n, tri_tmin, route, dres, dc);
     });
 }
 

@@ -157,12 +157,12 @@ int multi_render(rt_multi *m, const rt_params *p, void *out_dev_on_root, void *o
     const size_t frame_bytes = (size_t)W * H * px_bytes;
     if ((rc = ensure(root, m->stage, stage_off(n) + 16)) != RT_OK || (rc = ensure(root, m->rays, 8)) != RT_OK ||
         (!out_dev_on_root && (rc = ensure(root, m->frame, frame_bytes)) != RT_OK)) { m->err = root->err; return rc; }
-    RT_MHIP(m, hipMemsetAsync(m->rays.p, 0, 8, root->stream));
+    RT_MHIP(m, hipMemsetAsync(m->rays.p, 0, 8, own_stream(root)));
     // 1. every device renders its tiles; peers push them to the root as soon as they are done.  A failure part-way
     //    leaves work in flight on the devices already launched: drain them before returning, so that the caller may
     //    free or reuse its buffers and the next call starts from idle streams.
     auto drain = [&](int launched) {
-        for (int j = 0; j < launched; ++j) { (void)hipSetDevice(m->ctx[j]->device); (void)hipStreamSynchronize(m->ctx[j]->stream); }
+        for (int j = 0; j < launched; ++j) { (void)hipSetDevice(m->ctx[j]->device); (void)hipStreamSynchronize(own_stream(m->ctx[j])); }
         (void)hipSetDevice(root->device);
     };
     // each device's submission: returns a status, leaves its text in err_k[k] (the submit threads have their own thread-local error)
@@ -175,24 +175,24 @@ int multi_render(rt_multi *m, const rt_params *p, void *out_dev_on_root, void *o
         if (e != hipSuccess) { err_k[k] = std::string("hipSetDevice: ") + hipGetErrorString(e); return RT_ERR_HIP; }
         if ((r = ensure(c, m->local[k], std::max<size_t>((size_t)nrows[k] * W, 1) * sizeof(float4))) != RT_OK) { err_k[k] = c->err; return r; }
         rt_rows rows{k * R, nrows[k], R, n};
-        if ((r = launch_render(c, p, &rows, m->local[k].p, c->stream)) != RT_OK) { err_k[k] = c->err; return r; }
+        if ((r = launch_render(c, p, &rows, m->local[k].p, own_stream(c))) != RT_OK) { err_k[k] = c->err; return r; }
         const int64_t npix_k = (int64_t)nrows[k] * W;
         const void *piece = m->local[k].p;
         if (rgb8) {
             if ((r = ensure(c, m->local8[k], (size_t)std::max<int64_t>(npix_k, 1) * 3 + 16)) != RT_OK || (r = ensure(c, m->rays_k[k], 8)) != RT_OK) { err_k[k] = c->err; return r; }
-            e = hipMemsetAsync(m->rays_k[k].p, 0, 8, c->stream);
+            e = hipMemsetAsync(m->rays_k[k].p, 0, 8, own_stream(c));
             if (e == hipSuccess && npix_k > 0) {
-                hipLaunchKernelGGL(rtk::sum_rays_kernel, dim3((unsigned)((npix_k + 255) / 256)), dim3(256), 0, c->stream,
+                hipLaunchKernelGGL(rtk::sum_rays_kernel, dim3((unsigned)((npix_k + 255) / 256)), dim3(256), 0, own_stream(c),
                                    static_cast<const float4 *>(m->local[k].p), npix_k, static_cast<unsigned long long *>(m->rays_k[k].p));
-                if ((r = launch_tonemap(c, m->local[k].p, npix_k, m->local8[k].p, c->stream)) != RT_OK) { err_k[k] = c->err; return r; }
+                if ((r = launch_tonemap(c, m->local[k].p, npix_k, m->local8[k].p, own_stream(c))) != RT_OK) { err_k[k] = c->err; return r; }
             }
             if (e != hipSuccess) { err_k[k] = std::string("tonemap: ") + hipGetErrorString(e); return RT_ERR_HIP; }
             piece = m->local8[k].p;
         }
         if (k > 0) {
             if (nrows[k] > 0) e = hipMemcpyPeerAsync(static_cast<uint8_t *>(m->stage.p) + stage_off(k), root->device, piece, c->device,
-                                                     (size_t)npix_k * px_bytes, c->stream);
-            if (e == hipSuccess) e = hipEventRecord(m->done[k], c->stream);
+                                                     (size_t)npix_k * px_bytes, own_stream(c));
+            if (e == hipSuccess) e = hipEventRecord(m->done[k], own_stream(c));
             if (e != hipSuccess) { err_k[k] = std::string("tile exchange: ") + hipGetErrorString(e); return RT_ERR_HIP; }
         }
         return RT_OK;
@@ -209,8 +209,8 @@ int multi_render(rt_multi *m, const rt_params *p, void *out_dev_on_root, void *o
     }
     // 2. root: wait for the peers, restore row order
     RT_MHIP(m, hipSetDevice(root->device));
-    RT_MHIP(m, hipEventRecord(m->g0, root->stream));
-    for (int k = 1; k < n; ++k) RT_MHIP(m, hipStreamWaitEvent(root->stream, m->done[k], 0));
+    RT_MHIP(m, hipEventRecord(m->g0, own_stream(root)));
+    for (int k = 1; k < n; ++k) RT_MHIP(m, hipStreamWaitEvent(own_stream(root), m->done[k], 0));
     void *frame = out_dev_on_root ? out_dev_on_root : m->frame.p;
     const int64_t npix = (int64_t)W * H;
     if (rgb8) {
@@ -218,26 +218,26 @@ int multi_render(rt_multi *m, const rt_params *p, void *out_dev_on_root, void *o
         src.base[0] = static_cast<const uint8_t *>(m->local8[0].p);
         for (int k = 1; k < n; ++k) src.base[k] = static_cast<const uint8_t *>(m->stage.p) + stage_off(k);
         const int64_t words = ((int64_t)W * 3 + 3) / 4 * H;
-        hipLaunchKernelGGL(rtk::deinterleave_rgb8_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, root->stream, src, n, W, H, R, static_cast<uint8_t *>(frame));
+        hipLaunchKernelGGL(rtk::deinterleave_rgb8_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, own_stream(root), src, n, W, H, R, static_cast<uint8_t *>(frame));
     } else {
         rtk::MultiSrc src{};
         src.base[0] = static_cast<const float4 *>(m->local[0].p);
         for (int k = 1; k < n; ++k) src.base[k] = reinterpret_cast<const float4 *>(static_cast<const uint8_t *>(m->stage.p) + stage_off(k));
-        hipLaunchKernelGGL(rtk::deinterleave_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, root->stream, src, n, W, H, R, static_cast<float4 *>(frame),
+        hipLaunchKernelGGL(rtk::deinterleave_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, own_stream(root), src, n, W, H, R, static_cast<float4 *>(frame),
                            static_cast<unsigned long long *>(m->rays.p));
     }
     RT_MHIP(m, hipGetLastError());
-    RT_MHIP(m, hipEventRecord(m->g1, root->stream));
+    RT_MHIP(m, hipEventRecord(m->g1, own_stream(root)));
     unsigned long long rays = 0;
-    if (!rgb8) RT_MHIP(m, hipMemcpyAsync(&rays, m->rays.p, 8, hipMemcpyDeviceToHost, root->stream));
-    if (out_host) RT_MHIP(m, hipMemcpyAsync(out_host, frame, frame_bytes, hipMemcpyDeviceToHost, root->stream));
-    RT_MHIP(m, hipStreamSynchronize(root->stream));
+    if (!rgb8) RT_MHIP(m, hipMemcpyAsync(&rays, m->rays.p, 8, hipMemcpyDeviceToHost, own_stream(root)));
+    if (out_host) RT_MHIP(m, hipMemcpyAsync(out_host, frame, frame_bytes, hipMemcpyDeviceToHost, own_stream(root)));
+    RT_MHIP(m, hipStreamSynchronize(own_stream(root)));
     if (rgb8) {                                                       // every device counted its own rays; their streams are drained by now or here
         for (int k = 0; k < n; ++k) {
             unsigned long long rk = 0;
             RT_MHIP(m, hipSetDevice(m->ctx[k]->device));
-            RT_MHIP(m, hipMemcpyAsync(&rk, m->rays_k[k].p, 8, hipMemcpyDeviceToHost, m->ctx[k]->stream));
-            RT_MHIP(m, hipStreamSynchronize(m->ctx[k]->stream));
+            RT_MHIP(m, hipMemcpyAsync(&rk, m->rays_k[k].p, 8, hipMemcpyDeviceToHost, own_stream(m->ctx[k])));
+            RT_MHIP(m, hipStreamSynchronize(own_stream(m->ctx[k])));
             rays += rk;
         }
         RT_MHIP(m, hipSetDevice(root->device));
@@ -273,6 +273,7 @@ int rt_multi_create(rt_multi **out, const int *device_ids, int n_devices) {
     for (int k = 0; k < n_devices; ++k) {
         const int rc = rt_ctx_create(&m->ctx[k], device_ids[k]);
         if (rc != RT_OK) { rt_multi_destroy(m); return rc; }
+        m->ctx[k]->knobs.part_prio = 1;                                  // several contexts in one process: see Knobs::part_prio
     }
     for (int k = 1; k < n_devices; ++k) { m->worker[k] = new MultiWorker(); m->worker[k]->start(); }
     m->peer_access[0] = -1;                                               // the root itself
@@ -303,7 +304,7 @@ int rt_multi_destroy(rt_multi *m) {
     for (int k = 1; k < RT_MAX_DEVICES; ++k) if (m->worker[k]) { m->worker[k]->stop(); delete m->worker[k]; m->worker[k] = nullptr; }
     if (m->ctx[0]) {
         (void)hipSetDevice(m->ctx[0]->device);
-        if (m->ctx[0]->stream) (void)hipStreamSynchronize(m->ctx[0]->stream);
+        if (m->ctx[0]->stream_) (void)hipStreamSynchronize(m->ctx[0]->stream_);
         m->stage.release(); m->frame.release(); m->rays.release();
         if (m->g0) (void)hipEventDestroy(m->g0);
         if (m->g1) (void)hipEventDestroy(m->g1);
@@ -311,7 +312,7 @@ int rt_multi_destroy(rt_multi *m) {
     for (int k = 0; k < m->n; ++k) {
         if (!m->ctx[k]) continue;
         (void)hipSetDevice(m->ctx[k]->device);
-        if (m->ctx[k]->stream) (void)hipStreamSynchronize(m->ctx[k]->stream);
+        if (m->ctx[k]->stream_) (void)hipStreamSynchronize(m->ctx[k]->stream_);
         m->local[k].release(); m->local8[k].release(); m->rays_k[k].release();
         if (m->done[k]) (void)hipEventDestroy(m->done[k]);
         rt_ctx_destroy(m->ctx[k]);

@@ -4,6 +4,7 @@ the library's default for a lone frame (one frame, two concurrent sub-frames) an
 several ranks (two whole frames in flight, one context each, sub-frames off).
 usage: python tools/share_scaling.py [> profiles/roundN/share_scaling.txt]"""
 import os, sys, time
+os.environ.setdefault("RT_PART_PRIO", "1")       # three contexts live in this process (as in a bench.py rank with N > 1): see Knobs::part_prio in rt_capi.hip
 sys.path.insert(0, os.getcwd())
 import torch
 import raytracinggpu_amd as rt
