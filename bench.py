@@ -396,7 +396,7 @@ def main():
                 cs.append(c)
                 # a non-default torch stream per lane: its handle is non-NULL (NULL means "the context's own stream" in the C-ABI),
                 # so the lane's render kernels, torch's timing events and its gather are all ordered on ONE stream
-                ts.append(torch.cuda.Stream(device=dev))
+                ts.append(torch.cuda.Stream(device=dev, priority=-1 if (len(ts) & 1) else 0))   # odd lanes in the high-priority queue pool: never the even lane's hardware queue
             if kind == "lanes" and old_parts is None:
                 del os.environ["RT_PARTS"]
             pools[kind] = (cs, ts)
