@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--variant", default="auto")
     ap.add_argument("--gather", default="f32", choices=["f32", "rgb8"],
                     help="N > 1: what rank 0 gathers -- the float4 tiles (parity path, default) or the tonemapped RGB8 tiles (PNG path, 3 B/pixel)")
+    ap.add_argument("--transport", default="torch", choices=["torch", "capi"],
+                    help="N > 1: the gather goes through torch.distributed (nccl = RCCL; default) or through the product's own C-ABI "
+                         "(libraytrace_rccl.so: grouped ncclSend / ncclRecv, every tile received straight into its place in rank 0's frame)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--large-steps", type=int, default=4, help="frames of the second timed point (cat 7680x4320, BASELINE config 5) in the same run; 0 = skip")
@@ -369,6 +372,14 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     xdev = torch.device("cpu") if gloo else dev                       # where the exchange runs (gloo moves host tensors)
+    comm = None
+    if args.transport == "capi" and world > 1:
+        if gloo or cpu_only:
+            raise SystemExit("--transport capi is RCCL between GPUs: it has no gloo / CPU leg")
+        from raytracinggpu_amd import _rccl
+        box = [_rccl.unique_id() if rank == 0 else None]               # rank 0's communicator id reaches the others through the process group
+        dist.broadcast_object_list(box, src=0)
+        comm = _rccl.Comm(dev_index, rank, world, box[0])
 
     W, H = args.width, args.height
     # Frames in flight.  One GPU renders a whole 1080p frame as two concurrent sub-frames (the library's default) and a second frame
@@ -420,7 +431,8 @@ def main():
             self.local8 = tiling.local_buffer(H, W, world, dev, rgb8=True) if rgb8 else None
             src = self.local8 if rgb8 else self.local
             self.xlocal = torch.empty(src.shape, dtype=src.dtype, device=xdev, pin_memory=not cpu_only) if (gloo and world > 1 and not cpu_only) else src
-            self.gathered = tiling.gather_buffer(self.xlocal, world) if (world > 1 and rank == 0) else None
+            self.gathered = tiling.gather_buffer(self.xlocal, world) if (world > 1 and rank == 0 and comm is None) else None
+            self.frame = torch.empty((H, W) + tuple(src.shape[2:]), dtype=src.dtype, device=dev) if (comm is not None and rank == 0) else None
 
     class Point:
         """One timed workload: its parameters, this rank's tiles, and one Lane per frame in flight."""
@@ -448,6 +460,11 @@ def main():
             if rgb8:                                                  # tonemap this rank's tiles (cpu:714-716), gather 3 bytes per pixel
                 self.ctxs[ln.k].tonemap_device(ln.local.data_ptr(), self.rows.n_rows * self.W, ln.local8.data_ptr(), self.tstreams[ln.k].cuda_stream)
                 src = ln.local8
+            if comm is not None:                                      # the product's own transport: tiles land in place, nothing to assemble
+                comm.gather_tiles(src.data_ptr(), self.W, self.H, src.shape[2] * src.element_size(), ln.frame.data_ptr() if rank == 0 else None,
+                                  tile_rows=TILE_ROWS, stream=self.tstreams[ln.k].cuda_stream)
+                self.frame = ln.frame
+                return
             if ln.xlocal is not src:                                  # --share-gpu: the exchange runs over gloo on host tensors
                 ln.xlocal.copy_(src, non_blocking=True)
                 torch.cuda.current_stream().synchronize()
@@ -532,7 +549,7 @@ def main():
         ms_per_step = 1e3 * elapsed / args.steps
         value = rays_per_frame / (elapsed / args.steps) / 1e6
         workload = f"cat_{W}x{H}_spp{args.spp}_b{args.bounces}" if args.scene == "cpu" else f"{args.scene}_{W}x{H}_spp{args.spp}_b{args.bounces}"
-        backend = "gloo (test: ranks share GPU 0)" if args.share_gpu else "gloo (test: CPU stand-in renderer)" if cpu_only else "nccl (RCCL)"
+        backend = "gloo (test: ranks share GPU 0)" if args.share_gpu else "gloo (test: CPU stand-in renderer)" if cpu_only else "RCCL through libraytrace_rccl.so, tiles received in place" if comm is not None else "nccl (RCCL)"
         res = {"metric": "Mrays/s, cat mesh 1920x1080 (ms/frame in ms_per_step)", "value": None if cpu_only else round(value, 2), "unit": "Mrays/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

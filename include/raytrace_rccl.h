@@ -1,0 +1,84 @@
+/*
+ * raytrace_rccl.h -- C-ABI of libraytrace_rccl.so: the tile exchange of the one-process-per-GPU render path over RCCL / xGMI.
+ *
+ * BASELINE.json's north star: "The image is row-tile partitioned across the 8 GPUs of one node with a final RCCL gather over
+ * xGMI".  The reference renders on the implicit device 0 and has one device-to-host copy of the whole image
+ * (optimized.cu:849-856); with one process per GPU each rank renders its interleaved 8-row tiles (rt_render_device with an
+ * rt_rows{rank * tile_rows, n, tile_rows, world}, raytrace_hip.h) and this library moves them into the root's frame:
+ *
+ *     rank 0:  rt_comm_id_create(id)  -> hand the 128 bytes to every rank (file, environment, MPI, a socket)
+ *     every rank:  rt_comm_create(&c, device, rank, world, id)
+ *                  rt_render_device(ctx, &p, &rows, tiles_dev, rt_comm_stream(c));        // (+ rt_tonemap_device for the 8-bit image)
+ *                  rt_comm_gather_tiles(c, tiles_dev, W, H, bytes_per_pixel, tile_rows, 0, frame_dev_on_root, NULL);
+ *                  rt_comm_sync(c);
+ *
+ * A tile is contiguous in the frame, so the root receives every peer tile straight into place (one grouped ncclSend / ncclRecv
+ * per tile; no staging buffer, no de-interleave pass) and copies its own tiles device to device.  On MI355X's fully connected
+ * xGMI every peer has its own link into the root, so the seven transfers run side by side (not a ring).
+ * Kept out of libraytrace_hip.so so that the single-GPU path does not load librccl.
+ *
+ * Plain pointers and sizes only.  Every function returns RT_COMM_OK (0) or a negative code with a message in
+ * rt_comm_last_error; nothing exits or throws.  There is no fallback transport in this library.
+ */
+#ifndef RAYTRACE_RCCL_H
+#define RAYTRACE_RCCL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_COMM_ABI_VERSION 1
+#define RT_COMM_ID_BYTES 128     /* NCCL_UNIQUE_ID_BYTES */
+#define RT_COMM_MAX_TILES 8192   /* tiles of one frame (one send / receive each) */
+
+typedef enum rt_comm_status {
+    RT_COMM_OK = 0,
+    RT_COMM_ERR_INVALID = -1,    /* bad argument                                   */
+    RT_COMM_ERR_HIP = -2,        /* a HIP call failed                              */
+    RT_COMM_ERR_RCCL = -3        /* an RCCL call failed (message names the call)   */
+} rt_comm_status;
+
+typedef struct rt_comm rt_comm;
+
+int rt_comm_abi_version(void);
+/* rank 0, once per communicator: ncclGetUniqueId */
+int rt_comm_id_create(unsigned char id[RT_COMM_ID_BYTES]);
+/* every rank (collective: returns when all `world` ranks have called it): ncclCommInitRank on `device`, plus a stream of the
+ * communicator's own.  Two ranks of one communicator must not share a device (RCCL refuses duplicate devices). */
+int rt_comm_create(rt_comm **comm, int device, int rank, int world, const unsigned char id[RT_COMM_ID_BYTES]);
+int rt_comm_destroy(rt_comm *comm);
+const char *rt_comm_last_error(const rt_comm *comm);    /* comm may be NULL: last error of a call without a communicator */
+int rt_comm_rank(const rt_comm *comm);
+int rt_comm_world(const rt_comm *comm);
+/* the communicator's stream as a hipStream_t: pass it to rt_render_device / rt_tonemap_device so that render, tone mapping and
+ * exchange are ordered without a host-side wait */
+void *rt_comm_stream(const rt_comm *comm);
+/*
+ * The gather (collective).  tiles_dev: this rank's dense tile buffer -- the rows of its tiles (tile t belongs to rank t % world;
+ * rows [t * tile_rows, min(H, (t + 1) * tile_rows))) in tile order, bytes_per_pixel * W bytes per row (16 = the float4 frame,
+ * 3 = the tone-mapped RGB8 image).  frame_dev: on `root` the H x W frame in its device memory; ignored elsewhere (may be NULL).
+ * stream: a hipStream_t, or NULL for the communicator's own.  Asynchronous: rt_comm_sync waits for it.
+ */
+int rt_comm_gather_tiles(rt_comm *comm, const void *tiles_dev, int W, int H, int bytes_per_pixel, int tile_rows, int root,
+                         void *frame_dev, void *stream);
+/* The plan rt_comm_gather_tiles follows for tile t of a frame (host arithmetic, no device, no communicator: tests replay the whole
+ * exchange with it): the rank that renders the tile, where the tile starts in that rank's dense buffer and in the frame, its size. */
+typedef struct rt_comm_tile {
+    int32_t  owner;          /* t % world                                                        */
+    int32_t  rows;           /* tile_rows, fewer for the last tile of a frame whose height is not a multiple */
+    uint64_t local_offset;   /* bytes from the start of the owner's tile buffer                 */
+    uint64_t frame_offset;   /* bytes from the start of the frame                               */
+    uint64_t bytes;
+} rt_comm_tile;
+int rt_comm_tile_plan(int W, int H, int bytes_per_pixel, int tile_rows, int world, int t, rt_comm_tile *out);
+/* bytes the last rt_comm_gather_tiles of this rank sent (peers) or received (root) over the fabric */
+uint64_t rt_comm_last_bytes(const rt_comm *comm);
+int rt_comm_sync(rt_comm *comm);                         /* hipStreamSynchronize of the communicator's stream */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -24,7 +24,10 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+
 #include "raytrace_hip.h"
+#include "raytrace_rccl.h"
 
 namespace raytracer {
 
@@ -362,6 +365,68 @@ struct SceneArrays {
     static void count_nodes(const BVH *b, size_t &n) { ++n; if (b->left) count_nodes(b->left, n); if (b->right) count_nodes(b->right, n); }
 };
 
+// The RCCL transport of the one-process-per-GPU path (raytrace_rccl.h): every rank of the node makes one TileComm from the same
+// 128-byte id (rank 0 creates it with TileComm::make_id and hands it to the others -- a file, the environment, MPI).  The library
+// is loaded on first use, so a single-GPU program never loads librccl.  Two ranks of a communicator cannot share a device.
+class TileComm {
+public:
+    struct Api {
+        void *so = nullptr;
+        int (*id_create)(unsigned char *) = nullptr;
+        int (*create)(rt_comm **, int, int, int, const unsigned char *) = nullptr;
+        int (*destroy)(rt_comm *) = nullptr;
+        const char *(*last_error)(const rt_comm *) = nullptr;
+        void *(*stream)(const rt_comm *) = nullptr;
+        int (*gather_tiles)(rt_comm *, const void *, int, int, int, int, int, void *, void *) = nullptr;
+        uint64_t (*last_bytes)(const rt_comm *) = nullptr;
+        int (*sync)(rt_comm *) = nullptr;
+    };
+    static const Api &api() {
+        static Api a = [] {
+            Api x;
+            const char *path = std::getenv("RT_RCCL_LIB");            // default: next to the program / on the loader's path
+            x.so = dlopen(path ? path : "libraytrace_rccl.so", RTLD_NOW | RTLD_LOCAL);
+            if (!x.so) throw Error(RT_ERR_UNSUPPORTED, std::string("libraytrace_rccl.so: ") + dlerror());
+            auto sym = [&](const char *n) { void *f = dlsym(x.so, n); if (!f) throw Error(RT_ERR_UNSUPPORTED, std::string("libraytrace_rccl.so lacks ") + n); return f; };
+            x.id_create = reinterpret_cast<decltype(x.id_create)>(sym("rt_comm_id_create"));
+            x.create = reinterpret_cast<decltype(x.create)>(sym("rt_comm_create"));
+            x.destroy = reinterpret_cast<decltype(x.destroy)>(sym("rt_comm_destroy"));
+            x.last_error = reinterpret_cast<decltype(x.last_error)>(sym("rt_comm_last_error"));
+            x.stream = reinterpret_cast<decltype(x.stream)>(sym("rt_comm_stream"));
+            x.gather_tiles = reinterpret_cast<decltype(x.gather_tiles)>(sym("rt_comm_gather_tiles"));
+            x.last_bytes = reinterpret_cast<decltype(x.last_bytes)>(sym("rt_comm_last_bytes"));
+            x.sync = reinterpret_cast<decltype(x.sync)>(sym("rt_comm_sync"));
+            return x;
+        }();
+        return a;
+    }
+    static std::vector<unsigned char> make_id() {
+        std::vector<unsigned char> id(RT_COMM_ID_BYTES);
+        if (int rc = api().id_create(id.data()); rc != RT_COMM_OK) throw Error(RT_ERR_HIP, std::string("rt_comm_id_create: ") + api().last_error(nullptr));
+        return id;
+    }
+    TileComm(int device, int rank, int world, const std::vector<unsigned char> &id) : rank_(rank), world_(world) {
+        if (id.size() != RT_COMM_ID_BYTES) throw Error(RT_ERR_INVALID, "a communicator id is RT_COMM_ID_BYTES bytes");
+        if (int rc = api().create(&c_, device, rank, world, id.data()); rc != RT_COMM_OK) throw Error(RT_ERR_HIP, std::string("rt_comm_create: ") + api().last_error(nullptr));
+    }
+    ~TileComm() { if (c_) api().destroy(c_); }
+    TileComm(const TileComm &) = delete;
+    TileComm &operator=(const TileComm &) = delete;
+    int rank() const { return rank_; }
+    int world() const { return world_; }
+    void *stream() const { return api().stream(c_); }
+    void gather_tiles(const void *tiles_dev, int W, int H, int bytes_per_pixel, void *frame_dev_on_root, int root = 0, int tile_rows = RT_MULTI_TILE_ROWS) {
+        if (int rc = api().gather_tiles(c_, tiles_dev, W, H, bytes_per_pixel, tile_rows, root, frame_dev_on_root, nullptr); rc != RT_COMM_OK)
+            throw Error(RT_ERR_HIP, std::string("rt_comm_gather_tiles: ") + api().last_error(c_));
+    }
+    void sync() { if (int rc = api().sync(c_); rc != RT_COMM_OK) throw Error(RT_ERR_HIP, std::string("rt_comm_sync: ") + api().last_error(c_)); }
+    uint64_t last_bytes() const { return api().last_bytes(c_); }
+
+private:
+    rt_comm *c_ = nullptr;
+    int rank_ = 0, world_ = 1;
+};
+
 class Renderer {
 public:
     explicit Renderer(int device = 0) {
@@ -417,6 +482,30 @@ public:
         check(rt_tonemap_device(ctx_, rgba.p, (int64_t)n * s.W, rgb8.p, nullptr), "rt_tonemap_device");
         check(rt_synchronize(ctx_), "rt_synchronize");
         check(rt_device_to_host(ctx_, img.data(), rgb8.p, img.size()), "rt_device_to_host");
+        return img;
+    }
+    // The same with the exchange done here: this rank's tiles are rendered and tone-mapped on the communicator's stream, one RCCL
+    // gather moves every rank's tiles into the root's frame in device memory (each tile straight into its place), and the root
+    // returns the H x W RGB8 image -- the bytes render_rgb8 gives on one GPU.  Other ranks return an empty vector.  Collective.
+    std::vector<unsigned char> render_gather_rgb8(const RenderSettings &s, TileComm &comm, int root = 0, int tile_rows = RT_MULTI_TILE_ROWS) {
+        rt_params p = params(s);
+        const int rank = comm.rank(), world = comm.world();
+        const int n = (int)tile_rows_of(s.H, rank, world, tile_rows).size();
+        DeviceBuffer rgba(ctx_, (size_t)std::max(n, 1) * s.W * 16), rgb8(ctx_, (size_t)std::max(n, 1) * s.W * 3 + 16);
+        std::unique_ptr<DeviceBuffer> frame;
+        if (rank == root) frame = std::make_unique<DeviceBuffer>(ctx_, (size_t)s.H * s.W * 3 + 16);
+        if (n > 0) {
+            rt_rows rows{rank * tile_rows, n, tile_rows, world};
+            check(rt_render_device(ctx_, &p, &rows, rgba.p, comm.stream()), "rt_render_device");
+            check(rt_tonemap_device(ctx_, rgba.p, (int64_t)n * s.W, rgb8.p, comm.stream()), "rt_tonemap_device");
+        }
+        comm.gather_tiles(rgb8.p, s.W, s.H, 3, frame ? frame->p : nullptr, root, tile_rows);
+        comm.sync();
+        std::vector<unsigned char> img;
+        if (rank == root) {
+            img.resize((size_t)s.H * s.W * 3);
+            check(rt_device_to_host(ctx_, img.data(), frame->p, img.size()), "rt_device_to_host");
+        }
         return img;
     }
     static void assemble_tiles(std::vector<unsigned char> &frame, const std::vector<unsigned char> &tiles, int W, int H, int rank, int world,

@@ -8,6 +8,9 @@
 //   --devices 0,1,2,...          several GPUs from this one process (interleaved row tiles, rt_render_multi_rgb8)
 //   --tile-rank R --tile-world G --tiles FILE   one process per GPU: render only rank R's interleaved 8-row tiles and write
 //                                them (raw RGB8) to FILE; the processes' exchange is the caller's (RCCL / MPI / files)
+//   --tile-rank R --tile-world G --rccl-id FILE   one process per GPU with the exchange done here: rank 0 writes a fresh RCCL
+//                                communicator id to FILE (the others wait for it), every rank renders its tiles on --device and
+//                                one RCCL gather over xGMI puts them into rank 0's frame; rank 0 writes the PNG
 //   --assemble F0,F1,...         put the tile files of ranks 0..G-1 together and write the PNG (no GPU needed)
 #include <algorithm>
 #include <chrono>
@@ -16,6 +19,7 @@
 #include <iostream>
 #include <sstream>
 #include <string>
+#include <thread>
 
 #include "../../../include/raytracer.hpp"
 
@@ -32,7 +36,7 @@ int main(int argc, char *argv[]) {
     int W = 512, H = 512, device = 0, variant = RT_VARIANT_AUTO;
     std::vector<int> devices;
     int tile_rank = -1, tile_world = 0;
-    std::string tiles_file;
+    std::string tiles_file, rccl_id_file;
     std::vector<std::string> assemble;
     for (int i = 3; i + 1 < argc; i += 2) {
         const std::string k = argv[i], v = argv[i + 1];
@@ -47,6 +51,7 @@ int main(int argc, char *argv[]) {
         else if (k == "--tile-rank") tile_rank = atoi(v.c_str());
         else if (k == "--tile-world") tile_world = atoi(v.c_str());
         else if (k == "--tiles") tiles_file = v;
+        else if (k == "--rccl-id") rccl_id_file = v;
         else if (k == "--assemble") { std::stringstream ss(v); std::string tok; while (std::getline(ss, tok, ',')) assemble.push_back(tok); }
         else if (k == "--devices") { std::stringstream ss(v); std::string tok; while (std::getline(ss, tok, ',')) devices.push_back(atoi(tok.c_str())); }
         else { std::cerr << "unknown option " << k << "\n"; return 2; }
@@ -66,7 +71,7 @@ int main(int argc, char *argv[]) {
         if (!write_png(out.c_str(), W, H, frame.data())) { std::cerr << "cannot write " << out << "\n"; return 1; }
         return 0;
     }
-    if (tile_rank >= 0 && (tile_world < 1 || tile_rank >= tile_world || tiles_file.empty())) { std::cerr << "--tile-rank needs --tile-world and --tiles\n"; return 2; }
+    if (tile_rank >= 0 && (tile_world < 1 || tile_rank >= tile_world || (tiles_file.empty() && rccl_id_file.empty()))) { std::cerr << "--tile-rank needs --tile-world and --tiles or --rccl-id\n"; return 2; }
 
     try {
         Scene s;
@@ -105,6 +110,31 @@ int main(int argc, char *argv[]) {
             std::chrono::duration<float> run_time = std::chrono::system_clock::now() - start_time;
             std::cout << "Rendering time: " << run_time.count() << " s\n";
             std::cerr << st.n_devices << " devices, frame " << st.frame_ms << " ms, gather " << st.gather_ms << " ms (" << st.gather_bytes << " bytes), " << st.rays << " rays\n";
+            return 0;
+        }
+        if (tile_rank >= 0 && !rccl_id_file.empty()) {                // one process per GPU, tiles gathered over RCCL into rank 0
+            std::vector<unsigned char> id;
+            if (tile_rank == 0) {                                      // the id reaches the other ranks through a file, written whole before it gets its name
+                id = TileComm::make_id();
+                const std::string tmp = rccl_id_file + ".tmp";
+                { std::ofstream f(tmp, std::ios::binary); f.write(reinterpret_cast<const char *>(id.data()), (std::streamsize)id.size()); if (!f) { std::cerr << "cannot write " << tmp << "\n"; return 1; } }
+                if (std::rename(tmp.c_str(), rccl_id_file.c_str()) != 0) { std::cerr << "cannot rename " << tmp << "\n"; return 1; }
+            } else {
+                for (int tries = 0; tries < 1200 && id.size() != RT_COMM_ID_BYTES; ++tries) {   // up to two minutes
+                    std::ifstream f(rccl_id_file, std::ios::binary);
+                    if (f) id.assign((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+                    if (id.size() != RT_COMM_ID_BYTES) { id.clear(); std::this_thread::sleep_for(std::chrono::milliseconds(100)); }
+                }
+                if (id.size() != RT_COMM_ID_BYTES) { std::cerr << "no communicator id in " << rccl_id_file << "\n"; return 1; }
+            }
+            Renderer renderer(device);
+            renderer.upload(s);
+            TileComm comm(device, tile_rank, tile_world, id);
+            image = renderer.render_gather_rgb8(rs, comm);
+            if (tile_rank == 0 && !write_png(out.c_str(), W, H, image.data())) { std::cerr << "cannot write " << out << "\n"; return 1; }
+            std::chrono::duration<float> run_time = std::chrono::system_clock::now() - start_time;
+            std::cout << "Rendering time: " << run_time.count() << " s\n";
+            std::cerr << "rank " << tile_rank << " of " << tile_world << ": " << comm.last_bytes() << " bytes over RCCL\n";
             return 0;
         }
         if (tile_rank >= 0) {                                         // one process per GPU: this rank's tiles only
