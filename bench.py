@@ -45,6 +45,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--prewarm-ms", type=float, default=150.0,
+                    help="untimed frames of the same workload rendered before the W warm-up steps, worth about this much GPU time: after idling the "
+                         "device needs 20-40 ms of load to reach its sustained clock (tools/frame_ramp.py: the first 20 frames after an idle "
+                         "period run 1.13 -> 1.01 ms); 0 = none")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=1)
@@ -64,7 +68,9 @@ def parse():
     ap.add_argument("--renderer", default="hip", choices=["hip", "oracle"],
                     help="TEST: 'oracle' renders every rank's tiles with the CPU restatement over gloo (launcher / partition / gather plumbing without a GPU); its line carries value = null")
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="whole frames kept in flight, one context each (0 = auto: 1 on one GPU, 2 when the frame is shared by several ranks)")
+                    help="whole frames kept in flight (0 = auto).  One GPU: 2 = frames alternate between two device buffers on ONE context and "
+                         "stream with rt_ctx_set_pipelining (frame k+1's sub-frames follow frame k's directly; default), 1 = every frame joined before "
+                         "the next starts.  Several ranks: one context per frame in flight (default 2 for small shares, else 1)")
     ap.add_argument("--dump-frame", default="", help="rank 0 saves the (gathered) float4 frame of the first step as .npy (tests)")
     ap.add_argument("--check-frame", action="store_true", help="rank 0 renders the whole frame alone as well and reports whether the gathered frame equals it bit for bit")
     return ap.parse_args()
@@ -436,14 +442,23 @@ def main():
 
     class Point:
         """One timed workload: its parameters, this rank's tiles, and one Lane per frame in flight."""
-        def __init__(self, W, H):
+        def __init__(self, W, H, lanes=0):
             self.W, self.H = W, H
             self.p = rt.make_params(W, H, args.spp, args.bounces, variant=args.variant, **rt.scenes.CPU_LAUNCHER)
             self.rows, self.idx = rt.interleaved_rows(H, TILE_ROWS, rank, world)
-            want = args.frames_in_flight if args.frames_in_flight > 0 else (2 if (world > 1 and self.rows.n_rows * W <= SMALL_SHARE_PX) else 1)
+            want = lanes if lanes > 0 else args.frames_in_flight if args.frames_in_flight > 0 else (2 if (world == 1 or self.rows.n_rows * W <= SMALL_SHARE_PX) else 1)
             self.n_lanes = 1 if cpu_only else want
+            # one GPU renders the whole frame: the frames in flight share ONE context and stream (two buffers, rt_ctx_set_pipelining);
+            # a rank with a small share keeps one context per frame in flight
+            self.pipelined = (not cpu_only) and world == 1 and self.n_lanes > 1 and hasattr(pool("full", 1)[0][0], "set_pipelining")
             if not cpu_only:
-                self.ctxs, self.tstreams = pool("lanes", self.n_lanes) if self.n_lanes > 1 else pool("full", 1)
+                if world == 1:
+                    full = pool("full", 1)
+                    self.ctxs, self.tstreams = [full[0][0]] * self.n_lanes, [full[1][0]] * self.n_lanes
+                    if hasattr(full[0][0], "set_pipelining"):
+                        full[0][0].set_pipelining(self.pipelined)
+                else:
+                    self.ctxs, self.tstreams = pool("lanes", self.n_lanes) if self.n_lanes > 1 else pool("full", 1)
             self.lanes = [Lane(k, W, H) for k in range(self.n_lanes)]
             self.local = self.lanes[0].local
             self.frame = None
@@ -490,6 +505,10 @@ def main():
 
     def timed(pt, steps, warmup):
         """W warm-up steps, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
+        if not cpu_only and args.prewarm_ms > 0:                        # same count on every rank (the steps hold a collective)
+            est_ms = max(pt.W * pt.H / 2.0e6 / world, 0.2)
+            for _ in range(max(1, min(1000, int(args.prewarm_ms / est_ms)))):
+                pt.step()
         for _ in range(warmup):
             pt.step()
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)] if not cpu_only else []
@@ -544,6 +563,13 @@ def main():
                  "value": round(lrays / (lel / args.large_steps) / 1e6, 2), "unit": "Mrays/s", "rays_per_frame": lrays, "kernels_ms_max_over_ranks": round(lk, 4),
                  "frames_in_flight": lp.n_lanes}
         del lp
+    one_in_flight_ms = None
+    if world == 1 and not cpu_only and main_pt.n_lanes > 1:           # the same frames with every frame joined before the next one starts
+        p1 = Point(W, H, lanes=1)
+        e1, _ = timed(p1, args.steps, 2)
+        one_in_flight_ms = round(1e3 * e1 / args.steps, 4)
+        del p1
+        main_pt.ctxs[0].set_pipelining(False)
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -556,7 +582,10 @@ def main():
                "config": {"workload": workload, "scene": "cpu_launcher.cpp walls + cat.obj (3954 tris, 2019-node array BVH)",
                           "num_rays": args.spp, "num_bounce": args.bounces, "depth_convention": "cpu_launcher (b+1 segments)",
                           "rays_per_frame": rays_per_frame, "ranks": dist.get_world_size() if world > 1 else 1,
-                          "frames_in_flight": main_pt.n_lanes,
+                          "frames_in_flight": main_pt.n_lanes, "prewarm_ms": args.prewarm_ms,
+                          **({"frames_in_flight_is": "frames alternate between two device buffers on one context and one stream; each of frame k+1's two sub-frames "
+                                                     "follows the same sub-frame of frame k without a join in between (rt_ctx_set_pipelining); every frame is rendered in full",
+                              "ms_per_step_one_frame_in_flight": one_in_flight_ms} if one_in_flight_ms is not None else {}),
                           "tiling": f"{TILE_ROWS}-row tiles interleaved over {world} rank(s)"
                           + (f", one gather ({backend}) of the {'RGB8' if rgb8 else 'float4'} tiles to rank 0 per frame" if world > 1 else ""),
                           "variant": ctx.stats()["variant"] if ctx else None, "device": ctx.device_name if ctx else "cpu (oracle stand-in: not a measurement)",

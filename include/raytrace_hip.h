@@ -198,6 +198,18 @@ int rt_synchronize(rt_ctx *ctx);
 int rt_get_stats(rt_ctx *ctx, rt_stats *stats);        /* waits for the last render to finish */
 /* trav_ms / trav_launches are measured only on request (on != 0): production frames record no per-launch timing events */
 int rt_stats_enable(rt_ctx *ctx, int on);
+/* Frames in flight for a caller that renders frame after frame on ONE stream into ALTERNATING device buffers (rt_render_device,
+ * rt_render_pose_device).  A frame is rendered as two sub-frames on two internal streams; normally both are forked from the caller's
+ * stream when the call is made and joined back into it, so frame k+1 starts when ALL of frame k has finished and one internal stream
+ * idles at every frame boundary (~5 % of a 1080p frame).  With pipelining on, a frame whose output buffer does not overlap the previous
+ * frame's is ordered behind what was on the caller's stream when the PREVIOUS render call was made, and each of its sub-frames follows
+ * the same sub-frame of the previous frame directly.  What the caller gives up: work submitted to the stream BETWEEN two render calls
+ * is not waited for by the second call's kernels (work submitted before the first of the two is; consumers of a frame submitted after
+ * its call still see it complete, the join into the caller's stream stays).  So: alternate between two (or more) output buffers, and
+ * do not let anything the frame depends on -- a fill of its buffer, a wait for a reader on another stream -- be younger than the previous
+ * call.  Same stream, same size and parameters' layout, else the frame falls back to the full fork (results never change, only overlap).
+ * rt_render_async does this internally for its two slots (RT_ASYNC_PIPELINE=0 turns that off).  Off by default. */
+int rt_ctx_set_pipelining(rt_ctx *ctx, int on);
 
 /* --- pipelined frames for a host caller.  optimized.cu renders, synchronises and then copies (optimized.cu:849-856), so the
  *     33 MB of a 1080p float frame cross PCIe strictly after the kernels.  rt_render_async renders the whole frame into one of

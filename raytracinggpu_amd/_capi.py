@@ -25,7 +25,7 @@ EXPORTS = ["rt_abi_version", "rt_device_count", "rt_ctx_create", "rt_ctx_destroy
            "rt_progressive_frames",
            "rt_multi_create", "rt_multi_destroy", "rt_multi_last_error", "rt_multi_scene_upload", "rt_render_multi",
            "rt_render_multi_device", "rt_render_multi_rgb8", "rt_multi_get_stats",
-           "rt_stats_enable", "rt_render_async", "rt_wait", "rt_trace_rays", "rt_mesh_rebuild", "rt_host_alloc", "rt_host_free", "rt_device_alloc", "rt_device_free", "rt_device_to_host", "rt_kat_sphere", "rt_kat_box", "rt_kat_triangle", "rt_kat_mesh"]
+           "rt_stats_enable", "rt_ctx_set_pipelining", "rt_render_async", "rt_wait", "rt_trace_rays", "rt_mesh_rebuild", "rt_host_alloc", "rt_host_free", "rt_device_alloc", "rt_device_free", "rt_device_to_host", "rt_kat_sphere", "rt_kat_box", "rt_kat_triangle", "rt_kat_mesh"]
 MAX_DEVICES = 16
 
 
@@ -144,6 +144,7 @@ def load():
     L.rt_ctx_selfcheck.argtypes = [vp]
     L.rt_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.rt_stats_enable.argtypes = [vp, C.c_int]
+    L.rt_ctx_set_pipelining.argtypes = [vp, C.c_int]
     L.rt_render_async.argtypes = [vp, C.POINTER(Params), C.c_int, vp, C.c_int]
     L.rt_wait.argtypes = [vp, C.c_int]
     L.rt_trace_rays.argtypes = [vp, C.POINTER(C.c_float), C.c_int, C.c_float, C.c_int, C.POINTER(C.c_float)]
@@ -340,6 +341,10 @@ class Context:
     def stats_enable(self, on=True):
         """trav_ms / trav_launches of stats() are measured only while enabled (production frames record no per-launch events)."""
         self._check(self._L.rt_stats_enable(self._h, 1 if on else 0))
+
+    def set_pipelining(self, on=True):
+        """rt_ctx_set_pipelining: consecutive render_device calls on one stream into alternating buffers overlap at the frame boundary."""
+        self._check(self._L.rt_ctx_set_pipelining(self._h, 1 if on else 0))
 
     def tonemap_device(self, rgba_ptr, n_pixels, rgb8_ptr, stream=None):
         self._check(self._L.rt_tonemap_device(self._h, C.c_void_p(rgba_ptr), n_pixels, C.c_void_p(rgb8_ptr),

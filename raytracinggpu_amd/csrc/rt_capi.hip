@@ -59,6 +59,10 @@ struct Knobs {
                                // that holds SEVERAL contexts (rt_multi does this itself; bench.py with N > 1) should set it: with more streams than the runtime has
                                // hardware queues (four) two active streams may share one and a context's sub-frames then run one after the other (1/8 of
                                // 7680x4320: 2.7 instead of 2.0 ms).  Off by default: a lone context is 1 % faster with both sub-frames at equal priority.
+    int copy_prio = 1;         // RT_COPY_PRIO: the copy streams of rt_render_async in the low-priority class (1, default), the normal one (0) or the high one (-1).  The
+                               // runtime keeps a pool of hardware queues per class; in the normal class the copy stream can share a queue with one of the
+                               // sub-frame streams and the copy then waits behind kernels (pipelined float4 frames 1.72 instead of 1.19 ms)
+    int async_pipeline = 1;    // RT_ASYNC_PIPELINE=0: rt_render_async joins the sub-frames of frame k before frame k+1 starts (as rt_render_device does without rt_ctx_set_pipelining)
     int top_lds = 0;           // RT_TRAVQ_TOPLDS: nodes of the breadth-first top of the tree every ordinary (4-wave) workgroup of wf_travq stages in LDS
     int copy_split = 0;        // RT_COPY_SPLIT=1: rt_render_async sends the two halves of a big frame through two copy streams (measured SLOWER: 1.62 vs 1.48 ms per
                                // pipelined 1080p float4 frame -- one DMA already runs at the rate the PCIe link gives, two share it and add an event hop)
@@ -89,6 +93,8 @@ static Knobs read_knobs() {
     if (geti("RT_COPY_SPLIT", v)) k.copy_split = v != 0;
     if (geti("RT_PART_PRIO", v)) k.part_prio = v != 0;
     { const char *e = getenv("RT_CHUNK_MPX"); if (e && *e) { const double d = atof(e); if (d >= 0 && d < 1e4) k.chunk_mpx = d; } }
+    if (geti("RT_ASYNC_PIPELINE", v)) k.async_pipeline = v != 0;
+    if (geti("RT_COPY_PRIO", v)) k.copy_prio = v;
     if (geti("RT_TRAVQ_TOPLDS", v) && v >= 0 && v <= 1024) k.top_lds = v & ~1;
     if (geti("RT_PATH_SAMP_MB", v) && v >= 1) k.path_samp_bytes = (long long)v << 20;
 #ifdef RT_DEBUG
@@ -127,6 +133,21 @@ struct rt_ctx {
     hipStream_t part_stream[kMaxParts] = {};
     hipEvent_t part_ev[kMaxParts] = {};
     hipEvent_t fork_ev = nullptr;
+    // Chains on streams of their own (launch_render_chunk): consecutive chunks of one call -- and, with rt_ctx_set_pipelining, consecutive
+    // frames into different buffers -- follow each other per sub-frame without a join in between.
+    struct Pipe {
+        bool on = false;                   // rt_ctx_set_pipelining: frames of consecutive calls may overlap
+        hipEvent_t fork2[2] = {};          // the caller's stream at the start of this call / of the previous one
+        int cur = 0;
+        bool valid = false, prev_valid = false;   // the call before this one ended with its chains on their own streams (joined into `stream`)
+        int open_parts = 0;                // chains of an earlier chunk of THIS call that have not been joined into the caller's stream
+        hipStream_t stream = nullptr;      // ... and was issued on this stream,
+        uint64_t sig = 0;                  // ... with this state layout (sub-frames, sizes, offsets) in its last chunk,
+        const uint8_t *out_lo = nullptr, *out_hi = nullptr;   // ... into this output range
+        int call_chunk = 0, call_chunks = 1;                  // position of the chunk being issued in its call (launch_render)
+        const uint8_t *call_lo = nullptr, *call_hi = nullptr; // output range of the call being issued
+        hipEvent_t extra_wait = nullptr;   // this call's chains also wait for this event (rt_render_async: the slot's previous copy)
+    } pipe;
     bool trav_attr_set = false;
     bool stats_on = false;                                          // rt_stats_enable: bracket the traversal launches with timing events (production frames record none)
     static constexpr int kSlots = 2;                                // rt_render_async: double-buffered device frames, one copy stream
@@ -343,8 +364,8 @@ void wf_geometry(const Knobs &kn, int n_cus, int bpc, int parts, int wpb, bool o
 // maps a process's streams onto a handful of hardware queues (four by default); with three contexts' worth of idle streams in one process
 // the two ACTIVE streams of a context could land on the same queue and its sub-frames ran one after the other (a 1/8 share of
 // 7680x4320 took 2.7 instead of 2.0 ms next to two other contexts).
-int need_part_streams(rt_ctx *ctx, int parts) {
-    for (int j = 1; j < parts && j < rt_ctx::kMaxParts; ++j) {
+int need_part_streams(rt_ctx *ctx, int parts, bool chain0 = false) {
+    for (int j = chain0 ? 0 : 1; j < parts && j < rt_ctx::kMaxParts; ++j) {
         if (!ctx->part_stream[j]) {
             // the second sub-frame's stream in the HIGH-priority class: the runtime keeps a separate pool of hardware queues per priority, so
             // this stream can never be mapped onto the queue of the caller's (normal-priority) stream, whatever else the process has created
@@ -358,8 +379,11 @@ int need_part_streams(rt_ctx *ctx, int parts) {
     return RT_OK;
 }
 int need_copy_streams(rt_ctx *ctx, bool second) {
-    if (!ctx->copy_stream) RT_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-    if (second && !ctx->copy_stream2) RT_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream2, hipStreamNonBlocking));
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    const int pr = ctx->knobs.copy_prio > 0 ? lo : ctx->knobs.copy_prio < 0 ? hi : 0;   // RT_COPY_PRIO: 1 = the low-priority class' queue pool, -1 = the high one
+    if (!ctx->copy_stream) RT_HIP(ctx, hipStreamCreateWithPriority(&ctx->copy_stream, hipStreamNonBlocking, pr));
+    if (second && !ctx->copy_stream2) RT_HIP(ctx, hipStreamCreateWithPriority(&ctx->copy_stream2, hipStreamNonBlocking, pr));
     return RT_OK;
 }
 
@@ -655,7 +679,8 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
             (rc2 = ensure(ctx, ctx->wfSID, np * (size_t)nseg)) != RT_OK || (rc2 = ensure(ctx, ctx->wfLS, np * 4 * (size_t)nseg)) != RT_OK)
             return rc2;
         size_t q_slots = 0;                                           // traversal-queue slots of all parts (padding included)
-        uint64_t q_sig = 0xcbf29ce484222325ull;
+        uint64_t q_sig = 0xcbf29ce484222325ull, layout_sig = 0;
+        bool own0 = false, rejoin = false, zeroed = false;
         {
             for (Part &pt : pv) {
                 pt.qbase = q_slots;
@@ -663,11 +688,24 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
                 for (uint64_t v : {(uint64_t)pt.st.n_paths, (uint64_t)pt.st.log2S, (uint64_t)pt.st.Q, (uint64_t)pt.st.slots_per_block, (uint64_t)pt.tblocks})
                     q_sig = (q_sig ^ v) * 0x100000001b3ull;
             }
+            // chains on their own streams: a chunk whose state layout differs from the previous chunk's must not start while that one's
+            // chains are running (its sub-frames' state would overlap theirs), and neither may the queue's zero fill below
+            own0 = (ctx->pipe.on || ctx->pipe.call_chunks > 1) && parts > 1 && !work_dev && kn.debug_trav == -2;
+            layout_sig = q_sig;
+            for (const Part &pt : pv) for (uint64_t v : {(uint64_t)pt.base, (uint64_t)pt.pxbase, (uint64_t)pt.st.n_px, (uint64_t)fr.spp, (uint64_t)nseg}) layout_sig = (layout_sig ^ v) * 0x100000001b3ull;
+            if (ctx->pipe.open_parts > 0 && (!own0 || ctx->pipe.sig != layout_sig)) {
+                for (int j = 0; j < ctx->pipe.open_parts; ++j) RT_HIP(ctx, hipStreamWaitEvent(stream, ctx->part_ev[j], 0));   // join the previous chunk (its chains recorded part_ev)
+                ctx->pipe.open_parts = 0;
+                rejoin = true;
+            }
+            {
             const size_t had = ctx->wfQR.bytes;
             if ((rc2 = ensure(ctx, ctx->wfQR, q_slots * 32)) != RT_OK) return rc2;
             if (ctx->wfQR.bytes != had || ctx->qf_sig != q_sig) {         // padding slots are never written by the kernels: zero once per layout
                 RT_HIP(ctx, hipMemsetAsync(ctx->wfQR.p, 0, ctx->wfQR.bytes, stream));
                 ctx->qf_sig = q_sig;
+                zeroed = true;
+            }
             }
         }
         for (Part &pt : pv) {
@@ -684,14 +722,39 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
         ctx->stats.block_threads = tb;
         ctx->stats.grid_blocks = (int)pv[0].tblocks;
         ctx->stats.parts = parts;
-        if (int rs = need_part_streams(ctx, parts); rs != RT_OK) return rs;
+        if (int rs = need_part_streams(ctx, parts, own0); rs != RT_OK) return rs;
         if (rec_begin) RT_HIP(ctx, hipEventRecord(ctx->ev_k0, stream));
-        if (parts > 1) RT_HIP(ctx, hipEventRecord(ctx->fork_ev, stream));
+        // Where the chains start.  Chain 0 on the caller's stream, the others forked from it and joined back at the end (one chunk, no
+        // pipelining); or every chain on a stream of its own (own0): forked once per CALL, joined once per call, chunk after chunk
+        // following per sub-frame without a join -- a sub-frame's next chunk re-uses exactly its own state -- unless the layout changes.
+        // With rt_ctx_set_pipelining the same holds across calls: a frame into a buffer the previous frame did not use starts behind
+        // what was on the caller's stream when the PREVIOUS call was made (everything that could read or write this frame's buffer is
+        // older than that), so its sub-frames follow the previous frame's sub-frames one by one and no stream idles at a frame boundary.
+        rt_ctx::Pipe &pl = ctx->pipe;
+        hipEvent_t start_ev = ctx->fork_ev;
+        bool fork = parts > 1;
+        if (own0) {
+            if (!pl.fork2[0]) { RT_HIP(ctx, hipEventCreateWithFlags(&pl.fork2[0], hipEventDisableTiming)); RT_HIP(ctx, hipEventCreateWithFlags(&pl.fork2[1], hipEventDisableTiming)); }
+            if (pl.call_chunk == 0) {
+                const bool disjoint = pl.call_hi <= pl.out_lo || pl.out_hi <= pl.call_lo;
+                const bool relaxed = pl.on && pl.prev_valid && pl.stream == stream && pl.sig == layout_sig && disjoint && !zeroed;
+                pl.cur ^= 1;
+                RT_HIP(ctx, hipEventRecord(pl.fork2[pl.cur], stream));
+                start_ev = pl.fork2[relaxed ? pl.cur ^ 1 : pl.cur];
+            } else if (rejoin || zeroed || pl.open_parts == 0) {
+                RT_HIP(ctx, hipEventRecord(ctx->fork_ev, stream));
+            } else {
+                fork = false;                                            // the chains go on where the previous chunk left them
+            }
+        } else if (fork) {
+            RT_HIP(ctx, hipEventRecord(ctx->fork_ev, stream));
+        }
         for (int j = 0; j < parts; ++j) {
             Part &pt = pv[j];
-            hipStream_t q = j == 0 ? stream : ctx->part_stream[j];
-            if (j > 0) RT_HIP(ctx, hipStreamWaitEvent(q, ctx->fork_ev, 0));
-            if (pt.st.n_paths == 0) continue;
+            hipStream_t q = (j == 0 && !own0) ? stream : ctx->part_stream[j];
+            if (fork && (j > 0 || own0)) RT_HIP(ctx, hipStreamWaitEvent(q, start_ev, 0));
+            if (own0 && pl.call_chunk == 0 && pl.extra_wait) RT_HIP(ctx, hipStreamWaitEvent(q, pl.extra_wait, 0));
+            if (pt.st.n_paths == 0) { if (own0) RT_HIP(ctx, hipEventRecord(ctx->part_ev[j], q)); continue; }
             for (int s = 0; s < fr.spp; s += chunk) {
                 pt.st.samp0 = s;
                 if (work_dev) hipLaunchKernelGGL((rtk::wf_advance<true, true>), dim3(pt.pblocks), dim3(256), 0, q, scn, pt.fr, pt.st);
@@ -723,9 +786,19 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
                     hipLaunchKernelGGL(rtk::path_reduce, dim3((unsigned)((pt.st.n_px + 255) / 256)), dim3(256), 0, q, pt.fr, pt.st.n_px, tiles_x, std::min(chunk, fr.spp - s),
                                        static_cast<const float4 *>(pt.st.samp_out), static_cast<float4 *>(ctx->wfT.p) + pt.pxbase, s == 0 ? 1 : 0, s + chunk >= fr.spp ? 1 : 0);
             }
-            if (j > 0) { RT_HIP(ctx, hipEventRecord(ctx->part_ev[j], q)); }
+            if (j > 0 || own0) { RT_HIP(ctx, hipEventRecord(ctx->part_ev[j], q)); }
         }
-        for (int j = 1; j < parts; ++j) RT_HIP(ctx, hipStreamWaitEvent(stream, ctx->part_ev[j], 0));
+        if (!own0) {
+            for (int j = 1; j < parts; ++j) RT_HIP(ctx, hipStreamWaitEvent(stream, ctx->part_ev[j], 0));
+        } else {
+            pl.sig = layout_sig;
+            pl.open_parts = parts;
+            if (pl.call_chunk + 1 >= pl.call_chunks) {                   // the call's last chunk: its result is complete behind this join
+                for (int j = 0; j < parts; ++j) RT_HIP(ctx, hipStreamWaitEvent(stream, ctx->part_ev[j], 0));
+                pl.open_parts = 0;
+                pl.valid = true; pl.stream = stream; pl.out_lo = pl.call_lo; pl.out_hi = pl.call_hi;
+            }
+        }
 #ifdef RT_DEBUG
         if (dbg_env) {       // tools/dbg_travq.py: per-wave records of one traversal launch
             std::vector<unsigned long long> h(10 * (size_t)65536);
@@ -791,8 +864,14 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
     // smaller launches than the cache gives back: wavefront_lds 7.9 -> 9.1 ms at 3840x2160)
     const bool wf = v == RT_VARIANT_AUTO || v == RT_VARIANT_WAVEFRONT_QUEUE || v == RT_VARIANT_LDS_VERTS || v == RT_VARIANT_LDS_TOP || v == RT_VARIANT_LDS_ALL;
     const int64_t chunk_px = (int64_t)(ctx->knobs.chunk_mpx * 1e6);
-    if (!p || !rows || !wf || chunk_px <= 0 || p->width <= 0 || rows->tile_rows <= 0 || (int64_t)rows->n_rows * p->width <= chunk_px * 5 / 4)
+    rt_ctx::Pipe &pl = ctx->pipe;
+    pl.prev_valid = pl.valid; pl.valid = false;                          // every asynchronous user of the path state comes through here
+    pl.call_chunk = 0; pl.call_chunks = 1; pl.open_parts = 0;
+    pl.call_lo = static_cast<const uint8_t *>(out_dev);
+    pl.call_hi = pl.call_lo + ((p && rows && p->width > 0 && rows->n_rows > 0) ? (size_t)rows->n_rows * p->width * sizeof(float4) : 0);
+    if (!p || !rows || !wf || chunk_px <= 0 || p->width <= 0 || rows->tile_rows <= 0 || (int64_t)rows->n_rows * p->width <= chunk_px * 5 / 4) {
         return launch_render_chunk(ctx, p, rows, out_dev, stream, work_dev, pose, true, true);
+    }
     // rows per chunk: whole tiles (and whole 8-row wave tiles for contiguous rows), two sub-frames' worth at least
     int unit = rows->tile_step == 1 ? 16 : rows->tile_rows * 2;
     if (unit % rows->tile_rows != 0) unit *= rows->tile_rows;
@@ -800,15 +879,21 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
     int per = (int)(((int64_t)rows->n_rows + n_chunks - 1) / n_chunks);
     per = (per + unit - 1) / unit * unit;
     uint64_t pixels = 0;
-    for (int a = 0; a < rows->n_rows; a += per) {
+    pl.call_chunks = (rows->n_rows + per - 1) / per;
+    for (int a = 0; a < rows->n_rows; a += per, ++pl.call_chunk) {
         const int nr = std::min(per, rows->n_rows - a);
         rt_rows rc{rows->row0 + (a / rows->tile_rows) * rows->tile_rows * rows->tile_step, nr, rows->tile_rows, rows->tile_step};
         if (rows->tile_step == 1) { rc.row0 = rows->row0 + a; rc.tile_rows = nr; }      // contiguous rows: one tile of any height describes them
         const int r = launch_render_chunk(ctx, p, &rc, static_cast<uint8_t *>(out_dev) + (size_t)a * p->width * sizeof(float4), stream, work_dev, pose,
                                           a == 0, a + per >= rows->n_rows);
-        if (r != RT_OK) return r;
+        if (r != RT_OK) {                                                 // chains of earlier chunks may be running on their own streams: wait for them
+            for (hipStream_t q : ctx->part_stream) if (q) (void)hipStreamSynchronize(q);
+            pl.valid = false; pl.call_chunk = 0; pl.call_chunks = 1; pl.open_parts = 0;
+            return r;
+        }
         pixels += ctx->stats.pixels;
     }
+    pl.call_chunk = 0; pl.call_chunks = 1;
     ctx->stats.pixels = pixels;
     return RT_OK;
 }
@@ -1064,6 +1149,7 @@ int rt_ctx_destroy(rt_ctx *ctx) {
     for (hipEvent_t &e : ctx->part_ev) if (e) (void)hipEventDestroy(e);
     for (hipStream_t &q : ctx->part_stream) if (q) (void)hipStreamDestroy(q);
     if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
+    for (hipEvent_t &e : ctx->pipe.fork2) if (e) (void)hipEventDestroy(e);
     if (ctx->ev_k0) (void)hipEventDestroy(ctx->ev_k0);
     if (ctx->ev_k1) (void)hipEventDestroy(ctx->ev_k1);
     if (ctx->ev_t0) (void)hipEventDestroy(ctx->ev_t0);
@@ -1126,6 +1212,13 @@ int rt_render(rt_ctx *ctx, const rt_params *p, int row_begin, int row_end, float
     return RT_OK;
 }
 
+int rt_ctx_set_pipelining(rt_ctx *ctx, int on) {
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    ctx->pipe.on = on != 0;
+    ctx->pipe.valid = false;
+    return RT_OK;
+}
+
 int rt_stats_enable(rt_ctx *ctx, int on) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
     ctx->stats_on = on != 0;
@@ -1146,7 +1239,15 @@ int rt_render_async(rt_ctx *ctx, const rt_params *p, int slot, void *out_host, i
     // the slot's previous frame may still be on its way to the host: the kernels that overwrite its device buffer wait for that copy
     if (ctx->slot_pending[slot]) RT_HIP(ctx, hipStreamWaitEvent(own_stream(ctx), ctx->slot_done[slot], 0));
     rt_rows rows{0, p->height, p->height, 1};
-    if ((rc = launch_render(ctx, p, &rows, ctx->slot_rgba[slot].p, own_stream(ctx))) != RT_OK) return rc;
+    // frames alternate between the two slots: with the sub-frames' chains on their own streams frame k+1 follows frame k chain by chain
+    // (launch_render_chunk); what its kernels must not overtake -- the slot's previous copy -- is handed to the chains directly
+    const bool pipe_was = ctx->pipe.on;
+    ctx->pipe.on = ctx->knobs.async_pipeline != 0;
+    ctx->pipe.extra_wait = ctx->slot_pending[slot] ? ctx->slot_done[slot] : nullptr;
+    rc = launch_render(ctx, p, &rows, ctx->slot_rgba[slot].p, own_stream(ctx));
+    ctx->pipe.on = pipe_was;
+    ctx->pipe.extra_wait = nullptr;
+    if (rc != RT_OK) return rc;
     if (rgb8 && (rc = launch_tonemap(ctx, ctx->slot_rgba[slot].p, npix, ctx->slot_rgb8[slot].p, own_stream(ctx))) != RT_OK) return rc;
     RT_HIP(ctx, hipEventRecord(ctx->slot_rendered[slot], own_stream(ctx)));
     if ((rc = need_copy_streams(ctx, ctx->knobs.copy_split != 0)) != RT_OK) return rc;

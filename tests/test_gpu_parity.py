@@ -640,3 +640,38 @@ def test_smooth_normals(ctx, oracle, cat_golden):
     upload(ctx, "cpu", cat_golden)
     again = ctx.render(rt.make_params(W, H, 1, 0, **rt.scenes.CPU_LAUNCHER))
     np.testing.assert_array_equal(again.view(np.uint32), flat.view(np.uint32))
+
+
+def test_pipelined_frames_on_one_context_equal_lone_frames(ctx, cat_golden):
+    """rt_ctx_set_pipelining: frames rendered back to back on one stream into two (and three) alternating buffers, each sub-frame
+    following the previous frame's directly, with a consumer of every frame (the tone mapping) on the same stream in between -- every
+    frame and every 8-bit image bit for bit what a lone frame gives; one buffer only falls back to the joined form; a chunked frame
+    (RT_CHUNK_MPX far below the frame) runs its chunks the same way."""
+    import torch
+    upload(ctx, "cpu", cat_golden)
+    W, H = 640, 360
+    st = torch.cuda.Stream()
+    rows, _ = rt.interleaved_rows(H, 8, 0, 1)
+    ps = [rt.make_params(W, H, 1, 3, **rt.scenes.CPU_LAUNCHER), rt.make_params(W, H, 2, 1, **rt.scenes.CPU_LAUNCHER)]
+    refs = [ctx.render(p) for p in ps]
+    refs8 = [ctx.render_rgb8(p) for p in ps]
+    try:
+        ctx.set_pipelining(True)
+        for n_buf in (2, 3, 1):
+            bufs = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0") for _ in range(n_buf)]
+            img = [torch.zeros((H * W * 3 + 16,), dtype=torch.uint8, device="cuda:0") for _ in range(7)]
+            torch.cuda.synchronize()
+            which = []
+            for k in range(7):                                   # parameters change on the way (another layout: full fork for that frame)
+                w = 1 if k in (3, 4) else 0
+                which.append(w)
+                ctx.render_device(ps[w], rows, bufs[k % n_buf].data_ptr(), st.cuda_stream)
+                ctx.tonemap_device(bufs[k % n_buf].data_ptr(), H * W, img[k].data_ptr(), st.cuda_stream)
+            torch.cuda.synchronize()
+            for k in range(7):
+                np.testing.assert_array_equal(img[k][:H * W * 3].cpu().numpy().reshape(H, W, 3), refs8[which[k]], err_msg=f"{n_buf} buffers, frame {k}")
+            for k in range(7 - n_buf, 7):
+                np.testing.assert_array_equal(bufs[k % n_buf].cpu().numpy().view(np.uint32), refs[which[k]].view(np.uint32))
+    finally:
+        ctx.set_pipelining(False)
+    ctx.selfcheck()
