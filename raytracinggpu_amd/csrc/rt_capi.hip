@@ -1133,6 +1133,7 @@ int rt_ctx_destroy(rt_ctx *ctx) {
     if (!ctx) return RT_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream_) (void)hipStreamSynchronize(ctx->stream_);
+    for (hipStream_t q : ctx->part_stream) if (q) (void)hipStreamSynchronize(q);   // sub-frame chains of frames issued on a caller's stream
     if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
     if (ctx->copy_stream2) { (void)hipStreamSynchronize(ctx->copy_stream2); (void)hipStreamDestroy(ctx->copy_stream2); }
     for (int k = 0; k < rt_ctx::kSlots; ++k) if (ctx->slot_half[k]) (void)hipEventDestroy(ctx->slot_half[k]);
