@@ -44,3 +44,17 @@ for f in frames:
         run = sorted(e[2] for e in f if e[0] <= a and e[1] >= b)
         tot["+".join(run) or "idle"] += (b - a) / 1e3 / len(frames)
 print("mean over frames:", {k: round(v, 1) for k, v in sorted(tot.items(), key=lambda x: -x[1])})
+
+# the whole trace between its 20 % and 80 % points in time (frames in flight overlap: there are no gaps to split frames at)
+lo = ev[0][0] + (ev[-1][1] - ev[0][0]) // 5
+hi = ev[0][0] + (ev[-1][1] - ev[0][0]) * 4 // 5
+win = [e for e in ev if e[1] > lo and e[0] < hi]
+pts = sorted(set([max(e[0], lo) for e in win] + [min(e[1], hi) for e in win]))
+acc = collections.Counter()
+for a, b in zip(pts, pts[1:]):
+    run = sorted(e[2] for e in win if e[0] <= a and e[1] >= b)
+    acc["+".join(run) or "idle"] += (b - a)
+tot = float(hi - lo)
+print("steady window (%.1f ms): share of time by what runs: %s" % (tot / 1e6, {k: round(v / tot, 3) for k, v in sorted(acc.items(), key=lambda x: -x[1])}))
+nF = sum(1 for e in win if e[2] == "F")
+print("frames in the window (F launches / 2): %.1f -> %.4f ms per frame" % (nF / 2, tot / 1e6 / max(nF / 2, 1)))
