@@ -675,3 +675,14 @@ def test_pipelined_frames_on_one_context_equal_lone_frames(ctx, cat_golden):
     finally:
         ctx.set_pipelining(False)
     ctx.selfcheck()
+
+
+def test_pipelining_randomized_soak():
+    """tools/pipeline_stress.py: 250 frames of five sizes / parameter sets back to back with rt_ctx_set_pipelining, buffers rotating 1-3
+    deep, two streams, pipelining toggled and asynchronous host frames mixed in, a consumer behind every frame: all images exact."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "pipeline_stress.py"), "250", "7"], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and "differing 0" in r.stdout, r.stdout[-2000:]
