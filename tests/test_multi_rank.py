@@ -267,3 +267,11 @@ def test_multi_device_rgb8_gather_equals_single_device_png_bytes():
         assert st["peer_access"] == [-1] * world                          # all contexts on the one GPU of the test box
         m.close()
     one.close()
+
+
+def test_bench_capi_transport_has_no_cpu_leg():
+    """`--transport capi` is RCCL between GPUs through libraytrace_rccl.so: with the CPU stand-in renderer it stops with a message
+    instead of silently taking another transport."""
+    r, line = _bench("--gpus", "2", "--renderer", "oracle", "--transport", "capi", "--width", "64", "--height", "32", "--steps", "1", "--warmup", "0", "--large-steps", "0")
+    assert r.returncode != 0 and line is None
+    assert "no gloo / CPU leg" in (r.stderr + r.stdout)
