@@ -686,3 +686,44 @@ def test_pipelining_randomized_soak():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "pipeline_stress.py"), "250", "7"], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0 and "differing 0" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.parametrize("n", [161, 513])
+def test_large_mesh_bit_exact(ctx, oracle, n):
+    """Meshes well beyond the cat: a displaced grid of 160 x 160 (51 200 triangles) and 512 x 512 quads (524 288 triangles, ~260 000 BVH
+    nodes: 25 MB of triangle records and 8 MB of nodes, past the L1s and an XCD's L2; traversal stacks several times deeper).  Direct
+    lighting bit-exact against the oracle, equal work counters, bounce frame exact, through the default pipeline and the per-lane walk;
+    the device-built tree equals the host's."""
+    from raytracinggpu_amd import hostlib
+    rng = np.random.default_rng(11)
+    gx, gz = np.meshgrid(np.linspace(-18, 18, n), np.linspace(-14, 22, n), indexing="ij")
+    gy = -9.0 + 3.0 * np.sin(gx * 0.45) * np.cos(gz * 0.38) + 0.15 * rng.standard_normal((n, n))
+    v = np.stack([gx, gy, gz], -1).reshape(-1, 3).astype(np.float32)
+    i, j = np.meshgrid(np.arange(n - 1), np.arange(n - 1), indexing="ij")
+    a = (i * n + j).reshape(-1)
+    t = np.concatenate([np.stack([a, a + 1, a + n], 1), np.stack([a + 1, a + n + 1, a + n], 1)]).astype(np.int32)
+    assert len(t) == 2 * (n - 1) ** 2
+    om = oracle.Mesh.from_arrays(v, t).build_bvh()
+    osc = oracle.Scene.preset("cpu", om)
+    mesh = hostlib.build_mesh(v, t, albedo=rt.scenes.CAT_ALBEDO, object_slot=6)
+    ctx.scene_upload(rt.scenes.spheres("cpu"), mesh)
+    W, H = 384, 216
+    exp0, _, cnt0 = osc.render(W, H, 1, 0, want_rgb8=False)
+    for variant in ("auto", "wavefront"):
+        p0 = rt.make_params(W, H, 1, 0, variant=variant, **rt.scenes.CPU_LAUNCHER)
+        got = ctx.render(p0)
+        assert values_equal(got[..., :3], exp0[..., :3]).all(), variant
+        np.testing.assert_array_equal(got[..., 3], exp0[..., 3])
+        assert ctx.count_work(p0) == {k: cnt0[k] for k in ("rays", "box_tests", "nodes", "tri_tests")}, variant
+    exp2, _, _ = osc.render(W, H, 2, 3, want_rgb8=False)
+    got2 = ctx.render(rt.make_params(W, H, 2, 3, **rt.scenes.CPU_LAUNCHER))
+    assert values_equal(got2[..., :3], exp2[..., :3]).all()
+    np.testing.assert_array_equal(got2[..., 3], exp2[..., 3])
+    tris_up = np.asarray(mesh["indices"])[:, :3]                      # rt_mesh_rebuild: the same tree, built on the device from the uploaded order
+    arr, order = ctx.mesh_rebuild(len(tris_up))
+    again = hostlib.build_mesh(v, tris_up, albedo=rt.scenes.CAT_ALBEDO, object_slot=6)
+    np.testing.assert_array_equal(arr.view(np.uint32), np.ascontiguousarray(again["bvh_arr10"], np.float32).view(np.uint32))
+    assert sorted(order.tolist()) == list(range(len(tris_up)))
+    got3 = ctx.render(rt.make_params(W, H, 1, 0, **rt.scenes.CPU_LAUNCHER))
+    assert values_equal(got3[..., :3], exp0[..., :3]).all()
+    ctx.selfcheck()
