@@ -59,6 +59,8 @@ struct Knobs {
                                // that holds SEVERAL contexts (rt_multi does this itself; bench.py with N > 1) should set it: with more streams than the runtime has
                                // hardware queues (four) two active streams may share one and a context's sub-frames then run one after the other (1/8 of
                                // 7680x4320: 2.7 instead of 2.0 ms).  Off by default: a lone context is 1 % faster with both sub-frames at equal priority.
+    int adv_block = 64;        // RT_ADV_BLOCK: threads per workgroup of wf_advance (64 / 128 / 256).  One-wave workgroups slip into the wave slots the traversal
+                               // kernel of the other sub-frame frees one by one: 0.970 -> 0.957 ms per frame (128: 0.963; profiles/round3/ab_advance_block.log)
     int copy_prio = 1;         // RT_COPY_PRIO: the copy streams of rt_render_async in the low-priority class (1, default), the normal one (0) or the high one (-1).  The
                                // runtime keeps a pool of hardware queues per class; in the normal class the copy stream can share a queue with one of the
                                // sub-frame streams and the copy then waits behind kernels (pipelined float4 frames 1.72 instead of 1.19 ms)
@@ -95,6 +97,7 @@ static Knobs read_knobs() {
     { const char *e = getenv("RT_CHUNK_MPX"); if (e && *e) { const double d = atof(e); if (d >= 0 && d < 1e4) k.chunk_mpx = d; } }
     if (geti("RT_ASYNC_PIPELINE", v)) k.async_pipeline = v != 0;
     if (geti("RT_COPY_PRIO", v)) k.copy_prio = v;
+    if (geti("RT_ADV_BLOCK", v) && (v == 64 || v == 128 || v == 256)) k.adv_block = v;
     if (geti("RT_TRAVQ_TOPLDS", v) && v >= 0 && v <= 1024) k.top_lds = v & ~1;
     if (geti("RT_PATH_SAMP_MB", v) && v >= 1) k.path_samp_bytes = (long long)v << 20;
 #ifdef RT_DEBUG
@@ -671,7 +674,7 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
             int64_t tblocks = 0;
             wf_geometry(kn, ctx->n_cus, bpc, parts, wpb, queue && !qlds, pt.st, tblocks);
             pt.tblocks = tblocks;
-            pt.pblocks = (unsigned)((n_paths64 + 255) / 256);
+            pt.pblocks = (unsigned)((n_paths64 + kn.adv_block - 1) / kn.adv_block);
         }
         const size_t np = np_total;
         if ((rc2 = ensure(ctx, ctx->wfM, 2 * np * 8)) != RT_OK || (rc2 = ensure(ctx, ctx->wfPR, np * 16)) != RT_OK ||
@@ -759,8 +762,8 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
             if (pt.st.n_paths == 0) { if (own0) RT_HIP(ctx, hipEventRecord(ctx->part_ev[j], q)); continue; }
             for (int s = 0; s < fr.spp; s += chunk) {
                 pt.st.samp0 = s;
-                if (work_dev) hipLaunchKernelGGL((rtk::wf_advance<true, true>), dim3(pt.pblocks), dim3(256), 0, q, scn, pt.fr, pt.st);
-                else hipLaunchKernelGGL((rtk::wf_advance<false, true>), dim3(pt.pblocks), dim3(256), 0, q, scn, pt.fr, pt.st);
+                if (work_dev) hipLaunchKernelGGL((rtk::wf_advance<true, true>), dim3(pt.pblocks), dim3(kn.adv_block), 0, q, scn, pt.fr, pt.st);
+                else hipLaunchKernelGGL((rtk::wf_advance<false, true>), dim3(pt.pblocks), dim3(kn.adv_block), 0, q, scn, pt.fr, pt.st);
                 for (int it = 0; it < (segs > 0 ? segs + 1 : 0); ++it) {
                     if (have_mesh) {
 #ifdef RT_DEBUG
@@ -781,8 +784,8 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
                         if (timed) { RT_HIP(ctx, hipEventRecord(ctx->ev_trav[2 * it + 1], q)); ctx->n_trav_events = it + 1; }
                         pt.st.dbg = nullptr;
                     }
-                    if (work_dev) hipLaunchKernelGGL((rtk::wf_advance<true, false>), dim3(pt.pblocks), dim3(256), 0, q, scn, pt.fr, pt.st);
-                    else hipLaunchKernelGGL((rtk::wf_advance<false, false>), dim3(pt.pblocks), dim3(256), 0, q, scn, pt.fr, pt.st);
+                    if (work_dev) hipLaunchKernelGGL((rtk::wf_advance<true, false>), dim3(pt.pblocks), dim3(kn.adv_block), 0, q, scn, pt.fr, pt.st);
+                    else hipLaunchKernelGGL((rtk::wf_advance<false, false>), dim3(pt.pblocks), dim3(kn.adv_block), 0, q, scn, pt.fr, pt.st);
                 }
                 if (fr.spp > 1)                                       // the chain's samples, added in sample order (cpu:711), into the running sum / the frame
                     hipLaunchKernelGGL(rtk::path_reduce, dim3((unsigned)((pt.st.n_px + 255) / 256)), dim3(256), 0, q, pt.fr, pt.st.n_px, tiles_x, std::min(chunk, fr.spp - s),
