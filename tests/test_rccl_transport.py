@@ -144,8 +144,16 @@ def test_two_ranks_on_one_device_are_refused_not_hung(tmp_path):
     script = tmp_path / "two.py"
     script.write_text(_TWO_RANKS % {"root": ROOT})
     ps = [subprocess.Popen([sys.executable, str(script), str(r), str(tmp_path / "id")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
-    for p in ps:
-        out, _ = p.communicate(timeout=180)
+    outs = []
+    try:
+        for p in ps:
+            outs.append(p.communicate(timeout=180)[0])
+    finally:
+        for p in ps:                                                    # a rank that did hang must not outlive the test
+            if p.poll() is None:
+                p.kill()
+                p.communicate()
+    for out in outs:
         assert "REFUSED -3" in out, out
 
 
