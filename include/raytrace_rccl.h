@@ -12,8 +12,9 @@
  *                  rt_comm_gather_tiles(c, tiles_dev, W, H, bytes_per_pixel, tile_rows, 0, frame_dev_on_root, NULL);
  *                  rt_comm_sync(c);
  *
- * A tile is contiguous in the frame, so the root receives every peer tile straight into place (one grouped ncclSend / ncclRecv
- * per tile; no staging buffer, no de-interleave pass) and copies its own tiles device to device.  On MI355X's fully connected
+ * A tile is contiguous in the frame, so the root can receive every peer tile straight into place (one grouped ncclSend / ncclRecv
+ * per tile; no staging buffer, no de-interleave pass) and copy its own tiles device to device; small tiles travel coalesced instead,
+ * one message per peer plus one placement kernel (rt_comm_set_plan).  On MI355X's fully connected
  * xGMI every peer has its own link into the root, so the seven transfers run side by side (not a ring).
  * Kept out of libraytrace_hip.so so that the single-GPU path does not load librccl.
  *
@@ -30,9 +31,11 @@
 extern "C" {
 #endif
 
-#define RT_COMM_ABI_VERSION 1
+#define RT_COMM_ABI_VERSION 2
 #define RT_COMM_ID_BYTES 128     /* NCCL_UNIQUE_ID_BYTES */
 #define RT_COMM_MAX_TILES 8192   /* tiles of one frame (one send / receive each) */
+#define RT_COMM_MAX_WORLD 64     /* ranks of one communicator */
+#define RT_COMM_COALESCE_BELOW_DEFAULT (256u * 1024u)   /* AUTO plan: tiles smaller than this travel coalesced */
 
 typedef enum rt_comm_status {
     RT_COMM_OK = 0,
@@ -60,7 +63,7 @@ void *rt_comm_stream(const rt_comm *comm);
  * The gather (collective).  tiles_dev: this rank's dense tile buffer -- the rows of its tiles (tile t belongs to rank t % world;
  * rows [t * tile_rows, min(H, (t + 1) * tile_rows))) in tile order, bytes_per_pixel * W bytes per row (16 = the float4 frame,
  * 3 = the tone-mapped RGB8 image).  frame_dev: on `root` the H x W frame in its device memory; ignored elsewhere (may be NULL).
- * stream: a hipStream_t, or NULL for the communicator's own.  Asynchronous: rt_comm_sync waits for it.
+ * stream: a hipStream_t, or NULL for the communicator's own.  Asynchronous: rt_comm_sync waits for it (on whichever stream it went).
  */
 int rt_comm_gather_tiles(rt_comm *comm, const void *tiles_dev, int W, int H, int bytes_per_pixel, int tile_rows, int root,
                          void *frame_dev, void *stream);
@@ -74,9 +77,33 @@ typedef struct rt_comm_tile {
     uint64_t bytes;
 } rt_comm_tile;
 int rt_comm_tile_plan(int W, int H, int bytes_per_pixel, int tile_rows, int world, int t, rt_comm_tile *out);
+/*
+ * The exchange plan.  PER_TILE: one send / receive per tile, every tile received straight into its place in the frame (no staging, no
+ * second pass) -- right for big tiles (7680x4320 float4: 983 KB each).  COALESCED: every peer sends its whole dense buffer as ONE
+ * message into a staging area on the root, and one kernel on the root puts all tiles into place -- right for small ones (1920x1080
+ * RGB8 at world 8: 17 messages of 46 KB per peer become one of 783 KB).  AUTO (default) picks COALESCED when a full tile
+ * (W * bytes_per_pixel * tile_rows) is smaller than coalesce_below_bytes (0 = RT_COMM_COALESCE_BELOW_DEFAULT).  Every rank of a
+ * communicator must set the same plan and threshold: both sides of the exchange derive their message sizes from it.
+ */
+typedef enum rt_comm_plan { RT_COMM_PLAN_AUTO = 0, RT_COMM_PLAN_PER_TILE = 1, RT_COMM_PLAN_COALESCED = 2 } rt_comm_plan;
+int rt_comm_set_plan(rt_comm *comm, int plan, uint64_t coalesce_below_bytes);
+int rt_comm_last_plan(const rt_comm *comm);              /* the plan the last rt_comm_gather_tiles followed (PER_TILE for world 1) */
+/* what AUTO resolves to for a frame (host arithmetic) */
+int rt_comm_choose_plan(int plan, uint64_t coalesce_below_bytes, int W, int bytes_per_pixel, int tile_rows);
+/* The coalesced plan for rank `peer` (host arithmetic; tests replay the exchange with it and rt_comm_tile_plan): the one message it
+ * sends -- its whole dense buffer -- and where the root stages it.  The placement kernel then copies tile t from
+ * stage + stage_offset(owner) + tile_plan(t).local_offset (the root's own tiles from its own buffer) to tile_plan(t).frame_offset. */
+typedef struct rt_comm_peer {
+    uint64_t stage_offset;   /* bytes from the start of the root's staging area (256-byte aligned; 0 for the root itself) */
+    uint64_t bytes;          /* size of the rank's dense tile buffer = of its one message                                */
+    int32_t  n_tiles;        /* tiles it holds (0 when there are more ranks than tiles)                                  */
+    int32_t  reserved;
+} rt_comm_peer;
+int rt_comm_peer_plan(int W, int H, int bytes_per_pixel, int tile_rows, int world, int root, int peer, rt_comm_peer *out);
 /* bytes the last rt_comm_gather_tiles of this rank sent (peers) or received (root) over the fabric */
 uint64_t rt_comm_last_bytes(const rt_comm *comm);
-int rt_comm_sync(rt_comm *comm);                         /* hipStreamSynchronize of the communicator's stream */
+int rt_comm_sync(rt_comm *comm);                         /* waits for the last gather: hipStreamSynchronize of the stream it was issued on (the
+                                                            caller's, if one was passed) and of the communicator's own */
 
 #ifdef __cplusplus
 }

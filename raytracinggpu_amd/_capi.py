@@ -278,8 +278,10 @@ class Context:
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
-            self._L.rt_ctx_destroy(self._h)
+            self._L.rt_ctx_destroy(self._h)                           # synchronises the copy streams: no frame is in flight afterwards
             self._h = C.c_void_p()
+        if getattr(self, "_async_out", None):
+            self._async_out.clear()
 
     __del__ = close
 
@@ -324,10 +326,18 @@ class Context:
         wait(slot) returns when `out` holds the frame.  out: [H, W, 4] float32 or, rgb8, [H, W, 3] uint8 (PinnedArray: one DMA)."""
         want = (np.uint8, 3) if rgb8 else (np.float32, 4)
         assert out.dtype == want[0] and out.flags.c_contiguous and out.size == params.height * params.width * want[1]
+        # the copy stream writes into `out` until wait(slot): the context keeps the array (and through it a PinnedArray's block, which is
+        # freed when its last view goes) alive for exactly that long -- a caller may drop its own reference at once
+        if not hasattr(self, "_async_out"):
+            self._async_out = {}
+        self._async_out[int(slot)] = out
         self._check(self._L.rt_render_async(self._h, C.byref(params), int(slot), C.c_void_p(out.ctypes.data), 1 if rgb8 else 0))
 
     def wait(self, slot=0):
-        self._check(self._L.rt_wait(self._h, int(slot)))
+        try:
+            self._check(self._L.rt_wait(self._h, int(slot)))
+        finally:
+            getattr(self, "_async_out", {}).pop(int(slot), None)
 
     def trace_rays(self, rays, tri_tmin=1e-4, variant="auto"):
         """rt_trace_rays: rays [n, 6] (O, u) through the production traversal kernel of `variant` -> [n, 5] (hit, t, N)."""

@@ -11,11 +11,18 @@ ID_BYTES = 128
 
 # every symbol include/raytrace_rccl.h declares (tests check the .so exports each)
 EXPORTS = ["rt_comm_abi_version", "rt_comm_id_create", "rt_comm_create", "rt_comm_destroy", "rt_comm_last_error", "rt_comm_rank",
-           "rt_comm_world", "rt_comm_stream", "rt_comm_gather_tiles", "rt_comm_tile_plan", "rt_comm_last_bytes", "rt_comm_sync"]
+           "rt_comm_world", "rt_comm_stream", "rt_comm_gather_tiles", "rt_comm_tile_plan", "rt_comm_last_bytes", "rt_comm_sync",
+           "rt_comm_set_plan", "rt_comm_last_plan", "rt_comm_choose_plan", "rt_comm_peer_plan"]
+PLANS = {"auto": 0, "tile": 1, "coalesced": 2}
+COALESCE_BELOW_DEFAULT = 256 * 1024
 
 
 class Tile(C.Structure):
     _fields_ = [("owner", C.c_int32), ("rows", C.c_int32), ("local_offset", C.c_uint64), ("frame_offset", C.c_uint64), ("bytes", C.c_uint64)]
+
+
+class Peer(C.Structure):
+    _fields_ = [("stage_offset", C.c_uint64), ("bytes", C.c_uint64), ("n_tiles", C.c_int32), ("reserved", C.c_int32)]
 
 
 class CommError(RuntimeError):
@@ -53,6 +60,10 @@ def load():
     L.rt_comm_last_bytes.argtypes = [C.c_void_p]
     L.rt_comm_last_bytes.restype = C.c_uint64
     L.rt_comm_sync.argtypes = [C.c_void_p]
+    L.rt_comm_set_plan.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
+    L.rt_comm_last_plan.argtypes = [C.c_void_p]
+    L.rt_comm_choose_plan.argtypes = [C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int]
+    L.rt_comm_peer_plan.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Peer)]
     _lib = L
     return L
 
@@ -75,6 +86,22 @@ def tile_plan(W, H, bytes_per_pixel, tile_rows, world, t):
     if rc != 0:
         raise CommError(rc, L.rt_comm_last_error(None).decode())
     return out
+
+
+def peer_plan(W, H, bytes_per_pixel, tile_rows, world, root, peer):
+    """The coalesced plan for one rank: the single message it sends and where the root stages it (host arithmetic only)."""
+    L = load()
+    out = Peer()
+    rc = L.rt_comm_peer_plan(W, H, bytes_per_pixel, tile_rows, world, root, peer, C.byref(out))
+    if rc != 0:
+        raise CommError(rc, L.rt_comm_last_error(None).decode())
+    return out
+
+
+def choose_plan(plan, W, bytes_per_pixel, tile_rows, coalesce_below=0):
+    """What `plan` ("auto" | "tile" | "coalesced") resolves to for a frame: "tile" or "coalesced"."""
+    v = load().rt_comm_choose_plan(PLANS[plan], int(coalesce_below), W, bytes_per_pixel, tile_rows)
+    return {1: "tile", 2: "coalesced"}[v]
 
 
 class Comm:
@@ -103,6 +130,14 @@ class Comm:
 
     def sync(self):
         self._check(self._L.rt_comm_sync(self._h))
+
+    def set_plan(self, plan="auto", coalesce_below=0):
+        """Every rank of the communicator must set the same plan ("auto" | "tile" | "coalesced") and threshold."""
+        self._check(self._L.rt_comm_set_plan(self._h, PLANS[plan], int(coalesce_below)))
+
+    @property
+    def last_plan(self):
+        return {1: "tile", 2: "coalesced"}.get(self._L.rt_comm_last_plan(self._h))
 
     @property
     def last_bytes(self):

@@ -11,9 +11,16 @@
 //   --tile-rank R --tile-world G --rccl-id FILE   one process per GPU with the exchange done here: rank 0 writes a fresh RCCL
 //                                communicator id to FILE (the others wait for it), every rank renders its tiles on --device and
 //                                one RCCL gather over xGMI puts them into rank 0's frame; rank 0 writes the PNG
+//       [--rccl-nonce S]         what ties FILE to THIS launch (default: the parent process id; env RT_RCCL_NONCE): a file left by another
+//                                run is never accepted; rank 0 removes FILE before it writes and after the communicator is up
+//       [--rccl-timeout SEC]     give up (exit code 3) if the communicator is not up after SEC seconds (default 120)
 //   --assemble F0,F1,...         put the tile files of ranks 0..G-1 together and write the PNG (no GPU needed)
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <cstdlib>
+#include <memory>
+#include <unistd.h>
 #include <cmath>
 #include <fstream>
 #include <iostream>
@@ -37,6 +44,8 @@ int main(int argc, char *argv[]) {
     std::vector<int> devices;
     int tile_rank = -1, tile_world = 0;
     std::string tiles_file, rccl_id_file;
+    std::string rccl_nonce = getenv("RT_RCCL_NONCE") ? getenv("RT_RCCL_NONCE") : std::to_string((long)getppid());   // one launch = one nonce (the ranks' common parent by default)
+    int rccl_timeout_s = 120;
     std::vector<std::string> assemble;
     for (int i = 3; i + 1 < argc; i += 2) {
         const std::string k = argv[i], v = argv[i + 1];
@@ -52,6 +61,8 @@ int main(int argc, char *argv[]) {
         else if (k == "--tile-world") tile_world = atoi(v.c_str());
         else if (k == "--tiles") tiles_file = v;
         else if (k == "--rccl-id") rccl_id_file = v;
+        else if (k == "--rccl-nonce") rccl_nonce = v;
+        else if (k == "--rccl-timeout") rccl_timeout_s = std::max(1, atoi(v.c_str()));
         else if (k == "--assemble") { std::stringstream ss(v); std::string tok; while (std::getline(ss, tok, ',')) assemble.push_back(tok); }
         else if (k == "--devices") { std::stringstream ss(v); std::string tok; while (std::getline(ss, tok, ',')) devices.push_back(atoi(tok.c_str())); }
         else { std::cerr << "unknown option " << k << "\n"; return 2; }
@@ -113,28 +124,55 @@ int main(int argc, char *argv[]) {
             return 0;
         }
         if (tile_rank >= 0 && !rccl_id_file.empty()) {                // one process per GPU, tiles gathered over RCCL into rank 0
-            std::vector<unsigned char> id;
-            if (tile_rank == 0) {                                      // the id reaches the other ranks through a file, written whole before it gets its name
-                id = TileComm::make_id();
-                const std::string tmp = rccl_id_file + ".tmp";
-                { std::ofstream f(tmp, std::ios::binary); f.write(reinterpret_cast<const char *>(id.data()), (std::streamsize)id.size()); if (!f) { std::cerr << "cannot write " << tmp << "\n"; return 1; } }
-                if (std::rename(tmp.c_str(), rccl_id_file.c_str()) != 0) { std::cerr << "cannot rename " << tmp << "\n"; return 1; }
-            } else {
-                for (int tries = 0; tries < 1200 && id.size() != RT_COMM_ID_BYTES; ++tries) {   // up to two minutes
-                    std::ifstream f(rccl_id_file, std::ios::binary);
-                    if (f) id.assign((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
-                    if (id.size() != RT_COMM_ID_BYTES) { id.clear(); std::this_thread::sleep_for(std::chrono::milliseconds(100)); }
-                }
-                if (id.size() != RT_COMM_ID_BYTES) { std::cerr << "no communicator id in " << rccl_id_file << "\n"; return 1; }
-            }
+            // Everything that can fail on the host side happens BEFORE any rank enters the collective communicator set-up: a rank that
+            // throws here never publishes / consumes an id, and the others give up after their bounded wait below.
             Renderer renderer(device);
             renderer.upload(s);
-            TileComm comm(device, tile_rank, tile_world, id);
-            image = renderer.render_gather_rgb8(rs, comm);
+            // The id travels through a file.  A file left by an earlier or aborted run must never be taken for this run's: the file holds
+            // the id AND the launch's nonce (--rccl-nonce, default: the parent process id, which the ranks of one launcher script share),
+            // rank 0 removes whatever is at the path before it creates its id and removes its own file once the communicator exists (the
+            // set-up is collective: by then every rank has read it), and the other ranks accept only a file that carries their nonce.
+            const std::string tag = "rtid:" + rccl_nonce + ":";
+            std::vector<unsigned char> id;
+            if (tile_rank == 0) {
+                std::remove(rccl_id_file.c_str());
+                id = TileComm::make_id();
+                const std::string tmp = rccl_id_file + ".tmp";
+                {
+                    std::ofstream f(tmp, std::ios::binary);
+                    f.write(tag.data(), (std::streamsize)tag.size());
+                    f.write(reinterpret_cast<const char *>(id.data()), (std::streamsize)id.size());
+                    if (!f) { std::cerr << "cannot write " << tmp << "\n"; return 1; }
+                }
+                if (std::rename(tmp.c_str(), rccl_id_file.c_str()) != 0) { std::cerr << "cannot rename " << tmp << "\n"; return 1; }   // written whole before it gets its name
+            } else {
+                for (int tries = 0; tries < rccl_timeout_s * 10 && id.empty(); ++tries) {   // bounded: --rccl-timeout
+                    std::ifstream f(rccl_id_file, std::ios::binary);
+                    std::vector<unsigned char> raw;
+                    if (f) raw.assign((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+                    if (raw.size() == tag.size() + RT_COMM_ID_BYTES && std::equal(tag.begin(), tag.end(), raw.begin())) id.assign(raw.begin() + (long)tag.size(), raw.end());
+                    else std::this_thread::sleep_for(std::chrono::milliseconds(100));   // absent, half-written, or another launch's file
+                }
+                if (id.empty()) { std::cerr << "no communicator id of launch " << rccl_nonce << " in " << rccl_id_file << "\n"; return 1; }
+            }
+            // ncclCommInitRank blocks until every rank of the id has arrived.  If one never does (it failed above, or was never started) a
+            // process that has initialised the GPU must not sit there for ever: a watchdog ends it after --rccl-timeout seconds.
+            std::atomic<bool> comm_up{false};
+            std::thread watchdog([&comm_up, rccl_timeout_s, tile_rank] {
+                for (int k = 0; k < rccl_timeout_s * 10 && !comm_up.load(); ++k) std::this_thread::sleep_for(std::chrono::milliseconds(100));
+                if (!comm_up.load()) { std::cerr << "rank " << tile_rank << ": the RCCL communicator did not come up within " << rccl_timeout_s << " s (a rank missing or holding another id); giving up\n"; std::_Exit(3); }
+            });
+            std::unique_ptr<TileComm> comm;
+            try { comm.reset(new TileComm(device, tile_rank, tile_world, id)); }
+            catch (...) { comm_up.store(true); watchdog.join(); if (tile_rank == 0) std::remove(rccl_id_file.c_str()); throw; }
+            comm_up.store(true);
+            watchdog.join();
+            if (tile_rank == 0) std::remove(rccl_id_file.c_str());      // every rank has read it: nothing stale stays behind
+            image = renderer.render_gather_rgb8(rs, *comm);
             if (tile_rank == 0 && !write_png(out.c_str(), W, H, image.data())) { std::cerr << "cannot write " << out << "\n"; return 1; }
             std::chrono::duration<float> run_time = std::chrono::system_clock::now() - start_time;
             std::cout << "Rendering time: " << run_time.count() << " s\n";
-            std::cerr << "rank " << tile_rank << " of " << tile_world << ": " << comm.last_bytes() << " bytes over RCCL\n";
+            std::cerr << "rank " << tile_rank << " of " << tile_world << ": " << comm->last_bytes() << " bytes over RCCL\n";
             return 0;
         }
         if (tile_rank >= 0) {                                         // one process per GPU: this rank's tiles only

@@ -177,9 +177,10 @@ namespace {
 hipStream_t own_stream(rt_ctx *ctx) {
     if (!ctx->stream_) {
         (void)hipSetDevice(ctx->device);
-        if (hipStreamCreateWithFlags(&ctx->stream_, hipStreamNonBlocking) != hipSuccess) { ctx->stream_ = nullptr; (void)hipGetLastError(); }
+        const hipError_t e = hipStreamCreateWithFlags(&ctx->stream_, hipStreamNonBlocking);
+        if (e != hipSuccess) { ctx->stream_ = nullptr; (void)hipGetLastError(); ctx->err = std::string("hipStreamCreateWithFlags: ") + hipGetErrorString(e); g_last_error = ctx->err; }
     }
-    return ctx->stream_;
+    return ctx->stream_;   // nullptr: the entry points fail with RT_ERR_HIP (RT_OWN_STREAM) rather than fall back to the legacy default stream
 }
 
 int fail(rt_ctx *ctx, int code, const char *fmt, ...) {
@@ -197,6 +198,13 @@ int fail(rt_ctx *ctx, int code, const char *fmt, ...) {
     do {                                                                                      \
         hipError_t e_ = (call);                                                               \
         if (e_ != hipSuccess) return fail(ctx, RT_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+// Entry points that run on the context's own stream: its creation must have succeeded (a failure used to fall back to
+// stream 0 without a word).
+#define RT_OWN_STREAM(ctx)                                                                              \
+    do {                                                                                                \
+        if (!own_stream(ctx)) return fail(ctx, RT_ERR_HIP, "the context's stream: %s", (ctx)->err.c_str()); \
     } while (0)
 
 // Every allocation happens on the context's device, whatever the calling thread's current device is.
@@ -878,8 +886,10 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
         return launch_render_chunk(ctx, p, rows, out_dev, stream, work_dev, pose, true, true);
     }
     // rows per chunk: whole tiles (and whole 8-row wave tiles for contiguous rows), two sub-frames' worth at least
+    // (contiguous rows: tile_rows only says how the caller described them -- rt_render passes one tile of n_rows -- and every chunk is
+    // re-described below; only interleaved tiles must be cut at tile boundaries)
     int unit = rows->tile_step == 1 ? 16 : rows->tile_rows * 2;
-    if (unit % rows->tile_rows != 0) unit *= rows->tile_rows;
+    if (rows->tile_step != 1 && unit % rows->tile_rows != 0) unit *= rows->tile_rows;
     const int64_t n_chunks = ((int64_t)rows->n_rows * p->width + chunk_px - 1) / chunk_px;
     int per = (int)(((int64_t)rows->n_rows + n_chunks - 1) / n_chunks);
     per = (per + unit - 1) / unit * unit;
@@ -1198,11 +1208,14 @@ int rt_scene_upload(rt_ctx *ctx, const rt_sphere *spheres, int n_spheres, const 
 
 int rt_render_device(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *out_rgba_dev, void *stream) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
-    return launch_render(ctx, p, rows, out_rgba_dev, stream ? static_cast<hipStream_t>(stream) : own_stream(ctx));
+    const hipStream_t q_ = stream ? static_cast<hipStream_t>(stream) : own_stream(ctx);
+    if (!q_) return fail(ctx, RT_ERR_HIP, "the context's stream: %s", ctx->err.c_str());
+    return launch_render(ctx, p, rows, out_rgba_dev, q_);
 }
 
 int rt_render(rt_ctx *ctx, const rt_params *p, int row_begin, int row_end, float *out_rgba_host) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    RT_OWN_STREAM(ctx);
     if (!p) return fail(ctx, RT_ERR_INVALID, "params is NULL");
     if (row_begin < 0 || row_end < row_begin || row_end > p->height) return fail(ctx, RT_ERR_INVALID, "bad row range [%d,%d)", row_begin, row_end);
     if (!out_rgba_host) return fail(ctx, RT_ERR_INVALID, "output pointer is NULL");
@@ -1233,6 +1246,7 @@ int rt_stats_enable(rt_ctx *ctx, int on) {
 
 int rt_render_async(rt_ctx *ctx, const rt_params *p, int slot, void *out_host, int rgb8) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    RT_OWN_STREAM(ctx);
     if (!p) return fail(ctx, RT_ERR_INVALID, "params is NULL");
     if (slot < 0 || slot >= rt_ctx::kSlots) return fail(ctx, RT_ERR_INVALID, "slot %d outside [0,%d)", slot, rt_ctx::kSlots);
     if (!out_host) return fail(ctx, RT_ERR_INVALID, "output pointer is NULL");
@@ -1286,11 +1300,14 @@ int rt_wait(rt_ctx *ctx, int slot) {
 
 int rt_tonemap_device(rt_ctx *ctx, const void *rgba_dev, int64_t n_pixels, void *rgb8_dev, void *stream) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
-    return launch_tonemap(ctx, rgba_dev, n_pixels, rgb8_dev, stream ? static_cast<hipStream_t>(stream) : own_stream(ctx));
+    const hipStream_t q_ = stream ? static_cast<hipStream_t>(stream) : own_stream(ctx);
+    if (!q_) return fail(ctx, RT_ERR_HIP, "the context's stream: %s", ctx->err.c_str());
+    return launch_tonemap(ctx, rgba_dev, n_pixels, rgb8_dev, q_);
 }
 
 int rt_render_rgb8(rt_ctx *ctx, const rt_params *p, int row_begin, int row_end, uint8_t *out_rgb8_host) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    RT_OWN_STREAM(ctx);
     if (!p) return fail(ctx, RT_ERR_INVALID, "params is NULL");
     if (row_begin < 0 || row_end < row_begin || row_end > p->height) return fail(ctx, RT_ERR_INVALID, "bad row range [%d,%d)", row_begin, row_end);
     if (!out_rgb8_host) return fail(ctx, RT_ERR_INVALID, "output pointer is NULL");
@@ -1309,6 +1326,7 @@ int rt_render_rgb8(rt_ctx *ctx, const rt_params *p, int row_begin, int row_end, 
 
 int rt_count_work(rt_ctx *ctx, const rt_params *p, int row_begin, int row_end, rt_work *out) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    RT_OWN_STREAM(ctx);
     if (!p || !out) return fail(ctx, RT_ERR_INVALID, "params/out is NULL");
     if (row_begin < 0 || row_end < row_begin || row_end > p->height) return fail(ctx, RT_ERR_INVALID, "bad row range [%d,%d)", row_begin, row_end);
     const int n = row_end - row_begin;
@@ -1337,6 +1355,7 @@ int rt_count_work(rt_ctx *ctx, const rt_params *p, int row_begin, int row_end, r
 
 int rt_mesh_set_normals(rt_ctx *ctx, const float *normals_xyz, int n_normals, const int32_t *nidx, int index_stride, int n_triangles) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    RT_OWN_STREAM(ctx);
     if (!ctx->have_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_scene_upload has not been called");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipStreamSynchronize(own_stream(ctx)));
@@ -1361,6 +1380,7 @@ int rt_mesh_set_normals(rt_ctx *ctx, const float *normals_xyz, int n_normals, co
 
 int rt_mesh_transform(rt_ctx *ctx, const float rotation[9], const float translation[3]) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    RT_OWN_STREAM(ctx);
     if (!rotation || !translation) return fail(ctx, RT_ERR_INVALID, "rotation/translation is NULL");
     if (!ctx->have_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_scene_upload has not been called");
     rtk::Scene &sc = ctx->scene;
@@ -1406,6 +1426,7 @@ int rt_mesh_transform(rt_ctx *ctx, const float rotation[9], const float translat
 
 int rt_mesh_rebuild(rt_ctx *ctx, float *bvh_arr10_out, int32_t *tri_order_out, int32_t *n_nodes_out) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    RT_OWN_STREAM(ctx);
     if (!ctx->have_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_scene_upload has not been called");
     if (n_nodes_out) *n_nodes_out = 0;
     const rtk::Scene old = ctx->scene;
@@ -1509,6 +1530,7 @@ int rt_camera_basis(const rt_camera_pose *pose, float bx[3], float by[3], float 
 
 int rt_render_pose(rt_ctx *ctx, const rt_params *p, const rt_camera_pose *pose, float *out_rgba_host) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    RT_OWN_STREAM(ctx);
     if (!p || !pose || !out_rgba_host) return fail(ctx, RT_ERR_INVALID, "params/pose/out is NULL");
     const size_t bytes = (size_t)(p->height > 0 ? p->height : 0) * (p->width > 0 ? p->width : 0) * sizeof(float4);
     int rc = ensure(ctx, ctx->scratch_rgba, bytes);
@@ -1522,8 +1544,10 @@ int rt_render_pose(rt_ctx *ctx, const rt_params *p, const rt_camera_pose *pose, 
 
 int rt_render_pose_device(rt_ctx *ctx, const rt_params *p, const rt_camera_pose *pose, const rt_rows *rows, void *out_rgba_dev, void *stream) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    const hipStream_t q_ = stream ? static_cast<hipStream_t>(stream) : own_stream(ctx);
+    if (!q_) return fail(ctx, RT_ERR_HIP, "the context's stream: %s", ctx->err.c_str());
     if (!pose) return fail(ctx, RT_ERR_INVALID, "pose is NULL");
-    return launch_render(ctx, p, rows, out_rgba_dev, stream ? static_cast<hipStream_t>(stream) : own_stream(ctx), nullptr, pose);
+    return launch_render(ctx, p, rows, out_rgba_dev, q_, nullptr, pose);
 }
 
 int rt_progressive_reset(rt_ctx *ctx) {
@@ -1540,6 +1564,7 @@ int rt_progressive_frames(const rt_ctx *ctx, int *frames) {
 
 int rt_progressive_frame(rt_ctx *ctx, const rt_params *p, const rt_camera_pose *pose, float *display_rgba_host, uint8_t *rgb8_host) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    RT_OWN_STREAM(ctx);
     if (!p || !pose) return fail(ctx, RT_ERR_INVALID, "params/pose is NULL");
     if (p->width <= 0 || p->height <= 0) return fail(ctx, RT_ERR_INVALID, "width/height must be positive");
     const int64_t npix = (int64_t)p->width * p->height;
@@ -1622,6 +1647,7 @@ int rt_device_free(void *ptr) {
 
 int rt_device_to_host(rt_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    RT_OWN_STREAM(ctx);
     if (bytes && (!dst_host || !src_dev)) return fail(ctx, RT_ERR_INVALID, "bad copy arguments");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     if (bytes) RT_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, own_stream(ctx)));
@@ -1631,6 +1657,7 @@ int rt_device_to_host(rt_ctx *ctx, void *dst_host, const void *src_dev, size_t b
 
 int rt_synchronize(rt_ctx *ctx) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    RT_OWN_STREAM(ctx);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipStreamSynchronize(own_stream(ctx)));
     return RT_OK;

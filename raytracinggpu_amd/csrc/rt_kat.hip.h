@@ -179,6 +179,7 @@ int kat_run(rt_ctx *ctx, const float *in, int n, int width, float *out, int owid
     if (counts) *counts = rt_kat_counts{};
     if (n == 0) return RT_OK;
     RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_OWN_STREAM(ctx);
     DevBuf din, dout, dcnt;
     int rc;
     if ((rc = upload(ctx, din, in, (size_t)n * width * sizeof(float))) != RT_OK || (rc = ensure(ctx, dout, (size_t)n * owidth * sizeof(float))) != RT_OK ||

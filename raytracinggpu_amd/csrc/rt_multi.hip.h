@@ -157,6 +157,9 @@ int multi_render(rt_multi *m, const rt_params *p, void *out_dev_on_root, void *o
     const size_t frame_bytes = (size_t)W * H * px_bytes;
     if ((rc = ensure(root, m->stage, stage_off(n) + 16)) != RT_OK || (rc = ensure(root, m->rays, 8)) != RT_OK ||
         (!out_dev_on_root && (rc = ensure(root, m->frame, frame_bytes)) != RT_OK)) { m->err = root->err; return rc; }
+    for (int k = 0; k < n; ++k)                                             // every device's own stream must exist: no silent fall-back to stream 0
+        if (!own_stream(m->ctx[k])) return mfail(m, RT_ERR_HIP, "device %d: the context's stream: %s", m->ctx[k]->device, m->ctx[k]->err.c_str());
+    RT_MHIP(m, hipSetDevice(root->device));
     RT_MHIP(m, hipMemsetAsync(m->rays.p, 0, 8, own_stream(root)));
     // 1. every device renders its tiles; peers push them to the root as soon as they are done.  A failure part-way
     //    leaves work in flight on the devices already launched: drain them before returning, so that the caller may

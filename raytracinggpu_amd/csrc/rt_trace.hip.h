@@ -55,6 +55,7 @@ extern "C" int rt_trace_rays(rt_ctx *ctx, const float *rays, int n, float tri_tm
     if (variant == RT_VARIANT_WAVEFRONT_QUEUE && (sc.n_nodes + 2 >= (1 << rtk::kQNodeBits) || !ctx->travq_ok)) variant = RT_VARIANT_WAVEFRONT;
     if (variant == RT_VARIANT_PATH && sc.n_nodes + 2 >= (1 << rtk::kPNodeBits)) variant = RT_VARIANT_WAVEFRONT;
     RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_OWN_STREAM(ctx);
     hipStream_t q = own_stream(ctx);
     const Knobs &kn = ctx->knobs;
     const bool have_mesh = sc.mesh_slot >= 0 && sc.n_nodes > 0;

@@ -571,6 +571,16 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
             asm volatile("" :: "v"(x0), "v"(x1), "v"(x2), "v"(x3));
         }
 #endif
+#if defined(RT_DEBUG) && defined(RT_PAD_VMEM2)    // ... the same pair from the OTHER breadth-first copy (lo / hi form): four more loads to lines the step does not otherwise touch
+        {
+            const unsigned char *pp = reinterpret_cast<const unsigned char *>(sc.nodesq) + off_[0];
+            typedef float pad_v4f __attribute__((ext_vector_type(4)));
+            pad_v4f x0, x1, x2, x3;
+            asm volatile("global_load_dwordx4 %0, %4, off\n global_load_dwordx4 %1, %4, off offset:16\n global_load_dwordx4 %2, %4, off offset:32\n"
+                         "global_load_dwordx4 %3, %4, off offset:48\n s_waitcnt vmcnt(0)" : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3) : "v"(pp) : "memory");
+            asm volatile("" :: "v"(x0), "v"(x1), "v"(x2), "v"(x3));
+        }
+#endif
 #pragma unroll
         for (int k = 0; k < KP; ++k) {
             const bool act = act_[k];

@@ -8,6 +8,7 @@ RCCL needs more than one GPU: that leg has not run on hardware."""
 import os
 import re
 import subprocess
+import time
 import sys
 
 import numpy as np
@@ -28,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_rccl.EXPORTS) == names
-    assert lib.rt_comm_abi_version() == 1
+    assert lib.rt_comm_abi_version() == 2
 
 
 @pytest.mark.parametrize("W,H,bpp,tile_rows,world", [(400, 250, 16, 8, 1), (400, 250, 16, 8, 2), (400, 250, 3, 8, 3), (1920, 1080, 3, 8, 8),
@@ -64,6 +65,59 @@ def test_tile_plan_replayed_rebuilds_the_frame(W, H, bpp, tile_rows, world):
     assert sum(len(v) for v in sends.values()) == n_tiles
     with pytest.raises(_rccl.CommError):
         _rccl.tile_plan(W, H, bpp, tile_rows, world, n_tiles)
+
+
+@pytest.mark.parametrize("W,H,bpp,tile_rows", [(400, 250, 16, 8), (400, 250, 3, 8), (1920, 1080, 3, 8), (64, 7, 16, 8), (33, 130, 3, 16), (101, 57, 1, 8)])
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_coalesced_plan_replayed_rebuilds_the_frame(W, H, bpp, tile_rows, world):
+    """The second exchange plan, replayed on the host for world 1...8 and both roots that matter: every peer's
+    ONE message -- its whole dense buffer -- lands at its 256-byte aligned place in the root's staging area, the placement pass (what
+    place_tiles_kernel does, word by word) copies tile t from stage(owner) + tile_plan(t).local_offset, the root's own tiles from its
+    own buffer; the frame comes back whole, pieces of the staging area never overlap, ranks without tiles send nothing."""
+    rng = np.random.default_rng(W * 7 + H * 3 + world)
+    row_bytes = W * bpp
+    frame = rng.integers(0, 256, size=(H, row_bytes), dtype=np.uint8)
+    n_tiles = (H + tile_rows - 1) // tile_rows
+    for root in sorted({0, world - 1}):
+        local = []
+        for rank in range(world):
+            _, idx = rt.interleaved_rows(H, tile_rows, rank, world)
+            local.append(frame[idx].reshape(-1))
+        plans = [_rccl.peer_plan(W, H, bpp, tile_rows, world, root, r) for r in range(world)]
+        end = 0
+        for r in range(world):
+            pp = plans[r]
+            assert pp.bytes == local[r].size and pp.n_tiles == len(range(r, n_tiles, world))
+            if r == root:
+                assert pp.stage_offset == 0
+                continue
+            assert pp.stage_offset % 256 == 0 and pp.stage_offset >= end       # pieces in rank order, none overlapping
+            end = pp.stage_offset + pp.bytes
+        stage = np.full(end + 256, 0xEE, np.uint8)
+        messages = 0
+        for r in range(world):                                                  # the exchange: one message per peer that holds tiles
+            if r != root and plans[r].bytes:
+                stage[plans[r].stage_offset:plans[r].stage_offset + plans[r].bytes] = local[r]
+                messages += 1
+        assert messages == sum(1 for r in range(world) if r != root and r < n_tiles)
+        out = np.zeros(H * row_bytes, np.uint8)
+        for t in range(n_tiles):                                                # the placement pass
+            p = _rccl.tile_plan(W, H, bpp, tile_rows, world, t)
+            src = local[root] if p.owner == root else stage[plans[p.owner].stage_offset:]
+            out[p.frame_offset:p.frame_offset + p.bytes] = src[p.local_offset:p.local_offset + p.bytes]
+        np.testing.assert_array_equal(out.reshape(H, row_bytes), frame)
+    with pytest.raises(_rccl.CommError):
+        _rccl.peer_plan(W, H, bpp, tile_rows, world, 0, world)
+
+
+def test_auto_plan_follows_the_tile_size():
+    """AUTO = coalesced below the byte threshold, per tile at or above it; an explicit plan is never overridden."""
+    assert _rccl.choose_plan("auto", 1920, 3, 8) == "coalesced"                # 46 KB tiles (1080p RGB8)
+    assert _rccl.choose_plan("auto", 1920, 16, 8) == "coalesced"               # 245 KB (1080p float4): still below 256 KiB
+    assert _rccl.choose_plan("auto", 7680, 16, 8) == "tile"                    # 983 KB (config 5, float4)
+    assert _rccl.choose_plan("auto", 7680, 3, 8) == "coalesced"                # 184 KB (config 5, RGB8)
+    assert _rccl.choose_plan("auto", 7680, 3, 8, coalesce_below=100 * 1024) == "tile"
+    assert _rccl.choose_plan("tile", 64, 3, 8) == "tile" and _rccl.choose_plan("coalesced", 7680, 16, 8) == "coalesced"
 
 
 def test_bad_arguments_and_no_gpu_fail_loudly():
@@ -171,9 +225,30 @@ def test_launcher_rccl_path_writes_the_reference_png(tmp_path, cat_golden):
             f.write("v %.9g %.9g %.9g 1 1 1\r\n" % tuple(float(x) for x in v))
         for t in cat_golden["tri_obj_order"]:
             f.write("f %d/1/1 %d/1/1 %d/1/1\r\n" % tuple(int(x) + 1 for x in t))
+    (tmp_path / "id").write_bytes(b"x" * 128)                              # what an aborted earlier run may have left at the path: rank 0 removes it first
     r = subprocess.run([launcher, "1", "0", "--tile-rank", "0", "--tile-world", "1", "--rccl-id", str(tmp_path / "id"), "--out", "rccl.png"],
                        cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     assert "Rendering time: " in r.stdout                                  # (RCCL prints its version banner to stdout first)
     assert "over RCCL" in r.stderr
+    assert not (tmp_path / "id").exists()                                  # ... and leaves none behind once the communicator is up
     np.testing.assert_array_equal(np.array(Image.open(tmp_path / "rccl.png").convert("RGB")), g["cat"])
+
+
+@pytest.mark.gpu
+def test_launcher_rejects_a_stale_communicator_id(tmp_path):
+    """a rank other than 0 used to take ANY 128-byte file at the --rccl-id path for this run's id and then block for ever
+    in the collective set-up next to ranks holding another id.  The file now carries the launch's nonce: a leftover of another launch
+    (raw 128 bytes as the old format wrote them, or a well-formed file of another nonce) is ignored, the wait for the real one is
+    bounded by --rccl-timeout, and the process ends with an error instead of hanging with the GPU initialised."""
+    launcher = os.path.join(ROOT, "raytracinggpu_amd", "rt_launcher")
+    for stale in (b"\x01" * 128, b"rtid:someone-else:" + b"\x02" * 128):
+        (tmp_path / "id").write_bytes(stale)
+        t0 = time.time()
+        r = subprocess.run([launcher, "1", "0", "--scene", "spheres", "--tile-rank", "1", "--tile-world", "2", "--rccl-id", str(tmp_path / "id"),
+                            "--rccl-nonce", "this-launch", "--rccl-timeout", "2", "--width", "64", "--height", "64"],
+                           cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+        assert r.returncode == 1, (r.returncode, r.stderr)
+        assert "no communicator id of launch this-launch" in r.stderr
+        assert time.time() - t0 < 60
+        assert (tmp_path / "id").read_bytes() == stale                     # only rank 0 ever removes the file
