@@ -13,11 +13,14 @@ tiles to rank 0, which de-interleaves them (all inside the timed region).  Total
 
 Rank 0 prints one JSON line.  `value` = rays traced per second (1 ray = 1 Scene::intersect_all call:
 primary, shadow or bounce segment; counted exactly by the kernel in the framebuffer's .w channel).
-`roofline` prices the dominant kernel (wf_travq) against what binds it, vector-instruction issue: the vector wave-instructions of
-one launch -- step counts of the counting instantiation in THIS run x the static per-step instruction counts of the production
-code object (tools/static_counts.py, written by build()) -- over that launch's duration (HIP events on its stream), against
-1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction.  The nominal HBM figure of SURVEY 8d (24 B/box test + 16 B/node +
-48 B/triangle test of a cache-resident scene) stays beside it as `nominal_hbm_frac`.  `cpu_baseline` is the CPU restatement of
+`roofline` prices the dominant kernel (wf_travq) against vector-instruction issue: the vector wave-instructions of one launch --
+step counts of the counting instantiation in THIS run x the static per-step instruction counts of the production code object
+(tools/static_counts.py, written by build()), each instruction weighted by its measured issue cost -- over that launch's
+duration (HIP events on its stream), against 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (the guide's SIMD-32 issue
+rate).  `frac` is that WEIGHTED fraction; the unweighted count (`frac_unweighted`) and the nominal HBM figure of SURVEY 8d (24 B/box
+test + 16 B/node + 48 B/triangle test of a cache-resident scene, `nominal_hbm_frac`) stay beside it, and `roofline.kernels` prices
+the second hot kernel (wf_advance) against the HBM peak.  `config.end_to_end` times the whole program (rt_launcher 8 3 at 512x512:
+context, OBJ parse, BVH build, upload, render, D2H, PNG) as the reference times its own (cpu_launcher.cpp:660,721-723).  `cpu_baseline` is the CPU restatement of
 cpu_launcher.cpp (oracle/, OpenMP schedule(dynamic,1) over rows like cpu:695) timed on this host.
 """
 import argparse
@@ -35,9 +38,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-VALU_PEAK_GINST = 1024 * 2.4 / 4   # vector wave-instructions per ns the chip can issue: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64
-                                   # instruction (the guide's single-issue cost; min / max / compares take exactly that, fma / mul / add about
-                                   # half of it when several waves share a SIMD: tools/ubench/issue_table.hip, profiles/round3/issue_table.jsonl)
+HBM_ACHIEVABLE_GBS = 6290.0   # what a streaming kernel reaches on this part (same guide: "~6.3 TB/s achievable")
+VALU_PEAK_GINST = 1024 * 2.4 / 2   # vector wave-instructions per ns the chip can issue: 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64
+                                   # instruction (MI355X_MICROARCH.md: "issues each VALU instruction over 2 cycles"; tools/ubench/issue_table.hip
+                                   # agrees for fma / mul / add with 4+ waves per SIMD; min / max / compares / cndmask / conversions take ~1.75x
+                                   # that, transcendentals ~3.3x: the WEIGHTED count over this peak is `roofline.frac`)
+ADV_LAYOUT_BYTES_PER_PATH = 154   # wf_advance, HBM bytes per path and launch of the record layout (profiles/round3/pmc_wf_advance.json: 323 MB per 2.07 M paths)
 TILE_ROWS = 8              # == raytracinggpu_amd.tiling.TILE_ROWS
 
 def parse():
@@ -60,7 +66,14 @@ def parse():
     ap.add_argument("--transport", default="torch", choices=["torch", "capi"],
                     help="N > 1: the gather goes through torch.distributed (nccl = RCCL; default) or through the product's own C-ABI "
                          "(libraytrace_rccl.so: grouped ncclSend / ncclRecv, every tile received straight into its place in rank 0's frame)")
+    ap.add_argument("--comm-plan", default="auto", choices=["auto", "tile", "coalesced"],
+                    help="--transport capi: the exchange plan of rt_comm_gather_tiles (auto: coalesced -- one message per peer + one placement kernel -- "
+                         "when a tile is smaller than 256 KiB, else one receive per tile straight into the frame)")
+    ap.add_argument("--gather-only", action="store_true",
+                    help="N > 1: time the EXCHANGE alone -- the tiles are rendered once, the timed steps repeat the gather of the same buffers (no render); "
+                         "the line's value is null and config.gather_only holds ms per gather and GB/s into the root")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip config.end_to_end (three runs of the rt_launcher program, ~1 s each)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--large-steps", type=int, default=4, help="frames of the second timed point (cat 7680x4320, BASELINE config 5) in the same run; 0 = skip")
     ap.add_argument("--share-gpu", action="store_true",
@@ -201,6 +214,39 @@ def reference_check(sc, threads):
             "note": "the reference times its whole program (OBJ parse, BVH build, PNG) and draws from a clock()-seeded mt19937"}
 
 
+def end_to_end(threads):
+    """SURVEY 8d / VERDICT round 3 item 1: the GPU-side counterpart of `reference_check.reference_program_s` -- the whole PROGRAM, timed by
+    itself the way the reference times its own (cpu_launcher.cpp:660,721-723: first line of main to after the PNG is written):
+    `rt_launcher 8 3` at the reference's hard-wired 512x512, in a directory that holds the cat as an OBJ.  Includes HIP start-up,
+    context creation, OBJ parse, host BVH build, scene upload, the render, the device-to-host copy and the PNG encoder."""
+    import tempfile
+    import raytracinggpu_amd as rt
+    exe = os.path.join(ROOT, "raytracinggpu_amd", "rt_launcher")
+    if not os.path.exists(exe):
+        return {"skipped": "raytracinggpu_amd/rt_launcher not built"}
+    g = np.load(rt.scenes.CAT_FIXTURE, allow_pickle=False)
+    with tempfile.TemporaryDirectory() as d:
+        od = os.path.join(d, "cadnav.com_model", "Models_F0202A090")
+        os.makedirs(od)
+        with open(os.path.join(od, "cat.obj"), "w") as f:
+            for v in g["vertices"]:
+                f.write("v %.9g %.9g %.9g 1 1 1\r\n" % tuple(float(x) for x in v))
+            for t in g["tri_obj_order"]:
+                f.write("f %d/1/1 %d/1/1 %d/1/1\r\n" % tuple(int(x) + 1 for x in t))
+        times, kernel = [], []
+        for _ in range(3):
+            r = subprocess.run([exe, "8", "3"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=180)
+            if r.returncode != 0 or "Rendering time:" not in r.stdout:
+                return {"skipped": f"rt_launcher failed ({r.returncode}): {r.stderr.strip()[-200:]}"}
+            times.append(float(r.stdout.split("Rendering time:")[1].split()[0]))
+            if "kernel " in r.stderr:
+                kernel.append(float(r.stderr.split("kernel ")[1].split()[0]))
+    return {"config": "rt_launcher 8 3: 512x512, num_rays=8, num_bounce=3, cat scene (the reference program's own size and arguments)",
+            "program_s": round(statistics.median(times), 4), "program_s_runs": [round(t, 4) for t in times],
+            "render_kernels_ms": round(statistics.median(kernel), 3) if kernel else None,
+            "includes": "HIP start-up + context, OBJ parse, host BVH build, scene upload, render, D2H, PNG encode (the reference's timer spans the same: cpu_launcher.cpp:660,721-723)"}
+
+
 def single_stream_launch_ms(rt, args, p, rows, local, stream):
     """Average duration of ONE launch of the dominant kernel when it owns the chip: a second context created under
     RT_PARTS=1 (knobs are read once per context) renders the same frames as one sub-frame on one stream; the library
@@ -216,13 +262,17 @@ def single_stream_launch_ms(rt, args, p, rows, local, stream):
             os.environ["RT_PARTS"] = old
     build_scene(rt, c1, args.scene)
     c1.stats_enable(True)
-    ms, launches, frame = [], 0, []
+    ms, launches, frame, adv = [], 0, [], []
+    adv_info = None
     for k in range(8):
         c1.render_device(p, rows, local.data_ptr(), stream)
         st = c1.stats()
         if k >= 3 and st["trav_launches"] > 0:
             ms.append(st["trav_ms"] / st["trav_launches"]); launches = st["trav_launches"]; frame.append(st["kernel_ms"])
+            if st.get("adv_launches", 0) > 0:
+                adv.append(st["adv_ms"] / st["adv_launches"]); adv_info = (st["adv_launches"], st["adv_paths"])
     c1.close()
+    single_stream_launch_ms.adv = (statistics.median(adv), adv_info[0], adv_info[1]) if adv else None
     return (statistics.median(ms), launches, statistics.median(frame)) if ms else (None, 0, None)
 
 
@@ -290,13 +340,16 @@ def roofline(rt, ctx, args, p, rows, local, stream, counts, world, W, H, kernel_
         out.update({"kernel_ms": round(k_ms, 4), "launches_per_frame": launches, "concurrent_launches": parts})
     out["kernel_ms_two_streams"] = round(k_ms_conc, 4)                # the default configuration: the twin launch of the other sub-frame shares the chip
     valu_launch = ins["valu"] / launches
-    ach = valu_launch / (k_ms * 1e-3) / 1e9
+    weighted_launch = ins["valu_weight"] / launches                   # in units of one full-rate instruction (2 cycles of one SIMD)
+    ach = weighted_launch / (k_ms * 1e-3) / 1e9
     hbm_ach = trav_bytes / launches / (k_ms * 1e-3) / 1e9
     out.update({"kernel": "rtk::wf_travq<false, 64, false, false>", "achieved": round(ach, 1), "frac": round(ach / VALU_PEAK_GINST, 4),
-                "frac_is": "vector wave-instructions of one launch (step counters of this run x static per-step counts of the code object) / launch duration, "
-                           "over 1024 SIMDs x 2.4 GHz / 4 cycles; the kernel also leans on L1 bandwidth, LDS and the scalar unit (DESIGN.md section 5)",
-                "valu_wave_insts_per_launch": int(valu_launch), "salu_wave_insts_per_launch": int(ins["salu"] / launches),
-                "valu_issue_weighted_frac": round(ins["valu_weight"] / launches * 2 / (k_ms * 1e-3 * 2.4e9 * 1024), 4),
+                "frac_is": "issue-cost-weighted vector wave-instructions of one launch (step counters of this run x static per-step counts of the code object; "
+                           "weight 1 = fma / mul / add / logic, 1.75-2 = min / max / compare / cndmask / conversion / binary64, 4 = rcp / sqrt) / launch duration, "
+                           "over 1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction = 1228.8 G/s; what the kernel waits for the rest of the time is the CU's "
+                           "vector-memory path (profiles/round4/ab_pad_sensitivity.txt: +4 loads per BOX step cost +27 %, +32 vector instructions +7 %)",
+                "achieved_unweighted": round(valu_launch / (k_ms * 1e-3) / 1e9, 1), "frac_unweighted": round(valu_launch / (k_ms * 1e-3) / 1e9 / VALU_PEAK_GINST, 4),
+                "valu_wave_insts_per_launch": int(valu_launch), "valu_weighted_insts_per_launch": int(weighted_launch), "salu_wave_insts_per_launch": int(ins["salu"] / launches),
                 "valu_by_region_per_frame": ins["by_region_valu"], "steps_per_frame": counts["steps"],
                 "box_step_lane_occupancy": round((counts["box_tests"] - counts["rays"]) / (128.0 * max(counts["steps"]["box_steps"], 1)), 4),   # the root-box test of every ray belongs to the uniform kernel
                 "tri_step_lane_occupancy": round(counts["tri_tests"] / (128.0 * max(counts["steps"]["tri_steps"], 1)), 4),
@@ -304,7 +357,8 @@ def roofline(rt, ctx, args, p, rows, local, stream, counts, world, W, H, kernel_
                 "algorithmic_bytes_per_launch": int(trav_bytes / launches), "nominal_hbm_GBps": round(hbm_ach, 1), "nominal_hbm_frac": round(hbm_ach / HBM_PEAK_GBS, 4),
                 "nominal_hbm_frac_is": "SURVEY 8d: 24 B/box test + 16 B/node + 48 B/triangle test of a cache-resident scene over 8 TB/s; may exceed 1, NOT a utilisation"})
     # measured HBM traffic of the same launch: only from a PMC summary taken from THIS library
-    for rnd in ("round3", "round2"):
+    rnd = "round4"
+    for rnd in ("round4", "round3", "round2"):
         spath = os.path.join(ROOT, "profiles", rnd, "summary.json")
         if os.path.exists(spath) and workload == "cat_1920x1080_spp1_b3":
             summ = json.load(open(spath))
@@ -318,6 +372,31 @@ def roofline(rt, ctx, args, p, rows, local, stream, counts, world, W, H, kernel_
             else:
                 out["traffic_note"] = f"profiles/{rnd}/summary.json was taken from other code (hash differs): profile stale, traffic not quoted"
             break
+    # both hot kernels, each against the roofline that bounds it
+    kern = [{"kernel": "wf_travq", "bound": "valu_issue", "kernel_ms": out.get("kernel_ms"), "launches_per_frame": out.get("launches_per_frame"),
+             "achieved": out.get("achieved"), "peak": out["peak"], "unit": out["unit"], "frac": out.get("frac"), "traffic": out.get("traffic")}]
+    adv = getattr(single_stream_launch_ms, "adv", None)
+    adv_ms, adv_launches, adv_paths, conc = (adv[0], adv[1], adv[2], 1) if adv else (st["adv_ms"] / st["adv_launches"] if st.get("adv_launches") else None, st.get("adv_launches", 0), st.get("adv_paths", 0), parts)
+    if adv_ms:
+        # bytes one launch moves: measured (PMC, same source hash) when the committed profile belongs to this code, else the record layout's
+        # figure (path record 16 B read + 16 B written, continuation ray 32 B read back + 32 B written, shadow ray 32 B
+        # written, 8-16 B of traversal results, 5 B of shading terms per live path)
+        layout_b = ADV_LAYOUT_BYTES_PER_PATH * adv_paths
+        measured = None
+        if out.get("traffic") is not None:
+            try:
+                a = json.load(open(os.path.join(ROOT, "profiles", rnd, "summary.json")))["kernels"]["wf_advance"]
+                measured = int((a["hbm_read_bytes_per_launch"] + a["hbm_write_bytes_per_launch"]) * adv_paths / max(a.get("paths_per_launch", adv_paths), 1))
+            except (OSError, KeyError, ValueError):
+                measured = None
+        b = measured if measured is not None else layout_b
+        gbs = b / (adv_ms * 1e-3) / 1e9
+        kern.append({"kernel": "wf_advance", "bound": "hbm", "kernel_ms": round(adv_ms, 4), "launches_per_frame": adv_launches * conc, "concurrent_launches": conc,
+                     "paths_per_launch": adv_paths, "bytes_per_launch": int(b), "bytes_per_path": round(b / max(adv_paths, 1), 1),
+                     "bytes_are": "measured: rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE of this source hash" if measured is not None else "the record layout's figure (no PMC summary of this source hash)",
+                     "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                     "frac_of_achievable": round(gbs / HBM_ACHIEVABLE_GBS, 4), "traffic": measured})
+    out["kernels"] = kern
     return out
 
 
@@ -386,6 +465,7 @@ def main():
         box = [_rccl.unique_id() if rank == 0 else None]               # rank 0's communicator id reaches the others through the process group
         dist.broadcast_object_list(box, src=0)
         comm = _rccl.Comm(dev_index, rank, world, box[0])
+        comm.set_plan(args.comm_plan)                                  # the same on every rank: both sides derive their message sizes from it
 
     W, H = args.width, args.height
     # Frames in flight.  One GPU renders a whole 1080p frame as two concurrent sub-frames (the library's default) and a second frame
@@ -494,7 +574,8 @@ def main():
             with torch.cuda.stream(self.tstreams[ln.k]):
                 if ev:
                     ev[0].record()
-                self.render(ln)
+                if not (args.gather_only and self.n > self.n_lanes):  # --gather-only: every lane's tiles are rendered once, then only exchanged
+                    self.render(ln)
                 if ev:
                     ev[1].record()
                 self.exchange(ln)
@@ -592,10 +673,23 @@ def main():
                           "primary_Msamples_per_s": round(W * H * args.spp / (elapsed / args.steps) / 1e6, 1)}}
         if frame_ok is not None:
             res["config"]["frame_equals_single_device_frame"] = frame_ok
+        if comm is not None:
+            res["config"]["comm_plan"] = comm.last_plan
+        if args.gather_only and world > 1:
+            px_bytes = 3 if rgb8 else 16
+            moved = W * H * px_bytes * (world - 1) / world               # bytes that cross the fabric into the root per gather
+            res["value"] = None
+            res["config"]["gather_only"] = {"ms_per_gather": round(ms_per_step, 4), "bytes_into_root": int(moved), "GBps_into_root": round(moved / (ms_per_step * 1e-3) / 1e9, 2),
+                                            "note": "render skipped inside the timed region on purpose: this line measures the exchange, not the metric"}
         if large:
             res["config"]["large"] = large
         if world == 1 and not cpu_only:
             res["config"].update(host_frame_timings(rt, ctx, main_pt.p, W, H))
+            if args.scene == "cpu" and not args.no_end_to_end:
+                try:
+                    res["config"]["end_to_end"] = end_to_end(args.cpu_threads or host_cores())
+                except Exception as e:  # a timing extra: never takes the line down
+                    res["config"]["end_to_end"] = {"skipped": str(e)}
         if world == 1 and not args.no_cpu_baseline and not cpu_only:
             try:
                 res["cpu_baseline"] = cpu_baseline(args, rays_per_frame)

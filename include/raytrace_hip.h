@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 3
+#define RT_ABI_VERSION 4
 #define RT_MAX_SPHERES 16      /* reference: Geometry* objects[10], optimized.cu:663 */
 #define RT_MAX_SEGMENTS 16     /* reference: MAX_RAY_DEPTH 10, optimized.cu:22       */
 
@@ -144,7 +144,9 @@ typedef struct rt_stats {
                                       launches of the last sample of the last frame, and how many    */
     int32_t  trav_launches;
     int32_t  parts;                /* wavefront variant: concurrent sub-frames the call was cut into      */
-    int32_t  reserved;
+    int32_t  adv_launches;         /* ... and the same for the uniform kernel (wf_advance, the launches after the first): */
+    float    adv_ms;               /*     summed HIP-event time, launches, paths per launch (rt_stats_enable)             */
+    int32_t  adv_paths;
 } rt_stats;
 
 /* --- device / context -------------------------------------------------------- */
@@ -208,7 +210,12 @@ int rt_stats_enable(rt_ctx *ctx, int on);
  * its call still see it complete, the join into the caller's stream stays).  So: alternate between two (or more) output buffers, and
  * do not let anything the frame depends on -- a fill of its buffer, a wait for a reader on another stream -- be younger than the previous
  * call.  Same stream, same size and parameters' layout, else the frame falls back to the full fork (results never change, only overlap).
- * rt_render_async does this internally for its two slots (RT_ASYNC_PIPELINE=0 turns that off).  Off by default. */
+ * rt_render_async does this internally for its two slots (RT_ASYNC_PIPELINE=0 turns that off).  Off by default.
+ * What the library can check it does: work it put on the stream itself since the previous render call (rt_tonemap_device) is remembered
+ * with the buffers it reads and writes; a frame that would render into one of them takes the full fork instead (product build: results
+ * and ordering stay right, only the overlap is lost) and is REFUSED with RT_ERR_INVALID by a -DRT_DEBUG build
+ * (libraytrace_hip_debug.so), so that a test run shows the sequence breaks the rule.  Work the caller submits through HIP directly is
+ * invisible to any library: that part of the rule stays the caller's. */
 int rt_ctx_set_pipelining(rt_ctx *ctx, int on);
 
 /* --- pipelined frames for a host caller.  optimized.cu renders, synchronises and then copies (optimized.cu:849-856), so the

@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "liboracle.so")
+LIB_PATH = os.environ.get("RT_ORACLE_LIB") or os.path.join(HERE, "liboracle.so")   # RT_ORACLE_LIB: the sanitizer build (tools/sanitize_cpu.sh)
 
 
 class Counters(C.Structure):
@@ -31,6 +31,8 @@ class Params(C.Structure):
 
 
 def build(force=False):
+    if os.environ.get("RT_ORACLE_LIB"):
+        return LIB_PATH
     if force or not os.path.exists(LIB_PATH) or \
             os.path.getmtime(LIB_PATH) < os.path.getmtime(os.path.join(HERE, "rt_oracle.c")):
         subprocess.run(["make", "-C", HERE, "liboracle.so"], check=True, stdout=subprocess.DEVNULL)

@@ -73,7 +73,8 @@ class Work(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("kernel_ms", C.c_float), ("tonemap_ms", C.c_float), ("pixels", C.c_uint64), ("variant", C.c_int32),
                 ("lds_bytes", C.c_int32), ("block_threads", C.c_int32), ("grid_blocks", C.c_int32),
-                ("trav_ms", C.c_float), ("trav_launches", C.c_int32), ("parts", C.c_int32), ("reserved", C.c_int32)]
+                ("trav_ms", C.c_float), ("trav_launches", C.c_int32), ("parts", C.c_int32), ("adv_launches", C.c_int32),
+                ("adv_ms", C.c_float), ("adv_paths", C.c_int32)]
 
 
 class KatCounts(C.Structure):

@@ -150,6 +150,13 @@ struct rt_ctx {
         int call_chunk = 0, call_chunks = 1;                  // position of the chunk being issued in its call (launch_render)
         const uint8_t *call_lo = nullptr, *call_hi = nullptr; // output range of the call being issued
         hipEvent_t extra_wait = nullptr;   // this call's chains also wait for this event (rt_render_async: the slot's previous copy)
+        // What the library ITSELF put on the caller's stream since the previous render call and what that work touches (rt_tonemap_device:
+        // reads a frame, writes an image).  A frame that starts behind the PREVIOUS call does not wait for it, so a frame whose output overlaps
+        // one of these ranges must not take the relaxed start: the product falls back to the full fork, a -DRT_DEBUG build refuses the call
+        // with RT_ERR_INVALID so that the caller learns its sequence breaks the rule of rt_ctx_set_pipelining.  (Work the caller submits
+        // through HIP directly is invisible to the library: no run-time check can cover it.)
+        struct Range { const uint8_t *lo, *hi; hipStream_t stream; };
+        std::vector<Range> between;
     } pipe;
     bool trav_attr_set = false;
     bool stats_on = false;                                          // rt_stats_enable: bracket the traversal launches with timing events (production frames record none)
@@ -162,7 +169,8 @@ struct rt_ctx {
     bool travq_ok = true;                                           // the uploaded tree fits wf_travq's entry formats (leaf sizes, triangle offsets)
     static constexpr int kMaxTravEvents = 2 * RT_MAX_SEGMENTS;
     hipEvent_t ev_trav[2 * kMaxTravEvents] = {};
-    int n_trav_events = 0;
+    hipEvent_t ev_adv[2 * kMaxTravEvents] = {};                     // ... and of the uniform kernel's launches (rt_stats_enable)
+    int n_trav_events = 0, n_adv_events = 0, adv_paths = 0;
     int persist_blocks_per_cu[2] = {0, 0};   // [STATS]
     rt_stats stats{};
     std::string err;
@@ -466,7 +474,7 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
     ctx->stats.variant = (want_ldsv || want_ldsn) ? variant_req : variant;
     if (rows->n_rows == 0) { ctx->stats.grid_blocks = 0; ctx->have_kernel_time = false; return RT_OK; }
     const int nseg = segs > 0 ? segs : 1;
-    ctx->n_trav_events = 0;
+    ctx->n_trav_events = 0; ctx->n_adv_events = 0; ctx->adv_paths = 0;
     if (variant == RT_VARIANT_PATH) {
         // ONE persistent launch per sub-frame and sample chunk (rt_path.hip.h): a wave owns 64 paths (one per lane) from camera ray to framebuffer store
         const Knobs &kn = ctx->knobs;
@@ -750,7 +758,14 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
             if (!pl.fork2[0]) { RT_HIP(ctx, hipEventCreateWithFlags(&pl.fork2[0], hipEventDisableTiming)); RT_HIP(ctx, hipEventCreateWithFlags(&pl.fork2[1], hipEventDisableTiming)); }
             if (pl.call_chunk == 0) {
                 const bool disjoint = pl.call_hi <= pl.out_lo || pl.out_hi <= pl.call_lo;
-                const bool relaxed = pl.on && pl.prev_valid && pl.stream == stream && pl.sig == layout_sig && disjoint && !zeroed;
+                bool hazard = false;                                     // a library call younger than the previous render call touches this frame's buffer
+                for (const rt_ctx::Pipe::Range &r : pl.between) if (r.stream == stream && r.lo < pl.call_hi && pl.call_lo < r.hi) hazard = true;
+#ifdef RT_DEBUG
+                if (pl.on && pl.prev_valid && pl.stream == stream && hazard)
+                    return fail(ctx, RT_ERR_INVALID, "pipelining rule broken: work submitted to this stream after the previous render call (rt_tonemap_device) touches the buffer "
+                                                     "this frame renders into; with rt_ctx_set_pipelining the frame would not wait for it (raytrace_hip.h)");
+#endif
+                const bool relaxed = pl.on && pl.prev_valid && pl.stream == stream && pl.sig == layout_sig && disjoint && !zeroed && !hazard;
                 pl.cur ^= 1;
                 RT_HIP(ctx, hipEventRecord(pl.fork2[pl.cur], stream));
                 start_ev = pl.fork2[relaxed ? pl.cur ^ 1 : pl.cur];
@@ -792,8 +807,11 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
                         if (timed) { RT_HIP(ctx, hipEventRecord(ctx->ev_trav[2 * it + 1], q)); ctx->n_trav_events = it + 1; }
                         pt.st.dbg = nullptr;
                     }
+                    const bool timed_adv = ctx->stats_on && j == 0 && s + chunk >= fr.spp;
+                    if (timed_adv) RT_HIP(ctx, hipEventRecord(ctx->ev_adv[2 * it], q));
                     if (work_dev) hipLaunchKernelGGL((rtk::wf_advance<true, false>), dim3(pt.pblocks), dim3(kn.adv_block), 0, q, scn, pt.fr, pt.st);
                     else hipLaunchKernelGGL((rtk::wf_advance<false, false>), dim3(pt.pblocks), dim3(kn.adv_block), 0, q, scn, pt.fr, pt.st);
+                    if (timed_adv) { RT_HIP(ctx, hipEventRecord(ctx->ev_adv[2 * it + 1], q)); ctx->n_adv_events = it + 1; ctx->adv_paths = pt.st.n_paths; }
                 }
                 if (fr.spp > 1)                                       // the chain's samples, added in sample order (cpu:711), into the running sum / the frame
                     hipLaunchKernelGGL(rtk::path_reduce, dim3((unsigned)((pt.st.n_px + 255) / 256)), dim3(256), 0, q, pt.fr, pt.st.n_px, tiles_x, std::min(chunk, fr.spp - s),
@@ -880,6 +898,7 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
     rt_ctx::Pipe &pl = ctx->pipe;
     pl.prev_valid = pl.valid; pl.valid = false;                          // every asynchronous user of the path state comes through here
     pl.call_chunk = 0; pl.call_chunks = 1; pl.open_parts = 0;
+    struct ClearBetween { rt_ctx::Pipe &p; ~ClearBetween() { p.between.clear(); } } clear_between{pl};   // the ranges describe the gap BEFORE this call: consumed by it
     pl.call_lo = static_cast<const uint8_t *>(out_dev);
     pl.call_hi = pl.call_lo + ((p && rows && p->width > 0 && rows->n_rows > 0) ? (size_t)rows->n_rows * p->width * sizeof(float4) : 0);
     if (!p || !rows || !wf || chunk_px <= 0 || p->width <= 0 || rows->tile_rows <= 0 || (int64_t)rows->n_rows * p->width <= chunk_px * 5 / 4) {
@@ -919,6 +938,11 @@ int launch_tonemap(rt_ctx *ctx, const void *rgba_dev, int64_t npix, void *rgb8_d
     if (npix == 0) return RT_OK;
     RT_HIP(ctx, hipSetDevice(ctx->device));
     const int64_t quads = (npix + 3) / 4;
+    if (ctx->pipe.on && ctx->pipe.between.size() < 64) {              // (see Pipe::between)
+        const uint8_t *a = static_cast<const uint8_t *>(rgba_dev), *b = static_cast<const uint8_t *>(rgb8_dev);
+        ctx->pipe.between.push_back({a, a + (size_t)npix * sizeof(float4), stream});
+        ctx->pipe.between.push_back({b, b + (size_t)npix * 3, stream});
+    }
     RT_HIP(ctx, hipEventRecord(ctx->ev_t0, stream));
     hipLaunchKernelGGL(rtk::tonemap_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream,
                        static_cast<const float4 *>(rgba_dev), npix, static_cast<uint8_t *>(rgb8_dev));
@@ -1120,6 +1144,7 @@ int rt_ctx_create(rt_ctx **out, int device_id) {
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_t0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_t1);
     for (hipEvent_t &ev : ctx->ev_trav) if (e == hipSuccess) e = hipEventCreate(&ev);
+    for (hipEvent_t &ev : ctx->ev_adv) if (e == hipSuccess) e = hipEventCreate(&ev);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming);
     for (int k = 0; k < rt_ctx::kSlots; ++k) if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->slot_half[k], hipEventDisableTiming);
     for (int k = 0; k < rt_ctx::kSlots; ++k) {
@@ -1162,6 +1187,7 @@ int rt_ctx_destroy(rt_ctx *ctx) {
     ctx->pathSamp.release(); ctx->pathT.release(); ctx->tidx_up.release();
     for (DevBuf *b : {&ctx->bb_idx, &ctx->bb_cnt, &ctx->bb_pa, &ctx->bb_pb, &ctx->bb_tmp, &ctx->bb_nodes_i, &ctx->bb_nodes_f, &ctx->bb_counter, &ctx->bb_lvl, &ctx->bb_size, &ctx->bb_pre, &ctx->bb_arr}) b->release();
     for (hipEvent_t &e : ctx->ev_trav) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t &e : ctx->ev_adv) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t &e : ctx->part_ev) if (e) (void)hipEventDestroy(e);
     for (hipStream_t &q : ctx->part_stream) if (q) (void)hipStreamDestroy(q);
     if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
@@ -1670,6 +1696,7 @@ int rt_get_stats(rt_ctx *ctx, rt_stats *stats) {
     ctx->stats.tonemap_ms = 0.f;
     ctx->stats.trav_ms = 0.f;
     ctx->stats.trav_launches = 0;
+    ctx->stats.adv_ms = 0.f; ctx->stats.adv_launches = 0; ctx->stats.adv_paths = 0;
     if (ctx->have_kernel_time) {
         RT_HIP(ctx, hipEventSynchronize(ctx->ev_k1));
         RT_HIP(ctx, hipEventElapsedTime(&ctx->stats.kernel_ms, ctx->ev_k0, ctx->ev_k1));
@@ -1679,6 +1706,13 @@ int rt_get_stats(rt_ctx *ctx, rt_stats *stats) {
             ctx->stats.trav_ms += ms;
         }
         ctx->stats.trav_launches = ctx->n_trav_events;
+        for (int k = 0; k < ctx->n_adv_events; ++k) {
+            float ms = 0.f;
+            RT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_adv[2 * k], ctx->ev_adv[2 * k + 1]));
+            ctx->stats.adv_ms += ms;
+        }
+        ctx->stats.adv_launches = ctx->n_adv_events;
+        ctx->stats.adv_paths = ctx->adv_paths;
     }
     if (ctx->have_tonemap_time) {
         RT_HIP(ctx, hipEventSynchronize(ctx->ev_t1));

@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libraytrace_host.so")
+LIB_PATH = os.environ.get("RT_HOST_LIB") or os.path.join(HERE, "libraytrace_host.so")   # RT_HOST_LIB: the sanitizer build (tools/sanitize_cpu.sh)
 EXPORTS = ["rth_mesh_new", "rth_mesh_free", "rth_mesh_read_obj", "rth_mesh_set_arrays", "rth_mesh_rescale",
            "rth_mesh_build_bvh", "rth_mesh_num_vertices", "rth_mesh_num_triangles", "rth_mesh_num_nodes",
            "rth_mesh_get_vertices", "rth_mesh_get_indices", "rth_mesh_get_bvh_array", "rth_write_png"]

@@ -6,6 +6,8 @@ sin / cos of the bounce direction (rt_sincos.h) gives the same binary32 products
 (tools/check_sincos.cpp) -- so every such comparison asserts exact equality of every channel.  Only frames with
 pixel jitter (sigma != 0: device logf vs glibc) are held to the 1e-4 bound with a stated identical fraction.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -100,6 +102,7 @@ def test_optimized_cu_conventions(ctx, oracle, cat_golden):
     got = ctx.render(rt.make_params(384, 384, 2, 3, **kw))
     exp, _, _ = oracle.Scene.preset("optimized", m).render(384, 384, 2, 2, eps=1e-4, tri_tmin=0.0, want_rgb8=False)
     assert linf(oracle, got, exp) <= TOL
+    assert values_equal(got[..., :3], exp[..., :3]).all()              # sigma == 0: every channel bit-identical, not merely within the bound
     np.testing.assert_array_equal(got[..., 3], exp[..., 3])
 
 
@@ -292,8 +295,8 @@ def test_work_counters_equal_oracle_counters(ctx, oracle, oracle_cat, cat_golden
 
 def test_headline_config_full_frame_against_the_oracle(ctx, oracle, oracle_cat, cat_golden):
     """BASELINE config 3 (the bench workload: cat, 1920x1080, num_rays 1, num_bounce 3 = 4 segments): the WHOLE frame
-    against the oracle -- ray count per pixel equal, colours within the stated tolerance and > 99.9 % of the channels
-    bit-identical -- and every kernel variant writes the same bits."""
+    against the oracle -- ray count per pixel equal, EVERY channel of every pixel bit-identical (sigma = 0: asserted with
+    .all(), the 1e-4 bound beside it) -- every kernel variant writes the same bits, and the work counters equal the oracle's."""
     upload(ctx, "cpu", cat_golden)
     W, H = 1920, 1080
     exp, _, cnt = oracle.Scene.preset("cpu", oracle_cat).render(W, H, 1, 3, want_rgb8=False)
@@ -423,7 +426,8 @@ def test_config5_7680x4320_eight_way_tiles_are_bitwise_the_full_frame(ctx, oracl
     import torch
     upload(ctx, "cpu", cat_golden)
     W, H = 7680, 4320
-    p = rt.make_params(W, H, 1, 1, **rt.scenes.CPU_LAUNCHER)
+    B = 3                                                               # the bench's num_bounce (config.large of bench.py), not a lighter stand-in
+    p = rt.make_params(W, H, 1, B, **rt.scenes.CPU_LAUNCHER)
     full = ctx.render(p)
     assert int(full[..., 3].astype(np.float64).sum()) > W * H
     for rank in range(8):
@@ -434,9 +438,10 @@ def test_config5_7680x4320_eight_way_tiles_are_bitwise_the_full_frame(ctx, oracl
         np.testing.assert_array_equal(buf.cpu().numpy().view(np.uint32), full[idx].view(np.uint32))
         del buf
     sc = oracle.Scene.preset("cpu", oracle_cat)
-    for a, b in ((2158, 2162), (4316, 4320)):
-        exp, _, _ = sc.render(W, H, 1, 1, rows=(a, b), want_rgb8=False)
+    for a, b in ((0, 2), (2158, 2162), (4316, 4320)):
+        exp, _, _ = sc.render(W, H, 1, B, rows=(a, b), want_rgb8=False)
         assert linf(oracle, full[a:b], exp) <= TOL
+        assert values_equal(full[a:b, :, :3], exp[..., :3]).all()      # sigma == 0: bit for bit
         np.testing.assert_array_equal(full[a:b, :, 3], exp[..., 3])
     mesh = dict(vertices=cat_golden["vertices"], indices=cat_golden["tri_bvh_order"], bvh_arr10=cat_golden["bvh_arr10"],
                 albedo=rt.scenes.CAT_ALBEDO, object_slot=6)
@@ -675,6 +680,108 @@ def test_pipelined_frames_on_one_context_equal_lone_frames(ctx, cat_golden):
     finally:
         ctx.set_pipelining(False)
     ctx.selfcheck()
+
+
+def test_pipelining_hazard_the_library_can_see(ctx, cat_golden, tmp_path):
+    """rt_ctx_set_pipelining puts an ordering rule on the caller.  The part of it the library can see it now
+    enforces: render(A), render(B), tonemap(A -> img), render(A) -- the third frame would start behind the SECOND call and so not wait for the
+    tone mapping that still reads A.  The product build takes the full fork for that frame (every image and frame stays exact); the
+    -DRT_DEBUG build refuses the call with RT_ERR_INVALID so that a test run shows the sequence breaks the rule."""
+    import subprocess
+    import sys
+    import torch
+    upload(ctx, "cpu", cat_golden)
+    W, H = 640, 360
+    st = torch.cuda.Stream()
+    rows, _ = rt.interleaved_rows(H, 8, 0, 1)
+    p0, p1 = rt.make_params(W, H, 1, 3, **rt.scenes.CPU_LAUNCHER), rt.make_params(W, H, 1, 3, seed=7, **dict(rt.scenes.CPU_LAUNCHER, sigma=0.2))
+    ref0, ref1, ref8 = ctx.render(p0), ctx.render(p1), ctx.render_rgb8(p0)
+    A, B = (torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0") for _ in range(2))
+    img = torch.zeros((H * W * 3 + 16,), dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    try:
+        ctx.set_pipelining(True)
+        for _ in range(5):                                        # the race, had it been there, is a matter of timing: a few rounds
+            ctx.render_device(p0, rows, A.data_ptr(), st.cuda_stream)
+            ctx.render_device(p0, rows, B.data_ptr(), st.cuda_stream)
+            ctx.tonemap_device(A.data_ptr(), H * W, img.data_ptr(), st.cuda_stream)
+            ctx.render_device(p1, rows, A.data_ptr(), st.cuda_stream)     # other pixels: an early start would show in img
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(img[:H * W * 3].cpu().numpy().reshape(H, W, 3), ref8)
+            np.testing.assert_array_equal(A.cpu().numpy().view(np.uint32), ref1.view(np.uint32))
+            np.testing.assert_array_equal(B.cpu().numpy().view(np.uint32), ref0.view(np.uint32))
+    finally:
+        ctx.set_pipelining(False)
+    dbg = os.path.join(os.path.dirname(rt.__file__), "libraytrace_hip_debug.so")
+    assert os.path.exists(dbg), "build() compiles the -DRT_DEBUG library"
+    script = tmp_path / "break_the_rule.py"
+    script.write_text(f"""
+import sys
+sys.path.insert(0, {os.path.dirname(os.path.dirname(rt.__file__))!r})
+import numpy as np, torch
+import raytracinggpu_amd as rt
+g = np.load(rt.scenes.CAT_FIXTURE, allow_pickle=False)
+ctx = rt.Context(0)
+ctx.scene_upload(rt.scenes.spheres("cpu"), dict(vertices=g["vertices"], indices=g["tri_bvh_order"], bvh_arr10=g["bvh_arr10"], albedo=rt.scenes.CAT_ALBEDO, object_slot=6))
+W, H = 640, 360
+st = torch.cuda.Stream()
+rows, _ = rt.interleaved_rows(H, 8, 0, 1)
+p = rt.make_params(W, H, 1, 3, **rt.scenes.CPU_LAUNCHER)
+A, B = (torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0") for _ in range(2))
+img = torch.zeros((H * W * 3 + 16,), dtype=torch.uint8, device="cuda:0")
+ctx.set_pipelining(True)
+ctx.render_device(p, rows, A.data_ptr(), st.cuda_stream)
+ctx.render_device(p, rows, B.data_ptr(), st.cuda_stream)
+ctx.tonemap_device(B.data_ptr(), H * W, img.data_ptr(), st.cuda_stream)      # reads B: fine for a frame into A
+ctx.render_device(p, rows, A.data_ptr(), st.cuda_stream)
+ctx.render_device(p, rows, B.data_ptr(), st.cuda_stream)
+ctx.tonemap_device(A.data_ptr(), H * W, img.data_ptr(), st.cuda_stream)      # reads A ...
+try:
+    ctx.render_device(p, rows, A.data_ptr(), st.cuda_stream)                 # ... which this frame would overwrite without waiting
+    print("ACCEPTED")
+except rt.RtError as e:
+    print("REFUSED", e.code, e)
+torch.cuda.synchronize()
+""")
+    r = subprocess.run([sys.executable, str(script)], env=dict(os.environ, RT_LIB=dbg), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert "REFUSED -1" in r.stdout and "pipelining rule broken" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.parametrize("mpx", ["0.05", "0.11"])
+def test_chunked_frames_equal_unchunked_frames(cat_golden, mpx):
+    """launch_render's cut into cache-sized chunks (RT_CHUNK_MPX) never ran for contiguous rows (rt_render, rt_render_rgb8,
+    rt_render_async passed one tile of H rows and the chunk unit was scaled by it).  A context created under a small RT_CHUNK_MPX renders
+    several chunks per call -- the last one shorter, so its layout differs and the chains re-join -- for contiguous rows (rt_render), for a row
+    range, and for interleaved tiles (rt_render_device); every frame bit for bit the unchunked context's."""
+    import torch
+    W, H = 400, 250
+    ps = [rt.make_params(W, H, 1, 3, **rt.scenes.CPU_LAUNCHER), rt.make_params(W, H, 2, 1, **rt.scenes.CPU_LAUNCHER)]
+    plain = rt.Context(0)
+    upload(plain, "cpu", cat_golden)
+    refs = [plain.render(p) for p in ps]
+    old = os.environ.get("RT_CHUNK_MPX")
+    os.environ["RT_CHUNK_MPX"] = mpx                                # knobs are read when the context is created
+    try:
+        c = rt.Context(0)
+    finally:
+        if old is None:
+            del os.environ["RT_CHUNK_MPX"]
+        else:
+            os.environ["RT_CHUNK_MPX"] = old
+    upload(c, "cpu", cat_golden)
+    for p, ref in zip(ps, refs):
+        np.testing.assert_array_equal(c.render(p).view(np.uint32), ref.view(np.uint32))                       # contiguous, whole frame
+        np.testing.assert_array_equal(c.render(p, 13, 241).view(np.uint32), ref[13:241].view(np.uint32))        # a row range
+        for world in (1, 3):                                                                                 # interleaved 8-row tiles
+            for rank in range(world):
+                rows, idx = rt.interleaved_rows(H, 8, rank, world)
+                buf = torch.empty((rows.n_rows, W, 4), dtype=torch.float32, device="cuda:0")
+                c.render_device(p, rows, buf.data_ptr())
+                c.synchronize()
+                np.testing.assert_array_equal(buf.cpu().numpy().view(np.uint32), ref[idx].view(np.uint32))
+    assert c.stats()["pixels"] > 0
+    c.selfcheck()
+    c.close(); plain.close()
 
 
 def test_pipelining_randomized_soak():

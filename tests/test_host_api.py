@@ -123,3 +123,13 @@ def test_shared_reciprocal_quotients_equal_the_compilers_division(tmp_path):
     r = subprocess.run([exe], stdout=subprocess.PIPE, text=True)
     assert r.returncode == 0, r.stdout
     assert r.stdout.rstrip().endswith(": 0 differ from the compiler's division"), r.stdout
+
+
+def test_cpu_sanitizer_run_is_clean():
+    """SURVEY section 5 / VERDICT round 3 item 7: the oracle's C restatement, the host library and the two exactness checkers under
+    -fsanitize=address,undefined (CPU builds; `make -C oracle asan`, tools/sanitize_cpu.sh), with the oracle-pinning and host-API tests
+    run against the instrumented libraries.  The reference itself has undefined behaviour on this path (cpu_launcher.cpp:288-292 reads
+    t_left / t_right uninitialised); the restatement must have none."""
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "sanitize_cpu.sh")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
+    assert r.returncode == 0 and "sanitize_cpu: clean" in r.stdout, r.stdout[-3000:]
+    assert "runtime error" not in r.stdout and "AddressSanitizer" not in r.stdout

@@ -7,6 +7,7 @@ the exchange; RCCL itself needs one GPU per rank and runs in bench.py on the 8-G
 """
 import os
 import socket
+import subprocess
 import sys
 
 import numpy as np
@@ -275,3 +276,101 @@ def test_bench_capi_transport_has_no_cpu_leg():
     r, line = _bench("--gpus", "2", "--renderer", "oracle", "--transport", "capi", "--width", "64", "--height", "32", "--steps", "1", "--warmup", "0", "--large-steps", "0")
     assert r.returncode != 0 and line is None
     assert "no gloo / CPU leg" in (r.stderr + r.stdout)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# Tests that wake up on a second GPU.  The build's own test box has ONE MI355X: there they are collected and
+# skipped with that reason; on a box with two or more devices they run two real RCCL ranks / two real devices with nothing stubbed.
+# ---------------------------------------------------------------------------------------------------------------------------------------
+def _n_gpus():
+    return torch.cuda.device_count()
+
+
+needs_two_gpus = pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs: this box shows %d (one-GPU boxes cover the N-rank path with --share-gpu / gloo and a one-rank communicator)" % _n_gpus())
+
+
+@pytest.mark.gpu
+@needs_two_gpus
+@pytest.mark.parametrize("transport,gather,plan", [("torch", "f32", "auto"), ("torch", "rgb8", "auto"), ("capi", "f32", "tile"), ("capi", "f32", "coalesced"), ("capi", "rgb8", "auto")])
+def test_two_real_rccl_ranks_through_bench(transport, gather, plan):
+    """`bench.py --gpus 2`: one rank per GPU over RCCL -- through torch.distributed (nccl) and through the product's own transport
+    (libraytrace_rccl.so: per-tile receives in place, and the coalesced plan with its placement kernel) -- H not a multiple of 8; the
+    gathered float4 frame is bitwise the frame one device renders alone."""
+    args = ["--gpus", "2", "--transport", transport, "--gather", gather, "--comm-plan", plan, "--width", "640", "--height", "356", "--steps", "3", "--warmup", "1", "--large-steps", "0"]
+    if gather == "f32":
+        args.append("--check-frame")
+    r, line = _bench(*args)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert line["n_gpus"] == 2 and line["config"]["ranks"] == 2 and line["value"] > 0
+    if gather == "f32":
+        assert line["config"]["frame_equals_single_device_frame"] is True
+    if transport == "capi":
+        assert line["config"]["comm_plan"] in ("tile", "coalesced") and (plan == "auto" or line["config"]["comm_plan"] == plan)
+
+
+@pytest.mark.gpu
+@needs_two_gpus
+def test_two_real_rccl_ranks_more_ranks_than_tiles():
+    """n_tiles < world: a 640x8 frame is ONE tile, rank 1 holds nothing and sends nothing; both plans."""
+    for plan in ("tile", "coalesced"):
+        r, line = _bench("--gpus", "2", "--transport", "capi", "--comm-plan", plan, "--check-frame", "--width", "640", "--height", "8", "--steps", "2", "--warmup", "1", "--large-steps", "0")
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert line["config"]["frame_equals_single_device_frame"] is True
+
+
+@pytest.mark.gpu
+@needs_two_gpus
+def test_launcher_two_processes_rccl_png_equals_the_reference_bytes(tmp_path):
+    """`rt_launcher 1 0 --tile-rank r --tile-world 2 --rccl-id FILE --device r`: two C++ processes, one per GPU, the id through a file tied to
+    the launch by its nonce, one RCCL gather of the tone-mapped tiles; rank 0's PNG == the bytes of the reference's `./cpu 1 0`."""
+    from PIL import Image
+    from .conftest import load_golden
+    cat = load_golden("cat_mesh.npz")
+    g = load_golden("ref_cpu_png_1_0.npz")
+    launcher = os.path.join(ROOT, "raytracinggpu_amd", "rt_launcher")
+    d = tmp_path / "cadnav.com_model" / "Models_F0202A090"
+    d.mkdir(parents=True)
+    with open(d / "cat.obj", "w") as f:
+        for v in cat["vertices"]:
+            f.write("v %.9g %.9g %.9g 1 1 1\r\n" % tuple(float(x) for x in v))
+        for t in cat["tri_obj_order"]:
+            f.write("f %d/1/1 %d/1/1 %d/1/1\r\n" % tuple(int(x) + 1 for x in t))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    ps = [subprocess.Popen([launcher, "1", "0", "--tile-rank", str(rk), "--tile-world", "2", "--device", str(rk), "--rccl-id", str(tmp_path / "id"),
+                            "--rccl-nonce", "two-gpu-test", "--rccl-timeout", "120", "--out", "two.png"], cwd=tmp_path, env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for rk in (1, 0)]      # rank 1 first: it waits for the id
+    try:
+        outs = [p.communicate(timeout=300) for p in ps]
+    finally:
+        for p in ps:
+            if p.poll() is None:
+                p.kill(); p.communicate()
+    for p, (so, se) in zip(ps, outs):
+        assert p.returncode == 0, se[-2000:]
+        assert "over RCCL" in se
+    assert not (tmp_path / "id").exists()
+    np.testing.assert_array_equal(np.array(Image.open(tmp_path / "two.png").convert("RGB")), g["cat"])
+
+
+@pytest.mark.gpu
+@needs_two_gpus
+def test_single_process_two_real_devices_peer_access():
+    """rt_render_multi over devices {0, 1}: the peer pushes its tiles into the root's HBM over xGMI (peer_access == 1 for device 1, -1 = not
+    needed for the root); float4 frame and RGB8 image bitwise the single-device ones, twice in a row."""
+    import raytracinggpu_amd as rt
+    from .conftest import load_golden
+    g = load_golden("cat_mesh.npz")
+    mesh = dict(vertices=g["vertices"], indices=g["tri_bvh_order"], bvh_arr10=g["bvh_arr10"], albedo=rt.scenes.CAT_ALBEDO, object_slot=6)
+    one = rt.Context(0)
+    one.scene_upload(rt.scenes.spheres("cpu"), mesh)
+    m = rt.MultiContext([0, 1])
+    m.scene_upload(rt.scenes.spheres("cpu"), mesh)
+    for W, H in ((640, 356), (1920, 1080)):
+        p = rt.make_params(W, H, 1, 3, **rt.scenes.CPU_LAUNCHER)
+        ref, ref8 = one.render(p), one.render_rgb8(p)
+        for _ in range(2):
+            np.testing.assert_array_equal(m.render(p).view(np.uint32), ref.view(np.uint32))
+            np.testing.assert_array_equal(m.render_rgb8(p), ref8)
+        st = m.stats()
+        assert st["n_devices"] == 2 and list(st["peer_access"][:2]) == [-1, 1], st
+    m.close(); one.close()

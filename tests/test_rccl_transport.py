@@ -194,7 +194,7 @@ except _rccl.CommError as e:
 def test_two_ranks_on_one_device_are_refused_not_hung(tmp_path):
     """RCCL does not let two ranks of a communicator share a device: rt_comm_create reports RT_COMM_ERR_RCCL on both (and returns)."""
     if rt.device_count() > 1:
-        pytest.skip("more than one GPU: use them instead")
+        pytest.skip("more than one GPU: RCCL accepts the ranks on distinct devices -- tests/test_multi_rank.py::test_two_real_rccl_ranks_* run them")
     script = tmp_path / "two.py"
     script.write_text(_TWO_RANKS % {"root": ROOT})
     ps = [subprocess.Popen([sys.executable, str(script), str(r), str(tmp_path / "id")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]

@@ -8,7 +8,7 @@ for spec in "$@"; do
   envs=""; args=""
   for w in $spec; do case $w in *=*) envs="$envs $w";; *) args="$args $w";; esac; done
   echo "== $spec" >> gpurun_out/ab_$tag.log
-  env $envs timeout -k 10 240 python3 bench.py --no-cpu-baseline --steps ${STEPS:-20} --warmup 3 $args >> gpurun_out/ab_$tag.log 2>> gpurun_out/ab_$tag.err || { echo "FAILED: $spec" >> gpurun_out/ab_$tag.log; tail -3 gpurun_out/ab_$tag.err; echo "stopping after the first failure"; exit 1; }
+  env $envs timeout -k 10 240 python3 bench.py --no-cpu-baseline --no-end-to-end --steps ${STEPS:-20} --warmup 3 $args >> gpurun_out/ab_$tag.log 2>> gpurun_out/ab_$tag.err || { echo "FAILED: $spec" >> gpurun_out/ab_$tag.log; tail -3 gpurun_out/ab_$tag.err; echo "stopping after the first failure"; exit 1; }
 done
 done
 python3 - <<PY
