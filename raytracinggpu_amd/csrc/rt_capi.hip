@@ -98,7 +98,7 @@ static Knobs read_knobs() {
     if (geti("RT_ASYNC_PIPELINE", v)) k.async_pipeline = v != 0;
     if (geti("RT_COPY_PRIO", v)) k.copy_prio = v;
     if (geti("RT_ADV_BLOCK", v) && (v == 64 || v == 128 || v == 256)) k.adv_block = v;
-    if (geti("RT_TRAVQ_TOPLDS", v) && v >= 0 && v <= 1024) k.top_lds = v & ~1;
+    if (geti("RT_TRAVQ_TOPLDS", v) && v >= 0 && v <= 4096) k.top_lds = v & ~1;
     if (geti("RT_PATH_SAMP_MB", v) && v >= 1) k.path_samp_bytes = (long long)v << 20;
 #ifdef RT_DEBUG
     if (geti("RT_DEBUG_TRAV", v)) k.debug_trav = v;
@@ -589,13 +589,14 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
             qW = (int)std::min<int64_t>(qW, budget / carve);
             const int64_t room = budget - (int64_t)qW * carve;
             q_nlds = ldsn_q ? (int)(std::min<int64_t>(room / 32, ctx->scene.n_nodes + 1) & ~(int64_t)1) : 0;   // even: sibling pairs stay together
-            if (q_nlds <= 0 && !ldsv) { qW = 0; q_nlds = 0; }        // not even the root's children fit: plain kernel
+            if (q_nlds < 4) { q_nlds = 0; if (!ldsv) qW = 0; }       // not even the root's children (nodes 2, 3: the pair every ray starts with) fit, or the root is a leaf: plain kernel
         } else {
             qW = 0;
         }
         const bool qlds = queue && qW > 0;                            // ONE workgroup of qW waves per CU
         // RT_TRAVQ_TOPLDS: the ordinary launch (4-wave workgroups, 4 per CU) with the first levels of the tree staged per workgroup
         if (queue && !qlds && mesh_here && kn.top_lds > 0) q_nlds = std::min(kn.top_lds, (ctx->scene.n_nodes + 1) & ~1);
+        if (!qlds && q_nlds < 4) q_nlds = 0;                          // (the same for the per-workgroup staging)
         const bool qtop = queue && !qlds && q_nlds > 0;
         const bool qldsn = (qlds || qtop) && q_nlds > 0;
         const int q_low = kn.q_low;                                   // refill thresholds of the work-stack kernel (stack entries are sibling pairs)

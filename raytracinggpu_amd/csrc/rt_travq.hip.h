@@ -571,6 +571,33 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
             asm volatile("" :: "v"(x0), "v"(x1), "v"(x2), "v"(x3));
         }
 #endif
+#if defined(RT_DEBUG) && defined(RT_PAD_VMEM_N)   // what a vector load costs: N extra loads of W dwords each (RT_PAD_VMEM_N x RT_PAD_VMEM_W), same lines as the step's own
+        {
+            const unsigned char *pp = nodes + off_[0];
+            typedef float pad_v4f __attribute__((ext_vector_type(4)));
+#if RT_PAD_VMEM_W == 4
+#define RT_PAD_LD "global_load_dwordx4"
+            pad_v4f x0, x1, x2, x3;
+#elif RT_PAD_VMEM_W == 2
+#define RT_PAD_LD "global_load_dwordx2"
+            typedef float pad_v2f __attribute__((ext_vector_type(2)));
+            pad_v2f x0, x1, x2, x3;
+#else
+#define RT_PAD_LD "global_load_dword"
+            float x0, x1, x2, x3;
+#endif
+            asm volatile(RT_PAD_LD " %0, %1, off" : "=&v"(x0) : "v"(pp) : "memory");
+            if (RT_PAD_VMEM_N >= 2) asm volatile(RT_PAD_LD " %0, %1, off offset:16" : "=&v"(x1) : "v"(pp) : "memory");
+            if (RT_PAD_VMEM_N >= 3) asm volatile(RT_PAD_LD " %0, %1, off offset:32" : "=&v"(x2) : "v"(pp) : "memory");
+            if (RT_PAD_VMEM_N >= 4) asm volatile(RT_PAD_LD " %0, %1, off offset:48" : "=&v"(x3) : "v"(pp) : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("" :: "v"(x0));
+            if (RT_PAD_VMEM_N >= 2) asm volatile("" :: "v"(x1));
+            if (RT_PAD_VMEM_N >= 3) asm volatile("" :: "v"(x2));
+            if (RT_PAD_VMEM_N >= 4) asm volatile("" :: "v"(x3));
+#undef RT_PAD_LD
+        }
+#endif
 #if defined(RT_DEBUG) && defined(RT_PAD_VMEM2)    // ... the same pair from the OTHER breadth-first copy (lo / hi form): four more loads to lines the step does not otherwise touch
         {
             const unsigned char *pp = reinterpret_cast<const unsigned char *>(sc.nodesq) + off_[0];
