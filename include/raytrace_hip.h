@@ -292,7 +292,31 @@ int rt_mesh_transform(rt_ctx *ctx, const float rotation[9], const float translat
  *     follows (RT_ERR_HIP: out of device memory) leaves the context WITHOUT a scene (RT_ERR_NO_SCENE from the render calls):
  *     upload again.  Cost model: one workgroup per node and one blocking read-back per level, so the top levels of a mesh far
  *     larger than the cat's 3 954 triangles run on a single CU each (the build is a step before the hot path, not part of it). */
-int rt_mesh_rebuild(rt_ctx *ctx, float *bvh_arr10_out, int32_t *tri_order_out, int32_t *n_nodes_out);
+int rt_mesh_rebuild(rt_ctx *ctx, float *bvh_arr10_out, int32_t *tri_order_out, int32_t *n_nodes_out);   /* = rt_mesh_rebuild_mode(RT_BVH_REFERENCE) */
+
+/* --- ... or a DIFFERENT, better tree, built in parallel (SURVEY 8f3 "and a GPU LBVH build"; opt-in, RT_BVH_REFERENCE stays the default
+ *     everywhere).  The reference's stop rule (cpu_launcher.cpp:217) leaves leaves that grow with the mesh -- 2 M triangles: 357 triangle
+ *     tests per ray -- and its device builder is ONE thread (global_launcher.cu:298-331, :848-881).  RT_BVH_LBVH: Morton codes of the
+ *     triangle centroids (63 bits), radix sort, the binary radix tree over the sorted codes with one thread per node (Karras 2012),
+ *     boxes bottom-up by min / max of the vertex coordinates (the values compute_bbox, cpu:180-188, folds for the node's range), and for
+ *     every node the surface-area heuristic's choice between ONE leaf (at most 32 triangles) and its subtree -- the reference's traversal
+ *     never prunes by distance, so a ray pays for every box it pierces and every triangle of every leaf it enters: the cost the SAH models.  Same outputs in the same formats -- the flat `float[10]` tree of bvhTreeToArray and the order the
+ *     triangles are left in -- so every kernel variant runs on it unchanged and a CPU checker can be handed the very same tree
+ *     (oracle: or_mesh_set_bvh).  What changes against the reference tree: WHICH triangles a ray tests (far fewer), never what a
+ *     test returns; the image differs from the reference tree's only where two triangles are hit at bit-equal t (shared edges: the
+ *     scan order breaks the tie, cpu:301 / SURVEY H5).  A mesh of at most four triangles is a single leaf in either mode (the reference builder runs).
+ *     rt_mesh_build_stats: what the last rebuild did (device_build_ms = the builder's kernels, HIP events; install_ms = the
+ *     re-layout for the render kernels that follows, host side). */
+typedef enum rt_bvh_mode { RT_BVH_REFERENCE = 0, RT_BVH_LBVH = 1 } rt_bvh_mode;
+typedef struct rt_build_stats {
+    int32_t mode;                  /* the mode that ran                                        */
+    int32_t n_triangles, n_nodes;
+    int32_t n_leaves, max_leaf_tris, max_depth;   /* RT_BVH_LBVH only (0 otherwise)            */
+    float   device_build_ms;       /* builder kernels + sort, HIP events on the context's stream */
+    float   install_ms;            /* read-back + re-layout + upload of the kernels' formats    */
+} rt_build_stats;
+int rt_mesh_rebuild_mode(rt_ctx *ctx, int mode, float *bvh_arr10_out, int32_t *tri_order_out, int32_t *n_nodes_out);
+int rt_mesh_build_stats(const rt_ctx *ctx, rt_build_stats *out);
 
 /* --- smooth (interpolated) normals: get_smooth_normal of realtime_render.cu:221-245 / global_launcher.cu:207-231
  *     -- beta, gamma by the literal divisions, alpha = 1 - beta - gamma, N = normalize(alpha Na + beta Nb + gamma Nc) --

@@ -56,6 +56,7 @@ def lib():
     L.or_mesh_set_arrays.argtypes = [vp, fp, C.c_int, C.POINTER(C.c_int32), C.c_int]
     L.or_mesh_rescale.argtypes = [vp, C.c_float, fp]
     L.or_mesh_build_bvh.argtypes = [vp]
+    L.or_mesh_set_bvh.argtypes = [vp, fp, C.c_int, C.POINTER(C.c_int32)]
     L.or_mesh_set_normals.argtypes = [vp, fp, C.c_int, C.POINTER(C.c_int32)]
     L.or_mesh_transform.argtypes = [vp, fp, fp]
     L.or_mesh_refit.argtypes = [vp]
@@ -134,6 +135,16 @@ class Mesh:
 
     def build_bvh(self):
         lib().or_mesh_build_bvh(self.h)
+        return self
+
+    def set_bvh(self, arr10, order=None):
+        """A caller-supplied tree (flat bvhTreeToArray layout, node 0 = root) and the triangle order its ranges refer to (order[k] = current
+        index of the triangle that moves to position k): what rt_mesh_rebuild_mode returns, so that the traversal here walks the SAME tree."""
+        a = np.ascontiguousarray(arr10, np.float32).reshape(-1, 10)
+        o = None if order is None else np.ascontiguousarray(order, np.int32)
+        rc = lib().or_mesh_set_bvh(self.h, a.ctypes.data_as(C.POINTER(C.c_float)), len(a), None if o is None else o.ctypes.data_as(C.POINTER(C.c_int32)))
+        if rc != 0:
+            raise ValueError("or_mesh_set_bvh: malformed tree or order")
         return self
 
     def set_normals(self, normals, nidx):

@@ -343,6 +343,52 @@ void or_mesh_build_bvh(or_mesh *m) {
     build_bvh(m, m->bvh, 0, m->nt, 0);                              /* cpu:684 */
 }
 
+/* A caller-supplied tree (test infrastructure for SURVEY 8f3's LBVH: parity is "HIP == oracle ON THE SAME TREE").  arr10 is the flat layout
+ * of bvhTreeToArray (optimized.cu:512-534): per node [left, right, mn.xyz, mx.xyz, triangle_start, triangle_end), -1 = no child, node 0 the
+ * root, any numbering; order[k] = index (in the CURRENT triangle array) of the triangle that moves to position k -- the ranges refer to the
+ * new positions, as the reference's ranges refer to `indices` after its in-place partition.  The traversal (mesh_intersect) is unchanged:
+ * it walks whatever tree hangs off m->bvh.  Returns 0, or -1 for a malformed tree (nothing is changed then). */
+static bvh_node *bvh_from_array(const float *arr, int n_nodes, int idx, int depth, int *count, int *maxd, int nt, int *ok) {
+    if (idx < 0 || idx >= n_nodes || *count >= n_nodes || depth > 4096) { *ok = 0; return NULL; }
+    const float *a = arr + (size_t)idx * 10;
+    bvh_node *n = (bvh_node *)calloc(1, sizeof(bvh_node));
+    (*count)++;
+    if (depth > *maxd) *maxd = depth;
+    n->bb.mn = V(a[2], a[3], a[4]); n->bb.mx = V(a[5], a[6], a[7]);
+    n->triangle_start = (int)a[8]; n->triangle_end = (int)a[9];
+    if (n->triangle_start < 0 || n->triangle_end < n->triangle_start || n->triangle_end > nt) *ok = 0;
+    const int l = (int)a[0], r = (int)a[1];
+    if ((l < 0) != (r < 0)) *ok = 0;
+    if (l >= 0 && r >= 0 && *ok) {
+        n->left = bvh_from_array(arr, n_nodes, l, depth + 1, count, maxd, nt, ok);
+        n->right = bvh_from_array(arr, n_nodes, r, depth + 1, count, maxd, nt, ok);
+    }
+    return n;
+}
+int or_mesh_set_bvh(or_mesh *m, const float *arr10, int n_nodes, const int32_t *order) {
+    if (!m || !arr10 || n_nodes < 1) return -1;
+    if (order) {
+        char *seen = (char *)calloc((size_t)(m->nt > 0 ? m->nt : 1), 1);
+        for (int k = 0; k < m->nt; k++) {
+            if (order[k] < 0 || order[k] >= m->nt || seen[order[k]]) { free(seen); return -1; }   /* a permutation, nothing else */
+            seen[order[k]] = 1;
+        }
+        free(seen);
+    }
+    int count = 0, maxd = 0, ok = 1;
+    bvh_node *root = bvh_from_array(arr10, n_nodes, 0, 0, &count, &maxd, m->nt, &ok);
+    if (!ok || count != n_nodes) { bvh_free(root); return -1; }
+    if (order) {
+        tri_idx *nw = (tri_idx *)malloc(sizeof(tri_idx) * (size_t)(m->nt > 0 ? m->nt : 1));
+        for (int k = 0; k < m->nt; k++) nw[k] = m->indices[order[k]];
+        memcpy(m->indices, nw, sizeof(tri_idx) * (size_t)m->nt);
+        free(nw);
+    }
+    bvh_free(m->bvh);
+    m->bvh = root; m->n_nodes = n_nodes; m->max_depth = maxd;
+    return 0;
+}
+
 int or_mesh_num_vertices(const or_mesh *m) { return m->nv; }
 int or_mesh_num_triangles(const or_mesh *m) { return m->nt; }
 int or_mesh_num_nodes(const or_mesh *m) { return m->n_nodes; }

@@ -82,6 +82,9 @@ void     or_mesh_transform(or_mesh *m, const float rotation[9], const float tran
 void     or_mesh_refit(or_mesh *m);
 /* buildBVH(&bvh, 0, indices.size()) (cpu:190-224) */
 void     or_mesh_build_bvh(or_mesh *m);
+/* a caller-supplied tree in the flat layout of bvhTreeToArray (10 floats per node, node 0 = root) + the triangle order its ranges refer to
+ * (order[k] = current index of the triangle that moves to position k; NULL = keep): the traversal then walks THAT tree.  0 / -1 (malformed) */
+int      or_mesh_set_bvh(or_mesh *m, const float *arr10, int n_nodes, const int32_t *order);
 int      or_mesh_num_vertices(const or_mesh *m);
 int      or_mesh_num_triangles(const or_mesh *m);
 int      or_mesh_num_nodes(const or_mesh *m);

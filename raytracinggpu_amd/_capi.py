@@ -25,7 +25,7 @@ EXPORTS = ["rt_abi_version", "rt_device_count", "rt_ctx_create", "rt_ctx_destroy
            "rt_progressive_frames",
            "rt_multi_create", "rt_multi_destroy", "rt_multi_last_error", "rt_multi_scene_upload", "rt_render_multi",
            "rt_render_multi_device", "rt_render_multi_rgb8", "rt_multi_get_stats",
-           "rt_stats_enable", "rt_ctx_set_pipelining", "rt_render_async", "rt_wait", "rt_trace_rays", "rt_mesh_rebuild", "rt_host_alloc", "rt_host_free", "rt_device_alloc", "rt_device_free", "rt_device_to_host", "rt_kat_sphere", "rt_kat_box", "rt_kat_triangle", "rt_kat_mesh"]
+           "rt_stats_enable", "rt_ctx_set_pipelining", "rt_render_async", "rt_wait", "rt_trace_rays", "rt_mesh_rebuild", "rt_mesh_rebuild_mode", "rt_mesh_build_stats", "rt_host_alloc", "rt_host_free", "rt_device_alloc", "rt_device_free", "rt_device_to_host", "rt_kat_sphere", "rt_kat_box", "rt_kat_triangle", "rt_kat_mesh"]
 MAX_DEVICES = 16
 
 
@@ -75,6 +75,14 @@ class Stats(C.Structure):
                 ("lds_bytes", C.c_int32), ("block_threads", C.c_int32), ("grid_blocks", C.c_int32),
                 ("trav_ms", C.c_float), ("trav_launches", C.c_int32), ("parts", C.c_int32), ("adv_launches", C.c_int32),
                 ("adv_ms", C.c_float), ("adv_paths", C.c_int32)]
+
+
+class BuildStats(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("n_triangles", C.c_int32), ("n_nodes", C.c_int32), ("n_leaves", C.c_int32), ("max_leaf_tris", C.c_int32),
+                ("max_depth", C.c_int32), ("device_build_ms", C.c_float), ("install_ms", C.c_float)]
+
+
+BVH_MODES = {"reference": 0, "lbvh": 1}
 
 
 class KatCounts(C.Structure):
@@ -168,6 +176,8 @@ def load():
     L.rt_render_multi_rgb8.argtypes = [vp, C.POINTER(Params), C.POINTER(C.c_uint8)]
     L.rt_multi_get_stats.argtypes = [vp, C.POINTER(MultiStats)]
     L.rt_mesh_rebuild.argtypes = [vp, fp3, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.rt_mesh_rebuild_mode.argtypes = [vp, C.c_int, fp3, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.rt_mesh_build_stats.argtypes = [vp, C.POINTER(BuildStats)]
     L.rt_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
     L.rt_host_free.argtypes = [vp]
     L.rt_kat_sphere.argtypes = [vp, fp3, C.c_int, fp3]
@@ -383,13 +393,19 @@ class Context:
         t = np.ascontiguousarray(translation, np.float32).reshape(3)
         self._check(self._L.rt_mesh_transform(self._h, r.ctypes.data_as(C.POINTER(C.c_float)), t.ctypes.data_as(C.POINTER(C.c_float))))
 
-    def mesh_rebuild(self, n_triangles):
-        """Device-side buildBVH over the uploaded triangles and the current device vertices -> (bvh_arr10 [n_nodes, 10], order [n_triangles])."""
+    def mesh_rebuild(self, n_triangles, mode="reference"):
+        """Device-side BVH build over the uploaded triangles and the current device vertices -> (bvh_arr10 [n_nodes, 10], order [n_triangles]).
+        mode "reference": TriangleMesh::buildBVH bit for bit; "lbvh": Morton sort + parallel hierarchy, leaves of at most four triangles."""
         arr = np.zeros(((2 * n_triangles + 2), 10), np.float32)
         order = np.zeros(n_triangles, np.int32)
         n = C.c_int32(0)
-        self._check(self._L.rt_mesh_rebuild(self._h, arr.ctypes.data_as(C.POINTER(C.c_float)), order.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(n)))
+        self._check(self._L.rt_mesh_rebuild_mode(self._h, BVH_MODES[mode], arr.ctypes.data_as(C.POINTER(C.c_float)), order.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(n)))
         return arr[:n.value].copy(), order
+
+    def build_stats(self):
+        s = BuildStats()
+        self._check(self._L.rt_mesh_build_stats(self._h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in BuildStats._fields_}
 
     def mesh_set_normals(self, normals, nidx):
         """Smooth shading: vertex normals + per-triangle (ni, nj, nk) rows in the order of the uploaded indices; None = flat."""

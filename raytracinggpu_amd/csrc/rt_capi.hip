@@ -9,6 +9,7 @@
 #include "rt_path.hip.h"
 #include "rt_meshops.hip.h"
 #include "rt_bvhbuild.hip.h"
+#include "rt_lbvh.hip.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -120,6 +121,8 @@ struct rt_ctx {
     DevBuf tidx_up;                                                  // the same on the device (int4 per triangle)
     DevBuf bb_idx, bb_cnt, bb_pa, bb_pb, bb_tmp, bb_nodes_i, bb_nodes_f, bb_counter, bb_lvl, bb_size, bb_pre, bb_arr;   // device BVH build scratch
     DevBuf left_dev, lvl_nodes, lvl_off;                             // tree topology for the device-side refit
+    DevBuf lb_pool;                                                  // LBVH builder scratch (rt_lbvh.hip.h), one carved pool
+    rt_build_stats build{};                                          // what the last rt_mesh_rebuild_mode did
     int n_levels = 0;
     DevBuf node_lo, node_hi, nodes2, nodesq, nodesb, q2thr, tri, verts, tidx, scratch_rgba, scratch_rgb8, work, queue;
     int n_cus = 0;
@@ -1186,7 +1189,7 @@ int rt_ctx_destroy(rt_ctx *ctx) {
     ctx->wfM.release(); ctx->wfPR.release(); ctx->wfT.release(); ctx->wfLS.release(); ctx->wfSID.release(); ctx->wfSamp.release();
     ctx->wfQR.release(); ctx->accum.release(); ctx->dbgbuf.release();
     ctx->pathSamp.release(); ctx->pathT.release(); ctx->tidx_up.release();
-    for (DevBuf *b : {&ctx->bb_idx, &ctx->bb_cnt, &ctx->bb_pa, &ctx->bb_pb, &ctx->bb_tmp, &ctx->bb_nodes_i, &ctx->bb_nodes_f, &ctx->bb_counter, &ctx->bb_lvl, &ctx->bb_size, &ctx->bb_pre, &ctx->bb_arr}) b->release();
+    for (DevBuf *b : {&ctx->bb_idx, &ctx->bb_cnt, &ctx->bb_pa, &ctx->bb_pb, &ctx->bb_tmp, &ctx->bb_nodes_i, &ctx->bb_nodes_f, &ctx->bb_counter, &ctx->bb_lvl, &ctx->bb_size, &ctx->bb_pre, &ctx->bb_arr, &ctx->lb_pool}) b->release();
     for (hipEvent_t &e : ctx->ev_trav) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t &e : ctx->ev_adv) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t &e : ctx->part_ev) if (e) (void)hipEventDestroy(e);
@@ -1451,14 +1454,8 @@ int rt_mesh_transform(rt_ctx *ctx, const float rotation[9], const float translat
     return RT_OK;
 }
 
-int rt_mesh_rebuild(rt_ctx *ctx, float *bvh_arr10_out, int32_t *tri_order_out, int32_t *n_nodes_out) {
-    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
-    RT_OWN_STREAM(ctx);
-    if (!ctx->have_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_scene_upload has not been called");
-    if (n_nodes_out) *n_nodes_out = 0;
-    const rtk::Scene old = ctx->scene;
-    const int nt = ctx->n_up_tris, nv = old.n_verts;
-    if (old.mesh_slot < 0 || nt <= 0 || nv <= 0) return RT_OK;                     // no mesh: nothing to build
+// TriangleMesh::buildBVH on the device, bit for bit (rt_bvhbuild.hip.h): leaves the flat tree in ctx->bb_arr and the triangle order in ctx->bb_idx
+static int rebuild_reference_tree(rt_ctx *ctx, const int nt, int &n_nodes_out) {
     RT_HIP(ctx, hipSetDevice(ctx->device));
     const size_t cap = 2 * (size_t)nt + 2;                                          // nodes: every split makes two
     int rc;
@@ -1501,18 +1498,126 @@ int rt_mesh_rebuild(rt_ctx *ctx, float *bvh_arr10_out, int32_t *tri_order_out, i
         count = total - first;
     }
     const int n_nodes = first, n_levels = (int)lvl_first.size() - 1;
+    n_nodes_out = n_nodes;
     if (n_nodes >= (1 << 24)) return fail(ctx, RT_ERR_INVALID, "node indices are stored as floats: < 2^24 nodes");
     RT_HIP(ctx, hipMemcpyAsync(ctx->bb_lvl.p, lvl_first.data(), lvl_first.size() * sizeof(int), hipMemcpyHostToDevice, q));
     hipLaunchKernelGGL(rtk::bvh_flatten_kernel, dim3(1), dim3(1024), 0, q, a, static_cast<const int *>(ctx->bb_lvl.p), n_levels,
                        static_cast<int *>(ctx->bb_size.p), static_cast<int *>(ctx->bb_pre.p), static_cast<float *>(ctx->bb_arr.p));
     RT_HIP(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+// The LBVH builder (rt_lbvh.hip.h): Morton sort + parallel hierarchy emission, leaves of up to four triangles; same outputs
+static int rebuild_lbvh_tree(rt_ctx *ctx, const int nt, int &n_nodes_out) {
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t q = own_stream(ctx);
+    const size_t n = (size_t)nt, nc = 2 * n - 1;
+    int rc;
+    DevBuf &B = ctx->lb_pool;
+    // one pool, carved: keys (2 x 8n), vals (2 x 4n), 6 int arrays of n, flags, boxes (4 x 16n), alive + index (2 x 4 (2n)), bounds / stats
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    const size_t o_keys = carve(8 * n), o_keys2 = carve(8 * n), o_vals = carve(4 * n), o_vals2 = carve(4 * n);
+    const size_t o_left = carve(4 * n), o_right = carve(4 * n), o_parent = carve(4 * n), o_first = carve(4 * n), o_last = carve(4 * n), o_lparent = carve(4 * n), o_flag = carve(4 * n), o_cost = carve(4 * n), o_leafify = carve(4 * n);
+    const size_t o_ilo = carve(16 * n), o_ihi = carve(16 * n), o_llo = carve(16 * n), o_lhi = carve(16 * n);
+    const size_t o_alive = carve(4 * nc), o_index = carve(4 * nc), o_small = carve(64);
+    size_t sort_tmp = 0, scan_tmp = 0;
+    {
+        unsigned long long *k0 = nullptr; int *v0 = nullptr;
+        if (rocprim::radix_sort_pairs(nullptr, sort_tmp, k0, k0, v0, v0, n, 0, 63, q) != hipSuccess) return fail(ctx, RT_ERR_HIP, "rocprim::radix_sort_pairs (size query) failed");
+        if (rocprim::exclusive_scan(nullptr, scan_tmp, v0, v0, 0, nc, rocprim::plus<int>(), q) != hipSuccess) return fail(ctx, RT_ERR_HIP, "rocprim::exclusive_scan (size query) failed");
+    }
+    const size_t o_tmp = carve(std::max(sort_tmp, scan_tmp) + 256);
+    if ((rc = ensure(ctx, B, off)) != RT_OK) return rc;
+    if ((rc = ensure(ctx, ctx->bb_idx, n * sizeof(int))) != RT_OK) return rc;
+    uint8_t *base = static_cast<uint8_t *>(B.p);
+    rtk::LbvhArgs a{};
+    a.verts = static_cast<const float4 *>(ctx->verts.p); a.tidx_up = static_cast<const int4 *>(ctx->tidx_up.p); a.n = nt;
+    a.bounds = reinterpret_cast<unsigned int *>(base + o_small); a.stats = reinterpret_cast<int *>(base + o_small + 32);
+    a.keys = reinterpret_cast<unsigned long long *>(base + o_keys); a.vals = reinterpret_cast<int *>(base + o_vals);
+    a.left = reinterpret_cast<int *>(base + o_left); a.right = reinterpret_cast<int *>(base + o_right); a.parent = reinterpret_cast<int *>(base + o_parent);
+    a.first = reinterpret_cast<int *>(base + o_first); a.last = reinterpret_cast<int *>(base + o_last); a.leaf_parent = reinterpret_cast<int *>(base + o_lparent);
+    a.flag = reinterpret_cast<int *>(base + o_flag);
+    a.cost = reinterpret_cast<float *>(base + o_cost); a.leafify = reinterpret_cast<int *>(base + o_leafify);
+    a.ibox_lo = reinterpret_cast<float4 *>(base + o_ilo); a.ibox_hi = reinterpret_cast<float4 *>(base + o_ihi);
+    a.lbox_lo = reinterpret_cast<float4 *>(base + o_llo); a.lbox_hi = reinterpret_cast<float4 *>(base + o_lhi);
+    a.alive = reinterpret_cast<int *>(base + o_alive); a.index = reinterpret_cast<int *>(base + o_index);
+    const unsigned int binit[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
+    int zero4[4] = {0, 0, 0, 0};
+    RT_HIP(ctx, hipMemcpyAsync(a.bounds, binit, sizeof(binit), hipMemcpyHostToDevice, q));
+    RT_HIP(ctx, hipMemcpyAsync(a.stats, zero4, sizeof(zero4), hipMemcpyHostToDevice, q));
+    RT_HIP(ctx, hipStreamSynchronize(q));                                        // (the two sources live on this stack frame)
+    const dim3 gt((unsigned)((n + 255) / 256)), gc((unsigned)((nc + 255) / 256)), blk(256);
+    hipLaunchKernelGGL(rtk::lbvh_bounds_kernel, gt, blk, 0, q, a);
+    hipLaunchKernelGGL(rtk::lbvh_morton_kernel, gt, blk, 0, q, a);
+    {   // (code, triangle) pairs by code; the sorted arrays become a.keys / a.vals
+        unsigned long long *k2 = reinterpret_cast<unsigned long long *>(base + o_keys2);
+        int *v2 = reinterpret_cast<int *>(base + o_vals2);
+        size_t tmp = sort_tmp;
+        if (rocprim::radix_sort_pairs(base + o_tmp, tmp, a.keys, k2, a.vals, v2, n, 0, 63, q) != hipSuccess) return fail(ctx, RT_ERR_HIP, "rocprim::radix_sort_pairs failed");
+        a.keys = k2; a.vals = v2;
+    }
+    hipLaunchKernelGGL(rtk::lbvh_hierarchy_kernel, gt, blk, 0, q, a);
+    hipLaunchKernelGGL(rtk::lbvh_boxes_kernel, gt, blk, 0, q, a);          // boxes + the leaf-or-subtree decision, bottom-up
+    hipLaunchKernelGGL(rtk::lbvh_alive_kernel, gc, blk, 0, q, a);
+    {
+        size_t tmp = scan_tmp;
+        if (rocprim::exclusive_scan(base + o_tmp, tmp, a.alive, a.index, 0, nc, rocprim::plus<int>(), q) != hipSuccess) return fail(ctx, RT_ERR_HIP, "rocprim::exclusive_scan failed");
+    }
+    RT_HIP(ctx, hipGetLastError());
+    int last2[2] = {0, 0};                                                       // n_alive = index[last] + alive[last]
+    RT_HIP(ctx, hipMemcpyAsync(&last2[0], a.index + (nc - 1), sizeof(int), hipMemcpyDeviceToHost, q));
+    RT_HIP(ctx, hipMemcpyAsync(&last2[1], a.alive + (nc - 1), sizeof(int), hipMemcpyDeviceToHost, q));
+    RT_HIP(ctx, hipStreamSynchronize(q));
+    const int n_nodes = last2[0] + last2[1];
+    if (n_nodes < 1 || (size_t)n_nodes > nc) return fail(ctx, RT_ERR_INTERNAL, "LBVH build: %d nodes for %d triangles (scene unchanged)", n_nodes, nt);
+    if (n_nodes >= (1 << 24)) return fail(ctx, RT_ERR_INVALID, "node indices are stored as floats: < 2^24 nodes");
+    if ((rc = ensure(ctx, ctx->bb_arr, (size_t)n_nodes * 10 * sizeof(float))) != RT_OK) return rc;
+    a.arr10 = static_cast<float *>(ctx->bb_arr.p);
+    hipLaunchKernelGGL(rtk::lbvh_emit_kernel, gc, blk, 0, q, a);
+    RT_HIP(ctx, hipGetLastError());
+    RT_HIP(ctx, hipMemcpyAsync(ctx->bb_idx.p, a.vals, n * sizeof(int), hipMemcpyDeviceToDevice, q));   // the triangle order, where the shared tail expects it
+    int st[4] = {0, 0, 0, 0};
+    RT_HIP(ctx, hipMemcpyAsync(st, a.stats, sizeof(st), hipMemcpyDeviceToHost, q));
+    RT_HIP(ctx, hipStreamSynchronize(q));
+    ctx->build.n_leaves = st[0]; ctx->build.max_leaf_tris = st[1]; ctx->build.max_depth = st[2];
+    n_nodes_out = n_nodes;
+    return RT_OK;
+}
+
+int rt_mesh_rebuild_mode(rt_ctx *ctx, int mode, float *bvh_arr10_out, int32_t *tri_order_out, int32_t *n_nodes_out) {
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    RT_OWN_STREAM(ctx);
+    if (mode != RT_BVH_REFERENCE && mode != RT_BVH_LBVH) return fail(ctx, RT_ERR_INVALID, "unknown BVH mode %d", mode);
+    if (!ctx->have_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_scene_upload has not been called");
+    if (n_nodes_out) *n_nodes_out = 0;
+    const rtk::Scene old = ctx->scene;
+    const int nt = ctx->n_up_tris, nv = old.n_verts;
+    if (old.mesh_slot < 0 || nt <= 0 || nv <= 0) return RT_OK;                     // no mesh: nothing to build
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t q = own_stream(ctx);
+    int rc;
+    int n_nodes = 0;
+    ctx->build = rt_build_stats{};
+    hipEvent_t e0 = ctx->ev_t0, e1 = ctx->ev_t1;                                    // (the tone-mapping events are free here: nothing else runs on the stream)
+    RT_HIP(ctx, hipEventRecord(e0, q));
+    // a mesh of a single leaf's worth of triangles is a single leaf in either mode (cpu:217: fewer than five triangles are never split)
+    if (mode == RT_BVH_LBVH && nt > 4) rc = rebuild_lbvh_tree(ctx, nt, n_nodes);
+    else { mode = RT_BVH_REFERENCE; rc = rebuild_reference_tree(ctx, nt, n_nodes); }
+    if (rc != RT_OK) return rc;
+    RT_HIP(ctx, hipEventRecord(e1, q));
+    RT_HIP(ctx, hipEventSynchronize(e1));
+    RT_HIP(ctx, hipEventElapsedTime(&ctx->build.device_build_ms, e0, e1));
+    ctx->build.mode = mode; ctx->build.n_nodes = n_nodes; ctx->build.n_triangles = nt;
+    const auto t_install = std::chrono::steady_clock::now();
+    int *const order_dev = static_cast<int *>(ctx->bb_idx.p);
     // The tree is built.  The O(n) re-layout for the kernels (traversal order, visit-order triangle records, sibling pairs, refit
     // levels) reuses the upload path on the host: ~30 bytes per triangle over PCIe each way.
     std::vector<float> arr((size_t)n_nodes * 10);
     std::vector<int> order(nt);
     std::vector<float4> hv(nv);
     RT_HIP(ctx, hipMemcpyAsync(arr.data(), ctx->bb_arr.p, arr.size() * sizeof(float), hipMemcpyDeviceToHost, q));
-    RT_HIP(ctx, hipMemcpyAsync(order.data(), a.idx, order.size() * sizeof(int), hipMemcpyDeviceToHost, q));
+    RT_HIP(ctx, hipMemcpyAsync(order.data(), order_dev, order.size() * sizeof(int), hipMemcpyDeviceToHost, q));
     RT_HIP(ctx, hipMemcpyAsync(hv.data(), ctx->verts.p, hv.size() * sizeof(float4), hipMemcpyDeviceToHost, q));
     std::vector<float4> old_nrm;
     if (old.nrm != nullptr) {
@@ -1546,8 +1651,20 @@ int rt_mesh_rebuild(rt_ctx *ctx, float *bvh_arr10_out, int32_t *tri_order_out, i
     if (bvh_arr10_out) memcpy(bvh_arr10_out, arr.data(), arr.size() * sizeof(float));
     if (tri_order_out) memcpy(tri_order_out, order.data(), order.size() * sizeof(int));
     if (n_nodes_out) *n_nodes_out = n_nodes;
+    ctx->build.install_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_install).count();
     return RT_OK;
 }
+
+int rt_mesh_rebuild(rt_ctx *ctx, float *bvh_arr10_out, int32_t *tri_order_out, int32_t *n_nodes_out) {
+    return rt_mesh_rebuild_mode(ctx, RT_BVH_REFERENCE, bvh_arr10_out, tri_order_out, n_nodes_out);
+}
+
+int rt_mesh_build_stats(const rt_ctx *ctx, rt_build_stats *out) {
+    if (!ctx || !out) return fail(nullptr, RT_ERR_INVALID, "bad arguments");
+    *out = ctx->build;
+    return RT_OK;
+}
+
 
 int rt_camera_basis(const rt_camera_pose *pose, float bx[3], float by[3], float bz[3]) {
     if (!pose || !bx || !by || !bz) return fail(nullptr, RT_ERR_INVALID, "bad arguments");
@@ -1644,7 +1761,7 @@ int rt_ctx_selfcheck(rt_ctx *ctx) {
     const DevBuf *bufs[] = {&ctx->node_lo, &ctx->node_hi, &ctx->nodes2, &ctx->nodesq, &ctx->nodesb, &ctx->q2thr, &ctx->tri, &ctx->verts, &ctx->tidx, &ctx->tidx_up, &ctx->nrm,
                             &ctx->scratch_rgba, &ctx->scratch_rgb8, &ctx->work, &ctx->queue, &ctx->wfM, &ctx->wfPR, &ctx->wfT, &ctx->wfLS, &ctx->wfSID, &ctx->wfSamp,
                             &ctx->wfQR, &ctx->pathSamp, &ctx->pathT, &ctx->accum, &ctx->left_dev, &ctx->lvl_nodes, &ctx->lvl_off, &ctx->bb_idx, &ctx->bb_cnt, &ctx->bb_pa, &ctx->bb_pb, &ctx->bb_tmp,
-                            &ctx->bb_nodes_i, &ctx->bb_nodes_f, &ctx->bb_counter, &ctx->bb_lvl, &ctx->bb_size, &ctx->bb_pre, &ctx->bb_arr,
+                            &ctx->bb_nodes_i, &ctx->bb_nodes_f, &ctx->bb_counter, &ctx->bb_lvl, &ctx->bb_size, &ctx->bb_pre, &ctx->bb_arr, &ctx->lb_pool,
                             &ctx->slot_rgba[0], &ctx->slot_rgba[1], &ctx->slot_rgb8[0], &ctx->slot_rgb8[1]};
     for (const DevBuf *b : bufs) {
         if (!b->p) continue;

@@ -1,0 +1,158 @@
+"""rt_mesh_rebuild_mode(RT_BVH_LBVH) (SURVEY 8f3 "and a GPU LBVH build"): a DIFFERENT tree than the reference's,
+built on the device in parallel -- Morton sort, binary radix tree, leaves cut by the surface-area heuristic (at most 32 triangles).  Parity is "HIP == oracle ON THE
+SAME TREE": the tree and the triangle order the device returns are handed to the oracle (or_mesh_set_bvh), whose traversal
+(cpu_launcher.cpp:277-311 restated) then walks it; frames must be bit-identical and the work counters equal.  Against the REFERENCE tree
+the image may differ only where two triangles are hit at bit-equal t (the scan order breaks the tie); counted and bounded.
+-m gpu."""
+import numpy as np
+import pytest
+
+import raytracinggpu_amd as rt
+from raytracinggpu_amd import hostlib
+from .test_gpu_parity import _synthetic_mesh, values_equal
+
+pytestmark = pytest.mark.gpu
+KEYS = ("rays", "box_tests", "nodes", "tri_tests")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = rt.Context(0)
+    yield c
+    c.close()
+
+
+def _check_tree(arr, order, n_tris):
+    """A proper tree in the reference's flat layout: every node reachable once, leaves of 1..32 triangles covering [0, n) exactly."""
+    n = len(arr)
+    assert sorted(order.tolist()) == list(range(n_tris))
+    seen = np.zeros(n, bool)
+    covered = np.zeros(n_tris, np.int32)
+    stack = [0]
+    leaves = 0
+    while stack:
+        k = stack.pop()
+        assert 0 <= k < n and not seen[k]
+        seen[k] = True
+        l, r, s, e = int(arr[k, 0]), int(arr[k, 1]), int(arr[k, 8]), int(arr[k, 9])
+        assert 0 <= s < e <= n_tris
+        assert (arr[k, 2:5] <= arr[k, 5:8]).all()
+        if l < 0:
+            assert r < 0 and e - s <= 32
+            covered[s:e] += 1
+            leaves += 1
+        else:
+            assert e - s > 2
+            for c in (l, r):                                            # children nest inside the parent, ranges partition the parent's
+                assert (arr[c, 2:5] >= arr[k, 2:5]).all() and (arr[c, 5:8] <= arr[k, 5:8]).all()
+            assert {int(arr[l, 8]), int(arr[r, 8])} >= {s} and {int(arr[l, 9]), int(arr[r, 9])} >= {e}
+            assert int(arr[l, 9]) - int(arr[l, 8]) + int(arr[r, 9]) - int(arr[r, 8]) == e - s
+            stack += [l, r]
+    assert seen.all() and (covered == 1).all()
+    return leaves
+
+
+def _lbvh_against_oracle(ctx, oracle, v, tris_uploaded, W, H, bounces=(0, 2), counters=True):
+    nt = len(tris_uploaded)
+    arr, order = ctx.mesh_rebuild(nt, mode="lbvh")
+    st = ctx.build_stats()
+    om = oracle.Mesh.from_arrays(v, tris_uploaded)
+    if nt <= 4:                                                          # a single leaf in either mode: the reference builder ran
+        assert st["mode"] == 0 and len(arr) == 1
+    else:
+        assert st["mode"] == 1 and st["n_nodes"] == len(arr) and st["max_leaf_tris"] <= 32 and st["n_triangles"] == nt
+        assert _check_tree(arr, order, nt) == st["n_leaves"]
+    om.set_bvh(arr, order)
+    osc = oracle.Scene.preset("cpu", om)
+    for b in bounces:
+        exp, _, cnt = osc.render(W, H, 1, b, want_rgb8=False)
+        for variant in ("auto", "wavefront", "lockstep") if b == 0 else ("auto",):
+            p = rt.make_params(W, H, 1, b, variant=variant, **rt.scenes.CPU_LAUNCHER)
+            got = ctx.render(p)
+            assert values_equal(got[..., :3], exp[..., :3]).all(), (b, variant)   # sigma == 0: every channel bit-identical
+            np.testing.assert_array_equal(got[..., 3], exp[..., 3])
+            if counters:
+                assert ctx.count_work(p) == {k: cnt[k] for k in KEYS}, (b, variant)
+    return arr, order, st
+
+
+@pytest.mark.parametrize("kind", ["cat", "three_triangles", "axis_aligned_quads", "soup", "deep_strip", "geometric_chain"])
+def test_lbvh_frame_and_work_counters_equal_the_oracle_on_the_same_tree(ctx, oracle, cat_golden, kind):
+    if kind == "cat":
+        v, t = np.array(cat_golden["vertices"], np.float32), np.array(cat_golden["tri_obj_order"], np.int32)
+    else:
+        rng = np.random.default_rng({"three_triangles": 1, "axis_aligned_quads": 2, "soup": 3, "deep_strip": 4, "geometric_chain": 5}[kind])
+        v, t = _synthetic_mesh(kind, rng)
+    first = hostlib.build_mesh(v, t, albedo=rt.scenes.CAT_ALBEDO, object_slot=6)        # what a caller uploads: the reference tree
+    ctx.scene_upload(rt.scenes.spheres("cpu"), first)
+    up = np.ascontiguousarray(first["indices"][:, :3])
+    W, H = (640, 360) if kind == "cat" else (320, 200)
+    p0 = rt.make_params(W, H, 1, 0, **rt.scenes.CPU_LAUNCHER)
+    on_reference_tree = ctx.render(p0)
+    work_ref = ctx.count_work(p0)
+    arr, order, st = _lbvh_against_oracle(ctx, oracle, v, up, W, H, bounces=(0, 3) if kind == "cat" else (0, 2))
+    on_lbvh = ctx.render(p0)
+    # the two trees hold the same triangles: the images agree except where the nearest hit is a bit-exact tie between two triangles
+    diff = (~values_equal(on_lbvh[..., :3], on_reference_tree[..., :3])).any(-1)
+    print(f"{kind}: {len(up)} triangles, LBVH {st['n_nodes']} nodes / {st['n_leaves']} leaves (max {st['max_leaf_tris']}, depth {st['max_depth']}), build {st['device_build_ms']:.2f} ms + "
+          f"install {st['install_ms']:.1f} ms; pixels differing from the reference tree's image: {int(diff.sum())}; work per frame {ctx.count_work(p0)} vs reference tree {work_ref}")
+    np.testing.assert_array_equal(on_lbvh[..., 3], on_reference_tree[..., 3])            # rays per pixel do not depend on the tree
+    limit = {"soup": 0.05, "axis_aligned_quads": 0.10}.get(kind, 0.001)                   # duplicated triangles / coplanar quads sharing a diagonal tie on purpose
+    assert diff.mean() <= limit, (kind, int(diff.sum()))
+    # a second LBVH build starts from the order the first one left and gives the same frame; the reference builder still works afterwards
+    _lbvh_against_oracle(ctx, oracle, v, up[order], W, H, bounces=(0,), counters=False)
+    arr2, order2 = ctx.mesh_rebuild(len(up), mode="reference")
+    assert ctx.build_stats()["mode"] == 0
+    np.testing.assert_array_equal(ctx.render(p0)[..., 3], on_reference_tree[..., 3])
+
+
+def test_lbvh_after_device_transform_and_refit(ctx, oracle, cat_golden):
+    """LBVH, then the device-side transform with its bottom-up refit (global_launcher.cu:340-365): the tree's topology stays, the boxes move;
+    the oracle does the same to the same tree."""
+    v, t = np.array(cat_golden["vertices"], np.float32), np.array(cat_golden["tri_obj_order"], np.int32)
+    first = hostlib.build_mesh(v, t, albedo=rt.scenes.CAT_ALBEDO, object_slot=6)
+    ctx.scene_upload(rt.scenes.spheres("cpu"), first)
+    up = np.ascontiguousarray(first["indices"][:, :3])
+    arr, order = ctx.mesh_rebuild(len(up), mode="lbvh")
+    c, s = np.float32(np.cos(0.4)), np.float32(np.sin(0.4))
+    R = np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]], np.float32)
+    tr = (1.5, -0.5, 2.0)
+    ctx.mesh_transform(R, tr)
+    om = oracle.Mesh.from_arrays(v, up)
+    om.set_bvh(arr, order)
+    om.transform(R, tr).refit()
+    W, H = 400, 250
+    exp, _, cnt = oracle.Scene.preset("cpu", om).render(W, H, 1, 1, want_rgb8=False)
+    p = rt.make_params(W, H, 1, 1, **rt.scenes.CPU_LAUNCHER)
+    got = ctx.render(p)
+    assert values_equal(got[..., :3], exp[..., :3]).all()
+    assert ctx.count_work(p) == {k: cnt[k] for k in KEYS}
+
+
+@pytest.mark.parametrize("n", [513])
+def test_lbvh_large_mesh_bit_exact_and_much_less_work(ctx, oracle, n):
+    """524 288 triangles (the displaced grid of test_large_mesh_bit_exact): frame and work counters == the oracle on the LBVH tree; the
+    triangle tests per ray fall by an order of magnitude against the reference's tree (whose leaves grow with the mesh, cpu:217)."""
+    rng = np.random.default_rng(11)
+    gx, gz = np.meshgrid(np.linspace(-18, 18, n), np.linspace(-14, 22, n), indexing="ij")
+    gy = -9.0 + 3.0 * np.sin(gx * 0.45) * np.cos(gz * 0.38) + 0.15 * rng.standard_normal((n, n))
+    v = np.stack([gx, gy, gz], -1).reshape(-1, 3).astype(np.float32)
+    i, j = np.meshgrid(np.arange(n - 1), np.arange(n - 1), indexing="ij")
+    a = (i * n + j).reshape(-1)
+    t = np.concatenate([np.stack([a, a + 1, a + n], 1), np.stack([a + 1, a + n + 1, a + n], 1)]).astype(np.int32)
+    first = hostlib.build_mesh(v, t, albedo=rt.scenes.CAT_ALBEDO, object_slot=6)
+    ctx.scene_upload(rt.scenes.spheres("cpu"), first)
+    W, H = 480, 270
+    p0 = rt.make_params(W, H, 1, 0, **rt.scenes.CPU_LAUNCHER)
+    work_ref = ctx.count_work(p0)
+    img_ref = ctx.render(p0)
+    up = np.ascontiguousarray(first["indices"][:, :3])
+    arr, order, st = _lbvh_against_oracle(ctx, oracle, v, up, W, H, bounces=(0, 2))
+    work = ctx.count_work(p0)
+    diff = (~values_equal(ctx.render(p0)[..., :3], img_ref[..., :3])).any(-1)
+    print(f"{len(up)} triangles: LBVH {st['n_nodes']} nodes, depth {st['max_depth']}, build {st['device_build_ms']:.2f} ms + install {st['install_ms']:.0f} ms; "
+          f"triangle tests per ray {work['tri_tests'] / work['rays']:.1f} (reference tree {work_ref['tri_tests'] / work_ref['rays']:.1f}), "
+          f"box tests per ray {work['box_tests'] / work['rays']:.1f} ({work_ref['box_tests'] / work_ref['rays']:.1f}); tie pixels {int(diff.sum())}")
+    assert work["tri_tests"] * 2 < work_ref["tri_tests"]
+    assert diff.mean() <= 0.001
+    assert st["device_build_ms"] < 50.0

@@ -41,6 +41,8 @@ for key, pat in (("wf_travq", "wf_travq<false"), ("wf_advance", "wf_advance<fals
         "wave_cycles_waiting_frac": round(dv.get("SQ_WAIT_ANY/WAVE_CYCLES", 0), 4), "wave_cycles_issue_stalled_frac": round(dv.get("SQ_WAIT_INST_ANY/WAVE_CYCLES", 0), 4),
         "waves_per_launch": int(c.get("SQ_WAVES", 0)), "vgprs": c.get("_VGPR_Count"), "sgprs": c.get("_SGPR_Count"),
     }
+    if key == "wf_advance":                                           # one-wave workgroups, one lane per path: bench.py scales the measured bytes to its own launch size
+        res["kernels"][key]["paths_per_launch"] = int(c.get("SQ_WAVES", 0)) * 64
 # the code the counters were taken from (bench.py quotes `traffic` only when its own sources hash to the same value) and the check of
 # bench.py's in-run instruction estimate (step counters x static per-step counts) against the hardware counter
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
