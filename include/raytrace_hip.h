@@ -313,7 +313,10 @@ typedef struct rt_build_stats {
     int32_t n_triangles, n_nodes;
     int32_t n_leaves, max_leaf_tris, max_depth;   /* RT_BVH_LBVH only (0 otherwise)            */
     float   device_build_ms;       /* builder kernels + sort, HIP events on the context's stream */
-    float   install_ms;            /* read-back + re-layout + upload of the kernels' formats    */
+    float   install_ms;            /* the kernels' formats: on the device for RT_BVH_LBVH (closed forms over the builder's arrays), else
+                                      read-back + re-layout on the host + upload; wall clock                                    */
+    int32_t install_on_device;
+    int32_t reserved;
 } rt_build_stats;
 int rt_mesh_rebuild_mode(rt_ctx *ctx, int mode, float *bvh_arr10_out, int32_t *tri_order_out, int32_t *n_nodes_out);
 int rt_mesh_build_stats(const rt_ctx *ctx, rt_build_stats *out);

@@ -79,7 +79,7 @@ class Stats(C.Structure):
 
 class BuildStats(C.Structure):
     _fields_ = [("mode", C.c_int32), ("n_triangles", C.c_int32), ("n_nodes", C.c_int32), ("n_leaves", C.c_int32), ("max_leaf_tris", C.c_int32),
-                ("max_depth", C.c_int32), ("device_build_ms", C.c_float), ("install_ms", C.c_float)]
+                ("max_depth", C.c_int32), ("device_build_ms", C.c_float), ("install_ms", C.c_float), ("install_on_device", C.c_int32), ("reserved", C.c_int32)]
 
 
 BVH_MODES = {"reference": 0, "lbvh": 1}

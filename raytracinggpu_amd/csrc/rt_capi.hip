@@ -121,7 +121,10 @@ struct rt_ctx {
     DevBuf tidx_up;                                                  // the same on the device (int4 per triangle)
     DevBuf bb_idx, bb_cnt, bb_pa, bb_pb, bb_tmp, bb_nodes_i, bb_nodes_f, bb_counter, bb_lvl, bb_size, bb_pre, bb_arr;   // device BVH build scratch
     DevBuf left_dev, lvl_nodes, lvl_off;                             // tree topology for the device-side refit
-    DevBuf lb_pool;                                                  // LBVH builder scratch (rt_lbvh.hip.h), one carved pool
+    DevBuf lb_pool, lb_pool2, perm_dev;                              // LBVH builder / layout scratch (rt_lbvh.hip.h), carved pools; visit rank -> uploaded index on the device
+    rtk::LbvhArgs lb_args{};                                         // the builder's arrays of the last LBVH build (valid until the next one)
+    bool host_mesh_stale = false;                                    // tri_perm / up_indices describe an older layout: the device copies (perm_dev, tidx_up) are current
+    int lbvh_host_install = 0;                                       // RT_LBVH_HOST_INSTALL=1: re-lay an LBVH tree out on the host, as the reference-mode rebuild does (tests compare the two)
     rt_build_stats build{};                                          // what the last rt_mesh_rebuild_mode did
     int n_levels = 0;
     DevBuf node_lo, node_hi, nodes2, nodesq, nodesb, q2thr, tri, verts, tidx, scratch_rgba, scratch_rgb8, work, queue;
@@ -963,6 +966,7 @@ int install_scene(rt_ctx *ctx, rtk::Scene sc, const rt_mesh *mesh) {
     RT_HIP(ctx, hipSetDevice(ctx->device));
     if (ctx->stream_) RT_HIP(ctx, hipStreamSynchronize(ctx->stream_));   // (renders issued on a caller's stream are the caller's to order)
     ctx->have_scene = false;
+    ctx->host_mesh_stale = false;                                     // what follows rewrites tri_perm / up_indices
     ctx->tri_perm.clear();
     std::vector<float4> lo, hi, tri, verts;
     std::vector<int4> tidx;
@@ -1113,6 +1117,21 @@ int install_scene(rt_ctx *ctx, rtk::Scene sc, const rt_mesh *mesh) {
     return RT_OK;
 }
 
+// tri_perm / up_indices (host copies of the mesh's orders) after a device-side install: fetched when a host-side path needs them
+int refresh_host_mesh(rt_ctx *ctx) {
+    if (!ctx->host_mesh_stale) return RT_OK;
+    const size_t nt = (size_t)ctx->n_up_tris;
+    std::vector<int4> up(nt);
+    ctx->tri_perm.resize(nt);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipMemcpy(up.data(), ctx->tidx_up.p, nt * sizeof(int4), hipMemcpyDeviceToHost));
+    RT_HIP(ctx, hipMemcpy(ctx->tri_perm.data(), ctx->perm_dev.p, nt * sizeof(int), hipMemcpyDeviceToHost));
+    ctx->up_indices.resize(nt * 3);
+    for (size_t t = 0; t < nt; ++t) { ctx->up_indices[3 * t] = up[t].x; ctx->up_indices[3 * t + 1] = up[t].y; ctx->up_indices[3 * t + 2] = up[t].z; }
+    ctx->host_mesh_stale = false;
+    return RT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1140,6 +1159,7 @@ int rt_ctx_create(rt_ctx **out, int device_id) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "out of host memory");
     ctx->device = device_id;
     ctx->knobs = read_knobs();
+    { const char *e = getenv("RT_LBVH_HOST_INSTALL"); ctx->lbvh_host_install = (e && *e && atoi(e) != 0) ? 1 : 0; }
     hipDeviceProp_t prop;
     hipError_t e = hipSetDevice(device_id);
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device_id);
@@ -1189,7 +1209,7 @@ int rt_ctx_destroy(rt_ctx *ctx) {
     ctx->wfM.release(); ctx->wfPR.release(); ctx->wfT.release(); ctx->wfLS.release(); ctx->wfSID.release(); ctx->wfSamp.release();
     ctx->wfQR.release(); ctx->accum.release(); ctx->dbgbuf.release();
     ctx->pathSamp.release(); ctx->pathT.release(); ctx->tidx_up.release();
-    for (DevBuf *b : {&ctx->bb_idx, &ctx->bb_cnt, &ctx->bb_pa, &ctx->bb_pb, &ctx->bb_tmp, &ctx->bb_nodes_i, &ctx->bb_nodes_f, &ctx->bb_counter, &ctx->bb_lvl, &ctx->bb_size, &ctx->bb_pre, &ctx->bb_arr, &ctx->lb_pool}) b->release();
+    for (DevBuf *b : {&ctx->bb_idx, &ctx->bb_cnt, &ctx->bb_pa, &ctx->bb_pb, &ctx->bb_tmp, &ctx->bb_nodes_i, &ctx->bb_nodes_f, &ctx->bb_counter, &ctx->bb_lvl, &ctx->bb_size, &ctx->bb_pre, &ctx->bb_arr, &ctx->lb_pool, &ctx->lb_pool2, &ctx->perm_dev}) b->release();
     for (hipEvent_t &e : ctx->ev_trav) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t &e : ctx->ev_adv) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t &e : ctx->part_ev) if (e) (void)hipEventDestroy(e);
@@ -1390,6 +1410,7 @@ int rt_mesh_set_normals(rt_ctx *ctx, const float *normals_xyz, int n_normals, co
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipStreamSynchronize(own_stream(ctx)));
     if (!normals_xyz || !nidx) { ctx->scene.nrm = nullptr; return RT_OK; }          // back to flat shading
+    if (int rr = refresh_host_mesh(ctx); rr != RT_OK) return rr;
     if (ctx->scene.mesh_slot < 0) return fail(ctx, RT_ERR_INVALID, "the scene has no mesh");
     if (n_normals <= 0 || index_stride < 3) return fail(ctx, RT_ERR_INVALID, "bad normal array sizes");
     std::vector<float4> nr(ctx->tri_perm.size() * 3);
@@ -1581,7 +1602,100 @@ static int rebuild_lbvh_tree(rt_ctx *ctx, const int nt, int &n_nodes_out) {
     RT_HIP(ctx, hipMemcpyAsync(st, a.stats, sizeof(st), hipMemcpyDeviceToHost, q));
     RT_HIP(ctx, hipStreamSynchronize(q));
     ctx->build.n_leaves = st[0]; ctx->build.max_leaf_tris = st[1]; ctx->build.max_depth = st[2];
+    ctx->lb_args = a;
     n_nodes_out = n_nodes;
+    return RT_OK;
+}
+
+// The render kernels' formats from the LBVH builder's arrays, on the device (rt_lbvh.hip.h, second half): what install_scene does on the
+// host for an uploaded tree.  `old`: the scene in use (spheres, light, camera, albedo, mesh slot carry over).
+static int install_lbvh_device(rt_ctx *ctx, const rtk::Scene &old, const int n_nodes) {
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t q = own_stream(ctx);
+    const rtk::LbvhArgs &a = ctx->lb_args;
+    const size_t n = (size_t)a.n, N = (size_t)n_nodes, nc = 2 * n - 1;
+    int rc;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    const size_t o_flag = carve(4 * (n + 1)), o_scan = carve(4 * (n + 1)), o_X = carve(4 * N), o_bfs = carve(4 * N), o_key = carve(8 * N), o_key2 = carve(8 * N),
+                 o_val = carve(4 * N), o_val2 = carve(4 * N), o_hist = carve(4 * 80), o_upnew = carve(16 * n);
+    size_t sort_tmp = 0, scan_tmp = 0;
+    {
+        unsigned long long *k0 = nullptr; int *v0 = nullptr;
+        if (rocprim::radix_sort_pairs(nullptr, sort_tmp, k0, k0, v0, v0, N, 0, 64, q) != hipSuccess) return fail(ctx, RT_ERR_HIP, "rocprim::radix_sort_pairs (size query) failed");
+        if (rocprim::exclusive_scan(nullptr, scan_tmp, v0, v0, 0, n + 1, rocprim::plus<int>(), q) != hipSuccess) return fail(ctx, RT_ERR_HIP, "rocprim::exclusive_scan (size query) failed");
+    }
+    const size_t o_tmp = carve(std::max(sort_tmp, scan_tmp) + 256);
+    if ((rc = ensure(ctx, ctx->lb_pool2, off)) != RT_OK) return rc;
+    // the scene in use stays untouched until every allocation has succeeded
+    DevBuf *outs[] = {&ctx->node_lo, &ctx->node_hi, &ctx->nodes2, &ctx->nodesq, &ctx->nodesb, &ctx->q2thr, &ctx->left_dev, &ctx->lvl_nodes, &ctx->lvl_off, &ctx->tri, &ctx->tidx, &ctx->perm_dev};
+    const size_t need[] = {N * 16, N * 16, 2 * N * 16, 2 * (N + 1) * 16, 2 * (N + 1) * 16, (N + 1) * 4, N * 4, N * 4, 80 * 4, 3 * n * 16, n * 16, n * 4};
+    ctx->have_scene = false;                                                     // (a failure from here on leaves the context without a scene, as the host path does)
+    for (size_t k = 0; k < sizeof(need) / sizeof(need[0]); ++k) if ((rc = ensure(ctx, *outs[k], need[k])) != RT_OK) return rc;
+    uint8_t *base = static_cast<uint8_t *>(ctx->lb_pool2.p);
+    int *flag = reinterpret_cast<int *>(base + o_flag);
+    rtk::LbvhLayout y{};
+    y.n_nodes = n_nodes;
+    y.lscan = reinterpret_cast<int *>(base + o_scan); y.X = reinterpret_cast<int *>(base + o_X); y.bfs = reinterpret_cast<int *>(base + o_bfs);
+    y.bkey = reinterpret_cast<unsigned long long *>(base + o_key); y.bval = reinterpret_cast<int *>(base + o_val);
+    y.dhist = reinterpret_cast<int *>(base + o_hist);
+    y.node_lo = static_cast<float4 *>(ctx->node_lo.p); y.node_hi = static_cast<float4 *>(ctx->node_hi.p); y.nodes2 = static_cast<float4 *>(ctx->nodes2.p);
+    y.nodesq = static_cast<float4 *>(ctx->nodesq.p); y.nodesb = static_cast<float4 *>(ctx->nodesb.p); y.q2thr = static_cast<int *>(ctx->q2thr.p);
+    y.left_of = static_cast<int *>(ctx->left_dev.p); y.lvl_nodes = static_cast<int *>(ctx->lvl_nodes.p);
+    y.tidx_visit = static_cast<int4 *>(ctx->tidx.p); y.tidx_up_new = reinterpret_cast<int4 *>(base + o_upnew); y.perm = static_cast<int *>(ctx->perm_dev.p);
+    RT_HIP(ctx, hipMemsetAsync(flag, 0, 4 * (n + 1), q));
+    RT_HIP(ctx, hipMemsetAsync(y.dhist, 0, 4 * 80, q));
+    RT_HIP(ctx, hipMemsetAsync(y.nodesq, 0, 32, q));                              // entry 0 of the breadth-first arrays is padding
+    RT_HIP(ctx, hipMemsetAsync(y.nodesb, 0, 32, q));
+    RT_HIP(ctx, hipMemsetAsync(y.q2thr, 0, 4, q));
+    const dim3 gt((unsigned)((n + 255) / 256)), gc((unsigned)((nc + 255) / 256)), gn((unsigned)((N + 255) / 256)), blk(256);
+    hipLaunchKernelGGL(rtk::lbvh_leafflag_kernel, gc, blk, 0, q, a, flag);
+    { size_t tmp = scan_tmp; if (rocprim::exclusive_scan(base + o_tmp, tmp, flag, y.lscan, 0, n + 1, rocprim::plus<int>(), q) != hipSuccess) return fail(ctx, RT_ERR_HIP, "rocprim::exclusive_scan failed"); }
+    hipLaunchKernelGGL(rtk::lbvh_walk_kernel, gc, blk, 0, q, a, y);
+    unsigned long long *key2 = reinterpret_cast<unsigned long long *>(base + o_key2);
+    int *val2 = reinterpret_cast<int *>(base + o_val2);
+    { size_t tmp = sort_tmp; if (rocprim::radix_sort_pairs(base + o_tmp, tmp, y.bkey, key2, y.bval, val2, N, 0, 64, q) != hipSuccess) return fail(ctx, RT_ERR_HIP, "rocprim::radix_sort_pairs failed"); }
+    hipLaunchKernelGGL(rtk::lbvh_rank_kernel, gn, blk, 0, q, y, val2);
+    const int4 *up_old = static_cast<const int4 *>(ctx->tidx_up.p);
+    hipLaunchKernelGGL(rtk::lbvh_layout_kernel, gc, blk, 0, q, a, y, up_old);
+    hipLaunchKernelGGL(rtk::lbvh_reorder_kernel, gt, blk, 0, q, a, up_old, y.tidx_up_new);
+    RT_HIP(ctx, hipGetLastError());
+    RT_HIP(ctx, hipMemcpyAsync(ctx->tidx_up.p, y.tidx_up_new, n * sizeof(int4), hipMemcpyDeviceToDevice, q));   // the sorted order is the new uploaded order
+    hipLaunchKernelGGL(rtk::retri_kernel, gt, blk, 0, q, static_cast<const int4 *>(ctx->tidx.p), static_cast<const float4 *>(ctx->verts.p), static_cast<float4 *>(ctx->tri.p), (int)n);
+    RT_HIP(ctx, hipGetLastError());
+    int hist[65];
+    float4 root[2];
+    RT_HIP(ctx, hipMemcpyAsync(hist, y.dhist, sizeof(hist), hipMemcpyDeviceToHost, q));
+    RT_HIP(ctx, hipMemcpyAsync(&root[0], ctx->node_lo.p, sizeof(float4), hipMemcpyDeviceToHost, q));
+    RT_HIP(ctx, hipMemcpyAsync(&root[1], ctx->node_hi.p, sizeof(float4), hipMemcpyDeviceToHost, q));
+    RT_HIP(ctx, hipStreamSynchronize(q));
+    const int maxd = hist[64];
+    if (maxd > 58) return fail(ctx, RT_ERR_INTERNAL, "LBVH layout: depth %d exceeds the 58 path bits of the breadth-first sort key", maxd);
+    std::vector<int> lvl_off(maxd + 2, 0);
+    for (int d = 0; d <= maxd; ++d) lvl_off[d + 1] = lvl_off[d] + hist[d];
+    if (lvl_off[maxd + 1] != n_nodes) return fail(ctx, RT_ERR_INTERNAL, "LBVH layout: %d nodes in the depth histogram, %d in the tree", lvl_off[maxd + 1], n_nodes);
+    if ((rc = upload(ctx, ctx->lvl_off, lvl_off.data(), lvl_off.size() * sizeof(int))) != RT_OK) return rc;
+    ctx->n_levels = maxd + 1;
+    rtk::Scene sc = old;
+    sc.nrm = nullptr;
+    sc.n_nodes = n_nodes; sc.n_tris = (int)n;
+    sc.root_lo = root[0]; sc.root_hi = root[1];
+    bool fast = true;
+    const float rv[6] = {root[0].x, root[0].y, root[0].z, root[1].x, root[1].y, root[1].z};
+    float bm[3];
+    for (int k = 0; k < 3; ++k) {                                                // every box nests inside the root's (unions, bottom-up), min <= max by construction
+        if (!(rv[k] <= rv[k + 3]) || !(std::fabs(rv[k]) < 1e8f) || !(std::fabs(rv[k + 3]) < 1e8f)) fast = false;
+        bm[k] = std::max(std::fabs(rv[k]), std::fabs(rv[k + 3]));
+    }
+    sc.bmx = bm[0]; sc.bmy = bm[1]; sc.bmz = bm[2]; sc.fast_box = fast ? 1 : 0;
+    sc.node_lo = static_cast<const float4 *>(ctx->node_lo.p); sc.node_hi = static_cast<const float4 *>(ctx->node_hi.p);
+    sc.nodes = static_cast<const float4 *>(ctx->nodes2.p); sc.nodesq = static_cast<const float4 *>(ctx->nodesq.p); sc.nodesb = static_cast<const float4 *>(ctx->nodesb.p);
+    sc.q2thr = static_cast<const int *>(ctx->q2thr.p); sc.tri = static_cast<const float4 *>(ctx->tri.p);
+    sc.verts = static_cast<const float4 *>(ctx->verts.p); sc.tidx = static_cast<const int4 *>(ctx->tidx.p);
+    ctx->travq_ok = n_nodes + 2 < (1 << rtk::kQNodeBits) && (uint64_t)n * 48 < ((uint64_t)1 << 32);   // leaves hold at most kLbvhLeaf triangles
+    ctx->scene = sc;
+    ctx->host_mesh_stale = true;                                                 // tri_perm / up_indices: on the device now (perm_dev, tidx_up)
+    ctx->have_scene = true;
     return RT_OK;
 }
 
@@ -1611,6 +1725,18 @@ int rt_mesh_rebuild_mode(rt_ctx *ctx, int mode, float *bvh_arr10_out, int32_t *t
     ctx->build.mode = mode; ctx->build.n_nodes = n_nodes; ctx->build.n_triangles = nt;
     const auto t_install = std::chrono::steady_clock::now();
     int *const order_dev = static_cast<int *>(ctx->bb_idx.p);
+    if (mode == RT_BVH_LBVH && old.nrm == nullptr && !ctx->lbvh_host_install && ctx->build.max_depth <= 56) {
+        // the kernels' formats straight from the builder's arrays; the flat tree and the order travel to the host only if the caller asks
+        if ((rc = install_lbvh_device(ctx, old, n_nodes)) != RT_OK) return rc;
+        if (bvh_arr10_out) RT_HIP(ctx, hipMemcpyAsync(bvh_arr10_out, ctx->bb_arr.p, (size_t)n_nodes * 10 * sizeof(float), hipMemcpyDeviceToHost, q));
+        if (tri_order_out) RT_HIP(ctx, hipMemcpyAsync(tri_order_out, order_dev, (size_t)nt * sizeof(int), hipMemcpyDeviceToHost, q));
+        RT_HIP(ctx, hipStreamSynchronize(q));
+        if (n_nodes_out) *n_nodes_out = n_nodes;
+        ctx->build.install_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_install).count();
+        ctx->build.install_on_device = 1;
+        return RT_OK;
+    }
+    if ((rc = refresh_host_mesh(ctx)) != RT_OK) return rc;                          // the host path below starts from up_indices / tri_perm
     // The tree is built.  The O(n) re-layout for the kernels (traversal order, visit-order triangle records, sibling pairs, refit
     // levels) reuses the upload path on the host: ~30 bytes per triangle over PCIe each way.
     std::vector<float> arr((size_t)n_nodes * 10);
@@ -1761,7 +1887,7 @@ int rt_ctx_selfcheck(rt_ctx *ctx) {
     const DevBuf *bufs[] = {&ctx->node_lo, &ctx->node_hi, &ctx->nodes2, &ctx->nodesq, &ctx->nodesb, &ctx->q2thr, &ctx->tri, &ctx->verts, &ctx->tidx, &ctx->tidx_up, &ctx->nrm,
                             &ctx->scratch_rgba, &ctx->scratch_rgb8, &ctx->work, &ctx->queue, &ctx->wfM, &ctx->wfPR, &ctx->wfT, &ctx->wfLS, &ctx->wfSID, &ctx->wfSamp,
                             &ctx->wfQR, &ctx->pathSamp, &ctx->pathT, &ctx->accum, &ctx->left_dev, &ctx->lvl_nodes, &ctx->lvl_off, &ctx->bb_idx, &ctx->bb_cnt, &ctx->bb_pa, &ctx->bb_pb, &ctx->bb_tmp,
-                            &ctx->bb_nodes_i, &ctx->bb_nodes_f, &ctx->bb_counter, &ctx->bb_lvl, &ctx->bb_size, &ctx->bb_pre, &ctx->bb_arr, &ctx->lb_pool,
+                            &ctx->bb_nodes_i, &ctx->bb_nodes_f, &ctx->bb_counter, &ctx->bb_lvl, &ctx->bb_size, &ctx->bb_pre, &ctx->bb_arr, &ctx->lb_pool, &ctx->lb_pool2, &ctx->perm_dev,
                             &ctx->slot_rgba[0], &ctx->slot_rgba[1], &ctx->slot_rgb8[0], &ctx->slot_rgb8[1]};
     for (const DevBuf *b : bufs) {
         if (!b->p) continue;

@@ -156,3 +156,54 @@ def test_lbvh_large_mesh_bit_exact_and_much_less_work(ctx, oracle, n):
     assert work["tri_tests"] * 2 < work_ref["tri_tests"]
     assert diff.mean() <= 0.001
     assert st["device_build_ms"] < 50.0
+
+
+def test_lbvh_device_install_equals_host_install(oracle, cat_golden, monkeypatch):
+    """The render kernels' formats follow from the builder's arrays ON THE DEVICE (closed forms: subtree sizes from a prefix sum of leaf starts,
+    traversal order from one walk up per node, visit ranks from the leaf ranges, breadth-first pairs from a sort by (depth, path)).  A context
+    under RT_LBVH_HOST_INSTALL=1 takes the old road -- read the flat tree back, re-lay it out on the host as rt_scene_upload does, upload --
+    and must render the same bits with the same work counters through every traversal kernel; smooth normals (host-side tables) and a later
+    reference-mode rebuild (which starts from the host copies of the orders) still work after a device-side install."""
+    v, t = np.array(cat_golden["vertices"], np.float32), np.array(cat_golden["tri_obj_order"], np.int32)
+    first = hostlib.build_mesh(v, t, albedo=rt.scenes.CAT_ALBEDO, object_slot=6)
+    up = np.ascontiguousarray(first["indices"][:, :3])
+    dev = rt.Context(0)
+    monkeypatch.setenv("RT_LBVH_HOST_INSTALL", "1")
+    host = rt.Context(0)
+    monkeypatch.delenv("RT_LBVH_HOST_INSTALL")
+    outs = []
+    for c in (dev, host):
+        c.scene_upload(rt.scenes.spheres("cpu"), first)
+        outs.append(c.mesh_rebuild(len(up), mode="lbvh"))
+    assert dev.build_stats()["install_on_device"] == 1 and host.build_stats()["install_on_device"] == 0
+    np.testing.assert_array_equal(outs[0][0].view(np.uint32), outs[1][0].view(np.uint32))     # the same tree ...
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])                                     # ... and order
+    W, H = 400, 250
+    for variant in ("auto", "wavefront", "path", "lockstep", "lds_top"):
+        for b in (0, 2):
+            p = rt.make_params(W, H, 1, b, variant=variant, **rt.scenes.CPU_LAUNCHER)
+            np.testing.assert_array_equal(dev.render(p).view(np.uint32), host.render(p).view(np.uint32), err_msg=f"{variant} b={b}")
+            if b == 0:
+                assert dev.count_work(p) == host.count_work(p), variant
+    # device-side transform + refit on the device-installed layouts (levels, left children) == the same on the host-installed ones
+    c_, s_ = np.float32(np.cos(0.3)), np.float32(np.sin(0.3))
+    R = np.array([[c_, 0, s_], [0, 1, 0], [-s_, 0, c_]], np.float32)
+    for c in (dev, host):
+        c.mesh_transform(R, (0.5, 0.25, -1.0))
+    p = rt.make_params(W, H, 1, 1, **rt.scenes.CPU_LAUNCHER)
+    np.testing.assert_array_equal(dev.render(p).view(np.uint32), host.render(p).view(np.uint32))
+    # smooth normals need the host copy of the visit order: fetched from the device on demand
+    nrm = np.random.default_rng(5).normal(size=(len(v), 3)).astype(np.float32)
+    nidx = up[outs[0][1]]                                                                      # per-triangle normal indices = vertex indices, in the NEW uploaded order
+    for c in (dev, host):
+        c.mesh_set_normals(nrm, nidx)
+    np.testing.assert_array_equal(dev.render(p).view(np.uint32), host.render(p).view(np.uint32))
+    for c in (dev, host):
+        c.mesh_set_normals(None, None)
+    # and a reference-mode rebuild afterwards starts from the right order on both
+    a0, o0 = dev.mesh_rebuild(len(up), mode="reference")
+    a1, o1 = host.mesh_rebuild(len(up), mode="reference")
+    np.testing.assert_array_equal(a0.view(np.uint32), a1.view(np.uint32))
+    np.testing.assert_array_equal(o0, o1)
+    np.testing.assert_array_equal(dev.render(p).view(np.uint32), host.render(p).view(np.uint32))
+    dev.close(); host.close()
