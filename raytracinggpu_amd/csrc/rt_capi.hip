@@ -35,7 +35,8 @@ struct DevBuf {
 // Tuning / test knobs: environment variables read ONCE, when the context is created (rt_ctx_create).  Defaults are the
 // measured optimum on MI355X; tests create a context under a modified environment to reach the rare code paths.
 struct Knobs {
-    int travq_R = 64;          // RT_TRAVQ_R: ray slots per wave of the work-stack kernel (32 | 64)
+    int travq_R = 64;          // RT_TRAVQ_R: ray slots per wave of the work-stack kernel (32 | 64 | 128: two slots per lane, two sibling pairs per lane and BOX step;
+                               // measured 19 % slower per frame than 64 -- 10 waves per CU instead of 16: profiles/round4/ab_128_rays_per_wave.txt)
     int travq_cap = 0;         // RT_TRAVQ_CAP: stack capacity (>= 128; tests force the serial drain); 0 = the carve's capacity
     int travq_lds = 0;         // RT_TRAVQ_LDS: waves of the ONE workgroup per CU that stages the top of the BVH in LDS; 0 = nodes through L1/L2
     int q_low = 48;            // RT_TRAVQ_LOW: refill while the stack holds fewer sibling pairs than this (measured 1.19 / 1.21 / 1.25 ms per frame for 48 / 64 / 96)
@@ -76,7 +77,7 @@ static Knobs read_knobs() {
     Knobs k;
     auto geti = [](const char *name, int &out) { const char *e = getenv(name); if (e && *e) { out = atoi(e); return true; } return false; };
     int v;
-    if (geti("RT_TRAVQ_R", v) && v == 32) k.travq_R = 32;
+    if (geti("RT_TRAVQ_R", v) && (v == 32 || v == 64 || v == 128)) k.travq_R = v;
     if (geti("RT_TRAVQ_CAP", v) && v >= 128) k.travq_cap = v;
     if (geti("RT_TRAVQ_LDS", v) && v >= 1 && v <= 16) k.travq_lds = v;
     if (geti("RT_TRAVQ_LOW", v) && v >= 32 && v <= 320) k.q_low = v;
@@ -137,7 +138,7 @@ struct rt_ctx {
     int prog_frames = 0, prog_w = 0, prog_h = 0;
     uint64_t qf_sig = 0;                                            // layout the queue flags were last zeroed for
     int trav_blocks_per_cu[4] = {0, 0, 0, 0};
-    int travq_blocks_per_cu[4] = {0, 0, 0, 0};   // [STATS + 2 * (R == 32)]
+    int travq_blocks_per_cu[6] = {0, 0, 0, 0, 0, 0};   // [STATS + 2 * (R == 32) + 4 * (R == 128)]
     static constexpr int kMaxParts = 8;
     hipStream_t part_stream[kMaxParts] = {};
     hipEvent_t part_ev[kMaxParts] = {};
@@ -328,11 +329,15 @@ template <bool S, int R> TravqFn travq_pick(bool ldsn, bool ldsv) {
     return ldsn ? (ldsv ? rtk::wf_travq<S, R, true, true> : rtk::wf_travq<S, R, true, false>) : (ldsv ? rtk::wf_travq<S, R, false, true> : rtk::wf_travq<S, R, false, false>);
 }
 TravqFn travq_fn(bool stats, int R, bool ldsn, bool ldsv = false) {
-    if (stats) return R == 32 ? travq_pick<true, 32>(ldsn, ldsv) : travq_pick<true, 64>(ldsn, ldsv);
-    return R == 32 ? travq_pick<false, 32>(ldsn, ldsv) : travq_pick<false, 64>(ldsn, ldsv);
+    if (stats) return R == 32 ? travq_pick<true, 32>(ldsn, ldsv) : R == 128 ? travq_pick<true, 128>(ldsn, ldsv) : travq_pick<true, 64>(ldsn, ldsv);
+    return R == 32 ? travq_pick<false, 32>(ldsn, ldsv) : R == 128 ? travq_pick<false, 128>(ldsn, ldsv) : travq_pick<false, 64>(ldsn, ldsv);
 }
 size_t travq_carve_bytes(int R) {
-    return R == 64 ? (size_t)rtk::QCarve<64, rtk::QStackCap<64>::value, rtk::kQLeafCap>::kBytes : (size_t)rtk::QCarve<32, rtk::QStackCap<32>::value, rtk::kQLeafCap>::kBytes;
+    return R == 128 ? (size_t)rtk::QCarve<128, rtk::QStackCap<128>::value, rtk::QLeafCap<128>::value>::kBytes
+         : R == 64 ? (size_t)rtk::QCarve<64, rtk::QStackCap<64>::value, rtk::QLeafCap<64>::value>::kBytes : (size_t)rtk::QCarve<32, rtk::QStackCap<32>::value, rtk::QLeafCap<32>::value>::kBytes;
+}
+int travq_stack_cap(int R) { return R == 128 ? rtk::QStackCap<128>::value : R == 64 ? rtk::QStackCap<64>::value : rtk::QStackCap<32>::value; }
+int travq_block_threads(int R) { return R == 128 ? 128 : rtk::kQBlock;   // 128 resident rays per wave: 16 KB of LDS per wave, two-wave workgroups (five fit a CU)
 }
 
 // Camera::rotate(), realtime_render.cu:823-846 (host code there too: float cos/sin/sqrt)
@@ -578,7 +583,7 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
         const bool queue = variant == RT_VARIANT_WAVEFRONT_QUEUE;
         const Knobs &kn = ctx->knobs;
         const int qR = kn.travq_R;                                    // ray slots per wave of the work-stack kernel
-        int qcap = qR == 64 ? rtk::QStackCap<64>::value : rtk::QStackCap<32>::value;
+        int qcap = travq_stack_cap(qR);
         if (kn.travq_cap >= 128 && kn.travq_cap < qcap) qcap = kn.travq_cap;   // tests: force the serial drain
         // BVH nodes staged in LDS (breadth-first prefix) by ONE workgroup of qW waves per CU; 0 = nodes through L1/L2
         int qW = kn.travq_lds;
@@ -605,7 +610,7 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
         if (!qlds && q_nlds < 4) q_nlds = 0;                          // (the same for the per-workgroup staging)
         const bool qtop = queue && !qlds && q_nlds > 0;
         const bool qldsn = (qlds || qtop) && q_nlds > 0;
-        const int q_low = kn.q_low;                                   // refill thresholds of the work-stack kernel (stack entries are sibling pairs)
+        const int q_low = kn.q_low * (qR == 128 ? 2 : 1);              // refill thresholds of the work-stack kernel (stack entries are sibling pairs)
         const int q_minfree = (kn.q_minfree >= 1 && kn.q_minfree <= qR) ? kn.q_minfree : qR / 4;
         // begin, (trav, advance) x 2*segments per sample; path state SoA in HBM, tile-order path index.
         // The rows are cut into `parts` independent sub-frames (interleaved tiles), each running its own kernel
@@ -619,7 +624,7 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
         if (R % 8 != 0 || work_dev || kn.debug_trav != -2) parts = 1;
         if (parts > T) parts = T > 0 ? T : 1;
         const int tiles_x = (p->width + 7) / 8;
-        const int tb = qlds ? 64 * qW : queue ? rtk::kQBlock : ldsn ? rtk::kTravBlockLds : rtk::kTravBlock;
+        const int tb = qlds ? 64 * qW : queue ? travq_block_threads(qR) : ldsn ? rtk::kTravBlockLds : rtk::kTravBlock;
         const int wpb = tb / 64;
         const size_t q_lds = (size_t)wpb * travq_carve_bytes(qR) + 16 + (size_t)q_nlds * 32 + (ldsv ? (size_t)ctx->scene.n_verts * 16 : 0);
         const size_t trav_lds = queue ? q_lds : ldsn ? lds_nodes_bytes : (size_t)(rtk::kTravBlock / 64) * rtk::TravCarve<512, 8>::kBytes + 16;
@@ -638,17 +643,17 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
         }
         int bpc = ctx->trav_blocks_per_cu[si];                       // blocks per CU
         if (queue) {
-            const int qi = (work_dev ? 1 : 0) + (qR == 32 ? 2 : 0);
+            const int qi = (work_dev ? 1 : 0) + (qR == 32 ? 2 : qR == 128 ? 4 : 0);
             if (qlds) {
                 bpc = 1;
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(travq_fn(work_dev != nullptr, qR, qldsn, ldsv)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             } else {
                 if (ctx->travq_blocks_per_cu[qi] == 0 || qtop) {
                     int nb = 0;
-                    RT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, travq_fn(work_dev != nullptr, qR, qtop, false), rtk::kQBlock, trav_lds));
+                    RT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, travq_fn(work_dev != nullptr, qR, qtop, false), tb, trav_lds));
                     ctx->travq_blocks_per_cu[qi] = nb > 0 ? nb : 1;
                 }
-                bpc = std::min(ctx->travq_blocks_per_cu[qi], (kn.bpc5 ? 20 : 16) / (rtk::kQBlock / 64));    // a fifth workgroup per CU fits but does not pay (measured)
+                bpc = std::min(ctx->travq_blocks_per_cu[qi], (kn.bpc5 ? 20 : 16) / (tb / 64));    // a fifth workgroup per CU fits but does not pay (measured)
             }
         }
         if (!ldsn && kn.trav_waves >= 1 && kn.trav_waves <= bpc) bpc = kn.trav_waves;

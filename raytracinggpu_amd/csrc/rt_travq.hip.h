@@ -34,23 +34,25 @@ constexpr int kQBlock = RT_TRAVQ_BLOCK;      // 4 waves per workgroup share one 
 #ifndef RT_TRAVQ_KP
 #define RT_TRAVQ_KP 1                        // sibling pairs per lane and BOX step
 #endif
-constexpr int kQLeafCap = 256 * RT_TRAVQ_KP;  // leaf-queue entries per wave: < 64 before a BOX step, which appends up to 128 per pair
-// Stack entry (32 bits) = node << 10 | slot << 4: the sibling pair of nodes (node, node + 1) of the ray in slot `slot`.  Both fields are
-// stored the way they are used: entry & 0x3f0 is the byte offset of the slot's row in the four per-slot tables (16-byte rows),
-// (entry >> 5) & ~31 the byte offset of the pair in the node array (32 bytes per node).  A leaf-queue entry is (first triangle,
-// count << 10 | slot << 4).  Decoding costs two full-rate instructions per field (and, shift) instead of the shift-and-add forms
+template <int R> struct QPairs { static constexpr int value = R > 64 ? 2 : RT_TRAVQ_KP; };   // sibling pairs per lane and BOX step: two where a wave keeps 128 rays resident
+template <int R> struct QLeafCap { static constexpr int value = 256 * QPairs<R>::value; };       // leaf-queue entries per wave: < 64 before a BOX step, which appends up to 128 per pair
+constexpr int kQLeafCap = QLeafCap<64>::value;
+// Stack entry (32 bits) = node << 11 | slot << 4: the sibling pair of nodes (node, node + 1) of the ray in slot `slot` (up to 128 slots per
+// wave).  Both fields are stored the way they are used: entry & 0x7f0 is the byte offset of the slot's row in the four per-slot tables
+// (16-byte rows), (entry >> 6) & ~31 the byte offset of the pair in the node array (32 bytes per node).  A leaf-queue entry is (first triangle,
+// count << 11 | slot << 4).  Decoding costs two full-rate instructions per field (and, shift) instead of the shift-and-add forms
 // that issue at half rate on gfx950 (tools/ubench/issue_table: v_lshlrev_b32, v_lshl_add_u32, v_and_or_b32 ... take twice the
 // issue time of v_and_b32 / v_lshrrev_b32 / v_add_u32 / v_fma_f32).
-constexpr int kQNodeShift = 10, kQNodeBits = 22;
-constexpr unsigned int kQSlotMask = 0x3f0u;
-constexpr int kQMaxLeaf = 1 << 21;           // triangles per leaf: count << 10 must stay a positive int (the sign says "internal")
+constexpr int kQNodeShift = 11, kQNodeBits = 21;
+constexpr unsigned int kQSlotMask = 0x7f0u;
+constexpr int kQMaxLeaf = 1 << 20;           // triangles per leaf: count << 11 must stay a positive int (the sign says "internal")
 
 // stack capacity: sized so that four waves' carves (+ the cursor) fill 36 KiB (R = 64: 4 workgroups per CU) or less;
 // a fuller stack is drained serially (see above), which the cat never needs
 #ifndef RT_TRAVQ_SCAP
 #define RT_TRAVQ_SCAP 652
 #endif
-template <int R> struct QStackCap { static constexpr int value = RT_TRAVQ_SCAP; };
+template <int R> struct QStackCap { static constexpr int value = R > 64 ? 800 : RT_TRAVQ_SCAP; };   // (R = 128: twice the rays, two pairs per lane and step)
 
 // Per-wave LDS carve.  Four tables of 16-byte rows indexed by ray slot, so that ONE address register (wave base + slot * 16)
 // reaches everything a step needs about a ray through the instructions' immediate offsets:
@@ -236,17 +238,18 @@ __device__ __forceinline__ bool qtri_test(const float4 q0, const float4 q1, cons
 // executed blocks of the steps, counted per entry: the t-division block of a triangle test (some lane accepted the barycentrics), the
 // first and the second leaf-queue push of a BOX step.
 template <bool STATS, int R, bool LDSN, bool LDSV>
-__global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || kQBlock != 256 || RT_TRAVQ_KP > 1) ? 4 : 5) void wf_travq(const Scene sc, const Frame fr, const WfState st, const int cap, const int n_lds, const int kLow, const int kMinFree) {
+__global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || kQBlock != 256 || QPairs<R>::value > 1) ? 4 : 5) void wf_travq(const Scene sc, const Frame fr, const WfState st, const int cap, const int n_lds, const int kLow, const int kMinFree) {
     // kLow: refill while the stack holds fewer entries (sibling pairs) than this (default 48); kMinFree: ... and at least this
     // many slots are free, or the stack is short (default R / 4)
-    constexpr int SCAP = QStackCap<R>::value, LCAP = kQLeafCap;
+    constexpr int SCAP = QStackCap<R>::value, LCAP = QLeafCap<R>::value;
+    constexpr int NB = R > 64 ? 2 : 1;                      // ray slots per lane ("banks"): lane l owns slots l and, with 128 resident rays, l + 64
     using Carve = QCarve<R, SCAP, LCAP>;
-    static_assert(R <= 64 && (R & (R - 1)) == 0, "ray slots are owned by lanes");
+    static_assert(R <= 128 && (R & (R - 1)) == 0, "ray slots are owned by lanes: one per lane, or two");
     extern __shared__ __attribute__((aligned(16))) unsigned char travq_smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wib = tid >> 6;
-    const int wpb = (LDSN || LDSV) ? (int)(blockDim.x >> 6) : kQBlock / 64;
+    const int wpb = (int)(blockDim.x >> 6);
     unsigned char *const wl = travq_smem + wib * Carve::kBytes;
     int *const blk_cur = reinterpret_cast<int *>(travq_smem + wpb * Carve::kBytes);
     float4 *const lnodes = reinterpret_cast<float4 *>(travq_smem + wpb * Carve::kBytes + 16);
@@ -262,10 +265,10 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
     auto rowD = [&](unsigned int sb) -> float4 & { return *reinterpret_cast<float4 *>(wl + Carve::kTabD + sb); };
     auto pend = [&](unsigned int sb) -> int * { return reinterpret_cast<int *>(wl + Carve::kTabO + sb + 12); };
     auto best = [&](unsigned int sb) -> unsigned long long * { return reinterpret_cast<unsigned long long *>(wl + Carve::kTabD + sb + 8); };
-    const unsigned int my_sb = (unsigned int)lane << 4;            // lane r < R owns ray slot r
+    const unsigned int my_sb0 = (unsigned int)lane << 4;           // lane l owns ray slot l (bank 0) and l + 64 (bank 1, R = 128): row offsets
     if (tid == 0) *blk_cur = 0;
     marks[lane] = 0; marks[lane + 64] = 0;
-    if (lane < R) *pend(my_sb) = 0;
+    for (int b = 0; b < NB; ++b) if (lane + 64 * b < R) *pend(my_sb0 + 1024u * b) = 0;
     if (LDSN) for (int k = tid; k < 2 * n_lds; k += (int)blockDim.x) lnodes[k] = sc.nodesb[k];
     if (LDSV) for (int k = tid; k < sc.n_verts; k += (int)blockDim.x) lverts[k] = sc.verts[k];
     __syncthreads();
@@ -281,7 +284,8 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
     float2 sp1 = make_float2(0, 0);
     int spf = 0;
     const int root_hiw = __float_as_int(sc.root_hi.w);
-    int path = -1;                                // lane r < R owns ray slot r: the path index of the ray in it
+    int path_[NB];                                // the path index of the ray in each of the lane's slots, -1 = free
+    for (int b = 0; b < NB; ++b) path_[b] = -1;
     int top = 0;                                  // wave-uniform: entries on the stack
     unsigned int lhead = 0, ltail = 0;            // wave-uniform: leaf-queue cursors (monotonic)
     bool drained = false;
@@ -361,18 +365,24 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
         if (top < kLow) {
             if (STATS) n_refill++;
             WQ_MARK("refill_begin");
-            if (lane < R && path >= 0) {
-                if (*pend(my_sb) == 0) {
-                    st.M[path] = *best(my_sb);        // always: the emitter does not initialise M (WF_NOHIT = no triangle accepted)
-                    path = -1;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const unsigned int sbk = my_sb0 + 1024u * b;
+                if (lane + 64 * b < R && path_[b] >= 0) {
+                    if (*pend(sbk) == 0) {
+                        st.M[path_[b]] = *best(sbk);  // always: the emitter does not initialise M (WF_NOHIT = no triangle accepted)
+                        path_[b] = -1;
+                    }
                 }
             }
             // refill free slots.  The workgroup owns a spatially scrambled, contiguous share of the traversal queue; its
             // waves take 64 slots at a time through an LDS cursor, flag and record in ONE round trip, and park the rays that
             // need traversal in registers (the LDS staging index says which lane holds the k-th of them), from where free slots are filled.
             for (int round = 0; round < 6 && top < kLow; ++round) {
-                const unsigned long long freem = __ballot(lane < R && path < 0);
-                const int n_free = __popcll(freem);
+                unsigned long long freem_[NB];
+                int n_free = 0;
+#pragma unroll
+                for (int b = 0; b < NB; ++b) { freem_[b] = __ballot(lane + 64 * b < R && path_[b] < 0); n_free += __popcll(freem_[b]); }
                 if (n_free == 0 || (n_free < kMinFree && top >= 64)) break;
                 if (stage_used >= stage_n) {
                     if (drained) break;
@@ -399,43 +409,52 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
                 }
                 if (STATS) n_round++;                                  // hand-off rounds: staged rays go to free slots
                 WQ_MARK("round_begin");
-                const int take = n_free < stage_n - stage_used ? n_free : stage_n - stage_used;
-                const int rank = lanes_below(freem);
-                const bool got = lane < R && path < 0 && rank < take;
-                WQ_CHECK(!got || stage_used + rank < 64, 32, (void)0);
-                const int src = got ? (int)sidx[(stage_used + rank) & 63] : lane;   // the staged record lives in that lane's registers
-                const float4 r0 = make_float4(__shfl(sp0.x, src, 64), __shfl(sp0.y, src, 64), __shfl(sp0.z, src, 64), __shfl(sp0.w, src, 64));
-                const float2 r1 = make_float2(__shfl(sp1.x, src, 64), __shfl(sp1.y, src, 64));
-                const int rf = __shfl(spf, src, 64);
                 // the root box was tested when the ray was emitted (wf_emit_ray): start with what is below it
                 const int first = __float_as_int(sc.root_lo.w), cnt = root_hiw - first;
                 const bool work = root_hiw < 0 || cnt > 0;
-                if (got) {
-                    const f3 O = mk(r0.x, r0.y, r0.z), u = mk(r0.w, r1.x, r1.y);
-                    const RayBoxC rb = ray_box_c(O, u, mk(sc.bmx, sc.bmy, sc.bmz), sc.fast_box != 0);
-                    rowA(my_sb) = make_float4(rb.rx, rb.ry, rb.rz, rb.c0);
-                    rowO(my_sb) = make_float4(rb.ox, rb.oy, rb.oz, __int_as_float(work ? 1 : 0));      // .w: one outstanding entry
-                    rowC(my_sb) = r0;
-                    rowD(my_sb) = make_float4(r1.x, r1.y, __uint_as_float(0xffffffffu), __uint_as_float(0xffffffffu));   // .zw: WF_NOHIT
-                    path = rf - 1;
-                    WQ_CHECK(path >= 0 && path < 2 * st.n_paths, 1, path = 0);
-                }
-                stage_used += take;
-                const unsigned long long gm = __ballot(got);
-                if (dbg_on) { d_rounds++; d_rays += (unsigned int)__popcll(gm); }
-                if (root_hiw < 0) {
-                    if (got) stack[top + lanes_below(gm)] = 2u << kQNodeShift | my_sb;   // the root (node 1) has the children 2, 3
-                    top += __popcll(gm);
-                } else {                           // the root is a leaf
-                    if (cnt > 0) {
-                        if (got) {
-                            leafq[(ltail + (unsigned int)lanes_below(gm)) & (LCAP - 1)] = make_uint2((unsigned int)first, (unsigned int)cnt << kQNodeShift | my_sb);
-                            if (STATS) wk.tris += (uint32_t)cnt;
-                        }
-                        ltail += (unsigned int)__popcll(gm);
+                bool leaf_root_done = false;
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {                         // the lane's slots, one bank after the other
+                    const int avail = stage_n - stage_used;
+                    const int nf = __popcll(freem_[b]);
+                    if (avail <= 0 || nf == 0) continue;
+                    const unsigned int sbk = my_sb0 + 1024u * b;
+                    const int take = nf < avail ? nf : avail;
+                    const int rank = lanes_below(freem_[b]);
+                    const bool got = __builtin_amdgcn_inverse_ballot_w64(freem_[b]) && rank < take;
+                    WQ_CHECK(!got || stage_used + rank < 64, 32, (void)0);
+                    const int src = got ? (int)sidx[(stage_used + rank) & 63] : lane;   // the staged record lives in that lane's registers
+                    const float4 r0 = make_float4(__shfl(sp0.x, src, 64), __shfl(sp0.y, src, 64), __shfl(sp0.z, src, 64), __shfl(sp0.w, src, 64));
+                    const float2 r1 = make_float2(__shfl(sp1.x, src, 64), __shfl(sp1.y, src, 64));
+                    const int rf = __shfl(spf, src, 64);
+                    if (got) {
+                        const f3 O = mk(r0.x, r0.y, r0.z), u = mk(r0.w, r1.x, r1.y);
+                        const RayBoxC rb = ray_box_c(O, u, mk(sc.bmx, sc.bmy, sc.bmz), sc.fast_box != 0);
+                        rowA(sbk) = make_float4(rb.rx, rb.ry, rb.rz, rb.c0);
+                        rowO(sbk) = make_float4(rb.ox, rb.oy, rb.oz, __int_as_float(work ? 1 : 0));      // .w: one outstanding entry
+                        rowC(sbk) = r0;
+                        rowD(sbk) = make_float4(r1.x, r1.y, __uint_as_float(0xffffffffu), __uint_as_float(0xffffffffu));   // .zw: WF_NOHIT
+                        path_[b] = rf - 1;
+                        WQ_CHECK(path_[b] >= 0 && path_[b] < 2 * st.n_paths, 1, path_[b] = 0);
                     }
-                    break;                         // at most R leaf entries per pass: the TRI steps below drain them
+                    stage_used += take;
+                    const unsigned long long gm = __ballot(got);
+                    if (dbg_on) { d_rounds++; d_rays += (unsigned int)__popcll(gm); }
+                    if (root_hiw < 0) {
+                        if (got) stack[top + lanes_below(gm)] = 2u << kQNodeShift | sbk;   // the root (node 1) has the children 2, 3
+                        top += __popcll(gm);
+                    } else {                           // the root is a leaf
+                        if (cnt > 0) {
+                            if (got) {
+                                leafq[(ltail + (unsigned int)lanes_below(gm)) & (LCAP - 1)] = make_uint2((unsigned int)first, (unsigned int)cnt << kQNodeShift | sbk);
+                                if (STATS) wk.tris += (uint32_t)cnt;
+                            }
+                            ltail += (unsigned int)__popcll(gm);
+                        }
+                        leaf_root_done = true;
+                    }
                 }
+                if (leaf_root_done) break;             // at most R leaf entries per pass: the TRI steps below drain them
                 WQ_MARK("round_end");
             }
         }
@@ -515,7 +534,10 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
             continue;
         }
         if (top == 0) {
-            if (drained && stage_used >= stage_n && __ballot(path >= 0) == 0ull) break;   // every wave gets here: each step consumes entries
+            bool busy = false;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) busy = busy || path_[b] >= 0;
+            if (drained && stage_used >= stage_n && __ballot(busy) == 0ull) break;   // every wave gets here: each step consumes entries
             if (dbg_on) d_idle++;
             continue;
         }
@@ -530,7 +552,7 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
 #if defined(RT_DEBUG) && defined(RT_PAD_LDS)
         { unsigned int pl_ = marks[lane]; pl_ += marks[lane + 64]; pl_ += marks[lane]; pl_ += marks[lane + 64]; asm volatile("" :: "v"(pl_)); }
 #endif
-        constexpr int KP = RT_TRAVQ_KP;                             // sibling pairs per lane and step: the loads of all of them are in flight together
+        constexpr int KP = QPairs<R>::value;                        // sibling pairs per lane and step: the loads of all of them are in flight together
         const int n = top < 64 * KP ? top : 64 * KP;
         if (cap - top < 64 * KP) {                                         // no room for up to 128 pushes: serial drain of 64 entries
             if (STATS) n_serial++;
@@ -552,7 +574,7 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
             act_[k] = lane + 64 * k < n;
             e_[k] = act_[k] ? stack[top - 1 - lane - 64 * k] : 0u;   // node << 10 | slot << 4: the sibling nodes (one 64-byte line) of the ray in that slot
             sb_[k] = e_[k] & kQSlotMask;                             // the slot's table row
-            off_[k] = (e_[k] >> 5) & ~31u;                           // the pair's byte offset in the node array
+            off_[k] = (e_[k] >> (kQNodeShift - 5)) & ~31u;           // the pair's byte offset in the node array
             WQ_CHECK(!act_[k] || ((e_[k] >> kQNodeShift) >= 2u && (int)(e_[k] >> kQNodeShift) + 1 <= sc.n_nodes && ((e_[k] >> kQNodeShift) & 1u) == 0u), 4, off_[k] = 0u);
         }
         top -= n;

@@ -331,7 +331,7 @@ def test_config2_spheres_only_full_size(ctx, oracle, cat_golden):
     assert int(got[..., 3].astype(np.float64).sum()) == cnt["rays"]
 
 
-@pytest.mark.parametrize("env", [{"RT_TRAVQ_CAP": "128"}, {"RT_TRAVQ_R": "32"}, {"RT_TRAVQ_R": "32", "RT_TRAVQ_CAP": "128"},
+@pytest.mark.parametrize("env", [{"RT_TRAVQ_CAP": "128"}, {"RT_TRAVQ_R": "32"}, {"RT_TRAVQ_R": "32", "RT_TRAVQ_CAP": "128"}, {"RT_TRAVQ_R": "128"}, {"RT_TRAVQ_R": "128", "RT_TRAVQ_CAP": "256"},
                                  {"RT_TRAVQ_LDS": "12"}, {"RT_TRAVQ_LDS": "12", "RT_TRAVQ_R": "32"}, {"RT_TRAVQ_LDS": "16"},
                                  {"RT_TRAVQ_LDS": "8", "RT_TRAVQ_CAP": "128"}])
 def test_work_stack_traversal_bounded_stack_and_slot_counts(ctx, cat_golden, monkeypatch, env):

@@ -6,7 +6,7 @@ sys.path.insert(0, os.getcwd())
 import raytracinggpu_amd as rt
 from raytracinggpu_amd import hostlib, tiling
 ctx = rt.Context(0)
-for n in (45, 161, 513, 1025):
+for n in [int(x) for x in os.environ.get("BIG_N", "45,161,513,1025").split(",")]:
     rng = np.random.default_rng(11)
     gx, gz = np.meshgrid(np.linspace(-18, 18, n), np.linspace(-14, 22, n), indexing="ij")
     gy = -9.0 + 3.0 * np.sin(gx * 0.45) * np.cos(gz * 0.38) + 0.15 * rng.standard_normal((n, n))
