@@ -1727,6 +1727,7 @@ int rt_mesh_rebuild_mode(rt_ctx *ctx, int mode, float *bvh_arr10_out, int32_t *t
     RT_HIP(ctx, hipEventRecord(e1, q));
     RT_HIP(ctx, hipEventSynchronize(e1));
     RT_HIP(ctx, hipEventElapsedTime(&ctx->build.device_build_ms, e0, e1));
+    ctx->have_tonemap_time = false;                                                 // (the borrowed events no longer bracket a tone mapping)
     ctx->build.mode = mode; ctx->build.n_nodes = n_nodes; ctx->build.n_triangles = nt;
     const auto t_install = std::chrono::steady_clock::now();
     int *const order_dev = static_cast<int *>(ctx->bb_idx.p);
