@@ -43,7 +43,7 @@ VALU_PEAK_GINST = 1024 * 2.4 / 2   # vector wave-instructions per ns the chip ca
                                    # instruction (MI355X_MICROARCH.md: "issues each VALU instruction over 2 cycles"; tools/ubench/issue_table.hip
                                    # agrees for fma / mul / add with 4+ waves per SIMD; min / max / compares / cndmask / conversions take ~1.75x
                                    # that, transcendentals ~3.3x: the WEIGHTED count over this peak is `roofline.frac`)
-ADV_LAYOUT_BYTES_PER_PATH = 154   # wf_advance, HBM bytes per path and launch of the record layout (profiles/round3/pmc_wf_advance.json: 323 MB per 2.07 M paths)
+ADV_LAYOUT_BYTES_PER_PATH = 122   # wf_advance, HBM bytes per path and launch of the record layout (profiles/round4/pmc_wf_advance.json: 252 MB per 2.07 M paths; rounds 2-3: 154)
 TILE_ROWS = 8              # == raytracinggpu_amd.tiling.TILE_ROWS
 
 def parse():
@@ -379,13 +379,14 @@ def roofline(rt, ctx, args, p, rows, local, stream, counts, world, W, H, kernel_
     adv_ms, adv_launches, adv_paths, conc = (adv[0], adv[1], adv[2], 1) if adv else (st["adv_ms"] / st["adv_launches"] if st.get("adv_launches") else None, st.get("adv_launches", 0), st.get("adv_paths", 0), parts)
     if adv_ms:
         # bytes one launch moves: measured (PMC, same source hash) when the committed profile belongs to this code, else the record layout's
-        # figure (path record 16 B read + 16 B written, continuation ray 32 B read back + 32 B written, shadow ray 32 B
-        # written, 8-16 B of traversal results, 5 B of shading terms per live path)
+        # figure (the continuation ray's 32-byte record -- which also holds the path's flag word -- read back and written,
+        # the shadow ray's record written only if it passed the mesh's root box, 8-16 B of traversal results, 5 B of shading terms per live path)
         layout_b = ADV_LAYOUT_BYTES_PER_PATH * adv_paths
-        measured = None
+        measured, valu_busy = None, None
         if out.get("traffic") is not None:
             try:
                 a = json.load(open(os.path.join(ROOT, "profiles", rnd, "summary.json")))["kernels"]["wf_advance"]
+                valu_busy = a.get("valu_pipe_busy_frac")
                 measured = int((a["hbm_read_bytes_per_launch"] + a["hbm_write_bytes_per_launch"]) * adv_paths / max(a.get("paths_per_launch", adv_paths), 1))
             except (OSError, KeyError, ValueError):
                 measured = None
@@ -395,7 +396,9 @@ def roofline(rt, ctx, args, p, rows, local, stream, counts, world, W, H, kernel_
                      "paths_per_launch": adv_paths, "bytes_per_launch": int(b), "bytes_per_path": round(b / max(adv_paths, 1), 1),
                      "bytes_are": "measured: rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE of this source hash" if measured is not None else "the record layout's figure (no PMC summary of this source hash)",
                      "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                     "frac_of_achievable": round(gbs / HBM_ACHIEVABLE_GBS, 4), "traffic": measured})
+                     "frac_of_achievable": round(gbs / HBM_ACHIEVABLE_GBS, 4), "traffic": measured,
+                     **({"valu_pipe_busy_frac": valu_busy, "co_bound": "the kernel's vector pipes are this busy when it runs alone (PMC, same source hash): twelve correctly rounded "
+                         "square roots and two binary64 islands per path; it is bound by both, and the byte diet of round 4 moved it towards the VALU side"} if valu_busy else {})})
     out["kernels"] = kern
     return out
 

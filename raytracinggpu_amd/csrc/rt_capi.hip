@@ -130,7 +130,7 @@ struct rt_ctx {
     int n_levels = 0;
     DevBuf node_lo, node_hi, nodes2, nodesq, nodesb, q2thr, tri, verts, tidx, scratch_rgba, scratch_rgb8, work, queue;
     int n_cus = 0;
-    DevBuf wfM, wfPR, wfT, wfLS, wfSID, wfSamp;                     // wavefront path state (HBM); wfSamp / wfT: per-sample colours and their running sum (num_rays > 1)
+    DevBuf wfM, wfT, wfLS, wfSID, wfSamp;                     // wavefront path state (HBM); wfSamp / wfT: per-sample colours and their running sum (num_rays > 1)
     DevBuf wfQR;                                                    // traversal queue in slot order: the rays (32 B each)
     DevBuf pathSamp, pathT;                                         // wf_path with num_rays > 1: per-sample colours, running sum
     DevBuf dbgbuf;                                                  // -DRT_DEBUG builds: per-wave traversal records
@@ -705,7 +705,7 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
             pt.pblocks = (unsigned)((n_paths64 + kn.adv_block - 1) / kn.adv_block);
         }
         const size_t np = np_total;
-        if ((rc2 = ensure(ctx, ctx->wfM, 2 * np * 8)) != RT_OK || (rc2 = ensure(ctx, ctx->wfPR, np * 16)) != RT_OK ||
+        if ((rc2 = ensure(ctx, ctx->wfM, 2 * np * 8)) != RT_OK ||
             (rc2 = ensure(ctx, ctx->wfT, (fr.spp > 1 ? px_total : 1) * 16)) != RT_OK || (rc2 = ensure(ctx, ctx->wfSamp, (fr.spp > 1 ? np : 1) * 16)) != RT_OK ||
             (rc2 = ensure(ctx, ctx->wfSID, np * (size_t)nseg)) != RT_OK || (rc2 = ensure(ctx, ctx->wfLS, np * 4 * (size_t)nseg)) != RT_OK)
             return rc2;
@@ -746,7 +746,6 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
             st.QR = static_cast<float4 *>(ctx->wfQR.p) + 2 * pt.qbase;
             st.init_m = queue ? 0 : 1;                               // wf_trav merges split traversals with atomicMin
             st.M = static_cast<unsigned long long *>(ctx->wfM.p) + 2 * pt.base;
-            st.PR = static_cast<float4 *>(ctx->wfPR.p) + pt.base;
             st.samp_out = fr.spp > 1 ? static_cast<float4 *>(ctx->wfSamp.p) + pt.base : nullptr;
             st.LS = static_cast<float *>(ctx->wfLS.p) + pt.base * (size_t)nseg;   // LS[d * n_paths + i] inside the part's block
             st.SID = static_cast<unsigned char *>(ctx->wfSID.p) + pt.base * (size_t)nseg;
@@ -797,9 +796,11 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
             if (pt.st.n_paths == 0) { if (own0) RT_HIP(ctx, hipEventRecord(ctx->part_ev[j], q)); continue; }
             for (int s = 0; s < fr.spp; s += chunk) {
                 pt.st.samp0 = s;
+                pt.st.epoch = 0;
                 if (work_dev) hipLaunchKernelGGL((rtk::wf_advance<true, true>), dim3(pt.pblocks), dim3(kn.adv_block), 0, q, scn, pt.fr, pt.st);
                 else hipLaunchKernelGGL((rtk::wf_advance<false, true>), dim3(pt.pblocks), dim3(kn.adv_block), 0, q, scn, pt.fr, pt.st);
                 for (int it = 0; it < (segs > 0 ? segs + 1 : 0); ++it) {
+                    pt.st.epoch = it;
                     if (have_mesh) {
 #ifdef RT_DEBUG
                         pt.st.dbg = (dbg_env && it == dbg_it) ? static_cast<unsigned long long *>(ctx->dbgbuf.p) : nullptr;
@@ -1211,7 +1212,7 @@ int rt_ctx_destroy(rt_ctx *ctx) {
     }
     ctx->node_lo.release(); ctx->node_hi.release(); ctx->nodes2.release(); ctx->nodesq.release(); ctx->nodesb.release(); ctx->q2thr.release(); ctx->left_dev.release(); ctx->lvl_nodes.release(); ctx->lvl_off.release(); ctx->nrm.release(); ctx->tri.release(); ctx->verts.release(); ctx->tidx.release();
     ctx->scratch_rgba.release(); ctx->scratch_rgb8.release(); ctx->work.release(); ctx->queue.release();
-    ctx->wfM.release(); ctx->wfPR.release(); ctx->wfT.release(); ctx->wfLS.release(); ctx->wfSID.release(); ctx->wfSamp.release();
+    ctx->wfM.release(); ctx->wfT.release(); ctx->wfLS.release(); ctx->wfSID.release(); ctx->wfSamp.release();
     ctx->wfQR.release(); ctx->accum.release(); ctx->dbgbuf.release();
     ctx->pathSamp.release(); ctx->pathT.release(); ctx->tidx_up.release();
     for (DevBuf *b : {&ctx->bb_idx, &ctx->bb_cnt, &ctx->bb_pa, &ctx->bb_pb, &ctx->bb_tmp, &ctx->bb_nodes_i, &ctx->bb_nodes_f, &ctx->bb_counter, &ctx->bb_lvl, &ctx->bb_size, &ctx->bb_pre, &ctx->bb_arr, &ctx->lb_pool, &ctx->lb_pool2, &ctx->perm_dev}) b->release();
@@ -1891,7 +1892,7 @@ int rt_ctx_selfcheck(rt_ctx *ctx) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     const DevBuf *bufs[] = {&ctx->node_lo, &ctx->node_hi, &ctx->nodes2, &ctx->nodesq, &ctx->nodesb, &ctx->q2thr, &ctx->tri, &ctx->verts, &ctx->tidx, &ctx->tidx_up, &ctx->nrm,
-                            &ctx->scratch_rgba, &ctx->scratch_rgb8, &ctx->work, &ctx->queue, &ctx->wfM, &ctx->wfPR, &ctx->wfT, &ctx->wfLS, &ctx->wfSID, &ctx->wfSamp,
+                            &ctx->scratch_rgba, &ctx->scratch_rgb8, &ctx->work, &ctx->queue, &ctx->wfM, &ctx->wfT, &ctx->wfLS, &ctx->wfSID, &ctx->wfSamp,
                             &ctx->wfQR, &ctx->pathSamp, &ctx->pathT, &ctx->accum, &ctx->left_dev, &ctx->lvl_nodes, &ctx->lvl_off, &ctx->bb_idx, &ctx->bb_cnt, &ctx->bb_pa, &ctx->bb_pb, &ctx->bb_tmp,
                             &ctx->bb_nodes_i, &ctx->bb_nodes_f, &ctx->bb_counter, &ctx->bb_lvl, &ctx->bb_size, &ctx->bb_pre, &ctx->bb_arr, &ctx->lb_pool, &ctx->lb_pool2, &ctx->perm_dev,
                             &ctx->slot_rgba[0], &ctx->slot_rgba[1], &ctx->slot_rgb8[0], &ctx->slot_rgb8[1]};

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void trace_emit_kernel(const Scene sc, const W
     }
     st.M[r] = WF_NOHIT;
     st.QR[2 * (size_t)q] = make_float4(O.x, O.y, O.z, u.x);
-    st.QR[2 * (size_t)q + 1] = make_float4(u.y, u.z, __int_as_float(need ? r + 1 : 0), 0.f);
+    st.QR[2 * (size_t)q + 1] = make_float4(u.y, u.z, __int_as_float(need ? PQ_TRAV : 0), 0.f);
 }
 
 __global__ __launch_bounds__(256) void trace_close_kernel(const Scene sc, const unsigned long long *__restrict__ M, int n, float *__restrict__ out) {
@@ -120,6 +120,7 @@ extern "C" int rt_trace_rays(rt_ctx *ctx, const float *rays, int n, float tri_tm
         st.QR = static_cast<float4 *>(ctx->wfQR.p);
         st.M = M = static_cast<unsigned long long *>(ctx->wfM.p);
         st.init_m = queue ? 0 : 1;
+        st.epoch = 0;
         hipLaunchKernelGGL(rtk::trace_emit_kernel, dim3((unsigned)((2 * st.n_paths + 255) / 256)), dim3(256), 0, q, sc, st, static_cast<const float *>(din.p), n);
         if (have_mesh) {
             if (queue) hipLaunchKernelGGL(travq_fn(false, qR, false, false), dim3((unsigned)tblocks), dim3(tb), trav_lds, q, sc, fr, st, qcap, 0, kn.q_low * (qR == 128 ? 2 : 1),

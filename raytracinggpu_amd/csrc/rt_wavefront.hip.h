@@ -47,14 +47,23 @@ constexpr int PF_RAYS_SHIFT = 10, PF_RAYS_MASK = 63;        // rays traced so fa
 constexpr int PF_WINS_SHIFT = 16;                           // 10 bits: the Y ray's nearest sphere before / after the mesh slot (object id + 1)
 constexpr int PF_XSPHERE = 1 << 26;                         // the X ray is blocked by a sphere already (cpu:615 true whatever the mesh says)
 constexpr unsigned long long WF_NOHIT = ~0ull;
+// the wavefront pipeline keeps the path's flag word in its continuation (Y) slot's queue record; bits 0..15 as above, then:
+constexpr int PQ_WIN_SHIFT = 16;                            // 5 bits: object id + 1 of the Y ray's nearest sphere (0 = none); its t is the record's last word
+constexpr int PQ_WINB = 1 << 21;                            // that sphere comes AFTER the mesh in object order (the mesh wins a tie; before it the sphere does: cpu:554's strict '<')
+constexpr int PQ_XSPHERE = 1 << 22;                         // PF_XSPHERE of this record
+constexpr int PQ_REFR_SHIFT = 23;                           // 6 bits: Ray::refraction_index of the Y ray: 0 = 1.0, else (object id + 1) << 1 | (0: that object's n_in, 1: its n_out)
+constexpr int PQ_TRAV = 1 << 29;                            // (either slot) the record's ray passed the mesh's root box: the traversal launch whose number (WfState::epoch) equals the
+                                                            // record's depth field picks it up.  A shadow ray that misses the root box is not written at all: what its slot still
+                                                            // holds is an older launch's record (other depth), or the zero wf_advance<FIRST> put there
+__device__ __forceinline__ bool wq_live(int w0, int epoch) { return (w0 & PQ_TRAV) != 0 && ((w0 >> PF_DEPTH_SHIFT) & PF_DEPTH_MASK) == epoch; }
 
 // Path state of the wavefront pipeline, in HBM.  A ray lives in ONE place: its 32-byte record in the traversal queue (slot order;
 // the four rays of a group are one 128-byte line), which the uniform kernel writes when it emits the ray, the traversal kernel
-// reads, and the next uniform launch reads back to compute the hit point.  Per path and launch the uniform kernel moves ~150
-// bytes (round 1: ~300: every ray was stored twice, the shadow ray and its sphere hits were kept although one comparison needs
-// them, object ids, ray counts and sample sums were streamed with every launch).
+// reads, and the next uniform launch reads back to compute the hit point.  The record's two spare words hold the PATH's state as
+// well (flag word and the nearest sphere's t: round 4; rounds 2-3 kept a 16-byte path record beside the queue), so a path that is
+// alive costs one 32-byte read and one 32-byte write of its Y slot, the X slot's record when a shadow ray leaves, 8 bytes of
+// traversal result per ray and 5 bytes per shaded segment (round 1: ~300 B per path and launch, rounds 2-3: 154).
 struct WfState {
-    float4 *PR;           // [n_paths] path record (bits(flags | depth | rays | wins), tA, tB, refraction index): tA / tB = the Y ray's nearest sphere before / after the mesh slot
     unsigned long long *M;   // [2 n_paths] traversal result by ray (Y rays at [0, n_paths), X rays at [n_paths, 2 n_paths)): bits(t) << 32 | triangle index (visit order); WF_NOHIT if none
     float4 *samp_out;     // frames with more than one sample: [n_paths] (colour of the item's sample, rays traced); path_reduce adds them in sample order
     float *LS;            // l (cpu:623) of every diffuse segment, written when the segment is shaded and zeroed if its shadow ray is blocked: LS[d * n_paths + i]
@@ -67,11 +76,13 @@ struct WfState {
     // traversal scheduling: ray-slot q in [0, slots) maps to ray 4*g + (q & 3), g = ((q>>2) & (S-1)) * Q + ((q>>2) >> log2S)
     int log2S, Q, n_groups;   // n_groups = 2 n_paths / 4 (ray groups);  S * Q >= n_groups
     int slots_per_block;      // multiple of 4: ray slots owned by one workgroup, handed to its waves on demand
+    int epoch;                // index of the traversal launch inside its chain (0 after wf_advance<FIRST>): a queue record is live iff its flag word carries PQ_TRAV and this number
     int init_m;               // the traversal kernel merges partial results with atomicMin (wf_trav's work splitting): emitters initialise M
     unsigned long long *dbg;  // optional per-wave debug record (-DRT_DEBUG)
     // traversal queue: the rays in TRAVERSAL-SLOT order, so that the slots a traversal workgroup owns are contiguous and one
     // round trip brings flag and record
-    float4 *QR;               // [2 slots] record of slot q: QR[2q] = (O.xyz, u.x), QR[2q+1] = (u.y, u.z, bits(ray + 1 if the ray needs traversal else 0), -)
+    float4 *QR;               // [2 slots] record of slot q: QR[2q] = (O.xyz, u.x), QR[2q+1] = (u.y, u.z, bits(W0), W1).  Y slot (ray r < n_paths): W0 = the path's
+                              // flag word (PF_* | PQ_*; 0 = no path), W1 = t of the Y ray's nearest sphere; X slot: W0 = PQ_TRAV | depth, written only when the ray needs traversal
 };
 
 // n / d for 0 <= n < 2^32 with m = floor(2^32 / d) from the host: the estimate mulhi(n, m) is the quotient or one below it
@@ -133,10 +144,9 @@ __device__ __forceinline__ int wf_ray_to_slot(const WfState &st, int r) {
     return ((col << st.log2S | a) << 2) | (r & 3);
 }
 
-// Emit ray r into queue slot q: the record (always: the next uniform launch reads a continuation ray back), the mesh's root-box
-// test (cpu:279; wave-uniform node data from kernel arguments) and the traversal flag.  Returns whether the ray needs traversal.
+// The mesh's root-box test of an emitted ray (cpu:279; wave-uniform node data from kernel arguments): whether the ray needs traversal.
 template <bool STATS>
-__device__ __forceinline__ bool wf_emit_ray(const Scene &sc, const WfState &st, int r, int q, f3 O, f3 u, bool keep_record, Work &wk) {
+__device__ __forceinline__ bool wf_root_test(const Scene &sc, const WfState &st, int r, f3 O, f3 u, Work &wk) {
     bool need = false;
     if (sc.mesh_slot >= 0 && sc.n_nodes > 0) {
         if (STATS) wk.box++;
@@ -146,8 +156,6 @@ __device__ __forceinline__ bool wf_emit_ray(const Scene &sc, const WfState &st, 
             if (st.init_m) st.M[r] = WF_NOHIT;
         }
     }
-    if (need || keep_record) st.QR[2 * (size_t)q] = make_float4(O.x, O.y, O.z, u.x);
-    st.QR[2 * (size_t)q + 1] = make_float4(u.y, u.z, __int_as_float(need ? r + 1 : 0), 0.f);
     return need;
 }
 
@@ -360,7 +368,7 @@ __global__ __launch_bounds__(LDSN ? kTravBlockLds : kTravBlock) void wf_trav(con
                     if (ray < 0) {
                         const int qo = base + __popcll(idle & lane_lt);
                         const float4 rq = qo < blk_n ? st.QR[2 * ((size_t)blk_base + qo) + 1] : make_float4(0, 0, 0, 0);
-                        const int rf = __float_as_int(rq.z);                            // ray + 1 if the slot's ray needs traversal
+                        const int rf = wq_live(__float_as_int(rq.z), st.epoch) ? wf_slot_to_path(st, blk_base + qo) + 1 : 0;   // ray + 1 if the slot's ray needs traversal
                         if (rf != 0) {
                             const int path = rf - 1;
                             {
@@ -484,15 +492,16 @@ finished:
 // several of them at once as items, each writes its colour, and path_reduce adds the colours in sample order.
 template <bool STATS, bool FIRST>
 __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr, const WfState &st, const int i, Work &wk) {
-    float4 ST = FIRST ? make_float4(0, 0, 0, 1.f) : st.PR[i];        // Ray::refraction_index = 1 (cpu:100)
-    const int F = __float_as_int(ST.x);
+    const float4 kDead = make_float4(0, 0, 0, 0);                     // second half of a queue record without a ray (and, in a Y slot, without a path)
+    const int rx = st.n_paths + i;                                    // ray index of this path's shadow ray
+    const int qy = wf_ray_to_slot(st, i), qx = wf_ray_to_slot(st, rx);
+    const float4 y1 = FIRST ? kDead : st.QR[2 * (size_t)qy + 1];      // (u.y, u.z, flag word, t of the nearest sphere) of the continuation ray in flight
+    const int F = __float_as_int(y1.z);
     if (!FIRST && !(F & PF_ALIVE)) return;                            // finished (or padding): its queue flags are already 0
-    const float4 kDead = make_float4(0, 0, 0, 0);                     // second half of a queue record without a ray
     const float PI_F = (float)3.14159265358979323846;
     const double PI_D = 3.14159265358979323846;
     const f3 L = mk(sc.Lx, sc.Ly, sc.Lz);
-    const int rx = st.n_paths + i;                                    // ray index of this path's shadow ray
-    const int qy = wf_ray_to_slot(st, i), qx = wf_ray_to_slot(st, rx);
+    int refr_code = FIRST ? 0 : (F >> PQ_REFR_SHIFT) & 63;            // Ray::refraction_index = 1 (cpu:100)
     int d = 0, nrays = 0;
     bool emitY = false, emitX = false, finished = false;
     f3 Oy = mk(0, 0, 0), uy = mk(0, 0, 1), Ox = mk(0, 0, 0), ux = mk(0, 0, 1);
@@ -505,7 +514,7 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
     const int row = fr.row0 + (lrow / fr.tile_rows) * fr.tile_rows * fr.tile_step + (lrow % fr.tile_rows);
 
     if (FIRST) {
-        if (!valid) { st.PR[i] = kDead; st.QR[2 * (size_t)qy + 1] = kDead; st.QR[2 * (size_t)qx + 1] = kDead; return; }
+        if (!valid) { st.QR[2 * (size_t)qy + 1] = kDead; st.QR[2 * (size_t)qx + 1] = kDead; return; }
         if (fr.segs <= 0) {
             finished = true;                                          // optimized.cu convention with num_bounce 0: black
         } else {
@@ -537,12 +546,11 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
     } else {
         d = (F >> PF_DEPTH_SHIFT) & PF_DEPTH_MASK;                    // segment of the continuation ray in flight
         nrays = (F >> PF_RAYS_SHIFT) & PF_RAYS_MASK;
-        float refr = ST.w;
         // ---- (1) the shadow ray of segment d-1's hit came back: direct light or not (cpu:615) ----
         // cpu:615 compares |P' - P_adj|^2, P' = P_adj + t_min u, with |L - P_adj|^2; it is monotone in t_min (every rounding involved is),
         // so it holds iff it holds for the nearest sphere (decided when the ray was emitted: PF_XSPHERE) or for the nearest triangle
         if (F & PF_HASX) {
-            bool shadowed = (F & PF_XSPHERE) != 0;
+            bool shadowed = (F & PQ_XSPHERE) != 0;
             if (!shadowed && (F & PF_MESHX)) {
                 const unsigned long long m = st.M[rx];
                 if (m != WF_NOHIT) {
@@ -556,20 +564,21 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
         }
         // ---- (2) the continuation ray of segment d came back: Scene::getColor's branch for its hit (cpu:570-614) ----
         if (F & PF_HASY) {
-            const float4 r0 = st.QR[2 * (size_t)qy], r1 = st.QR[2 * (size_t)qy + 1];
-            f3 O = mk(r0.x, r0.y, r0.z), u = mk(r0.w, r1.x, r1.y);
+            const float4 r0 = st.QR[2 * (size_t)qy];
+            f3 O = mk(r0.x, r0.y, r0.z), u = mk(r0.w, y1.x, y1.y);
             int sid = 0xff;                                           // object id if the hit is diffuse
-            // Scene::intersect_all's running minimum replayed in object order: spheres before the mesh, mesh, spheres after (strict '<', cpu:554)
-            float t_min = ST.y;
-            int win = ((F >> PF_WINS_SHIFT) & 31) - 1, tri_win = -1;
+            // Scene::intersect_all's running minimum (strict '<' in object order, cpu:554) over  spheres before the mesh, mesh, spheres after:
+            // the spheres' own winner was decided at emission (the later group wins only if strictly nearer); against it the mesh wins a
+            // tie iff the sphere comes after it in object order
+            float t_min = y1.w;
+            int win = ((F >> PQ_WIN_SHIFT) & 31) - 1, tri_win = -1;
             if (F & PF_MESHY) {
                 const unsigned long long m = st.M[i];
                 if (m != WF_NOHIT) {
                     const float tm = __uint_as_float((unsigned int)(m >> 32));
-                    if (tm < t_min) { t_min = tm; win = sc.mesh_slot; tri_win = (int)(unsigned int)m; }
+                    if ((F & PQ_WINB) ? !(t_min < tm) : (tm < t_min)) { t_min = tm; win = sc.mesh_slot; tri_win = (int)(unsigned int)m; }
                 }
             }
-            if (ST.z < t_min) { t_min = ST.z; win = ((F >> (PF_WINS_SHIFT + 5)) & 31) - 1; }
             if (win >= 0) {                                           // a miss is black (cpu:571): nothing to emit
                 const f3 P = O + t_min * u;                           // cpu:560
                 f3 N;
@@ -596,6 +605,8 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
                     cont = true;
                 } else if (m.n_in != m.n_out) {                       // cpu:580-604
                     float ratio;
+                    float refr = 1.f;                                 // the ray's index: 1, or the n_in / n_out of the surface it last crossed
+                    if (refr_code != 0) { const Material mr = material_of(sc, (refr_code >> 1) - 1); refr = (refr_code & 1) ? mr.n_out : mr.n_in; }
                     const bool out2in = refr == m.n_out;
                     if (out2in) ratio = m.n_out / m.n_in;
                     else { ratio = m.n_in / m.n_out; N = -N; }
@@ -608,7 +619,7 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
                         const f3 Nc = (-rt_sqrtf(1 - (ratio * ratio) * (1 - un * un))) * N;
                         const f3 Tc = ratio * (u - un * N);
                         u = Nc + Tc;
-                        refr = out2in ? m.n_in : m.n_out;
+                        refr_code = (win + 1) << 1 | (out2in ? 0 : 1);    // refr = out2in ? m.n_in : m.n_out
                     }
                     cont = true;
                 } else {                                              // cpu:605-642: diffuse
@@ -642,7 +653,7 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
                         const f3 T2 = cross(N, T1);
                         u = x * T1 + y * T2 + zz * N;
                         O = Pa;
-                        refr = 1.f;                                   // Ray(P_adjusted, random_direction): index 1
+                        refr_code = 0;                                // Ray(P_adjusted, random_direction): index 1
                         cont = true;
                     }
                 }
@@ -654,7 +665,6 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
             st.SID[(size_t)d * st.n_paths + i] = (unsigned char)sid;
             d = d + 1;
         }
-        ST.w = refr;
         finished = !(emitX || emitY);
     }
 
@@ -680,33 +690,37 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
             const float n = fr.cam_mode == 1 ? 1.f : (float)fr.spp;
             fr.out[out_index(fr, lrow, px)] = make_float4(t.x / n, t.y / n, t.z / n, t.w);
         }
-        st.PR[i] = kDead;
-        st.QR[2 * (size_t)qy + 1] = kDead; st.QR[2 * (size_t)qx + 1] = kDead;
+        st.QR[2 * (size_t)qy + 1] = kDead;                            // the path is over; its X slot keeps a record of an older launch, which no later one takes for its own
+        if (FIRST) st.QR[2 * (size_t)qx + 1] = kDead;
         return;
     }
 
     // ---- (3) emission: sphere tests (cpu:512-527), root-box test (cpu:279), queue records ----
-    int flags = PF_ALIVE | (d << PF_DEPTH_SHIFT) | (nrays << PF_RAYS_SHIFT);
+    int flags = PF_ALIVE | (d << PF_DEPTH_SHIFT) | (nrays << PF_RAYS_SHIFT) | (refr_code << PQ_REFR_SHIFT);
     SphereHit h, hx;
     spheres_split2(sc, emitX ? Ox : Oy, uy, emitY, ux, emitX, h, hx);   // a shadow ray and a bounce ray leave the same point (Oy == Ox == P_adjusted)
-    if (emitY) {
-        ST.y = h.tA; ST.z = h.tB;
-        flags |= PF_HASY | wf_pack_wins_path(h);
-        if (wf_emit_ray<STATS>(sc, st, i, qy, Oy, uy, true, wk)) flags |= PF_MESHY;
-    } else {
-        st.QR[2 * (size_t)qy + 1] = kDead;
-    }
+    float t_sph = 0.f;
     if (emitX) {
         const float tS = hx.tB < hx.tA ? hx.tB : hx.tA;               // only the value of the shadow ray's nearest hit matters
         const f3 Pp = Ox + tS * ux;                                   // cpu:560
         flags |= PF_HASX;
-        if (norm2(Pp - Ox) <= norm2(L - Ox)) flags |= PF_XSPHERE;      // cpu:615 holds for the sphere already (the mesh is still intersected, as intersect_all does)
-        if (wf_emit_ray<STATS>(sc, st, rx, qx, Ox, ux, false, wk)) flags |= PF_MESHX;
-    } else {
-        st.QR[2 * (size_t)qx + 1] = kDead;
+        if (norm2(Pp - Ox) <= norm2(L - Ox)) flags |= PQ_XSPHERE;      // cpu:615 holds for the sphere already (the mesh is still intersected, as intersect_all does)
+        if (wf_root_test<STATS>(sc, st, rx, Ox, ux, wk)) {             // only then does anybody read the record: the traversal, and this kernel if the mesh is hit
+            flags |= PF_MESHX;
+            st.QR[2 * (size_t)qx] = make_float4(Ox.x, Ox.y, Ox.z, ux.x);
+            st.QR[2 * (size_t)qx + 1] = make_float4(ux.y, ux.z, __int_as_float(PQ_TRAV | (d << PF_DEPTH_SHIFT)), 0.f);
+        }
+    } else if (FIRST) {
+        st.QR[2 * (size_t)qx + 1] = kDead;                            // once per chain: the previous chain's records carry the same depth numbers
     }
-    ST.x = __int_as_float(flags);
-    st.PR[i] = ST;
+    if (emitY) {
+        const bool after = h.tB < h.tA;                               // the later group's sphere replaces the earlier one's only if strictly nearer
+        t_sph = after ? h.tB : h.tA;
+        flags |= PF_HASY | ((((after ? h.winB : h.winA) + 1) & 31) << PQ_WIN_SHIFT) | (after ? PQ_WINB : 0);
+        if (wf_root_test<STATS>(sc, st, i, Oy, uy, wk)) flags |= PF_MESHY | PQ_TRAV;
+    }
+    st.QR[2 * (size_t)qy] = make_float4(Oy.x, Oy.y, Oy.z, uy.x);    // whole sectors also when no continuation ray leaves (then nobody reads this half)
+    st.QR[2 * (size_t)qy + 1] = make_float4(emitY ? uy.y : 0.f, emitY ? uy.z : 0.f, __int_as_float(flags), t_sph);   // the path's state travels with its Y slot
 }
 
 template <bool STATS, bool FIRST>
