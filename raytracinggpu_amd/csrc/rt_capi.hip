@@ -8,6 +8,7 @@
 #include "rt_travq.hip.h"
 #include "rt_path.hip.h"
 #include "rt_meshops.hip.h"
+#include "rt_qnodes.hip.h"
 #include "rt_bvhbuild.hip.h"
 #include "rt_lbvh.hip.h"
 
@@ -40,6 +41,8 @@ struct Knobs {
     int travq_cap = 0;         // RT_TRAVQ_CAP: stack capacity (>= 128; tests force the serial drain); 0 = the carve's capacity
     int travq_lds = 0;         // RT_TRAVQ_LDS: waves of the ONE workgroup per CU that stages the top of the BVH in LDS; 0 = nodes through L1/L2
     int q_low = 48;            // RT_TRAVQ_LOW: refill while the stack holds fewer sibling pairs than this (measured 1.19 / 1.21 / 1.25 ms per frame for 48 / 64 / 96)
+    int q16 = 0;               // RT_TRAVQ_Q16=1: the BOX step reads 16-bit fixed-point sibling pairs (32 bytes: two loads instead of four) when the tree allows it (rt_qnodes.hip.h).
+                               // Bit-exact like the default, measured no faster once every leaf decision is exact (profiles/round4/ab_fixed_point_pairs.txt): opt-in
     int q_minfree = 0;         // RT_TRAVQ_MINFREE: ... and at least this many slots are free (0 = R / 4)
     int parts = 2;             // RT_PARTS: concurrent sub-frames of the wavefront pipeline
     int bpc5 = 0;              // RT_TRAVQ_BPC5: allow a fifth workgroup per CU
@@ -82,6 +85,7 @@ static Knobs read_knobs() {
     if (geti("RT_TRAVQ_LDS", v) && v >= 1 && v <= 16) k.travq_lds = v;
     if (geti("RT_TRAVQ_LOW", v) && v >= 32 && v <= 320) k.q_low = v;
     if (geti("RT_TRAVQ_MINFREE", v) && v >= 1 && v <= 64) k.q_minfree = v;
+    if (geti("RT_TRAVQ_Q16", v)) k.q16 = v != 0;
     if (geti("RT_PARTS", v) && v >= 1 && v <= 8) k.parts = v;
     if (getenv("RT_TRAVQ_BPC5")) k.bpc5 = 1;
     if (geti("RT_TRAV_WAVES", v) && v >= 1) k.trav_waves = v;
@@ -128,6 +132,8 @@ struct rt_ctx {
     int lbvh_host_install = 0;                                       // RT_LBVH_HOST_INSTALL=1: re-lay an LBVH tree out on the host, as the reference-mode rebuild does (tests compare the two)
     rt_build_stats build{};                                          // what the last rt_mesh_rebuild_mode did
     int n_levels = 0;
+    DevBuf nodesh, tri2leaf;                                        // 16-bit fixed-point sibling pairs and the triangle -> leaf table (rt_qnodes.hip.h)
+    bool q16_topo_ok = false;                                       // the tree's shape allows them (leaf sizes, node count, boxes nest)
     DevBuf node_lo, node_hi, nodes2, nodesq, nodesb, q2thr, tri, verts, tidx, scratch_rgba, scratch_rgb8, work, queue;
     int n_cus = 0;
     DevBuf wfM, wfT, wfLS, wfSID, wfSamp;                     // wavefront path state (HBM); wfSamp / wfT: per-sample colours and their running sum (num_rays > 1)
@@ -328,7 +334,8 @@ using TravqFn = void (*)(const rtk::Scene, const rtk::Frame, const rtk::WfState,
 template <bool S, int R> TravqFn travq_pick(bool ldsn, bool ldsv) {
     return ldsn ? (ldsv ? rtk::wf_travq<S, R, true, true> : rtk::wf_travq<S, R, true, false>) : (ldsv ? rtk::wf_travq<S, R, false, true> : rtk::wf_travq<S, R, false, false>);
 }
-TravqFn travq_fn(bool stats, int R, bool ldsn, bool ldsv = false) {
+TravqFn travq_fn(bool stats, int R, bool ldsn, bool ldsv = false, bool qn = false) {
+    if (qn && !stats && R == 64 && !ldsn && !ldsv) return rtk::wf_travq<false, 64, false, false, true>;
     if (stats) return R == 32 ? travq_pick<true, 32>(ldsn, ldsv) : R == 128 ? travq_pick<true, 128>(ldsn, ldsv) : travq_pick<true, 64>(ldsn, ldsv);
     return R == 32 ? travq_pick<false, 32>(ldsn, ldsv) : R == 128 ? travq_pick<false, 128>(ldsn, ldsv) : travq_pick<false, 64>(ldsn, ldsv);
 }
@@ -809,7 +816,7 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
                         if (timed) RT_HIP(ctx, hipEventRecord(ctx->ev_trav[2 * it], q));
                         const dim3 tg((unsigned)pt.tblocks), tbd(tb);
                         if (queue) {
-                            hipLaunchKernelGGL(travq_fn(work_dev != nullptr, qR, qldsn, ldsv), tg, tbd, trav_lds, q, scn, pt.fr, pt.st, qcap, q_nlds, q_low, q_minfree);
+                            hipLaunchKernelGGL(travq_fn(work_dev != nullptr, qR, qldsn, ldsv, kn.q16 && scn.nodesh != nullptr), tg, tbd, trav_lds, q, scn, pt.fr, pt.st, qcap, q_nlds, q_low, q_minfree);
                         } else if (ldsn) {
                             if (work_dev) hipLaunchKernelGGL((rtk::wf_trav<true, true>), tg, tbd, trav_lds, q, scn, pt.fr, pt.st);
                             else hipLaunchKernelGGL((rtk::wf_trav<false, true>), tg, tbd, trav_lds, q, scn, pt.fr, pt.st);
@@ -968,6 +975,27 @@ int launch_tonemap(rt_ctx *ctx, const void *rgba_dev, int64_t npix, void *rgb8_d
 // The part of rt_scene_upload after validation of the sphere / light / camera arguments: layout conversion of the mesh (the
 // reference's arrays -> traversal-order nodes, visit-order triangle records, breadth-first sibling pairs, refit levels) and
 // the uploads.  `sc` carries the spheres, light and camera; rt_mesh_rebuild re-enters here with the tree it built on the device.
+// (Re)derive the 16-bit fixed-point sibling pairs and the triangle -> leaf table from the breadth-first arrays on the device (rt_qnodes.hip.h), on stream q
+// (the upload passes the null stream, as its copies do: creating the context's own stream here would change which hardware queues the sub-frame streams
+// get later, profiles/round3/ab_hw_queues_parts.log), joined before returning.  ctx->scene must be final (root box, node arrays); trees the format does not fit keep scene.nodesh = nullptr.
+int requantize(rt_ctx *ctx, hipStream_t q) {
+    rtk::Scene &sc = ctx->scene;
+    sc.nodesh = nullptr; sc.tri2leaf = nullptr;
+    if (!ctx->knobs.q16 || !ctx->q16_topo_ok || !ctx->travq_ok || !sc.fast_box || sc.mesh_slot < 0 || sc.n_nodes < 3 || sc.n_tris <= 0) return RT_OK;
+    int rc;
+    if ((rc = ensure(ctx, ctx->nodesh, ((size_t)sc.n_nodes + 2) * 16)) != RT_OK || (rc = ensure(ctx, ctx->tri2leaf, (size_t)sc.n_tris * sizeof(int))) != RT_OK) return rc;
+    const rtk::QGrid g = rtk::q16_grid(sc.root_lo, sc.root_hi);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipMemsetAsync(ctx->nodesh.p, 0, 32, q));            // nodes 0 (padding) and 1 (the root: tested when a ray is emitted)
+    hipLaunchKernelGGL(rtk::qnodes_kernel, dim3((unsigned)((sc.n_nodes + 255) / 256)), dim3(256), 0, q, sc.nodesq, sc.nodesb, sc.n_nodes, g,
+                       static_cast<uint4 *>(ctx->nodesh.p), static_cast<int *>(ctx->tri2leaf.p), sc.n_tris, rtk::kQNodeShift);
+    RT_HIP(ctx, hipGetLastError());
+    RT_HIP(ctx, hipStreamSynchronize(q));
+    sc.nodesh = static_cast<const uint4 *>(ctx->nodesh.p); sc.tri2leaf = static_cast<const int *>(ctx->tri2leaf.p);
+    sc.qgx = g.gx; sc.qgy = g.gy; sc.qgz = g.gz; sc.qsx = g.sx; sc.qsy = g.sy; sc.qsz = g.sz;
+    return RT_OK;
+}
+
 int install_scene(rt_ctx *ctx, rtk::Scene sc, const rt_mesh *mesh) {
     RT_HIP(ctx, hipSetDevice(ctx->device));
     if (ctx->stream_) RT_HIP(ctx, hipStreamSynchronize(ctx->stream_));   // (renders issued on a caller's stream are the caller's to order)
@@ -1087,6 +1115,17 @@ int install_scene(rt_ctx *ctx, rtk::Scene sc, const rt_mesh *mesh) {
             qb[2 * (k + 1)] = cb; qb[2 * (k + 1) + 1] = hb;
         }
         if ((rc = upload(ctx, ctx->nodesb, qb.data(), qb.size() * sizeof(float4))) != RT_OK) return rc;
+        {   // may this tree use the 16-bit fixed-point pairs (rt_qnodes.hip.h)?  Leaf sizes and counts fit the payload word, and every box nests inside its parent's
+            bool topo = order.size() >= 3 && order.size() + 2 < (size_t)rtk::kQ16MaxNodes && tri.size() / 3 <= (size_t)rtk::kQ16MaxTris;
+            for (size_t x = 0; topo && x < n; ++x) {
+                if (left_of[x] < 0) { if (__builtin_bit_cast(int, hi[x].w) - __builtin_bit_cast(int, lo[x].w) > rtk::kQ16MaxLeaf) topo = false; continue; }
+                for (const int c : {(int)x + 1, left_of[x]}) {
+                    const float4 cl = lo[c], ch = hi[c], pl = lo[x], ph = hi[x];
+                    if (!(cl.x >= pl.x && cl.y >= pl.y && cl.z >= pl.z && ch.x <= ph.x && ch.y <= ph.y && ch.z <= ph.z)) topo = false;   // also false for NaN
+                }
+            }
+            ctx->q16_topo_ok = topo;
+        }
         sc.bmx = bm[0]; sc.bmy = bm[1]; sc.bmz = bm[2];
         sc.fast_box = fast ? 1 : 0;
         ctx->travq_ok = travq_ok && (uint64_t)tri.size() * 16 < ((uint64_t)1 << 32);   // 32-bit byte offsets into the triangle records
@@ -1120,7 +1159,7 @@ int install_scene(rt_ctx *ctx, rtk::Scene sc, const rt_mesh *mesh) {
     sc.tidx = static_cast<const int4 *>(ctx->tidx.p);
     ctx->scene = sc;
     ctx->have_scene = true;
-    return RT_OK;
+    return requantize(ctx, nullptr);
 }
 
 // tri_perm / up_indices (host copies of the mesh's orders) after a device-side install: fetched when a host-side path needs them
@@ -1210,7 +1249,7 @@ int rt_ctx_destroy(rt_ctx *ctx) {
         if (ctx->slot_rendered[k]) (void)hipEventDestroy(ctx->slot_rendered[k]);
         if (ctx->slot_done[k]) (void)hipEventDestroy(ctx->slot_done[k]);
     }
-    ctx->node_lo.release(); ctx->node_hi.release(); ctx->nodes2.release(); ctx->nodesq.release(); ctx->nodesb.release(); ctx->q2thr.release(); ctx->left_dev.release(); ctx->lvl_nodes.release(); ctx->lvl_off.release(); ctx->nrm.release(); ctx->tri.release(); ctx->verts.release(); ctx->tidx.release();
+    ctx->node_lo.release(); ctx->node_hi.release(); ctx->nodes2.release(); ctx->nodesq.release(); ctx->nodesb.release(); ctx->nodesh.release(); ctx->tri2leaf.release(); ctx->q2thr.release(); ctx->left_dev.release(); ctx->lvl_nodes.release(); ctx->lvl_off.release(); ctx->nrm.release(); ctx->tri.release(); ctx->verts.release(); ctx->tidx.release();
     ctx->scratch_rgba.release(); ctx->scratch_rgb8.release(); ctx->work.release(); ctx->queue.release();
     ctx->wfM.release(); ctx->wfT.release(); ctx->wfLS.release(); ctx->wfSID.release(); ctx->wfSamp.release();
     ctx->wfQR.release(); ctx->accum.release(); ctx->dbgbuf.release();
@@ -1478,7 +1517,7 @@ int rt_mesh_transform(rt_ctx *ctx, const float rotation[9], const float translat
     }
     sc.bmx = bm[0]; sc.bmy = bm[1]; sc.bmz = bm[2];
     sc.fast_box = fast ? 1 : 0;
-    return RT_OK;
+    return requantize(ctx, own_stream(ctx));                                          // the fixed-point pairs follow the refitted boxes (same topology: q16_topo_ok stands; unions nest)
 }
 
 // TriangleMesh::buildBVH on the device, bit for bit (rt_bvhbuild.hip.h): leaves the flat tree in ctx->bb_arr and the triangle order in ctx->bb_idx
@@ -1702,7 +1741,8 @@ static int install_lbvh_device(rt_ctx *ctx, const rtk::Scene &old, const int n_n
     ctx->scene = sc;
     ctx->host_mesh_stale = true;                                                 // tri_perm / up_indices: on the device now (perm_dev, tidx_up)
     ctx->have_scene = true;
-    return RT_OK;
+    ctx->q16_topo_ok = n_nodes + 2 < rtk::kQ16MaxNodes && n <= rtk::kQ16MaxTris;    // leaves of at most kLbvhLeaf triangles; boxes are unions, bottom-up: they nest
+    return requantize(ctx, q);
 }
 
 int rt_mesh_rebuild_mode(rt_ctx *ctx, int mode, float *bvh_arr10_out, int32_t *tri_order_out, int32_t *n_nodes_out) {

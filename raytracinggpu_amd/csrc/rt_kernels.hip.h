@@ -56,6 +56,11 @@ struct Scene {
     const int *q2thr;         // nodesq index -> index of the same node in `nodes`
     const float4 *nodesb;     // the same breadth-first array in the form wf_travq reads (rt_travq.hip.h): (centre.xyz, payload) (half extent.xyz, kind)
     float bmx, bmy, bmz;      // per axis: max |bound| over every node box (the absolute term of wf_travq's box filter)
+    const uint4 *nodesh;      // the sibling pairs once more in 16-bit fixed point, 32 bytes per pair (rt_travq.hip.h, QN): per child (centre.xyz, half extent.xyz) on the
+                              // grid below, rounded OUTWARDS, and one payload word (rt_qnodes.hip.h); nullptr = not available for this tree
+    const int *tri2leaf;      // triangle (visit order) -> breadth-first index of its leaf (the exact box of a flagged leaf: rt_qnodes.hip.h)
+    float qgx, qgy, qgz;      // grid origin (the root box's lower corner) and cell size per axis
+    float qsx, qsy, qsz;
     int fast_box;             // every node box is finite, ordered (lo <= hi) and below 1e8 in magnitude: the centre / half-extent filter may decide
     const float4 *nrm;        // smooth shading (wavefront variants): 3 vertex normals per triangle, visit order; nullptr = flat
     const float4 *tri;

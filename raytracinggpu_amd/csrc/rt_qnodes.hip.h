@@ -1,0 +1,74 @@
+// rt_qnodes.hip.h -- the sibling pairs of the breadth-first node array once more, in 16-bit fixed point (round 4).
+//
+// wf_travq's BOX step is bound by the NUMBER of vector-memory instructions it issues (profiles/round4/ab_load_cost_model.txt): a pair of
+// (centre, half extent, payload, kind) nodes is 64 bytes = four 16-byte loads per lane.  Here a node is 16 bytes -- centre and half
+// extent of each axis as unsigned 16-bit numbers on a grid laid over the root box, and one payload word -- so a pair is TWO loads.
+// Every face is rounded OUTWARDS: the fixed-point box contains the real one, and no face is further than three cells from the real one:
+//     cq = round((c - g) / s),   hq = ceil((h + |c - (g + cq s)|) / s) + 1          (binary64; c, h = exact centre / half extent of lo, hi)
+// The kernel (wf_travq<.., QN = true>) uses the fixed-point box in two ways, both conservative with respect to BoundingBox::intersect
+// (cpu_launcher.cpp:146-157) on the real box:
+//   * a box the ray misses even enlarged is missed by the reference (no entry pushed, no triangle tested);
+//   * a LEAF the ray hits by more than the enlargement is hit by the reference (its triangles are tested); a leaf in between is
+//     tested too, but carries a flag, and a triangle accepted in it counts only if the reference's own test of the leaf's REAL box
+//     (slab_filtered on the (lo, hi) copy, found through tri2leaf) says hit;
+//   * an INTERNAL node that is not excluded is entered.  That visits a superset of the nodes the reference visits, which changes no
+//     result: for a ray without zero / denormal / huge components and a tree whose boxes nest (child inside parent), the reference's
+//     test is monotone -- every bound (b - O) / u is a monotone function of b under round-to-nearest, so a child's interval per axis
+//     lies inside its parent's and "hit child => hit parent" holds in the COMPUTED values -- hence the leaves the reference reaches
+//     are exactly the leaves whose own box it hits, and those are decided exactly as above.  Rays outside that class never use the
+//     fixed-point pairs (they are walked serially with the literal test at hand-off), trees that do not nest keep the 64-byte pairs.
+// Payload word: internal node = first child << kQNodeShift (bit 31 clear: fewer than 2^20 nodes); leaf = 1 << 31 | count << 20 | first
+// triangle (count <= 2047, first < 2^20).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace rtk {
+
+struct QGrid { float gx, gy, gz, sx, sy, sz; };
+
+constexpr int kQ16MaxLeaf = 2047, kQ16MaxTris = 1 << 20, kQ16MaxNodes = 1 << 20;
+constexpr double kQ16Cells = 65000.0;           // cells per axis over the root box (the rest of the 16-bit range is slack for the outward rounding)
+
+__host__ inline QGrid q16_grid(float4 root_lo, float4 root_hi) {
+    QGrid g;
+    g.gx = root_lo.x; g.gy = root_lo.y; g.gz = root_lo.z;
+    const double ex = (double)root_hi.x - (double)root_lo.x, ey = (double)root_hi.y - (double)root_lo.y, ez = (double)root_hi.z - (double)root_lo.z;
+    g.sx = (float)(ex / kQ16Cells > 1e-30 ? ex / kQ16Cells : 1e-30);
+    g.sy = (float)(ey / kQ16Cells > 1e-30 ? ey / kQ16Cells : 1e-30);
+    g.sz = (float)(ez / kQ16Cells > 1e-30 ? ez / kQ16Cells : 1e-30);
+    return g;
+}
+
+__device__ __forceinline__ void q16_axis(float lo, float hi, float g, float s, unsigned int &cq, unsigned int &hq) {
+    const double c = ((double)lo + (double)hi) * 0.5, h = ((double)hi - (double)lo) * 0.5;
+    double ci = floor((c - (double)g) / (double)s + 0.5);
+    ci = ci < 0.0 ? 0.0 : (ci > 65535.0 ? 65535.0 : ci);
+    const double cw = (double)g + ci * (double)s;
+    double hi_ = ceil((h + fabs(c - cw)) / (double)s) + 1.0;
+    hi_ = hi_ > 65535.0 ? 65535.0 : (hi_ >= 1.0 ? hi_ : 65535.0);       // NaN or an out-of-range box: the widest box (never excluded)
+    cq = (unsigned int)ci; hq = (unsigned int)hi_;
+}
+
+// one thread per breadth-first node b in [1, n_bfs]: nodesq[2b], [2b+1] = (lo, hi) of the node, nodesb[2b].w / [2b+1].w = payload / kind as wf_travq carries them
+__global__ __launch_bounds__(256) void qnodes_kernel(const float4 *__restrict__ nodesq, const float4 *__restrict__ nodesb, int n_bfs, QGrid g,
+                                                     uint4 *__restrict__ nodesh, int *__restrict__ tri2leaf, int n_tris, int node_shift) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    if (b > n_bfs) return;
+    const float4 lo = nodesq[2 * (size_t)b], hi = nodesq[2 * (size_t)b + 1];
+    const unsigned int payload = __float_as_uint(nodesb[2 * (size_t)b].w);
+    const int kind = __float_as_int(nodesb[2 * (size_t)b + 1].w);
+    unsigned int cx, cy, cz, hx, hy, hz;
+    q16_axis(lo.x, hi.x, g.gx, g.sx, cx, hx);
+    q16_axis(lo.y, hi.y, g.gy, g.sy, cy, hy);
+    q16_axis(lo.z, hi.z, g.gz, g.sz, cz, hz);
+    unsigned int pay;
+    if (kind < 0) pay = payload;                                                 // first child << node_shift
+    else {
+        const int cnt = kind >> node_shift, first = (int)payload;
+        pay = 0x80000000u | (unsigned int)cnt << 20 | (unsigned int)first;
+        for (int t = 0; t < cnt; ++t) if (first + t < n_tris) tri2leaf[first + t] = b;
+    }
+    nodesh[b] = make_uint4(cx | cy << 16, cz | hx << 16, hy | hz << 16, pay);
+}
+
+}  // namespace rtk

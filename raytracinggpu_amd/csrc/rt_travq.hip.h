@@ -159,6 +159,14 @@ __device__ __forceinline__ void cbox_filter(const float4 n0, const float4 n1, co
     hit = d > band;
     miss = d < -band;
 }
+// the same planes, returning d = far - near and the band instead of the two decisions (the fixed-point BOX step compares d with two thresholds)
+__device__ __forceinline__ void cbox_dband(const float4 n0, const float4 n1, const float4 A, const float4 Oo, float &d, float &band) {
+    const float kx = fmaf(n0.x, A.x, -Oo.x), ky = fmaf(n0.y, A.y, -Oo.y), kz = fmaf(n0.z, A.z, -Oo.z);
+    const float tn = vmax3(fmaf(-n1.x, fabsf(A.x), kx), fmaf(-n1.y, fabsf(A.y), ky), fmaf(-n1.z, fabsf(A.z), kz));
+    const float tf = vmin3(fmaf(n1.x, fabsf(A.x), kx), fmaf(n1.y, fabsf(A.y), ky), fmaf(n1.z, fabsf(A.z), kz));
+    d = tf - tn;
+    band = fmaf(fabsf(tf), kRel, fmaf(fabsf(tn), kRel, A.w));
+}
 // centre / half extent of one axis as the upload and the device-side refit form them (binary64 sum / difference: exact; one rounding)
 __host__ __device__ inline float box_centre(float lo, float hi) { return (float)(((double)lo + (double)hi) * 0.5); }
 __host__ __device__ inline float box_half(float lo, float hi) { return (float)(((double)hi - (double)lo) * 0.5); }
@@ -237,7 +245,7 @@ __device__ __forceinline__ bool qtri_test(const float4 q0, const float4 q1, cons
 // entered, refill rounds, queue fetches, TRI steps, BOX steps, literal-box fall-backs taken, serial drains; then the conditionally
 // executed blocks of the steps, counted per entry: the t-division block of a triangle test (some lane accepted the barycentrics), the
 // first and the second leaf-queue push of a BOX step.
-template <bool STATS, int R, bool LDSN, bool LDSV>
+template <bool STATS, int R, bool LDSN, bool LDSV, bool QN = false>
 __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || kQBlock != 256 || QPairs<R>::value > 1) ? 4 : 5) void wf_travq(const Scene sc, const Frame fr, const WfState st, const int cap, const int n_lds, const int kLow, const int kMinFree) {
     // kLow: refill while the stack holds fewer entries (sibling pairs) than this (default 48); kMinFree: ... and at least this
     // many slots are free, or the stack is short (default R / 4)
@@ -431,18 +439,31 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
                     if (got) {
                         const f3 O = mk(r0.x, r0.y, r0.z), u = mk(r0.w, r1.x, r1.y);
                         const RayBoxC rb = ray_box_c(O, u, mk(sc.bmx, sc.bmy, sc.bmz), sc.fast_box != 0);
+                        if (QN) {     // the same planes in grid units: k = fma(cq, r s, -(O - g) r)
+                            rowA(sbk) = make_float4(rb.rx * sc.qsx, rb.ry * sc.qsy, rb.rz * sc.qsz, 4.f * rb.c0);
+                            rowO(sbk) = make_float4((O.x - sc.qgx) * rb.rx, (O.y - sc.qgy) * rb.ry, (O.z - sc.qgz) * rb.rz, __int_as_float(work ? 1 : 0));
+                        } else {
                         rowA(sbk) = make_float4(rb.rx, rb.ry, rb.rz, rb.c0);
                         rowO(sbk) = make_float4(rb.ox, rb.oy, rb.oz, __int_as_float(work ? 1 : 0));      // .w: one outstanding entry
+                        }
                         rowC(sbk) = r0;
                         rowD(sbk) = make_float4(r1.x, r1.y, __uint_as_float(0xffffffffu), __uint_as_float(0xffffffffu));   // .zw: WF_NOHIT
                         path_[b] = rf - 1;
                         WQ_CHECK(path_[b] >= 0 && path_[b] < 2 * st.n_paths, 1, path_[b] = 0);
                     }
                     stage_used += take;
-                    const unsigned long long gm = __ballot(got);
+                    bool pushes = got;
+                    if (QN && root_hiw < 0) {     // a ray with a zero / denormal / huge component: the box test is not monotone for it, so it never meets the fixed-point pairs
+                        const bool serial = got && !(rowA(sbk).w < __builtin_inff());
+                        if (__builtin_expect(__ballot(serial) != 0ull, 0)) {
+                            if (serial) { *pend(sbk) = 0; drain_serial(sbk, 2); drain_serial(sbk, 3); }   // the root's children and everything below them, literally; the slot retires at the next pass
+                        }
+                        pushes = got && !serial;
+                    }
+                    const unsigned long long gm = __ballot(pushes);
                     if (dbg_on) { d_rounds++; d_rays += (unsigned int)__popcll(gm); }
                     if (root_hiw < 0) {
-                        if (got) stack[top + lanes_below(gm)] = 2u << kQNodeShift | sbk;   // the root (node 1) has the children 2, 3
+                        if (pushes) stack[top + lanes_below(gm)] = 2u << kQNodeShift | sbk;   // the root (node 1) has the children 2, 3
                         top += __popcll(gm);
                     } else {                           // the root is a leaf
                         if (cnt > 0) {
@@ -520,12 +541,20 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
                 wk.lit_tri += ((t0 && (how0 & 3) == 2) ? 1u : 0u) + ((t1 && (how1 & 3) == 2) ? 1u : 0u);
                 n_tdiv += (__ballot((how0 & 4) != 0) != 0ull ? 1u : 0u) + (__ballot((how1 & 4) != 0) != 0ull ? 1u : 0u);   // division blocks some lane entered
             }
-            if (ok0) atomicMin(best(o0), (unsigned long long)__float_as_uint(ta) << 32 | (unsigned int)i0);
-            if (ok1) atomicMin(best(o1), (unsigned long long)__float_as_uint(tb_) << 32 | (unsigned int)i1);
+            bool ok0_ = ok0, ok1_ = ok1;
+            if (QN) {       // a triangle accepted in a flagged leaf counts only if the reference's test of the leaf's real box says hit (rare: behind a vote)
+                const bool ch0 = ok0 && (y0 & 1u) != 0u, ch1 = ok1 && (y1 & 1u) != 0u;
+                if (__builtin_expect(__ballot(ch0 || ch1) != 0ull, 0)) {
+                    if (ch0) { const int lf = sc.tri2leaf[i0]; const f3 Or = mk(C0.x, C0.y, C0.z), ur = mk(C0.w, D0.x, D0.y); ok0_ = slab_filtered(sc.nodesq[2 * (size_t)lf], sc.nodesq[2 * (size_t)lf + 1], Or, ur, ray_inv(ur)); }
+                    if (ch1) { const int lf = sc.tri2leaf[i1]; const f3 Or = mk(C1.x, C1.y, C1.z), ur = mk(C1.w, D1.x, D1.y); ok1_ = slab_filtered(sc.nodesq[2 * (size_t)lf], sc.nodesq[2 * (size_t)lf + 1], Or, ur, ray_inv(ur)); }
+                }
+            }
+            if (ok0_) atomicMin(best(o0), (unsigned long long)__float_as_uint(ta) << 32 | (unsigned int)i0);
+            if (ok1_) atomicMin(best(o1), (unsigned long long)__float_as_uint(tb_) << 32 | (unsigned int)i1);
             const bool full = part && P + c <= 128u;
             if (part && !full) {                                     // at most one entry straddles position 127: keep its rest
                 const unsigned int took = 128u - P;
-                leafq[(lhead + (unsigned int)lane) & (LCAP - 1)] = make_uint2(E.x + took, (E.y & kQSlotMask) | (c - took) << kQNodeShift);
+                leafq[(lhead + (unsigned int)lane) & (LCAP - 1)] = make_uint2(E.x + took, (E.y & (kQSlotMask | 1u)) | (c - took) << kQNodeShift);
             }
             lhead += (unsigned int)__popcll(__ballot(full));
             if (full) atomicAdd(pend(E.y & kQSlotMask), -1);        // after the mins above (LDS operations stay in order)
@@ -575,14 +604,23 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
             act_[k] = lane + 64 * k < n;
             e_[k] = act_[k] ? stack[top - 1 - lane - 64 * k] : 0u;   // node << 10 | slot << 4: the sibling nodes (one 64-byte line) of the ray in that slot
             sb_[k] = e_[k] & kQSlotMask;                             // the slot's table row
-            off_[k] = (e_[k] >> (kQNodeShift - 5)) & ~31u;           // the pair's byte offset in the node array
+            off_[k] = QN ? (e_[k] >> (kQNodeShift - 4)) & ~31u : (e_[k] >> (kQNodeShift - 5)) & ~31u;   // the pair's byte offset in the node array (QN: 32 bytes per pair)
             WQ_CHECK(!act_[k] || ((e_[k] >> kQNodeShift) >= 2u && (int)(e_[k] >> kQNodeShift) + 1 <= sc.n_nodes && ((e_[k] >> kQNodeShift) & 1u) == 0u), 4, off_[k] = 0u);
         }
         top -= n;
 #pragma unroll
         for (int k = 0; k < KP; ++k) {                                // all loads first: they are in flight together
             A_[k] = rowA(sb_[k]); Oo_[k] = rowO(sb_[k]);              // siblings belong to one ray: one table read for both
+            if (QN) {
+                const uint4 *qp = reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(sc.nodesh) + off_[k]);
+                const uint4 q0 = qp[0], q1 = qp[1];
+                c0_[k] = make_float4((float)(q0.x & 0xffffu), (float)(q0.x >> 16), (float)(q0.y & 0xffffu), __uint_as_float(q0.w));
+                h0_[k] = make_float4((float)(q0.y >> 16), (float)(q0.z & 0xffffu), (float)(q0.z >> 16), 0.f);
+                c1_[k] = make_float4((float)(q1.x & 0xffffu), (float)(q1.x >> 16), (float)(q1.y & 0xffffu), __uint_as_float(q1.w));
+                h1_[k] = make_float4((float)(q1.y >> 16), (float)(q1.z & 0xffffu), (float)(q1.z >> 16), 0.f);
+            } else {
             load_pair(off_[k], c0_[k], h0_[k], c1_[k], h1_[k]);
+            }
         }
 #if defined(RT_DEBUG) && defined(RT_PAD_VMEM)     // sensitivity experiment: the four 16-byte loads of the pair once more (L1 hits: address / tag pipeline only)
         {
@@ -641,15 +679,31 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
             // execution mask of an `if` (or the selector of a v_cndmask) for free.  Written with bools the compiler materialises each
             // combined predicate as 0 / 1 in a vector register and compares it back into a mask for its ballot: ten half-rate
             // instructions per step.
-            bool hit0, miss0, hit1, miss1;
+            bool hit0 = false, miss0 = false, hit1 = false, miss1 = false;
+            if (!QN) {
             cbox_filter(c0, h0, A, Oo, hit0, miss0);
             cbox_filter(c1, h1, A, Oo, hit1, miss1);
+            }
             const unsigned long long mact = __ballot(act);
+            unsigned long long mflag0 = 0ull, mflag1 = 0ull;   // QN: leaves hit by less than the fixed-point box's enlargement (their real box is tested when a triangle is accepted)
+            if (QN) {
+                // the fixed-point box contains the real one and no face is further than 3 cells from the real face (rt_qnodes.hip.h): in the
+                // ray's parameter that is 3 max|r'| per face, 6 for d = far - near.  `miss` (d < -band) therefore holds for the real box too, and so
+                // does a hit by more than band + 6 max|r'|; what lies between enters internal nodes (a superset of the reference's visits: harmless,
+                // its box test is monotone along a path of nested boxes) and flags leaves
+                const float slack = 6.f * vmax3abs(A.x, A.y, A.z);
+                float d0, d1, band0, band1;
+                cbox_dband(c0, h0, A, Oo, d0, band0);
+                cbox_dband(c1, h1, A, Oo, d1, band1);
+                miss0 = d0 < -band0; miss1 = d1 < -band1;
+                hit0 = !miss0; hit1 = !miss1;
+                mflag0 = __ballot(!(d0 > band0 + slack)); mflag1 = __ballot(!(d1 > band1 + slack));
+            }
             unsigned long long mh0 = __ballot(hit0), mh1 = __ballot(hit1);
             const unsigned long long md0 = mh0 | __ballot(miss0), md1 = mh1 | __ballot(miss1);
             const unsigned long long und = mact & ~(md0 & md1);
             // literal arithmetic for undecided lanes behind a wave-uniform branch (six IEEE divisions per box, almost never needed)
-            if (__builtin_expect(und != 0ull, 0)) {
+            if (!QN && __builtin_expect(und != 0ull, 0)) {
                 if (STATS) n_lit++;
                 bool l0 = false, l1 = false;
                 const bool u0 = __builtin_amdgcn_inverse_ballot_w64(mact & ~md0), u1 = __builtin_amdgcn_inverse_ballot_w64(mact & ~md1);
@@ -665,8 +719,12 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
                 mh1 = (mh1 & md1) | __ballot(l1);
             }
             {
-                const int k0 = __float_as_int(h0.w), k1 = __float_as_int(h1.w);               // kind: < 0 internal, > 0 leaf (count << 10), 0 empty leaf
-                const unsigned int p0 = __float_as_uint(c0.w), p1 = __float_as_uint(c1.w);   // payload: first child << 10 | first triangle
+                int k0 = __float_as_int(h0.w), k1 = __float_as_int(h1.w);               // kind: < 0 internal, > 0 leaf (count << 10), 0 empty leaf
+                unsigned int p0 = __float_as_uint(c0.w), p1 = __float_as_uint(c1.w);   // payload: first child << 10 | first triangle
+                if (QN) {   // one word: internal = first child << 11 (bit 31 clear); leaf = 1 << 31 | count << 20 | first triangle
+                    k0 = (int)p0 < 0 ? (int)((p0 >> 20) & 0x7ffu) << kQNodeShift : -1; k1 = (int)p1 < 0 ? (int)((p1 >> 20) & 0x7ffu) << kQNodeShift : -1;
+                    p0 = (int)p0 < 0 ? p0 & 0xfffffu : p0; p1 = (int)p1 < 0 ? p1 & 0xfffffu : p1;
+                }
                 const unsigned long long g0 = mh0 & mact, g1 = mh1 & mact;
                 const unsigned long long mI0 = g0 & __ballot(k0 < 0), mI1 = g1 & __ballot(k1 < 0), mL0 = g0 & __ballot(k0 > 0), mL1 = g1 & __ballot(k1 > 0);
                 if (STATS) {
@@ -685,9 +743,16 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
                 const unsigned int oL = ltail + (unsigned int)lanes_below2(mL0, mL1);
                 if (STATS) { n_lpush += (mL0 | mL1) != 0ull ? 1u : 0u; n_lpush2 += (mL0 & mL1) != 0ull ? 1u : 0u; }
                 WQ_MARK("lpush_begin");
+                if (QN) {
+                    const unsigned int f0 = __builtin_amdgcn_inverse_ballot_w64(mflag0) ? 1u : 0u, f1 = __builtin_amdgcn_inverse_ballot_w64(mflag1) ? 1u : 0u;
+                    if (__builtin_amdgcn_inverse_ballot_w64(mL0 | mL1)) leafq[oL & (LCAP - 1)] = make_uint2(sL0 ? p0 : p1, (unsigned int)(sL0 ? k0 : k1) | sb | (sL0 ? f0 : f1));
+                    WQ_MARK("lpush2_begin");
+                    if (__builtin_amdgcn_inverse_ballot_w64(mL0 & mL1)) leafq[(oL + 1u) & (LCAP - 1)] = make_uint2(p1, (unsigned int)k1 | sb | f1);
+                } else {
                 if (__builtin_amdgcn_inverse_ballot_w64(mL0 | mL1)) leafq[oL & (LCAP - 1)] = make_uint2(sL0 ? p0 : p1, (unsigned int)(sL0 ? k0 : k1) | sb);
                 WQ_MARK("lpush2_begin");
                 if (__builtin_amdgcn_inverse_ballot_w64(mL0 & mL1)) leafq[(oL + 1u) & (LCAP - 1)] = make_uint2(p1, (unsigned int)k1 | sb);
+                }
                 WQ_MARK("lpush_end");
                 ltail += (unsigned int)(__popcll(mL0) + __popcll(mL1));
                 // outstanding entries of the ray: this pair is gone (-1), every pushed pair and leaf entry counts +1: one LDS add per lane

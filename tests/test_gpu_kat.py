@@ -126,6 +126,25 @@ def test_reference_mesh_vectors_through_the_serial_drain(cat_golden, monkeypatch
     c.close()
 
 
+def test_reference_mesh_vectors_through_the_fixed_point_box_step(cat_golden, monkeypatch):
+    """RT_TRAVQ_Q16=1: the BOX step decides on 16-bit fixed-point boxes rounded outwards (a superset of the reference's visits), flags leaves it
+    cannot be sure of and lets the reference's test of the leaf's real box decide when a triangle is accepted there (rt_qnodes.hip.h): the
+    reference's 6 600 mesh vectors, bit for bit, and the frame of the default kernel."""
+    monkeypatch.setenv("RT_TRAVQ_Q16", "1")
+    c = rt.Context(0)
+    monkeypatch.delenv("RT_TRAVQ_Q16")
+    mesh = dict(vertices=cat_golden["vertices"], indices=cat_golden["tri_bvh_order"], bvh_arr10=cat_golden["bvh_arr10"], albedo=rt.scenes.CAT_ALBEDO, object_slot=6)
+    c.scene_upload(rt.scenes.spheres("cpu"), mesh)
+    g = load_golden("kat.npz")
+    hit = _check_mesh_rows(c.trace_rays(g["mesh_in"], 1e-4, "wavefront_queue"), g["mesh_out"])
+    assert hit.sum() > 1500
+    d = rt.Context(0)
+    d.scene_upload(rt.scenes.spheres("cpu"), mesh)
+    p = rt.make_params(960, 540, 1, 3, **rt.scenes.CPU_LAUNCHER)
+    np.testing.assert_array_equal(c.render(p).view(np.uint32), d.render(p).view(np.uint32))
+    c.close(); d.close()
+
+
 @pytest.mark.parametrize("variant", ["wavefront_queue", "path", "wavefront"])
 def test_degenerate_rays_through_the_production_traversal_kernels(ctx, oracle, oracle_cat, variant):
     """Rays a camera or a bounce never produces -- zero, denormal, huge and axis-parallel direction components, origins inside the

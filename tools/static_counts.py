@@ -132,7 +132,7 @@ def main():
     asm = subprocess.run([hipcc, *flags, "-S", "--cuda-device-only", "-o", "-", SRC], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True).stdout
     res = {"source": "hipcc -S --cuda-device-only of raytracinggpu_amd/csrc/rt_capi.hip with the flags of __graft_entry__.HIP_FLAGS",
            "weights": "valu_weight: 1 = full-rate instruction (2 SIMD cycles per wave64), 2 = half rate, 4 = quarter, 8 = binary64 transcendental"}
-    tq = kernel_text(asm, "_ZN3rtk8wf_travqILb0ELi64ELb0ELb0EEEvNS_5SceneENS_5FrameENS_7WfStateEiiii")
+    tq = kernel_text(asm, "_ZN3rtk8wf_travqILb0ELi64ELb0ELb0ELb0EEEvNS_5SceneENS_5FrameENS_7WfStateEiiii")
     if not tq:
         raise SystemExit("static_counts: wf_travq<false, 64, false, false> not found in the assembly")
     res["wf_travq"] = travq_counts(tq)
