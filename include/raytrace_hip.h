@@ -268,6 +268,7 @@ typedef struct rt_kat_counts {
     uint64_t tri_decided, tri_literal;
 } rt_kat_counts;
 int rt_kat_sphere(rt_ctx *ctx, const float *in, int n, float *out);
+int rt_kat_sqrt(rt_ctx *ctx, const float *in, int n, float *out);   /* out[i] = the device's correctly rounded square root (every sqrt of cpu_launcher.cpp: Vector::norm, Sphere::intersect, getColor) */
 int rt_kat_box(rt_ctx *ctx, const float *in, int n, int route, float *out, rt_kat_counts *counts);
 int rt_kat_triangle(rt_ctx *ctx, const float *in, int n, float *out, rt_kat_counts *counts);
 int rt_kat_mesh(rt_ctx *ctx, const float *in, int n, float tri_tmin, int route, float *out, rt_kat_counts *counts);

@@ -25,7 +25,7 @@ EXPORTS = ["rt_abi_version", "rt_device_count", "rt_ctx_create", "rt_ctx_destroy
            "rt_progressive_frames",
            "rt_multi_create", "rt_multi_destroy", "rt_multi_last_error", "rt_multi_scene_upload", "rt_render_multi",
            "rt_render_multi_device", "rt_render_multi_rgb8", "rt_multi_get_stats",
-           "rt_stats_enable", "rt_ctx_set_pipelining", "rt_render_async", "rt_wait", "rt_trace_rays", "rt_mesh_rebuild", "rt_mesh_rebuild_mode", "rt_mesh_build_stats", "rt_host_alloc", "rt_host_free", "rt_device_alloc", "rt_device_free", "rt_device_to_host", "rt_kat_sphere", "rt_kat_box", "rt_kat_triangle", "rt_kat_mesh"]
+           "rt_stats_enable", "rt_ctx_set_pipelining", "rt_render_async", "rt_wait", "rt_trace_rays", "rt_mesh_rebuild", "rt_mesh_rebuild_mode", "rt_mesh_build_stats", "rt_host_alloc", "rt_host_free", "rt_device_alloc", "rt_device_free", "rt_device_to_host", "rt_kat_sphere", "rt_kat_sqrt", "rt_kat_box", "rt_kat_triangle", "rt_kat_mesh"]
 MAX_DEVICES = 16
 
 
@@ -181,6 +181,7 @@ def load():
     L.rt_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
     L.rt_host_free.argtypes = [vp]
     L.rt_kat_sphere.argtypes = [vp, fp3, C.c_int, fp3]
+    L.rt_kat_sqrt.argtypes = [vp, fp3, C.c_int, fp3]
     L.rt_kat_box.argtypes = [vp, fp3, C.c_int, C.c_int, fp3, C.POINTER(KatCounts)]
     L.rt_kat_triangle.argtypes = [vp, fp3, C.c_int, fp3, C.POINTER(KatCounts)]
     L.rt_kat_mesh.argtypes = [vp, fp3, C.c_int, C.c_float, C.c_int, fp3, C.POINTER(KatCounts)]
@@ -457,6 +458,9 @@ class Context:
 
     def kat_sphere(self, rows):
         return self._kat(self._L.rt_kat_sphere, rows, 10, 5, counts=False)[0]
+
+    def kat_sqrt(self, x):
+        return self._kat(self._L.rt_kat_sqrt, x, 1, 1, counts=False)[0][:, 0]
 
     def kat_box(self, rows, route):
         out, c = self._kat(self._L.rt_kat_box, rows, 12, 1, int(route))

@@ -21,6 +21,12 @@ __device__ __forceinline__ void kat_count(unsigned long long *cnt, bool decided,
 }
 
 // in: C[3] R O[3] u[3]; out: hit t N[3]  (N = normalize(O + t u - C), cpu:524-525)
+// rt_sqrtf (rt_kernels.hip.h): one value per lane; waves hold plain and special arguments mixed, so both of its routes run
+__global__ __launch_bounds__(256) void kat_sqrt_kernel(const float *__restrict__ in, int n, float *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = rt_sqrtf(in[i]);
+}
+
 __global__ __launch_bounds__(256) void kat_sphere_kernel(const float *__restrict__ in, int n, float *__restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -202,6 +208,12 @@ int kat_run(rt_ctx *ctx, const float *in, int n, int width, float *out, int owid
 }  // namespace
 
 extern "C" {
+
+int rt_kat_sqrt(rt_ctx *ctx, const float *in, int n, float *out) {
+    return kat_run(ctx, in, n, 1, out, 1, nullptr, [&](const float *di, float *dres, unsigned long long *, dim3 g, dim3 b) {
+        hipLaunchKernelGGL(rtk::kat_sqrt_kernel, g, b, 0, own_stream(ctx), di, n, dres);
+    });
+}
 
 int rt_kat_sphere(rt_ctx *ctx, const float *in, int n, float *out) {
     return kat_run(ctx, in, n, 10, out, 5, nullptr, [&](const float *di, float *dres, unsigned long long *, dim3 g, dim3 b) {

@@ -108,7 +108,23 @@ __device__ __forceinline__ f3 cross(f3 a, f3 b) {
 }
 // IEEE-754 correctly rounded binary32 square root.  NOT __fsqrt_rn: ROCm 7.2 maps that to the native
 // (1-ulp) v_sqrt_f32; sqrtf under -fhip-fp32-correctly-rounded-divide-sqrt gets the fix-up sequence.
-__device__ __forceinline__ float rt_sqrtf(float x) { return __builtin_sqrtf(x); }
+// The compiler's sequence is: scale arguments below 2^-96 up, v_sqrt_f32 (1 ulp), pick among s - 1 ulp, s, s + 1 ulp by the signs of the
+// residuals fma(-s', s, x), scale back, pass +-0 / +inf through -- 17 instructions of which only the middle eight matter for an argument in
+// [2^-96, inf): there no scaling happens, the residuals are normal numbers and the result is what the full sequence returns (it IS that
+// sequence minus the parts that do nothing for such an argument).  Everything else -- zero, tiny, negative, inf, NaN -- takes the builtin
+// behind a wave-uniform branch.
+__device__ __forceinline__ float rt_sqrtf(float x) {
+    const bool plain = (__float_as_uint(x) - 0x0f800000u) < (0x7f800000u - 0x0f800000u);     // 2^-96 <= x < inf (false for negatives and NaN)
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sd = __uint_as_float(__float_as_uint(s) - 1u), su = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rd = __builtin_fmaf(-sd, s, x), ru = __builtin_fmaf(-su, s, x);
+    float r = (0.f >= rd) ? sd : s;
+    r = (0.f < ru) ? su : r;
+    if (__builtin_expect(__ballot(!plain) != 0ull, 0)) {
+        if (!plain) r = __builtin_sqrtf(x);
+    }
+    return r;
+}
 __device__ __forceinline__ float norm2(f3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
 // cpu:58-63: three divisions by sqrt(norm2).  The three quotients share one reciprocal (rt_div.h: the compiler's own correctly rounded
 // sequence with its denominator part done once); lanes with a component or a norm outside [2^-60, 2^60] -- zero, denormal, overflowed,

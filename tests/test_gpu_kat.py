@@ -29,6 +29,29 @@ def ctx(cat_golden):
     c.close()
 
 
+def test_square_root_is_correctly_rounded_on_device(ctx):
+    """rt_sqrtf: v_sqrt_f32 (1 ulp) + the two-residual fix-up for arguments in [2^-96, inf), the compiler's full sequence for the rest
+    (zero, tiny, denormal, negative, inf, NaN) behind a wave vote -- against IEEE-754 (numpy's float32 sqrt is correctly rounded): 4 M
+    random bit patterns over the whole range, every power of two with its neighbours, perfect squares +- 1 ulp, and the special values,
+    mixed inside waves so that both routes run together."""
+    rng = np.random.default_rng(7)
+    bits = rng.integers(0, 1 << 32, 4_000_000, dtype=np.uint64).astype(np.uint32)
+    e = (np.arange(1, 255, dtype=np.uint32) << 23)
+    near = np.concatenate([e, e + 1, e - 1, e + 0x400000, e + 0x7fffff])
+    k = rng.integers(1, 1 << 12, 100_000).astype(np.float32)
+    sq = (k * k).view(np.uint32)
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 1.17549435e-38, 1.2621774e-29, 1.26217737e-29, 3.4028235e38, -1.0, 1.0, 2.0, 0.25], np.float32).view(np.uint32)
+    x = np.concatenate([bits, near, sq, sq + 1, sq - 1, np.tile(special, 64)]).view(np.float32)
+    rng.shuffle(x)
+    got = ctx.kat_sqrt(x)
+    with np.errstate(invalid="ignore"):
+        exp = np.sqrt(x)
+    nan = np.isnan(exp)
+    assert (np.isnan(got) == nan).all()
+    assert (got[~nan].view(np.uint32) == exp[~nan].view(np.uint32)).all()
+    assert ((x >= 2.0 ** -96) & np.isfinite(x)).sum() > 1_000_000 and ((x < 2.0 ** -96) & (x > 0)).sum() > 100_000
+
+
 def test_kat_sphere_on_device(ctx):
     g = load_golden("kat.npz")
     got = ctx.kat_sphere(g["sphere_in"])
