@@ -404,7 +404,7 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
                         const size_t q = (size_t)blk_base + (size_t)(base + lane);
                         const float4 qb = st.QR[2 * q + 1];             // the slot's 32-byte record: flag and ray in one round trip
                         sp0 = st.QR[2 * q]; sp1 = make_float2(qb.x, qb.y);
-                        spf = wq_live(__float_as_int(qb.z), st.epoch) ? wf_slot_to_path(st, (int)q) + 1 : 0;   // ray + 1 if the slot's ray needs traversal
+                        spf = wq_live(__float_as_int(qb.z), st.epoch, st.nonce) ? wf_slot_to_path(st, (int)q) + 1 : 0;   // ray + 1 if the slot's record is live for this launch   // ray + 1 if the slot's ray needs traversal
                     }
                     const unsigned long long am = __ballot(spf != 0);
                     if (spf != 0) sidx[lanes_below(am)] = (unsigned char)lane;

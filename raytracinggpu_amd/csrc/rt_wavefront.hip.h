@@ -54,8 +54,15 @@ constexpr int PQ_XSPHERE = 1 << 22;                         // PF_XSPHERE of thi
 constexpr int PQ_REFR_SHIFT = 23;                           // 6 bits: Ray::refraction_index of the Y ray: 0 = 1.0, else (object id + 1) << 1 | (0: that object's n_in, 1: its n_out)
 constexpr int PQ_TRAV = 1 << 29;                            // (either slot) the record's ray passed the mesh's root box: the traversal launch whose number (WfState::epoch) equals the
                                                             // record's depth field picks it up.  A shadow ray that misses the root box is not written at all: what its slot still
-                                                            // holds is an older launch's record (other depth), or the zero wf_advance<FIRST> put there
-__device__ __forceinline__ bool wq_live(int w0, int epoch) { return (w0 & PQ_TRAV) != 0 && ((w0 >> PF_DEPTH_SHIFT) & PF_DEPTH_MASK) == epoch; }
+                                                            // holds is an older launch's record (other depth or another chain's number), or the zero of the layout's memset
+constexpr int PQ_NONCE_SHIFT = 30, PQ_NONCE_MASK = 3;        // (either slot) the launch chain's number mod 4, so that wf_advance<FIRST> need not clear the shadow slots of the previous chain
+constexpr int PQ_LIVE_MASK = (int)((unsigned)PQ_TRAV | ((unsigned)PF_DEPTH_MASK << PF_DEPTH_SHIFT) | ((unsigned)PQ_NONCE_MASK << PQ_NONCE_SHIFT));
+// the record is live for traversal launch `epoch` of the chain numbered `nonce`: one masked compare.  A stale shadow record that passes (written four chains ago at the
+// same depth into a slot nobody wrote since) costs one wasted traversal and nothing else: wf_advance reads a shadow ray's result only if ITS OWN flag word says the
+// ray went to the mesh (PF_MESHX)
+__device__ __forceinline__ bool wq_live(int w0, int epoch, int nonce) {
+    return (w0 & PQ_LIVE_MASK) == (int)((unsigned)PQ_TRAV | (unsigned)epoch << PF_DEPTH_SHIFT | (unsigned)nonce << PQ_NONCE_SHIFT);
+}
 
 // Path state of the wavefront pipeline, in HBM.  A ray lives in ONE place: its 32-byte record in the traversal queue (slot order;
 // the four rays of a group are one 128-byte line), which the uniform kernel writes when it emits the ray, the traversal kernel
@@ -76,13 +83,14 @@ struct WfState {
     // traversal scheduling: ray-slot q in [0, slots) maps to ray 4*g + (q & 3), g = ((q>>2) & (S-1)) * Q + ((q>>2) >> log2S)
     int log2S, Q, n_groups;   // n_groups = 2 n_paths / 4 (ray groups);  S * Q >= n_groups
     int slots_per_block;      // multiple of 4: ray slots owned by one workgroup, handed to its waves on demand
+    int nonce;                // number of the launch chain mod 4 (from a counter of the context): part of every live record's flag word
     int epoch;                // index of the traversal launch inside its chain (0 after wf_advance<FIRST>): a queue record is live iff its flag word carries PQ_TRAV and this number
     int init_m;               // the traversal kernel merges partial results with atomicMin (wf_trav's work splitting): emitters initialise M
     unsigned long long *dbg;  // optional per-wave debug record (-DRT_DEBUG)
     // traversal queue: the rays in TRAVERSAL-SLOT order, so that the slots a traversal workgroup owns are contiguous and one
     // round trip brings flag and record
     float4 *QR;               // [2 slots] record of slot q: QR[2q] = (O.xyz, u.x), QR[2q+1] = (u.y, u.z, bits(W0), W1).  Y slot (ray r < n_paths): W0 = the path's
-                              // flag word (PF_* | PQ_*; 0 = no path), W1 = t of the Y ray's nearest sphere; X slot: W0 = PQ_TRAV | depth, written only when the ray needs traversal
+                              // flag word (PF_* | PQ_*; 0 = no path), W1 = t of the Y ray's nearest sphere; X slot: W0 = PQ_TRAV | depth | chain number, written only when the ray needs traversal
 };
 
 // n / d for 0 <= n < 2^32 with m = floor(2^32 / d) from the host: the estimate mulhi(n, m) is the quotient or one below it
@@ -368,7 +376,7 @@ __global__ __launch_bounds__(LDSN ? kTravBlockLds : kTravBlock) void wf_trav(con
                     if (ray < 0) {
                         const int qo = base + __popcll(idle & lane_lt);
                         const float4 rq = qo < blk_n ? st.QR[2 * ((size_t)blk_base + qo) + 1] : make_float4(0, 0, 0, 0);
-                        const int rf = wq_live(__float_as_int(rq.z), st.epoch) ? wf_slot_to_path(st, blk_base + qo) + 1 : 0;   // ray + 1 if the slot's ray needs traversal
+                        const int rf = wq_live(__float_as_int(rq.z), st.epoch, st.nonce) ? wf_slot_to_path(st, blk_base + qo) + 1 : 0;   // ray + 1 if the slot's ray needs traversal
                         if (rf != 0) {
                             const int path = rf - 1;
                             {
@@ -514,7 +522,7 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
     const int row = fr.row0 + (lrow / fr.tile_rows) * fr.tile_rows * fr.tile_step + (lrow % fr.tile_rows);
 
     if (FIRST) {
-        if (!valid) { st.QR[2 * (size_t)qy + 1] = kDead; st.QR[2 * (size_t)qx + 1] = kDead; return; }
+        if (!valid) { st.QR[2 * (size_t)qy + 1] = kDead; return; }       // (the X slot of a pixel outside the frame is never written: zero from the layout's memset)
         if (fr.segs <= 0) {
             finished = true;                                          // optimized.cu convention with num_bounce 0: black
         } else {
@@ -691,12 +699,11 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
             fr.out[out_index(fr, lrow, px)] = make_float4(t.x / n, t.y / n, t.z / n, t.w);
         }
         st.QR[2 * (size_t)qy + 1] = kDead;                            // the path is over; its X slot keeps a record of an older launch, which no later one takes for its own
-        if (FIRST) st.QR[2 * (size_t)qx + 1] = kDead;
         return;
     }
 
     // ---- (3) emission: sphere tests (cpu:512-527), root-box test (cpu:279), queue records ----
-    int flags = PF_ALIVE | (d << PF_DEPTH_SHIFT) | (nrays << PF_RAYS_SHIFT) | (refr_code << PQ_REFR_SHIFT);
+    int flags = PF_ALIVE | (d << PF_DEPTH_SHIFT) | (nrays << PF_RAYS_SHIFT) | (refr_code << PQ_REFR_SHIFT) | (int)((unsigned)st.nonce << PQ_NONCE_SHIFT);
     SphereHit h, hx;
     spheres_split2(sc, emitX ? Ox : Oy, uy, emitY, ux, emitX, h, hx);   // a shadow ray and a bounce ray leave the same point (Oy == Ox == P_adjusted)
     float t_sph = 0.f;
@@ -708,10 +715,8 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
         if (wf_root_test<STATS>(sc, st, rx, Ox, ux, wk)) {             // only then does anybody read the record: the traversal, and this kernel if the mesh is hit
             flags |= PF_MESHX;
             st.QR[2 * (size_t)qx] = make_float4(Ox.x, Ox.y, Ox.z, ux.x);
-            st.QR[2 * (size_t)qx + 1] = make_float4(ux.y, ux.z, __int_as_float(PQ_TRAV | (d << PF_DEPTH_SHIFT)), 0.f);
+            st.QR[2 * (size_t)qx + 1] = make_float4(ux.y, ux.z, __int_as_float((int)((unsigned)(PQ_TRAV | (d << PF_DEPTH_SHIFT)) | (unsigned)st.nonce << PQ_NONCE_SHIFT)), 0.f);
         }
-    } else if (FIRST) {
-        st.QR[2 * (size_t)qx + 1] = kDead;                            // once per chain: the previous chain's records carry the same depth numbers
     }
     if (emitY) {
         const bool after = h.tB < h.tA;                               // the later group's sphere replaces the earlier one's only if strictly nearer
