@@ -41,8 +41,9 @@ struct Knobs {
     int travq_cap = 0;         // RT_TRAVQ_CAP: stack capacity (>= 128; tests force the serial drain); 0 = the carve's capacity
     int travq_lds = 0;         // RT_TRAVQ_LDS: waves of the ONE workgroup per CU that stages the top of the BVH in LDS; 0 = nodes through L1/L2
     int q_low = 48;            // RT_TRAVQ_LOW: refill while the stack holds fewer sibling pairs than this (measured 1.19 / 1.21 / 1.25 ms per frame for 48 / 64 / 96)
-    int q16 = 0;               // RT_TRAVQ_Q16=1: the BOX step reads 16-bit fixed-point sibling pairs (32 bytes: two loads instead of four) when the tree allows it (rt_qnodes.hip.h).
-                               // Bit-exact like the default, measured no faster once every leaf decision is exact (profiles/round4/ab_fixed_point_pairs.txt): opt-in
+    int q16 = -1;              // RT_TRAVQ_Q16: the BOX step reads 16-bit fixed-point sibling pairs (32 bytes: two loads instead of four; rt_qnodes.hip.h) when the tree allows it.
+                               // -1 (default) = for trees of at least kQ16AutoNodes nodes, 0 = never, 1 = always.  Bit-exact either way; on the cat (2 019 nodes, L1-resident) it measures
+                               // +-0 once every leaf decision is exact (profiles/round4/ab_fixed_point_pairs.txt), on 55 000 / 533 000 nodes -8 % / -18 % per frame (big_mesh_bench.txt)
     int q_minfree = 0;         // RT_TRAVQ_MINFREE: ... and at least this many slots are free (0 = R / 4)
     int parts = 2;             // RT_PARTS: concurrent sub-frames of the wavefront pipeline
     int bpc5 = 0;              // RT_TRAVQ_BPC5: allow a fifth workgroup per CU
@@ -85,7 +86,7 @@ static Knobs read_knobs() {
     if (geti("RT_TRAVQ_LDS", v) && v >= 1 && v <= 16) k.travq_lds = v;
     if (geti("RT_TRAVQ_LOW", v) && v >= 32 && v <= 320) k.q_low = v;
     if (geti("RT_TRAVQ_MINFREE", v) && v >= 1 && v <= 64) k.q_minfree = v;
-    if (geti("RT_TRAVQ_Q16", v)) k.q16 = v != 0;
+    if (geti("RT_TRAVQ_Q16", v) && v >= -1 && v <= 1) k.q16 = v;
     if (geti("RT_PARTS", v) && v >= 1 && v <= 8) k.parts = v;
     if (getenv("RT_TRAVQ_BPC5")) k.bpc5 = 1;
     if (geti("RT_TRAV_WAVES", v) && v >= 1) k.trav_waves = v;
@@ -134,6 +135,7 @@ struct rt_ctx {
     int n_levels = 0;
     DevBuf nodesh, tri2leaf;                                        // 16-bit fixed-point sibling pairs and the triangle -> leaf table (rt_qnodes.hip.h)
     unsigned chain_nonce = 0;                                       // launch chains started so far (WfState::nonce)
+    int q16_leaf_shift = 0;                                         // where a leaf's triangle count sits in its payload word (rtk::q16_leaf_shift), 0 = leaves too large
     bool q16_topo_ok = false;                                       // the tree's shape allows them (leaf sizes, node count, boxes nest)
     DevBuf node_lo, node_hi, nodes2, nodesq, nodesb, q2thr, tri, verts, tidx, scratch_rgba, scratch_rgb8, work, queue;
     int n_cus = 0;
@@ -742,7 +744,8 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
             {
             const size_t had = ctx->wfQR.bytes;
             if ((rc2 = ensure(ctx, ctx->wfQR, q_slots * 32)) != RT_OK) return rc2;
-            if (ctx->wfQR.bytes != had || ctx->qf_sig != q_sig) {         // padding slots are never written by the kernels: zero once per layout
+            if (ctx->wfQR.bytes != had || ctx->qf_sig != q_sig || work_dev) {   // padding slots are never written by the kernels: zero once per layout.  (A counting run zeroes too:
+                                                                                   // a stale shadow record that passes wq_live costs only a traversal, but the counters would see it)
                 RT_HIP(ctx, hipMemsetAsync(ctx->wfQR.p, 0, ctx->wfQR.bytes, stream));
                 ctx->qf_sig = q_sig;
                 zeroed = true;
@@ -818,7 +821,7 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
                         if (timed) RT_HIP(ctx, hipEventRecord(ctx->ev_trav[2 * it], q));
                         const dim3 tg((unsigned)pt.tblocks), tbd(tb);
                         if (queue) {
-                            hipLaunchKernelGGL(travq_fn(work_dev != nullptr, qR, qldsn, ldsv, kn.q16 && scn.nodesh != nullptr), tg, tbd, trav_lds, q, scn, pt.fr, pt.st, qcap, q_nlds, q_low, q_minfree);
+                            hipLaunchKernelGGL(travq_fn(work_dev != nullptr, qR, qldsn, ldsv, scn.nodesh != nullptr), tg, tbd, trav_lds, q, scn, pt.fr, pt.st, qcap, q_nlds, q_low, q_minfree);
                         } else if (ldsn) {
                             if (work_dev) hipLaunchKernelGGL((rtk::wf_trav<true, true>), tg, tbd, trav_lds, q, scn, pt.fr, pt.st);
                             else hipLaunchKernelGGL((rtk::wf_trav<false, true>), tg, tbd, trav_lds, q, scn, pt.fr, pt.st);
@@ -977,24 +980,25 @@ int launch_tonemap(rt_ctx *ctx, const void *rgba_dev, int64_t npix, void *rgb8_d
 // The part of rt_scene_upload after validation of the sphere / light / camera arguments: layout conversion of the mesh (the
 // reference's arrays -> traversal-order nodes, visit-order triangle records, breadth-first sibling pairs, refit levels) and
 // the uploads.  `sc` carries the spheres, light and camera; rt_mesh_rebuild re-enters here with the tree it built on the device.
+constexpr int kQ16AutoNodes = 16384;                                 // RT_TRAVQ_Q16 = -1: from this many nodes on (the node array no longer sits in the L1s)
 // (Re)derive the 16-bit fixed-point sibling pairs and the triangle -> leaf table from the breadth-first arrays on the device (rt_qnodes.hip.h), on stream q
 // (the upload passes the null stream, as its copies do: creating the context's own stream here would change which hardware queues the sub-frame streams
 // get later, profiles/round3/ab_hw_queues_parts.log), joined before returning.  ctx->scene must be final (root box, node arrays); trees the format does not fit keep scene.nodesh = nullptr.
 int requantize(rt_ctx *ctx, hipStream_t q) {
     rtk::Scene &sc = ctx->scene;
     sc.nodesh = nullptr; sc.tri2leaf = nullptr;
-    if (!ctx->knobs.q16 || !ctx->q16_topo_ok || !ctx->travq_ok || !sc.fast_box || sc.mesh_slot < 0 || sc.n_nodes < 3 || sc.n_tris <= 0) return RT_OK;
+    if (!(ctx->knobs.q16 == 1 || (ctx->knobs.q16 < 0 && sc.n_nodes >= kQ16AutoNodes)) || !ctx->q16_topo_ok || ctx->q16_leaf_shift == 0 || !ctx->travq_ok || !sc.fast_box || sc.mesh_slot < 0 || sc.n_nodes < 3 || sc.n_tris <= 0) return RT_OK;
     int rc;
     if ((rc = ensure(ctx, ctx->nodesh, ((size_t)sc.n_nodes + 2) * 16)) != RT_OK || (rc = ensure(ctx, ctx->tri2leaf, (size_t)sc.n_tris * sizeof(int))) != RT_OK) return rc;
     const rtk::QGrid g = rtk::q16_grid(sc.root_lo, sc.root_hi);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipMemsetAsync(ctx->nodesh.p, 0, 32, q));            // nodes 0 (padding) and 1 (the root: tested when a ray is emitted)
     hipLaunchKernelGGL(rtk::qnodes_kernel, dim3((unsigned)((sc.n_nodes + 255) / 256)), dim3(256), 0, q, sc.nodesq, sc.nodesb, sc.n_nodes, g,
-                       static_cast<uint4 *>(ctx->nodesh.p), static_cast<int *>(ctx->tri2leaf.p), sc.n_tris, rtk::kQNodeShift);
+                       static_cast<uint4 *>(ctx->nodesh.p), static_cast<int *>(ctx->tri2leaf.p), sc.n_tris, rtk::kQLeafShift, ctx->q16_leaf_shift);
     RT_HIP(ctx, hipGetLastError());
     RT_HIP(ctx, hipStreamSynchronize(q));
     sc.nodesh = static_cast<const uint4 *>(ctx->nodesh.p); sc.tri2leaf = static_cast<const int *>(ctx->tri2leaf.p);
-    sc.qgx = g.gx; sc.qgy = g.gy; sc.qgz = g.gz; sc.qsx = g.sx; sc.qsy = g.sy; sc.qsz = g.sz;
+    sc.qgx = g.gx; sc.qgy = g.gy; sc.qgz = g.gz; sc.qsx = g.sx; sc.qsy = g.sy; sc.qsz = g.sz; sc.qleaf_shift = ctx->q16_leaf_shift;
     return RT_OK;
 }
 
@@ -1106,27 +1110,29 @@ int install_scene(rt_ctx *ctx, rtk::Scene sc, const rt_mesh *mesh) {
                 bm[a] = std::max(bm[a], std::max(std::fabs(v[a]), std::fabs(v[a + 3])));
             }
             if (left_of[x] >= 0) {
-                cb.w = __builtin_bit_cast(float, (bfs_of[x + 1] + 1) << rtk::kQNodeShift);
+                cb.w = __builtin_bit_cast(float, (uint32_t)(bfs_of[x + 1] + 1) << rtk::kQNodeShift);
                 hb.w = __builtin_bit_cast(float, (int)0x80000000);
             } else {
                 const int first = __builtin_bit_cast(int, l.w), cnt = __builtin_bit_cast(int, h.w) - first;
                 if (cnt >= rtk::kQMaxLeaf) travq_ok = false;
                 cb.w = __builtin_bit_cast(float, first);
-                hb.w = __builtin_bit_cast(float, cnt > 0 && cnt < rtk::kQMaxLeaf ? cnt << rtk::kQNodeShift : 0);
+                hb.w = __builtin_bit_cast(float, cnt > 0 && cnt < rtk::kQMaxLeaf ? cnt << rtk::kQLeafShift : 0);
             }
             qb[2 * (k + 1)] = cb; qb[2 * (k + 1) + 1] = hb;
         }
         if ((rc = upload(ctx, ctx->nodesb, qb.data(), qb.size() * sizeof(float4))) != RT_OK) return rc;
         {   // may this tree use the 16-bit fixed-point pairs (rt_qnodes.hip.h)?  Leaf sizes and counts fit the payload word, and every box nests inside its parent's
-            bool topo = order.size() >= 3 && order.size() + 2 < (size_t)rtk::kQ16MaxNodes && tri.size() / 3 <= (size_t)rtk::kQ16MaxTris;
+            bool topo = order.size() >= 3;
+            int max_leaf = 0;
             for (size_t x = 0; topo && x < n; ++x) {
-                if (left_of[x] < 0) { if (__builtin_bit_cast(int, hi[x].w) - __builtin_bit_cast(int, lo[x].w) > rtk::kQ16MaxLeaf) topo = false; continue; }
+                if (left_of[x] < 0) { max_leaf = std::max(max_leaf, __builtin_bit_cast(int, hi[x].w) - __builtin_bit_cast(int, lo[x].w)); continue; }
                 for (const int c : {(int)x + 1, left_of[x]}) {
                     const float4 cl = lo[c], ch = hi[c], pl = lo[x], ph = hi[x];
                     if (!(cl.x >= pl.x && cl.y >= pl.y && cl.z >= pl.z && ch.x <= ph.x && ch.y <= ph.y && ch.z <= ph.z)) topo = false;   // also false for NaN
                 }
             }
             ctx->q16_topo_ok = topo;
+            ctx->q16_leaf_shift = rtk::q16_leaf_shift(max_leaf, (long long)(tri.size() / 3));
         }
         sc.bmx = bm[0]; sc.bmy = bm[1]; sc.bmz = bm[2];
         sc.fast_box = fast ? 1 : 0;
@@ -1743,7 +1749,8 @@ static int install_lbvh_device(rt_ctx *ctx, const rtk::Scene &old, const int n_n
     ctx->scene = sc;
     ctx->host_mesh_stale = true;                                                 // tri_perm / up_indices: on the device now (perm_dev, tidx_up)
     ctx->have_scene = true;
-    ctx->q16_topo_ok = n_nodes + 2 < rtk::kQ16MaxNodes && n <= rtk::kQ16MaxTris;    // leaves of at most kLbvhLeaf triangles; boxes are unions, bottom-up: they nest
+    ctx->q16_topo_ok = true;                                                     // boxes are unions, bottom-up: they nest
+    ctx->q16_leaf_shift = rtk::q16_leaf_shift(rtk::kLbvhLeaf, n);                // leaves of at most kLbvhLeaf triangles
     return requantize(ctx, q);
 }
 

@@ -61,6 +61,7 @@ struct Scene {
     const int *tri2leaf;      // triangle (visit order) -> breadth-first index of its leaf (the exact box of a flagged leaf: rt_qnodes.hip.h)
     float qgx, qgy, qgz;      // grid origin (the root box's lower corner) and cell size per axis
     float qsx, qsy, qsz;
+    int qleaf_shift;          // a leaf's payload word in nodesh = 1 << 31 | count << qleaf_shift | first triangle (20 or 24: rt_qnodes.hip.h)
     int fast_box;             // every node box is finite, ordered (lo <= hi) and below 1e8 in magnitude: the centre / half-extent filter may decide
     const float4 *nrm;        // smooth shading (wavefront variants): 3 vertex normals per triangle, visit order; nullptr = flat
     const float4 *tri;

@@ -319,13 +319,13 @@ __global__ __launch_bounds__(256) void lbvh_layout_kernel(const LbvhArgs a, cons
         lo.w = __int_as_float(x + size); hi.w = __int_as_float(-1);     // next node on a box miss: past the subtree
         y.left_of[x] = y.X[jl];
         ql.w = __int_as_float(y.bfs[jr]); qh.w = __int_as_float(-1);     // first child of the pair: the right one (visited first)
-        cb.w = __int_as_float(y.bfs[jr] << kQNodeShift); hb.w = __int_as_float((int)0x80000000);
+        cb.w = __uint_as_float((unsigned int)y.bfs[jr] << kQNodeShift); hb.w = __int_as_float((int)0x80000000);
     } else {
         const int fv = n - e, cnt = e - s;                               // visit ranks of the leaf's triangles
         lo.w = __int_as_float(fv); hi.w = __int_as_float(fv + cnt);
         y.left_of[x] = -1;
         ql.w = lo.w; qh.w = hi.w;
-        cb.w = __int_as_float(fv); hb.w = __int_as_float(cnt << kQNodeShift);
+        cb.w = __int_as_float(fv); hb.w = __int_as_float(cnt << kQLeafShift);
         for (int k = s; k < e; ++k) {
             y.tidx_visit[fv + (k - s)] = tidx_up_old[a.vals[k]];
             y.perm[fv + (k - s)] = k;

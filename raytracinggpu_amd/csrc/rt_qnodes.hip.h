@@ -17,8 +17,8 @@
 //     lies inside its parent's and "hit child => hit parent" holds in the COMPUTED values -- hence the leaves the reference reaches
 //     are exactly the leaves whose own box it hits, and those are decided exactly as above.  Rays outside that class never use the
 //     fixed-point pairs (they are walked serially with the literal test at hand-off), trees that do not nest keep the 64-byte pairs.
-// Payload word: internal node = first child << kQNodeShift (bit 31 clear: fewer than 2^20 nodes); leaf = 1 << 31 | count << 20 | first
-// triangle (count <= 2047, first < 2^20).
+// Payload word: internal node = first child << (kQNodeShift - 1) (bit 31 clear: the kernel shifts it once more for the stack entry); leaf =
+// 1 << 31 | count << S | first triangle with S = 24 (leaves of at most 127 triangles, 2^24 triangles) or S = 20 (2 047 and 2^20): q16_leaf_shift.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -26,7 +26,12 @@ namespace rtk {
 
 struct QGrid { float gx, gy, gz, sx, sy, sz; };
 
-constexpr int kQ16MaxLeaf = 2047, kQ16MaxTris = 1 << 20, kQ16MaxNodes = 1 << 20;
+// S for a tree whose largest leaf holds max_leaf triangles, 0 = the payload word cannot hold its leaves
+__host__ inline int q16_leaf_shift(int max_leaf, long long n_tris) {
+    if (max_leaf <= 127 && n_tris <= (1ll << 24)) return 24;
+    if (max_leaf <= 2047 && n_tris <= (1ll << 20)) return 20;
+    return 0;
+}
 constexpr double kQ16Cells = 65000.0;           // cells per axis over the root box (the rest of the 16-bit range is slack for the outward rounding)
 
 __host__ inline QGrid q16_grid(float4 root_lo, float4 root_hi) {
@@ -51,7 +56,7 @@ __device__ __forceinline__ void q16_axis(float lo, float hi, float g, float s, u
 
 // one thread per breadth-first node b in [1, n_bfs]: nodesq[2b], [2b+1] = (lo, hi) of the node, nodesb[2b].w / [2b+1].w = payload / kind as wf_travq carries them
 __global__ __launch_bounds__(256) void qnodes_kernel(const float4 *__restrict__ nodesq, const float4 *__restrict__ nodesb, int n_bfs, QGrid g,
-                                                     uint4 *__restrict__ nodesh, int *__restrict__ tri2leaf, int n_tris, int node_shift) {
+                                                     uint4 *__restrict__ nodesh, int *__restrict__ tri2leaf, int n_tris, int leaf_kind_shift, int leaf_shift) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x + 1;
     if (b > n_bfs) return;
     const float4 lo = nodesq[2 * (size_t)b], hi = nodesq[2 * (size_t)b + 1];
@@ -62,10 +67,10 @@ __global__ __launch_bounds__(256) void qnodes_kernel(const float4 *__restrict__ 
     q16_axis(lo.y, hi.y, g.gy, g.sy, cy, hy);
     q16_axis(lo.z, hi.z, g.gz, g.sz, cz, hz);
     unsigned int pay;
-    if (kind < 0) pay = payload;                                                 // first child << node_shift
+    if (kind < 0) pay = payload >> 1;                                            // first child << (kQNodeShift - 1): the child index is even
     else {
-        const int cnt = kind >> node_shift, first = (int)payload;
-        pay = 0x80000000u | (unsigned int)cnt << 20 | (unsigned int)first;
+        const int cnt = kind >> leaf_kind_shift, first = (int)payload;
+        pay = 0x80000000u | (unsigned int)cnt << leaf_shift | (unsigned int)first;
         for (int t = 0; t < cnt; ++t) if (first + t < n_tris) tri2leaf[first + t] = b;
     }
     nodesh[b] = make_uint4(cx | cy << 16, cz | hx << 16, hy | hz << 16, pay);

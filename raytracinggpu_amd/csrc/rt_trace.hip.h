@@ -123,7 +123,7 @@ extern "C" int rt_trace_rays(rt_ctx *ctx, const float *rays, int n, float tri_tm
         st.epoch = 0; st.nonce = 0;
         hipLaunchKernelGGL(rtk::trace_emit_kernel, dim3((unsigned)((2 * st.n_paths + 255) / 256)), dim3(256), 0, q, sc, st, static_cast<const float *>(din.p), n);
         if (have_mesh) {
-            if (queue) hipLaunchKernelGGL(travq_fn(false, qR, false, false, kn.q16 && sc.nodesh != nullptr), dim3((unsigned)tblocks), dim3(tb), trav_lds, q, sc, fr, st, qcap, 0, kn.q_low * (qR == 128 ? 2 : 1),
+            if (queue) hipLaunchKernelGGL(travq_fn(false, qR, false, false, sc.nodesh != nullptr), dim3((unsigned)tblocks), dim3(tb), trav_lds, q, sc, fr, st, qcap, 0, kn.q_low * (qR == 128 ? 2 : 1),
                                           (kn.q_minfree >= 1 && kn.q_minfree <= qR) ? kn.q_minfree : qR / 4);
             else hipLaunchKernelGGL((rtk::wf_trav<false, false>), dim3((unsigned)tblocks), dim3(tb), trav_lds, q, sc, fr, st);
         }

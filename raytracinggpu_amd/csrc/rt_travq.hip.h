@@ -43,7 +43,8 @@ constexpr int kQLeafCap = QLeafCap<64>::value;
 // count << 11 | slot << 4).  Decoding costs two full-rate instructions per field (and, shift) instead of the shift-and-add forms
 // that issue at half rate on gfx950 (tools/ubench/issue_table: v_lshlrev_b32, v_lshl_add_u32, v_and_or_b32 ... take twice the
 // issue time of v_and_b32 / v_lshrrev_b32 / v_add_u32 / v_fma_f32).
-constexpr int kQNodeShift = 11, kQNodeBits = 21;
+constexpr int kQNodeShift = 10, kQNodeBits = 22;   // stack entry = node << 10 | slot << 4: the node of an entry is EVEN (a sibling pair), so its lowest bit may share bit 10 with the seventh slot bit (128 resident rays)
+constexpr int kQLeafShift = 11;                    // leaf-queue entry / a leaf's kind word = triangle count << 11 | slot << 4 (| flag): counts may be odd, they start above the slot bits
 constexpr unsigned int kQSlotMask = 0x7f0u;
 constexpr int kQMaxLeaf = 1 << 20;           // triangles per leaf: count << 11 must stay a positive int (the sign says "internal")
 
@@ -67,7 +68,7 @@ template <int R, int SCAP, int LCAP> struct QCarve {
     static constexpr int kTabD = kTabC + 16 * R;
     static constexpr int kMarks = kTabD + 16 * R;         // u8[128]: TRI-step expansion marks (all zero between steps)
     static constexpr int kStack = kMarks + 128;           // u32[SCAP]
-    static constexpr int kLeaf = kStack + 4 * SCAP;       // uint2[LCAP]: (first triangle, count << 10 | slot << 4)
+    static constexpr int kLeaf = kStack + 4 * SCAP;       // uint2[LCAP]: (first triangle, count << 11 | slot << 4 | flag)
     static constexpr int kStage = kLeaf + 8 * LCAP;       // u8[64]: lanes whose registers hold a fetched ray record that has no slot yet
     static constexpr int kBytes = kStage + 64;
     static_assert(kBytes % 16 == 0 && kLeaf % 8 == 0 && kStack % 4 == 0, "the next wave's float4 tables start at kBytes");
@@ -283,7 +284,7 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
 
     // breadth-first order from index 1 (0 is padding), 32 bytes per node: (centre.xyz, payload) (half extent.xyz, kind);
     // internal node: payload = first child << 10 (even; the other child is next to it), kind < 0;  leaf: payload = first triangle,
-    // kind = triangle count << 10 (0 for an empty leaf)
+    // kind = triangle count << 11 (0 for an empty leaf)
     const unsigned char *const nodes = reinterpret_cast<const unsigned char *>(sc.nodesb);
     const size_t blk_base = (size_t)blockIdx.x * (size_t)st.slots_per_block;
     const int blk_n = st.slots_per_block;
@@ -468,7 +469,7 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
                     } else {                           // the root is a leaf
                         if (cnt > 0) {
                             if (got) {
-                                leafq[(ltail + (unsigned int)lanes_below(gm)) & (LCAP - 1)] = make_uint2((unsigned int)first, (unsigned int)cnt << kQNodeShift | sbk);
+                                leafq[(ltail + (unsigned int)lanes_below(gm)) & (LCAP - 1)] = make_uint2((unsigned int)first, (unsigned int)cnt << kQLeafShift | sbk);
                                 if (STATS) wk.tris += (uint32_t)cnt;
                             }
                             ltail += (unsigned int)__popcll(gm);
@@ -490,7 +491,7 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
             const unsigned int m = lcount < 64u ? lcount : 64u;
             uint2 E = make_uint2(0u, 0u);
             if ((unsigned int)lane < m) E = leafq[(lhead + (unsigned int)lane) & (LCAP - 1)];
-            const unsigned int c = E.y >> kQNodeShift;               // >= 1 for queued entries, 0 beyond them
+            const unsigned int c = E.y >> kQLeafShift;               // >= 1 for queued entries, 0 beyond them
             const unsigned int incl = wave_incl_scan(c);
             const unsigned int P = incl - c;                         // position of this entry's first triangle
             const bool part = c > 0u && P < 128u;
@@ -554,7 +555,7 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
             const bool full = part && P + c <= 128u;
             if (part && !full) {                                     // at most one entry straddles position 127: keep its rest
                 const unsigned int took = 128u - P;
-                leafq[(lhead + (unsigned int)lane) & (LCAP - 1)] = make_uint2(E.x + took, (E.y & (kQSlotMask | 1u)) | (c - took) << kQNodeShift);
+                leafq[(lhead + (unsigned int)lane) & (LCAP - 1)] = make_uint2(E.x + took, (E.y & (kQSlotMask | 1u)) | (c - took) << kQLeafShift);
             }
             lhead += (unsigned int)__popcll(__ballot(full));
             if (full) atomicAdd(pend(E.y & kQSlotMask), -1);        // after the mins above (LDS operations stay in order)
@@ -590,7 +591,7 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
             const bool actd = lane < nd;
             const unsigned int ed = actd ? stack[top - 1 - lane] : 0u;
             top -= nd;
-            if (actd) { const unsigned int sd = ed & kQSlotMask; const int cd = (int)(ed >> kQNodeShift); drain_serial(sd, cd); drain_serial(sd, cd + 1); atomicAdd(pend(sd), -1); }
+            if (actd) { const unsigned int sd = ed & kQSlotMask; const int cd = (int)((ed >> kQNodeShift) & ~1u); drain_serial(sd, cd); drain_serial(sd, cd + 1); atomicAdd(pend(sd), -1); }
             if (dbg_on) d_serial++;
             WQ_STAMP(cy_box);
             continue;
@@ -604,8 +605,8 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
             act_[k] = lane + 64 * k < n;
             e_[k] = act_[k] ? stack[top - 1 - lane - 64 * k] : 0u;   // node << 10 | slot << 4: the sibling nodes (one 64-byte line) of the ray in that slot
             sb_[k] = e_[k] & kQSlotMask;                             // the slot's table row
-            off_[k] = QN ? (e_[k] >> (kQNodeShift - 4)) & ~31u : (e_[k] >> (kQNodeShift - 5)) & ~31u;   // the pair's byte offset in the node array (QN: 32 bytes per pair)
-            WQ_CHECK(!act_[k] || ((e_[k] >> kQNodeShift) >= 2u && (int)(e_[k] >> kQNodeShift) + 1 <= sc.n_nodes && ((e_[k] >> kQNodeShift) & 1u) == 0u), 4, off_[k] = 0u);
+            off_[k] = QN ? (e_[k] >> (kQNodeShift - 4)) & ~31u : (e_[k] >> (kQNodeShift - 5)) & ~63u;   // the pair's byte offset in the node array (QN: 32 bytes per pair)
+            WQ_CHECK(!act_[k] || (((e_[k] >> kQNodeShift) & ~1u) >= 2u && (int)((e_[k] >> kQNodeShift) & ~1u) + 1 <= sc.n_nodes), 4, off_[k] = 0u);
         }
         top -= n;
 #pragma unroll
@@ -719,18 +720,19 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
                 mh1 = (mh1 & md1) | __ballot(l1);
             }
             {
-                int k0 = __float_as_int(h0.w), k1 = __float_as_int(h1.w);               // kind: < 0 internal, > 0 leaf (count << 10), 0 empty leaf
+                int k0 = __float_as_int(h0.w), k1 = __float_as_int(h1.w);               // kind: < 0 internal, > 0 leaf (count << 11), 0 empty leaf
                 unsigned int p0 = __float_as_uint(c0.w), p1 = __float_as_uint(c1.w);   // payload: first child << 10 | first triangle
-                if (QN) {   // one word: internal = first child << 11 (bit 31 clear); leaf = 1 << 31 | count << 20 | first triangle
-                    k0 = (int)p0 < 0 ? (int)((p0 >> 20) & 0x7ffu) << kQNodeShift : -1; k1 = (int)p1 < 0 ? (int)((p1 >> 20) & 0x7ffu) << kQNodeShift : -1;
-                    p0 = (int)p0 < 0 ? p0 & 0xfffffu : p0; p1 = (int)p1 < 0 ? p1 & 0xfffffu : p1;
+                if (QN) {   // one word: internal = first child << (kQNodeShift - 1) (bit 31 clear); leaf = 1 << 31 | count << S | first triangle, S = sc.qleaf_shift
+                    const unsigned int S = (unsigned int)sc.qleaf_shift, fm = (1u << S) - 1u;
+                    k0 = (int)p0 < 0 ? (int)(((p0 & 0x7fffffffu) >> S) << kQLeafShift) : -1; k1 = (int)p1 < 0 ? (int)(((p1 & 0x7fffffffu) >> S) << kQLeafShift) : -1;
+                    p0 = (int)p0 < 0 ? p0 & fm : p0 << 1; p1 = (int)p1 < 0 ? p1 & fm : p1 << 1;
                 }
                 const unsigned long long g0 = mh0 & mact, g1 = mh1 & mact;
                 const unsigned long long mI0 = g0 & __ballot(k0 < 0), mI1 = g1 & __ballot(k1 < 0), mL0 = g0 & __ballot(k0 > 0), mL1 = g1 & __ballot(k1 > 0);
                 if (STATS) {
                     const bool b0 = __builtin_amdgcn_inverse_ballot_w64(g0), b1 = __builtin_amdgcn_inverse_ballot_w64(g1);
                     wk.box += act ? 2u : 0u; wk.nodes += (b0 ? 1u : 0u) + (b1 ? 1u : 0u);
-                    wk.tris += ((b0 && k0 > 0) ? (uint32_t)(k0 >> kQNodeShift) : 0u) + ((b1 && k1 > 0) ? (uint32_t)(k1 >> kQNodeShift) : 0u);
+                    wk.tris += ((b0 && k0 > 0) ? (uint32_t)(k0 >> kQLeafShift) : 0u) + ((b1 && k1 > 0) ? (uint32_t)(k1 >> kQLeafShift) : 0u);
                 }
                 // a hit internal node pushes ITS pair of children; the order of entries on the stack does not matter (the traversal is a bag),
                 // so a lane's one or two entries go next to each other: one prefix count over both masks, one address
