@@ -44,6 +44,7 @@ struct Knobs {
     int q16 = -1;              // RT_TRAVQ_Q16: the BOX step reads 16-bit fixed-point sibling pairs (32 bytes: two loads instead of four; rt_qnodes.hip.h) when the tree allows it.
                                // -1 (default) = for trees of at least kQ16AutoNodes nodes, 0 = never, 1 = always.  Bit-exact either way; on the cat (2 019 nodes, L1-resident) it measures
                                // +-0 once every leaf decision is exact (profiles/round4/ab_fixed_point_pairs.txt), on 55 000 / 533 000 nodes -8 % / -18 % per frame (big_mesh_bench.txt)
+    float lbvh_ct = 0.f;       // RT_LBVH_CT: cost of a triangle test relative to a box test in the LBVH's leaf cut (0 = kLbvhCt)
     int q_minfree = 0;         // RT_TRAVQ_MINFREE: ... and at least this many slots are free (0 = R / 4)
     int parts = 2;             // RT_PARTS: concurrent sub-frames of the wavefront pipeline
     int bpc5 = 0;              // RT_TRAVQ_BPC5: allow a fifth workgroup per CU
@@ -86,6 +87,7 @@ static Knobs read_knobs() {
     if (geti("RT_TRAVQ_LDS", v) && v >= 1 && v <= 16) k.travq_lds = v;
     if (geti("RT_TRAVQ_LOW", v) && v >= 32 && v <= 320) k.q_low = v;
     if (geti("RT_TRAVQ_MINFREE", v) && v >= 1 && v <= 64) k.q_minfree = v;
+    if (const char *e = std::getenv("RT_LBVH_CT")) { const float f = (float)std::atof(e); if (f > 0.f && f < 100.f) k.lbvh_ct = f; }
     if (geti("RT_TRAVQ_Q16", v) && v >= -1 && v <= 1) k.q16 = v;
     if (geti("RT_PARTS", v) && v >= 1 && v <= 8) k.parts = v;
     if (getenv("RT_TRAVQ_BPC5")) k.bpc5 = 1;
@@ -1606,6 +1608,9 @@ static int rebuild_lbvh_tree(rt_ctx *ctx, const int nt, int &n_nodes_out) {
     if ((rc = ensure(ctx, ctx->bb_idx, n * sizeof(int))) != RT_OK) return rc;
     uint8_t *base = static_cast<uint8_t *>(B.p);
     rtk::LbvhArgs a{};
+    // the leaf cut's triangle cost: kLbvhCt (wf_travq's step times on 64-byte pairs) for small trees; 1.0 for trees that will use the 32-byte fixed-point pairs, where a box test is
+    // cheaper still but a triangle's 48-byte gather is not (swept on 524 288 / 2 M triangles: Ct 1.0 / 1.6 / 2.5 / 4 / 8 = 2.77 / 2.84 / 2.99 / 3.04 / 3.06 and 8.21 / 8.40 / 8.72 / 8.73 / 8.80 ms per frame)
+    a.ct = ctx->knobs.lbvh_ct > 0.f ? ctx->knobs.lbvh_ct : (nt >= kQ16AutoNodes ? 1.0f : rtk::kLbvhCt); a.cb = rtk::kLbvhCb;
     a.verts = static_cast<const float4 *>(ctx->verts.p); a.tidx_up = static_cast<const int4 *>(ctx->tidx_up.p); a.n = nt;
     a.bounds = reinterpret_cast<unsigned int *>(base + o_small); a.stats = reinterpret_cast<int *>(base + o_small + 32);
     a.keys = reinterpret_cast<unsigned long long *>(base + o_keys); a.vals = reinterpret_cast<int *>(base + o_vals);

@@ -55,6 +55,7 @@ struct LbvhArgs {
     int *index;                          // [2 n - 1] exclusive prefix sum of alive: the node's number in the output
     float *arr10;                        // [n_alive * 10] output
     int *stats;                          // [4]: leaves, largest leaf, deepest leaf (filled by lbvh_emit_kernel)
+    float ct, cb;                        // cost of one triangle test / one box test in the leaf cut (kLbvhCt, kLbvhCb unless RT_LBVH_CT says otherwise)
 };
 
 // float <-> unsigned key with the same order (for atomicMin / atomicMax on floats)
@@ -193,9 +194,9 @@ __global__ __launch_bounds__(256) void lbvh_boxes_kernel(const LbvhArgs a) {
         auto area = [](const float4 p0, const float4 p1) { const float dx = p1.x - p0.x, dy = p1.y - p0.y, dz = p1.z - p0.z; return dx * dy + dy * dz + dz * dx; };
         const int cnt = a.last[cur] - a.first[cur] + 1;
         const float A = area(lo, hi);
-        const float cl = (lc & kLbvhLeafBit) ? kLbvhCt : a.cost[lc], cr = (rc & kLbvhLeafBit) ? kLbvhCt : a.cost[rc];
+        const float cl = (lc & kLbvhLeafBit) ? a.ct : a.cost[lc], cr = (rc & kLbvhLeafBit) ? a.ct : a.cost[rc];
         const float wl = A > 0.f ? area(l0, l1) / A : 1.f, wr = A > 0.f ? area(r0, r1) / A : 1.f;
-        const float inner = 2.f * kLbvhCb + wl * cl + wr * cr, leaf = kLbvhCt * (float)cnt;
+        const float inner = 2.f * a.cb + wl * cl + wr * cr, leaf = a.ct * (float)cnt;
         const bool as_leaf = cnt <= kLbvhMinLeaf || (cnt <= kLbvhLeaf && leaf <= inner);
         a.cost[cur] = as_leaf ? leaf : inner;
         a.leafify[cur] = as_leaf ? 1 : 0;
