@@ -168,12 +168,7 @@ def test_reference_mesh_vectors_through_the_fixed_point_box_step(cat_golden, mon
     c.close(); d.close()
 
 
-@pytest.mark.parametrize("variant", ["wavefront_queue", "path", "wavefront"])
-def test_degenerate_rays_through_the_production_traversal_kernels(ctx, oracle, oracle_cat, variant):
-    """Rays a camera or a bounce never produces -- zero, denormal, huge and axis-parallel direction components, origins inside the
-    mesh and on its box faces, unnormalised directions -- against the oracle's TriangleMesh::intersect (pinned to the reference by
-    tests/test_oracle_pinned.py): hit flag, t and normal bit-exact through every production traversal kernel.  These rays reach
-    wf_travq's c0 = +inf route (literal box tests for every pair) and, with tri_tmin = 0, moller_trumbore's own t > 0."""
+def _degenerate_rays(oracle_cat):
     rng = np.random.default_rng(20260410)
     n = 1200
     O = rng.uniform(-30, 30, (n, 3)).astype(np.float32)
@@ -188,17 +183,43 @@ def test_degenerate_rays_through_the_production_traversal_kernels(ctx, oracle, o
     u[840:880] *= np.float32(1e-20)
     bb = oracle_cat.bvh_array()[0]
     O[880:940, 0] = bb[2]; O[940:1000, 1] = bb[6]                     # on the root box's faces
-    rays = np.concatenate([O, u], axis=1)
+    return O, u, np.concatenate([O, u], axis=1)
+
+
+def _check_degenerate(c, oracle_cat, variant):
+    O, u, rays = _degenerate_rays(oracle_cat)
+    n = len(rays)
     for tmin in (1e-4, 0.0):
         exp = np.zeros((n, 5), np.float32)
         for i in range(n):
             h, t, N = oracle_cat.intersect(O[i], u[i], tmin)
             exp[i, 0] = 1.0 if h else 0.0
             exp[i, 1] = t; exp[i, 2:5] = N
-        got = ctx.trace_rays(rays, tmin, variant)
+        got = c.trace_rays(rays, tmin, variant)
         hit = _check_mesh_rows(got, exp)
         assert hit.sum() > 50 and (~hit).sum() > 50
     assert ((rays[:, 3:6] == 0).any(axis=1)).sum() >= 500
+
+
+@pytest.mark.parametrize("variant", ["wavefront_queue", "path", "wavefront"])
+def test_degenerate_rays_through_the_production_traversal_kernels(ctx, oracle, oracle_cat, variant):
+    """Rays a camera or a bounce never produces -- zero, denormal, huge and axis-parallel direction components, origins inside the
+    mesh and on its box faces, unnormalised directions -- against the oracle's TriangleMesh::intersect (pinned to the reference by
+    tests/test_oracle_pinned.py): hit flag, t and normal bit-exact through every production traversal kernel.  These rays reach
+    wf_travq's c0 = +inf route (literal box tests for every pair) and, with tri_tmin = 0, moller_trumbore's own t > 0."""
+    _check_degenerate(ctx, oracle_cat, variant)
+
+
+def test_degenerate_rays_through_the_fixed_point_box_step(oracle, oracle_cat, cat_golden, monkeypatch):
+    """The same rays with RT_TRAVQ_Q16=1: the box test is not monotone for a ray with a zero / denormal / huge component, so such a ray never meets the
+    fixed-point pairs -- it is walked serially with the literal test when it is handed its slot (rt_qnodes.hip.h) -- while the rest of the batch does."""
+    monkeypatch.setenv("RT_TRAVQ_Q16", "1")
+    c = rt.Context(0)
+    monkeypatch.delenv("RT_TRAVQ_Q16")
+    mesh = dict(vertices=cat_golden["vertices"], indices=cat_golden["tri_bvh_order"], bvh_arr10=cat_golden["bvh_arr10"], albedo=rt.scenes.CAT_ALBEDO, object_slot=6)
+    c.scene_upload(rt.scenes.spheres("cpu"), mesh)
+    _check_degenerate(c, oracle_cat, "wavefront_queue")
+    c.close()
 
 
 def test_trace_rays_error_paths_and_empty_scene(ctx):
