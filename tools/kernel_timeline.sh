@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/$tag
 rm -rf $out && mkdir -p $out
-rocprofv3 --kernel-trace --output-format csv -d $out/t -o trace -- python3 bench.py --no-cpu-baseline --large-steps 0 --steps 6 --warmup 3 > $out/bench.json 2> $out/t.err || { tail -5 $out/t.err; exit 1; }
+rocprofv3 --kernel-trace --output-format csv -d $out/t -o trace -- python3 bench.py --no-cpu-baseline --no-end-to-end --large-steps 0 --steps 6 --warmup 3 > $out/bench.json 2> $out/t.err || { tail -5 $out/t.err; exit 1; }
 cp $(find $out/t -name "*kernel_trace.csv" | head -1) $out/kernel_trace.csv
 rm -rf $out/t
 python3 tools/kernel_timeline.py $out/kernel_trace.csv > $out/timeline.txt

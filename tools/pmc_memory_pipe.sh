@@ -17,7 +17,7 @@ for grp in \
   "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum TCP_UTCL1_STALL_INFLIGHT_MAX_sum" \
   "GRBM_GUI_ACTIVE GRBM_COUNT" "SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES"; do
   i=$((i+1))
-  RT_PARTS=1 timeout -k 5 ${PASS_TIMEOUT:-60} rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/p$i -o pmc -- python3 bench.py --no-cpu-baseline --large-steps 0 --prewarm-ms 0 --steps 4 --warmup 1 > $out/p$i.json 2> $out/p$i.err || { echo "pass $i ($grp) failed"; grep -m3 -i "error\|abort\|fail\|invalid" $out/p$i.err || true; }
+  RT_PARTS=1 timeout -k 5 ${PASS_TIMEOUT:-60} rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/p$i -o pmc -- python3 bench.py --no-cpu-baseline --no-end-to-end --large-steps 0 --prewarm-ms 0 --steps 4 --warmup 1 > $out/p$i.json 2> $out/p$i.err || { echo "pass $i ($grp) failed"; grep -m3 -i "error\|abort\|fail\|invalid" $out/p$i.err || true; }
 done
 python3 tools/pmc_summary.py $out "$kern" > $out/pmc_memory_pipe.json
 rm -rf $out/p[0-9]*
