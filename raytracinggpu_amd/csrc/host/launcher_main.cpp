@@ -15,12 +15,16 @@
 //                                run is never accepted; rank 0 removes FILE before it writes and after the communicator is up
 //       [--rccl-timeout SEC]     give up (exit code 3) if the communicator is not up after SEC seconds (default 120)
 //   --assemble F0,F1,...         put the tile files of ranks 0..G-1 together and write the PNG (no GPU needed)
+//   --timing 1                   where the program's wall time goes, phase by phase, on stderr (the reference times all of main, cpu:660,721-723): the time before
+//                                main (loader), OBJ + BVH, context creation, upload, the frame (the library adds its own phases: RT_TIMING), the PNG
 #include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <memory>
 #include <unistd.h>
+#include <time.h>
+#include <cstdio>
 #include <cmath>
 #include <fstream>
 #include <iostream>
@@ -39,6 +43,14 @@ int main(int argc, char *argv[]) {
     }
     const int num_rays = atoi(argv[1]), num_bounce = atoi(argv[2]);
     auto start_time = std::chrono::system_clock::now();
+    auto lap_t = std::chrono::steady_clock::now();
+    bool timing = false;
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "timing: %-44s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(n - lap_t).count());
+        lap_t = n;
+    };
     std::string program = "cpu", scene_name = "cat", out, obj = "cadnav.com_model/Models_F0202A090/cat.obj";
     int W = 512, H = 512, device = 0, variant = RT_VARIANT_AUTO;
     std::vector<int> devices;
@@ -63,9 +75,21 @@ int main(int argc, char *argv[]) {
         else if (k == "--rccl-id") rccl_id_file = v;
         else if (k == "--rccl-nonce") rccl_nonce = v;
         else if (k == "--rccl-timeout") rccl_timeout_s = std::max(1, atoi(v.c_str()));
+        else if (k == "--timing") { timing = atoi(v.c_str()) != 0; if (timing) setenv("RT_TIMING", "1", 1); }
         else if (k == "--assemble") { std::stringstream ss(v); std::string tok; while (std::getline(ss, tok, ',')) assemble.push_back(tok); }
         else if (k == "--devices") { std::stringstream ss(v); std::string tok; while (std::getline(ss, tok, ',')) devices.push_back(atoi(tok.c_str())); }
         else { std::cerr << "unknown option " << k << "\n"; return 2; }
+    }
+    if (timing) {                                                       // process start -> main: /proc/self/stat field 22 (start time in clock ticks since boot) against the boot clock
+        std::ifstream st("/proc/self/stat");
+        std::string all((std::istreambuf_iterator<char>(st)), std::istreambuf_iterator<char>());
+        const size_t rp = all.rfind(')');
+        std::stringstream ss(rp == std::string::npos ? std::string() : all.substr(rp + 2));
+        std::string tok; double ticks = -1;
+        for (int f = 3; f <= 22 && (ss >> tok); ++f) if (f == 22) ticks = atof(tok.c_str());
+        timespec bt{}; clock_gettime(CLOCK_BOOTTIME, &bt);
+        if (ticks >= 0) fprintf(stderr, "timing: %-44s %9.3f ms (10 ms resolution)\n", "process start -> main (loader, libamdhip64)", (bt.tv_sec + bt.tv_nsec * 1e-9 - ticks / sysconf(_SC_CLK_TCK)) * 1e3);
+        lap_t = std::chrono::steady_clock::now();
     }
     const bool optimized = program == "optimized";
     if (out.empty()) out = optimized ? "image_optimized.png" : "image.png";   // opt:862 / cpu:719
@@ -94,6 +118,7 @@ int main(int argc, char *argv[]) {
             mesh_ptr->albedo = Vector(0.25, 0.25, 0.25);                  // cpu:683
             mesh_ptr->buildBVH(&(mesh_ptr->bvh), 0, (int)mesh_ptr->indices.size());   // cpu:684
         }
+        lap("readOBJ + buildBVH (host)");
         if (scene_name == "demo10") {                                     // the commented objects, cpu:669-672
             s.addObject(new Sphere(Vector(0, 0, 0), 10, Vector(0., 0., 0.), 0, 1.5, 1));
             s.addObject(new Sphere(Vector(-20, 0, 0), 10, Vector(0., 0., 0.), 1));
@@ -187,9 +212,13 @@ int main(int argc, char *argv[]) {
             return 0;
         }
         Renderer renderer(device);
+        lap("Renderer (rt_ctx_create), total");
         renderer.upload(s);
+        lap("upload (flatten + rt_scene_upload), total");
         image = renderer.render_rgb8(rs);
+        lap("render_rgb8, total");
         if (!write_png(out.c_str(), W, H, image.data())) { std::cerr << "cannot write " << out << "\n"; return 1; }
+        lap("write_png");
         const rt_stats st = renderer.stats();
         auto end_time = std::chrono::system_clock::now();
         std::chrono::duration<float> run_time = end_time - start_time;

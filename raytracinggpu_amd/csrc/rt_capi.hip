@@ -44,6 +44,10 @@ struct Knobs {
     int q16 = -1;              // RT_TRAVQ_Q16: the BOX step reads 16-bit fixed-point sibling pairs (32 bytes: two loads instead of four; rt_qnodes.hip.h) when the tree allows it.
                                // -1 (default) = for trees of at least kQ16AutoNodes nodes, 0 = never, 1 = always.  Bit-exact either way; on the cat (2 019 nodes, L1-resident) it measures
                                // +-0 once every leaf decision is exact (profiles/round4/ab_fixed_point_pairs.txt), on 55 000 / 533 000 nodes -8 % / -18 % per frame (big_mesh_bench.txt)
+    int qw = 0;                // RT_TRAVQ_QW: the BOX step is four boxes wide (fixed-point quads: the children of both nodes of a sibling pair in 64 bytes, every other level of the tree
+                               // skipped; exact leaf decisions in the TRI step; rt_travq.hip.h, QW).  0 = off, 1 = on where the tree allows the fixed-point format
+    int qw_count = 0;          // RT_TRAVQ_QW_COUNT=1: rt_count_work runs the 4-wide kernel's counting instantiation (its own step counters; the box / node counts then describe
+                               // THAT kernel, not the reference's traversal)
     float lbvh_ct = 0.f;       // RT_LBVH_CT: cost of a triangle test relative to a box test in the LBVH's leaf cut (0 = kLbvhCt)
     int q_minfree = 0;         // RT_TRAVQ_MINFREE: ... and at least this many slots are free (0 = R / 4)
     int parts = 2;             // RT_PARTS: concurrent sub-frames of the wavefront pipeline
@@ -72,7 +76,6 @@ struct Knobs {
                                // runtime keeps a pool of hardware queues per class; in the normal class the copy stream can share a queue with one of the
                                // sub-frame streams and the copy then waits behind kernels (pipelined float4 frames 1.72 instead of 1.19 ms)
     int async_pipeline = 1;    // RT_ASYNC_PIPELINE=0: rt_render_async joins the sub-frames of frame k before frame k+1 starts (as rt_render_device does without rt_ctx_set_pipelining)
-    int top_lds = 0;           // RT_TRAVQ_TOPLDS: nodes of the breadth-first top of the tree every ordinary (4-wave) workgroup of wf_travq stages in LDS
     int copy_split = 0;        // RT_COPY_SPLIT=1: rt_render_async sends the two halves of a big frame through two copy streams (measured SLOWER: 1.62 vs 1.48 ms per
                                // pipelined 1080p float4 frame -- one DMA already runs at the rate the PCIe link gives, two share it and add an event hop)
     int debug_trav = -2;       // RT_DEBUG_TRAV: traversal launch whose per-wave records are dumped (-DRT_DEBUG builds only)
@@ -89,6 +92,8 @@ static Knobs read_knobs() {
     if (geti("RT_TRAVQ_MINFREE", v) && v >= 1 && v <= 64) k.q_minfree = v;
     if (const char *e = std::getenv("RT_LBVH_CT")) { const float f = (float)std::atof(e); if (f > 0.f && f < 100.f) k.lbvh_ct = f; }
     if (geti("RT_TRAVQ_Q16", v) && v >= -1 && v <= 1) k.q16 = v;
+    if (geti("RT_TRAVQ_QW", v) && v >= 0 && v <= 1) k.qw = v;
+    if (geti("RT_TRAVQ_QW_COUNT", v)) k.qw_count = v != 0;
     if (geti("RT_PARTS", v) && v >= 1 && v <= 8) k.parts = v;
     if (getenv("RT_TRAVQ_BPC5")) k.bpc5 = 1;
     if (geti("RT_TRAV_WAVES", v) && v >= 1) k.trav_waves = v;
@@ -107,7 +112,6 @@ static Knobs read_knobs() {
     if (geti("RT_ASYNC_PIPELINE", v)) k.async_pipeline = v != 0;
     if (geti("RT_COPY_PRIO", v)) k.copy_prio = v;
     if (geti("RT_ADV_BLOCK", v) && (v == 64 || v == 128 || v == 256)) k.adv_block = v;
-    if (geti("RT_TRAVQ_TOPLDS", v) && v >= 0 && v <= 4096) k.top_lds = v & ~1;
     if (geti("RT_PATH_SAMP_MB", v) && v >= 1) k.path_samp_bytes = (long long)v << 20;
 #ifdef RT_DEBUG
     if (geti("RT_DEBUG_TRAV", v)) k.debug_trav = v;
@@ -136,6 +140,8 @@ struct rt_ctx {
     rt_build_stats build{};                                          // what the last rt_mesh_rebuild_mode did
     int n_levels = 0;
     DevBuf nodesh, tri2leaf;                                        // 16-bit fixed-point sibling pairs and the triangle -> leaf table (rt_qnodes.hip.h)
+    DevBuf nodesw, leafbox;                                         // 4-wide fixed-point nodes and the leaves' real boxes by first triangle (RT_TRAVQ_QW)
+    int travq_blocks_per_cu_qw[2] = {0, 0};                         // [STATS]
     unsigned chain_nonce = 0;                                       // launch chains started so far (WfState::nonce)
     int q16_leaf_shift = 0;                                         // where a leaf's triangle count sits in its payload word (rtk::q16_leaf_shift), 0 = leaves too large
     bool q16_topo_ok = false;                                       // the tree's shape allows them (leaf sizes, node count, boxes nest)
@@ -208,6 +214,20 @@ hipStream_t own_stream(rt_ctx *ctx) {
     }
     return ctx->stream_;   // nullptr: the entry points fail with RT_ERR_HIP (RT_OWN_STREAM) rather than fall back to the legacy default stream
 }
+
+// RT_TIMING=1: host-side wall time of the library's start-up phases on stderr (rt_launcher --timing 1 sets it): where a short program's time goes
+// -- runtime initialisation, the first launch's code-object load, uploads, the frame itself, the copy back.
+struct PhaseClock {
+    bool on;
+    std::chrono::steady_clock::time_point t;
+    PhaseClock() : on([] { const char *e = getenv("RT_TIMING"); return e && *e && atoi(e) != 0; }()), t(std::chrono::steady_clock::now()) {}
+    void lap(const char *what) {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "timing: %-44s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
 
 int fail(rt_ctx *ctx, int code, const char *fmt, ...) {
     char buf[512];
@@ -339,16 +359,18 @@ using TravqFn = void (*)(const rtk::Scene, const rtk::Frame, const rtk::WfState,
 template <bool S, int R> TravqFn travq_pick(bool ldsn, bool ldsv) {
     return ldsn ? (ldsv ? rtk::wf_travq<S, R, true, true> : rtk::wf_travq<S, R, true, false>) : (ldsv ? rtk::wf_travq<S, R, false, true> : rtk::wf_travq<S, R, false, false>);
 }
-TravqFn travq_fn(bool stats, int R, bool ldsn, bool ldsv = false, bool qn = false) {
+TravqFn travq_fn(bool stats, int R, bool ldsn, bool ldsv = false, bool qn = false, bool qw = false) {
+    if (qw && R == 64 && !ldsn && !ldsv) return stats ? rtk::wf_travq<true, 64, false, false, true, true> : rtk::wf_travq<false, 64, false, false, true, true>;
     if (qn && !stats && R == 64 && !ldsn && !ldsv) return rtk::wf_travq<false, 64, false, false, true>;
     if (stats) return R == 32 ? travq_pick<true, 32>(ldsn, ldsv) : R == 128 ? travq_pick<true, 128>(ldsn, ldsv) : travq_pick<true, 64>(ldsn, ldsv);
     return R == 32 ? travq_pick<false, 32>(ldsn, ldsv) : R == 128 ? travq_pick<false, 128>(ldsn, ldsv) : travq_pick<false, 64>(ldsn, ldsv);
 }
-size_t travq_carve_bytes(int R) {
+size_t travq_carve_bytes(int R, bool qw = false) {
+    if (qw) return (size_t)rtk::QCarve<64, rtk::kQwStackCap, rtk::kQwLeafCap>::kBytes;
     return R == 128 ? (size_t)rtk::QCarve<128, rtk::QStackCap<128>::value, rtk::QLeafCap<128>::value>::kBytes
          : R == 64 ? (size_t)rtk::QCarve<64, rtk::QStackCap<64>::value, rtk::QLeafCap<64>::value>::kBytes : (size_t)rtk::QCarve<32, rtk::QStackCap<32>::value, rtk::QLeafCap<32>::value>::kBytes;
 }
-int travq_stack_cap(int R) { return R == 128 ? rtk::QStackCap<128>::value : R == 64 ? rtk::QStackCap<64>::value : rtk::QStackCap<32>::value; }
+int travq_stack_cap(int R, bool qw = false) { return qw ? rtk::kQwStackCap : R == 128 ? rtk::QStackCap<128>::value : R == 64 ? rtk::QStackCap<64>::value : rtk::QStackCap<32>::value; }
 int travq_block_threads(int R) { return R == 128 ? 128 : rtk::kQBlock;   // 128 resident rays per wave: 16 KB of LDS per wave, two-wave workgroups (five fit a CU)
 }
 
@@ -595,7 +617,9 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
         const bool queue = variant == RT_VARIANT_WAVEFRONT_QUEUE;
         const Knobs &kn = ctx->knobs;
         const int qR = kn.travq_R;                                    // ray slots per wave of the work-stack kernel
-        int qcap = travq_stack_cap(qR);
+        // the 4-wide BOX step (RT_TRAVQ_QW): plain launches only; a counting run keeps the binary instantiation (its counters are the reference's) unless RT_TRAVQ_QW_COUNT
+        const bool qw = queue && scn.nodesw != nullptr && qR == 64 && !want_ldsv && !want_ldsn && kn.travq_lds == 0 && (work_dev == nullptr || kn.qw_count);
+        int qcap = travq_stack_cap(qR, qw);
         if (kn.travq_cap >= 128 && kn.travq_cap < qcap) qcap = kn.travq_cap;   // tests: force the serial drain
         // BVH nodes staged in LDS (breadth-first prefix) by ONE workgroup of qW waves per CU; 0 = nodes through L1/L2
         int qW = kn.travq_lds;
@@ -617,11 +641,9 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
             qW = 0;
         }
         const bool qlds = queue && qW > 0;                            // ONE workgroup of qW waves per CU
-        // RT_TRAVQ_TOPLDS: the ordinary launch (4-wave workgroups, 4 per CU) with the first levels of the tree staged per workgroup
-        if (queue && !qlds && mesh_here && kn.top_lds > 0) q_nlds = std::min(kn.top_lds, (ctx->scene.n_nodes + 1) & ~1);
-        if (!qlds && q_nlds < 4) q_nlds = 0;                          // (the same for the per-workgroup staging)
-        const bool qtop = queue && !qlds && q_nlds > 0;
-        const bool qldsn = (qlds || qtop) && q_nlds > 0;
+        // (round 4's RT_TRAVQ_TOPLDS -- the ordinary 4-wave launch with the top of the tree staged per workgroup -- lost by 7-20 % and is gone: DESIGN.md section 10)
+        if (!qlds) q_nlds = 0;
+        const bool qldsn = qlds && q_nlds > 0;
         const int q_low = kn.q_low * (qR == 128 ? 2 : 1);              // refill thresholds of the work-stack kernel (stack entries are sibling pairs)
         const int q_minfree = (kn.q_minfree >= 1 && kn.q_minfree <= qR) ? kn.q_minfree : qR / 4;
         // begin, (trav, advance) x 2*segments per sample; path state SoA in HBM, tile-order path index.
@@ -638,7 +660,7 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
         const int tiles_x = (p->width + 7) / 8;
         const int tb = qlds ? 64 * qW : queue ? travq_block_threads(qR) : ldsn ? rtk::kTravBlockLds : rtk::kTravBlock;
         const int wpb = tb / 64;
-        const size_t q_lds = (size_t)wpb * travq_carve_bytes(qR) + 16 + (size_t)q_nlds * 32 + (ldsv ? (size_t)ctx->scene.n_verts * 16 : 0);
+        const size_t q_lds = (size_t)wpb * travq_carve_bytes(qR, qw) + 16 + (size_t)q_nlds * 32 + (ldsv ? (size_t)ctx->scene.n_verts * 16 : 0);
         const size_t trav_lds = queue ? q_lds : ldsn ? lds_nodes_bytes : (size_t)(rtk::kTravBlock / 64) * rtk::TravCarve<512, 8>::kBytes + 16;
         if (!ctx->trav_attr_set) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(rtk::wf_trav<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -659,10 +681,18 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
             if (qlds) {
                 bpc = 1;
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(travq_fn(work_dev != nullptr, qR, qldsn, ldsv)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            } else {
-                if (ctx->travq_blocks_per_cu[qi] == 0 || qtop) {
+            } else if (qw) {
+                int &nbq = ctx->travq_blocks_per_cu_qw[work_dev ? 1 : 0];
+                if (nbq == 0) {
                     int nb = 0;
-                    RT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, travq_fn(work_dev != nullptr, qR, qtop, false), tb, trav_lds));
+                    RT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, travq_fn(work_dev != nullptr, qR, false, false, true, true), tb, trav_lds));
+                    nbq = nb > 0 ? nb : 1;
+                }
+                bpc = std::min(nbq, 16 / (tb / 64));
+            } else {
+                if (ctx->travq_blocks_per_cu[qi] == 0) {
+                    int nb = 0;
+                    RT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, travq_fn(work_dev != nullptr, qR, false, false), tb, trav_lds));
                     ctx->travq_blocks_per_cu[qi] = nb > 0 ? nb : 1;
                 }
                 bpc = std::min(ctx->travq_blocks_per_cu[qi], (kn.bpc5 ? 20 : 16) / (tb / 64));    // a fifth workgroup per CU fits but does not pay (measured)
@@ -823,7 +853,7 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
                         if (timed) RT_HIP(ctx, hipEventRecord(ctx->ev_trav[2 * it], q));
                         const dim3 tg((unsigned)pt.tblocks), tbd(tb);
                         if (queue) {
-                            hipLaunchKernelGGL(travq_fn(work_dev != nullptr, qR, qldsn, ldsv, scn.nodesh != nullptr), tg, tbd, trav_lds, q, scn, pt.fr, pt.st, qcap, q_nlds, q_low, q_minfree);
+                            hipLaunchKernelGGL(travq_fn(work_dev != nullptr, qR, qldsn, ldsv, scn.nodesh != nullptr, qw), tg, tbd, trav_lds, q, scn, pt.fr, pt.st, qcap, q_nlds, q_low, q_minfree);
                         } else if (ldsn) {
                             if (work_dev) hipLaunchKernelGGL((rtk::wf_trav<true, true>), tg, tbd, trav_lds, q, scn, pt.fr, pt.st);
                             else hipLaunchKernelGGL((rtk::wf_trav<false, true>), tg, tbd, trav_lds, q, scn, pt.fr, pt.st);
@@ -988,18 +1018,28 @@ constexpr int kQ16AutoNodes = 16384;                                 // RT_TRAVQ
 // get later, profiles/round3/ab_hw_queues_parts.log), joined before returning.  ctx->scene must be final (root box, node arrays); trees the format does not fit keep scene.nodesh = nullptr.
 int requantize(rt_ctx *ctx, hipStream_t q) {
     rtk::Scene &sc = ctx->scene;
-    sc.nodesh = nullptr; sc.tri2leaf = nullptr;
-    if (!(ctx->knobs.q16 == 1 || (ctx->knobs.q16 < 0 && sc.n_nodes >= kQ16AutoNodes)) || !ctx->q16_topo_ok || ctx->q16_leaf_shift == 0 || !ctx->travq_ok || !sc.fast_box || sc.mesh_slot < 0 || sc.n_nodes < 3 || sc.n_tris <= 0) return RT_OK;
+    sc.nodesh = nullptr; sc.tri2leaf = nullptr; sc.nodesw = nullptr; sc.leafbox = nullptr;
+    const bool want_qw = ctx->knobs.qw == 1 && ctx->q16_leaf_shift == 24 && sc.n_nodes + 2 < (1 << 21);   // the quad's payload word: leaves of <= 127 triangles, child << 10 positive
+    if (!(ctx->knobs.q16 == 1 || (ctx->knobs.q16 < 0 && sc.n_nodes >= kQ16AutoNodes) || want_qw) || !ctx->q16_topo_ok || ctx->q16_leaf_shift == 0 || !ctx->travq_ok || !sc.fast_box || sc.mesh_slot < 0 || sc.n_nodes < 3 || sc.n_tris <= 0) return RT_OK;
     int rc;
     if ((rc = ensure(ctx, ctx->nodesh, ((size_t)sc.n_nodes + 2) * 16)) != RT_OK || (rc = ensure(ctx, ctx->tri2leaf, (size_t)sc.n_tris * sizeof(int))) != RT_OK) return rc;
     const rtk::QGrid g = rtk::q16_grid(sc.root_lo, sc.root_hi);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipMemsetAsync(ctx->nodesh.p, 0, 32, q));            // nodes 0 (padding) and 1 (the root: tested when a ray is emitted)
+    if (want_qw) {
+        if ((rc = ensure(ctx, ctx->nodesw, ((size_t)sc.n_nodes + 4) * 32)) != RT_OK || (rc = ensure(ctx, ctx->leafbox, (size_t)sc.n_tris * 32)) != RT_OK) return rc;
+        RT_HIP(ctx, hipMemsetAsync(ctx->leafbox.p, 0, (size_t)sc.n_tris * 32, q));
+    }
     hipLaunchKernelGGL(rtk::qnodes_kernel, dim3((unsigned)((sc.n_nodes + 255) / 256)), dim3(256), 0, q, sc.nodesq, sc.nodesb, sc.n_nodes, g,
-                       static_cast<uint4 *>(ctx->nodesh.p), static_cast<int *>(ctx->tri2leaf.p), sc.n_tris, rtk::kQLeafShift, ctx->q16_leaf_shift);
+                       static_cast<uint4 *>(ctx->nodesh.p), static_cast<int *>(ctx->tri2leaf.p), sc.n_tris, rtk::kQLeafShift, ctx->q16_leaf_shift,
+                       want_qw ? static_cast<float4 *>(ctx->leafbox.p) : nullptr);
+    if (want_qw)
+        hipLaunchKernelGGL(rtk::qquads_kernel, dim3((unsigned)((sc.n_nodes / 2 + 1 + 255) / 256)), dim3(256), 0, q, static_cast<const uint4 *>(ctx->nodesh.p), sc.n_nodes,
+                           rtk::kQNodeShift, ctx->q16_leaf_shift, static_cast<uint4 *>(ctx->nodesw.p));
     RT_HIP(ctx, hipGetLastError());
     RT_HIP(ctx, hipStreamSynchronize(q));
     sc.nodesh = static_cast<const uint4 *>(ctx->nodesh.p); sc.tri2leaf = static_cast<const int *>(ctx->tri2leaf.p);
+    if (want_qw) { sc.nodesw = static_cast<const uint4 *>(ctx->nodesw.p); sc.leafbox = static_cast<const float4 *>(ctx->leafbox.p); }
     sc.qgx = g.gx; sc.qgy = g.gy; sc.qgz = g.gz; sc.qsx = g.sx; sc.qsy = g.sy; sc.qsz = g.sz; sc.qleaf_shift = ctx->q16_leaf_shift;
     return RT_OK;
 }
@@ -1206,7 +1246,9 @@ int rt_ctx_create(rt_ctx **out, int device_id) {
     if (!out) return fail(nullptr, RT_ERR_INVALID, "ctx out-pointer is NULL");
     *out = nullptr;
     int n = 0;
+    PhaseClock pc;
     int rc = rt_device_count(&n);
+    pc.lap("hipGetDeviceCount (runtime initialisation)");
     if (rc != RT_OK) return rc;
     if (n == 0) return fail(nullptr, RT_ERR_NO_DEVICE, "no HIP device visible");
     if (device_id < 0 || device_id >= n) return fail(nullptr, RT_ERR_INVALID, "device %d out of range [0,%d)", device_id, n);
@@ -1217,7 +1259,9 @@ int rt_ctx_create(rt_ctx **out, int device_id) {
     { const char *e = getenv("RT_LBVH_HOST_INSTALL"); ctx->lbvh_host_install = (e && *e && atoi(e) != 0) ? 1 : 0; }
     hipDeviceProp_t prop;
     hipError_t e = hipSetDevice(device_id);
+    pc.lap("hipSetDevice");
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device_id);
+    pc.lap("hipGetDeviceProperties");
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_k0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_k1);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_t0);
@@ -1235,6 +1279,7 @@ int rt_ctx_create(rt_ctx **out, int device_id) {
         rt_ctx_destroy(ctx);
         return code;
     }
+    pc.lap("events");
     snprintf(ctx->name, sizeof(ctx->name), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
     ctx->n_cus = prop.multiProcessorCount;
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
@@ -1259,7 +1304,7 @@ int rt_ctx_destroy(rt_ctx *ctx) {
         if (ctx->slot_rendered[k]) (void)hipEventDestroy(ctx->slot_rendered[k]);
         if (ctx->slot_done[k]) (void)hipEventDestroy(ctx->slot_done[k]);
     }
-    ctx->node_lo.release(); ctx->node_hi.release(); ctx->nodes2.release(); ctx->nodesq.release(); ctx->nodesb.release(); ctx->nodesh.release(); ctx->tri2leaf.release(); ctx->q2thr.release(); ctx->left_dev.release(); ctx->lvl_nodes.release(); ctx->lvl_off.release(); ctx->nrm.release(); ctx->tri.release(); ctx->verts.release(); ctx->tidx.release();
+    ctx->node_lo.release(); ctx->node_hi.release(); ctx->nodes2.release(); ctx->nodesq.release(); ctx->nodesb.release(); ctx->nodesh.release(); ctx->tri2leaf.release(); ctx->nodesw.release(); ctx->leafbox.release(); ctx->q2thr.release(); ctx->left_dev.release(); ctx->lvl_nodes.release(); ctx->lvl_off.release(); ctx->nrm.release(); ctx->tri.release(); ctx->verts.release(); ctx->tidx.release();
     ctx->scratch_rgba.release(); ctx->scratch_rgb8.release(); ctx->work.release(); ctx->queue.release();
     ctx->wfM.release(); ctx->wfT.release(); ctx->wfLS.release(); ctx->wfSID.release(); ctx->wfSamp.release();
     ctx->wfQR.release(); ctx->accum.release(); ctx->dbgbuf.release();
@@ -1308,7 +1353,10 @@ int rt_scene_upload(rt_ctx *ctx, const rt_sphere *spheres, int n_spheres, const 
     sc.Lx = light->position[0]; sc.Ly = light->position[1]; sc.Lz = light->position[2]; sc.intensity = light->intensity;
     sc.camx = camera->position[0]; sc.camy = camera->position[1]; sc.camz = camera->position[2]; sc.fov = camera->fov;
 
-    return install_scene(ctx, sc, mesh);
+    PhaseClock pc;
+    const int rc = install_scene(ctx, sc, mesh);
+    pc.lap("rt_scene_upload (layouts, hipMalloc, copies)");
+    return rc;
 }
 
 int rt_render_device(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *out_rgba_dev, void *stream) {
@@ -1418,14 +1466,19 @@ int rt_render_rgb8(rt_ctx *ctx, const rt_params *p, int row_begin, int row_end, 
     if (!out_rgb8_host) return fail(ctx, RT_ERR_INVALID, "output pointer is NULL");
     const int n = row_end - row_begin;
     const int64_t npix = (int64_t)n * (p->width > 0 ? p->width : 0);
+    PhaseClock pc;
     int rc = ensure(ctx, ctx->scratch_rgba, (size_t)npix * sizeof(float4));
     if (rc != RT_OK) return rc;
     if ((rc = ensure(ctx, ctx->scratch_rgb8, (size_t)npix * 3 + 16)) != RT_OK) return rc;
+    pc.lap("rt_render_rgb8: frame buffers (hipMalloc)");
     rt_rows rows{row_begin, n, n > 0 ? n : 1, 1};
     if ((rc = launch_render(ctx, p, &rows, ctx->scratch_rgba.p, own_stream(ctx))) != RT_OK) return rc;
+    pc.lap("rt_render_rgb8: enqueue (path state, code object)");
     if ((rc = launch_tonemap(ctx, ctx->scratch_rgba.p, npix, ctx->scratch_rgb8.p, own_stream(ctx))) != RT_OK) return rc;
+    if (pc.on) { RT_HIP(ctx, hipStreamSynchronize(own_stream(ctx))); pc.lap("rt_render_rgb8: kernels (wait)"); }
     RT_HIP(ctx, hipMemcpyAsync(out_rgb8_host, ctx->scratch_rgb8.p, (size_t)npix * 3, hipMemcpyDeviceToHost, own_stream(ctx)));
     RT_HIP(ctx, hipStreamSynchronize(own_stream(ctx)));
+    pc.lap("rt_render_rgb8: copy to the host");
     return RT_OK;
 }
 

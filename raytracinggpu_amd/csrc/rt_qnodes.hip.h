@@ -56,7 +56,8 @@ __device__ __forceinline__ void q16_axis(float lo, float hi, float g, float s, u
 
 // one thread per breadth-first node b in [1, n_bfs]: nodesq[2b], [2b+1] = (lo, hi) of the node, nodesb[2b].w / [2b+1].w = payload / kind as wf_travq carries them
 __global__ __launch_bounds__(256) void qnodes_kernel(const float4 *__restrict__ nodesq, const float4 *__restrict__ nodesb, int n_bfs, QGrid g,
-                                                     uint4 *__restrict__ nodesh, int *__restrict__ tri2leaf, int n_tris, int leaf_kind_shift, int leaf_shift) {
+                                                     uint4 *__restrict__ nodesh, int *__restrict__ tri2leaf, int n_tris, int leaf_kind_shift, int leaf_shift,
+                                                     float4 *__restrict__ leafbox) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x + 1;
     if (b > n_bfs) return;
     const float4 lo = nodesq[2 * (size_t)b], hi = nodesq[2 * (size_t)b + 1];
@@ -72,8 +73,39 @@ __global__ __launch_bounds__(256) void qnodes_kernel(const float4 *__restrict__ 
         const int cnt = kind >> leaf_kind_shift, first = (int)payload;
         pay = 0x80000000u | (unsigned int)cnt << leaf_shift | (unsigned int)first;
         for (int t = 0; t < cnt; ++t) if (first + t < n_tris) tri2leaf[first + t] = b;
+        if (leafbox && cnt > 0 && first >= 0 && first < n_tris) { leafbox[2 * (size_t)first] = nodesb[2 * (size_t)b]; leafbox[2 * (size_t)first + 1] = nodesb[2 * (size_t)b + 1]; }   // QW: the real box (centre, half extent), by first triangle
     }
     nodesh[b] = make_uint4(cx | cy << 16, cz | hx << 16, hy | hz << 16, pay);
+}
+
+// The 4-wide nodes of wf_travq<.., QW> (rt_travq.hip.h): one thread per sibling pair c = 2, 4, .. of the breadth-first array.  The quad of the pair (c, c + 1), at
+// uint4 index 2 c, is the nodesh records of the children of c and of c + 1 -- the boxes a ray meets two levels below the pair's parent -- where a LEAF of the pair
+// stands for itself next to an empty place.  Index 0 (what an idle lane's zero entry addresses) is four empty places.
+__global__ __launch_bounds__(256) void qquads_kernel(const uint4 *__restrict__ nodesh, int n_bfs, int node_shift, int leaf_shift, uint4 *__restrict__ nodesw) {
+    const int c = 2 * (blockIdx.x * blockDim.x + threadIdx.x);
+    if (c > n_bfs) return;
+    uint4 *out = nodesw + 2 * (size_t)c;
+    const uint4 none = make_uint4(0u, 0u, 0u, 0u);
+    if (c == 0) { out[0] = out[1] = out[2] = out[3] = none; return; }
+    // a nodesh record with the payload word the 4-wide step wants: internal = first child << node_shift (> 0: the tree has fewer than 2^21 nodes), leaf = 1 << 31 |
+    // count << 24 | first triangle (count <= 127, first < 2^24), nothing = 0
+    auto conv = [&](uint4 r) {
+        if ((int)r.w >= 0) { r.w = r.w << 1; return r; }
+        const unsigned int cnt = (r.w & 0x7fffffffu) >> leaf_shift, first = r.w & ((1u << leaf_shift) - 1u);
+        if (cnt == 0u) return none;
+        r.w = 0x80000000u | cnt << 24 | first;
+        return r;
+    };
+    for (int s = 0; s < 2; ++s) {
+        const int x = c + s;
+        const uint4 rec = x <= n_bfs ? nodesh[x] : make_uint4(0u, 0u, 0u, 0x80000000u);
+        if ((int)rec.w > 0) {                                                   // internal: its two children
+            const int p = (int)((rec.w << 1) >> node_shift);
+            out[2 * s] = conv(nodesh[p]); out[2 * s + 1] = conv(nodesh[p + 1]);
+        } else {
+            out[2 * s] = conv(rec); out[2 * s + 1] = none;
+        }
+    }
 }
 
 }  // namespace rtk

@@ -95,14 +95,15 @@ extern "C" int rt_trace_rays(rt_ctx *ctx, const float *rays, int n, float tri_tm
     } else {
         const bool queue = variant == RT_VARIANT_WAVEFRONT_QUEUE;
         const int qR = kn.travq_R;
-        int qcap = travq_stack_cap(qR);
+        const bool qw = queue && sc.nodesw != nullptr && qR == 64;    // the 4-wide BOX step, as a frame would run it (RT_TRAVQ_QW)
+        int qcap = travq_stack_cap(qR, qw);
         if (kn.travq_cap >= 128 && kn.travq_cap < qcap) qcap = kn.travq_cap;   // tests: force the serial drain
         const int tb = queue ? travq_block_threads(qR) : rtk::kTravBlock;
         const int wpb = tb / 64;
-        const size_t trav_lds = queue ? (size_t)wpb * travq_carve_bytes(qR) + 16 : (size_t)(rtk::kTravBlock / 64) * rtk::TravCarve<512, 8>::kBytes + 16;
+        const size_t trav_lds = queue ? (size_t)wpb * travq_carve_bytes(qR, qw) + 16 : (size_t)(rtk::kTravBlock / 64) * rtk::TravCarve<512, 8>::kBytes + 16;
         int bpc = 0;
         if (queue) {
-            RT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, travq_fn(false, qR, false, false), tb, trav_lds));
+            RT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, travq_fn(false, qR, false, false, qw, qw), tb, trav_lds));
             bpc = std::min(bpc > 0 ? bpc : 1, (kn.bpc5 ? 20 : 16) / (tb / 64));
         } else {
             RT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, rtk::wf_trav<false, false>, rtk::kTravBlock, trav_lds));
@@ -123,7 +124,7 @@ extern "C" int rt_trace_rays(rt_ctx *ctx, const float *rays, int n, float tri_tm
         st.epoch = 0; st.nonce = 0;
         hipLaunchKernelGGL(rtk::trace_emit_kernel, dim3((unsigned)((2 * st.n_paths + 255) / 256)), dim3(256), 0, q, sc, st, static_cast<const float *>(din.p), n);
         if (have_mesh) {
-            if (queue) hipLaunchKernelGGL(travq_fn(false, qR, false, false, sc.nodesh != nullptr), dim3((unsigned)tblocks), dim3(tb), trav_lds, q, sc, fr, st, qcap, 0, kn.q_low * (qR == 128 ? 2 : 1),
+            if (queue) hipLaunchKernelGGL(travq_fn(false, qR, false, false, sc.nodesh != nullptr, qw), dim3((unsigned)tblocks), dim3(tb), trav_lds, q, sc, fr, st, qcap, 0, kn.q_low * (qR == 128 ? 2 : 1),
                                           (kn.q_minfree >= 1 && kn.q_minfree <= qR) ? kn.q_minfree : qR / 4);
             else hipLaunchKernelGGL((rtk::wf_trav<false, false>), dim3((unsigned)tblocks), dim3(tb), trav_lds, q, sc, fr, st);
         }

@@ -54,6 +54,12 @@ constexpr int kQMaxLeaf = 1 << 20;           // triangles per leaf: count << 11 
 #define RT_TRAVQ_SCAP 652
 #endif
 template <int R> struct QStackCap { static constexpr int value = R > 64 ? 800 : RT_TRAVQ_SCAP; };   // (R = 128: twice the rays, two pairs per lane and step)
+// 4-wide BOX step (QW, below): a step may append up to 256 stack entries and 256 leaf entries, but it knows how many before it writes one (the
+// masks are scalar registers): the carve stays the pair kernel's, and a step that would not fit walks its popped pairs serially instead
+constexpr int kQwStackCap = QStackCap<64>::value, kQwLeafCap = QLeafCap<64>::value;
+// payload word of a quad's child (qquads_kernel): > 0 internal = first child << kQNodeShift (a stack entry without its slot bits; trees below 2^21 nodes),
+// < 0 leaf = 1 << 31 | triangle count << 24 | first triangle (leaves of at most 127 triangles, 2^24 triangles), 0 = nothing there
+constexpr int kQwLeafShift = 24;
 
 // Per-wave LDS carve.  Four tables of 16-byte rows indexed by ray slot, so that ONE address register (wave base + slot * 16)
 // reaches everything a step needs about a ray through the instructions' immediate offsets:
@@ -100,6 +106,16 @@ __device__ __forceinline__ int lane_count4_minus(unsigned long long m0, unsigned
     asm("v_cndmask_b32_e64 %0, 0, -1, %5\n\tv_addc_co_u32_e64 %0, vcc, 0, %0, %1\n\tv_addc_co_u32_e64 %0, vcc, 0, %0, %2\n\t"
         "v_addc_co_u32_e64 %0, vcc, 0, %0, %3\n\tv_addc_co_u32_e64 %0, vcc, 0, %0, %4"
         : "=&v"(d) : "s"(m0), "s"(m1), "s"(m2), "s"(m3), "s"(act) : "vcc");
+    return d;
+}
+
+// the same over eight masks (the 4-wide BOX step: four internal and four leaf masks)
+__device__ __forceinline__ int lane_count8_minus(const unsigned long long (&a)[4], const unsigned long long (&b)[4], unsigned long long act) {
+    int d;
+    asm("v_cndmask_b32_e64 %0, 0, -1, %9\n\tv_addc_co_u32_e64 %0, vcc, 0, %0, %1\n\tv_addc_co_u32_e64 %0, vcc, 0, %0, %2\n\t"
+        "v_addc_co_u32_e64 %0, vcc, 0, %0, %3\n\tv_addc_co_u32_e64 %0, vcc, 0, %0, %4\n\tv_addc_co_u32_e64 %0, vcc, 0, %0, %5\n\t"
+        "v_addc_co_u32_e64 %0, vcc, 0, %0, %6\n\tv_addc_co_u32_e64 %0, vcc, 0, %0, %7\n\tv_addc_co_u32_e64 %0, vcc, 0, %0, %8"
+        : "=&v"(d) : "s"(a[0]), "s"(a[1]), "s"(a[2]), "s"(a[3]), "s"(b[0]), "s"(b[1]), "s"(b[2]), "s"(b[3]), "s"(act) : "vcc");
     return d;
 }
 
@@ -246,11 +262,22 @@ __device__ __forceinline__ bool qtri_test(const float4 q0, const float4 q1, cons
 // entered, refill rounds, queue fetches, TRI steps, BOX steps, literal-box fall-backs taken, serial drains; then the conditionally
 // executed blocks of the steps, counted per entry: the t-division block of a triangle test (some lane accepted the barycentrics), the
 // first and the second leaf-queue push of a BOX step.
-template <bool STATS, int R, bool LDSN, bool LDSV, bool QN = false>
+//
+// QW (round 5; implies QN): the BOX step is FOUR boxes wide.  An entry still names the sibling pair (c, c + 1), but the step reads the pair's QUAD from
+// sc.nodesw -- the children of c and the children of c + 1 (a leaf child of the pair stands for itself), four 16-byte fixed-point records = the same four
+// loads a step of the float pairs issues -- tests the four boxes and pushes one entry per hit internal grandchild: every other level of the tree is
+// never tested, a ray's chain of dependent steps is half as long and a frame runs half as many BOX steps.  Exactness: the fixed-point boxes contain the
+// real ones and the reference's test is monotone along nested boxes (rt_qnodes.hip.h), so the leaves the reference reaches are exactly the leaves whose
+// OWN box its test hits; here every leaf entry meets the reference's test of its real box (sc.leafbox, indexed by the leaf's first triangle; slab_filtered)
+// in the TRI step that consumes it -- one test per ENTRY, beside the triangle loads, for every entry: no flags, no second threshold in the BOX step -- and a
+// triangle accepted in a leaf counts only if that test says hit.  Work counters of this instantiation differ from the oracle's by construction (no test
+// of the skipped level, a superset of internal nodes entered): the counter tests use the binary instantiation, this one is held to frames and ray counts.
+template <bool STATS, int R, bool LDSN, bool LDSV, bool QN = false, bool QW = false>
 __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || kQBlock != 256 || QPairs<R>::value > 1) ? 4 : 5) void wf_travq(const Scene sc, const Frame fr, const WfState st, const int cap, const int n_lds, const int kLow, const int kMinFree) {
     // kLow: refill while the stack holds fewer entries (sibling pairs) than this (default 48); kMinFree: ... and at least this
     // many slots are free, or the stack is short (default R / 4)
-    constexpr int SCAP = QStackCap<R>::value, LCAP = QLeafCap<R>::value;
+    static_assert(!QW || (QN && R == 64 && !LDSN && !LDSV), "the 4-wide step reads fixed-point quads through L1 / L2, one ray slot per lane");
+    constexpr int SCAP = QW ? kQwStackCap : QStackCap<R>::value, LCAP = QW ? kQwLeafCap : QLeafCap<R>::value;
     constexpr int NB = R > 64 ? 2 : 1;                      // ray slots per lane ("banks"): lane l owns slots l and, with 128 resident rays, l + 64
     using Carve = QCarve<R, SCAP, LCAP>;
     static_assert(R <= 128 && (R & (R - 1)) == 0, "ray slots are owned by lanes: one per lane, or two");
@@ -469,7 +496,8 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
                     } else {                           // the root is a leaf
                         if (cnt > 0) {
                             if (got) {
-                                leafq[(ltail + (unsigned int)lanes_below(gm)) & (LCAP - 1)] = make_uint2((unsigned int)first, (unsigned int)cnt << kQLeafShift | sbk);
+                                leafq[(ltail + (unsigned int)lanes_below(gm)) & (LCAP - 1)] = QW ? make_uint2(0x80000000u | (unsigned int)cnt << kQwLeafShift | (unsigned int)first, sbk | 1u)
+                                                                                                 : make_uint2((unsigned int)first, (unsigned int)cnt << kQLeafShift | sbk);
                                 if (STATS) wk.tris += (uint32_t)cnt;
                             }
                             ltail += (unsigned int)__popcll(gm);
@@ -491,7 +519,18 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
             const unsigned int m = lcount < 64u ? lcount : 64u;
             uint2 E = make_uint2(0u, 0u);
             if ((unsigned int)lane < m) E = leafq[(lhead + (unsigned int)lane) & (LCAP - 1)];
-            const unsigned int c = E.y >> kQLeafShift;               // >= 1 for queued entries, 0 beyond them
+            // QW: the reference's test of the entry's REAL leaf box (one entry per lane, loads in flight beside the triangle loads below); bit 0 of the
+            // entry = already decided (the rest of a leaf an earlier step cut in two)
+            float4 xc = make_float4(0, 0, 0, 0), xh = xc, xC = xc; float2 xD = make_float2(0, 0); float xc0 = 0.f;
+            if (QW) {
+                const unsigned int xf = E.x & ((1u << kQwLeafShift) - 1u);
+                WQ_CHECK((int)xf >= 0 && (int)xf < sc.n_tris, 2, (void)0);
+                xc = sc.leafbox[2 * (size_t)xf]; xh = sc.leafbox[2 * (size_t)xf + 1];      // (centre, half extent) of the real box, as the pair kernel's filter takes them
+                xC = rowC(E.y & kQSlotMask); xD = *reinterpret_cast<const float2 *>(&rowD(E.y & kQSlotMask));
+                xc0 = 0.25f * rowA(E.y & kQSlotMask).w;                                      // the slot's c0 (the row keeps 4 c0: exact)
+            }
+            const unsigned int c = QW ? (E.x >> kQwLeafShift) & 0x7fu : E.y >> kQLeafShift;               // >= 1 for queued entries, 0 beyond them (QW: the entry is (payload word, slot << 4 | decided))
+            if (QW) E.x &= (1u << kQwLeafShift) - 1u;
             const unsigned int incl = wave_incl_scan(c);
             const unsigned int P = incl - c;                         // position of this entry's first triangle
             const bool part = c > 0u && P < 128u;
@@ -543,7 +582,27 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
                 n_tdiv += (__ballot((how0 & 4) != 0) != 0ull ? 1u : 0u) + (__ballot((how1 & 4) != 0) != 0ull ? 1u : 0u);   // division blocks some lane entered
             }
             bool ok0_ = ok0, ok1_ = ok1;
-            if (QN) {       // a triangle accepted in a flagged leaf counts only if the reference's test of the leaf's real box says hit (rare: behind a vote)
+            bool xok = true;
+            if (QW) {       // a triangle counts only if the reference's test of its leaf's real box says hit: the entry's lane decides, the triangle's lane looks the bit up
+                // cbox_filter on the values ray_box_c formed at hand-off (v_rcp_f32 and the products are deterministic: recomputed, not stored); an undecided
+                // lane -- almost never -- takes the literal test on the (lo, hi) copy of its leaf
+                const float xrx = __builtin_amdgcn_rcpf(xC.w), xry = __builtin_amdgcn_rcpf(xD.x), xrz = __builtin_amdgcn_rcpf(xD.y);
+                bool xhit, xmiss;
+                cbox_filter(xc, xh, make_float4(xrx, xry, xrz, xc0), make_float4(xC.x * xrx, xC.y * xry, xC.z * xrz, 0.f), xhit, xmiss);
+                const bool xdone = (E.y & 1u) != 0u;
+                xok = xdone || xhit;
+                if (__builtin_expect(__ballot((unsigned int)lane < m && !xdone && !xhit && !xmiss) != 0ull, 0)) {
+                    if ((unsigned int)lane < m && !xdone && !xhit && !xmiss) {
+                        const int lf = sc.tri2leaf[E.x];
+                        xok = slab(sc.nodesq[2 * (size_t)lf], sc.nodesq[2 * (size_t)lf + 1], mk(xC.x, xC.y, xC.z), mk(xC.w, xD.x, xD.y));
+                        if (STATS) wk.lit_box++;
+                    }
+                }
+                const unsigned long long mok = __ballot(xok);
+                ok0_ = ok0 && ((mok >> ((unsigned int)(j0 >> 2) & 63u)) & 1ull) != 0ull;
+                ok1_ = ok1 && ((mok >> ((unsigned int)(j1 >> 2) & 63u)) & 1ull) != 0ull;
+            }
+            if (QN && !QW) {       // a triangle accepted in a flagged leaf counts only if the reference's test of the leaf's real box says hit (rare: behind a vote)
                 const bool ch0 = ok0 && (y0 & 1u) != 0u, ch1 = ok1 && (y1 & 1u) != 0u;
                 if (__builtin_expect(__ballot(ch0 || ch1) != 0ull, 0)) {
                     if (ch0) { const int lf = sc.tri2leaf[i0]; const f3 Or = mk(C0.x, C0.y, C0.z), ur = mk(C0.w, D0.x, D0.y); ok0_ = slab_filtered(sc.nodesq[2 * (size_t)lf], sc.nodesq[2 * (size_t)lf + 1], Or, ur, ray_inv(ur)); }
@@ -552,10 +611,11 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
             }
             if (ok0_) atomicMin(best(o0), (unsigned long long)__float_as_uint(ta) << 32 | (unsigned int)i0);
             if (ok1_) atomicMin(best(o1), (unsigned long long)__float_as_uint(tb_) << 32 | (unsigned int)i1);
-            const bool full = part && P + c <= 128u;
+            const bool full = part && (P + c <= 128u || (QW && !xok));   // (QW: a leaf whose real box is missed is done, whatever part of it this step took)
             if (part && !full) {                                     // at most one entry straddles position 127: keep its rest
                 const unsigned int took = 128u - P;
-                leafq[(lhead + (unsigned int)lane) & (LCAP - 1)] = make_uint2(E.x + took, (E.y & (kQSlotMask | 1u)) | (c - took) << kQLeafShift);
+                if (QW) leafq[(lhead + (unsigned int)lane) & (LCAP - 1)] = make_uint2(0x80000000u | (c - took) << kQwLeafShift | (E.x + took), (E.y & kQSlotMask) | 1u);
+                else leafq[(lhead + (unsigned int)lane) & (LCAP - 1)] = make_uint2(E.x + took, (E.y & (kQSlotMask | 1u)) | (c - took) << kQLeafShift);
             }
             lhead += (unsigned int)__popcll(__ballot(full));
             if (full) atomicAdd(pend(E.y & kQSlotMask), -1);        // after the mins above (LDS operations stay in order)
@@ -585,7 +645,7 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
 #endif
         constexpr int KP = QPairs<R>::value;                        // sibling pairs per lane and step: the loads of all of them are in flight together
         const int n = top < 64 * KP ? top : 64 * KP;
-        if (cap - top < 64 * KP) {                                         // no room for up to 128 pushes: serial drain of 64 entries
+        if (!QW && cap - top < 64 * KP) {                                  // no room for up to 128 pushes: serial drain of 64 entries (QW counts what a step found before it writes)
             if (STATS) n_serial++;
             const int nd = top < 64 ? top : 64;
             const bool actd = lane < nd;
@@ -597,6 +657,77 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
             continue;
         }
         if (STATS) n_box++;
+        if (QW) {
+            // =============================== 4-wide BOX step: the quad of one sibling pair (4 boxes) per lane ===============================
+            WQ_MARK("boxw_begin");
+            const bool act = lane < n;
+            const unsigned int e = act ? stack[top - 1 - lane] : 0u;   // node << 10 | slot << 4, as ever: the pair (c, c + 1)
+            const unsigned int sb = e & kQSlotMask;
+            unsigned int off = (e >> (kQNodeShift - 5)) & ~63u;         // the pair's quad: 64 bytes at 32 * c
+            WQ_CHECK(!act || (((e >> kQNodeShift) & ~1u) >= 2u && (int)((e >> kQNodeShift) & ~1u) + 1 <= sc.n_nodes), 4, off = 0u);
+            top -= n;
+            const float4 A = rowA(sb), Oo = rowO(sb);
+            const uint4 *qp = reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(sc.nodesw) + off);
+            const uint4 q0 = qp[0], q1 = qp[1], q2 = qp[2], q3 = qp[3];
+            const unsigned long long mact = __ballot(act);
+            unsigned long long mI[4], mL[4];
+            unsigned int p_[4];
+            auto child = [&](const uint4 q, const int j) {
+                const float4 cq = make_float4((float)(q.x & 0xffffu), (float)(q.x >> 16), (float)(q.y & 0xffffu), 0.f);
+                const float4 hq = make_float4((float)(q.y >> 16), (float)(q.z & 0xffffu), (float)(q.z >> 16), 0.f);
+                float d, band;
+                cbox_dband(cq, hq, A, Oo, d, band);
+                const unsigned long long g = mact & ~__ballot(d < -band);       // not excluded (a NaN is not excluded either)
+                p_[j] = q.w;                                                     // > 0 internal (the entry), < 0 leaf (count, first triangle), 0 nothing
+                mL[j] = g & __ballot((int)q.w < 0);
+                mI[j] = (j & 1) ? g & __ballot((int)q.w > 0) : g & ~mL[j];      // places 0 and 2 always hold a node (qquads_kernel): only 1 and 3 can be empty
+                if (STATS) {
+                    wk.box += act ? 1u : 0u;
+                    if (__builtin_amdgcn_inverse_ballot_w64(mI[j] | mL[j])) wk.nodes++;
+                    if (__builtin_amdgcn_inverse_ballot_w64(mL[j])) wk.tris += (q.w >> kQwLeafShift) & 0x7fu;
+                }
+            };
+            child(q0, 0); child(q1, 1); child(q2, 2); child(q3, 3);
+            const int nI = __popcll(mI[0]) + __popcll(mI[1]) + __popcll(mI[2]) + __popcll(mI[3]);
+            const int nL = __popcll(mL[0]) + __popcll(mL[1]) + __popcll(mL[2]) + __popcll(mL[3]);
+            if (__builtin_expect(top + nI > cap || (int)(ltail - lhead) + nL > LCAP, 0)) {   // no room for what this step found: its pairs are walked serially instead
+                if (STATS) n_serial++;
+                if (act) { const int cd = (int)((e >> kQNodeShift) & ~1u); drain_serial(sb, cd); drain_serial(sb, cd + 1); atomicAdd(pend(sb), -1); }
+                if (dbg_on) d_serial++;
+                WQ_STAMP(cy_box);
+                continue;
+            }
+            // pushes, child by child (the stack is a bag): position = entries before this child's + set lanes below
+            int base = top;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (mI[j] != 0ull) {
+                    const int pos = base + lanes_below(mI[j]);
+                    if (__builtin_amdgcn_inverse_ballot_w64(mI[j])) stack[pos] = p_[j] | sb;
+                    base += __popcll(mI[j]);
+                }
+            }
+            top = base;
+            unsigned int lb = ltail;
+            if (STATS) n_lpush += nL != 0 ? 1u : 0u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (mL[j] != 0ull) {
+                    const unsigned int pos = lb + (unsigned int)lanes_below(mL[j]);
+                    if (__builtin_amdgcn_inverse_ballot_w64(mL[j])) leafq[pos & (LCAP - 1)] = make_uint2(p_[j], sb);
+                    lb += (unsigned int)__popcll(mL[j]);
+                }
+            }
+            ltail = lb;
+            const int delta = lane_count8_minus(mI, mL, mact);
+            if (delta != 0) atomicAdd(pend(sb), delta);
+            WQ_CHECK(top >= 0 && top <= cap && top <= SCAP, 8, (void)0);
+            WQ_CHECK(ltail - lhead <= (unsigned int)LCAP, 16, (void)0);
+            if (dbg_on) { d_box++; d_boxl += 4u * (unsigned int)n; if ((unsigned int)top > d_maxtop) d_maxtop = (unsigned int)top; }
+            WQ_STAMP(cy_box);
+            WQ_MARK("boxw_end");
+            continue;
+        }
         WQ_MARK("box_begin");
         bool act_[KP]; unsigned int e_[KP], sb_[KP], off_[KP];
         float4 A_[KP], Oo_[KP], c0_[KP], h0_[KP], c1_[KP], h1_[KP];

@@ -133,13 +133,7 @@ def test_lbvh_after_device_transform_and_refit(ctx, oracle, cat_golden):
 def test_lbvh_large_mesh_bit_exact_and_much_less_work(ctx, oracle, n):
     """524 288 triangles (the displaced grid of test_large_mesh_bit_exact): frame and work counters == the oracle on the LBVH tree; the
     triangle tests per ray fall by an order of magnitude against the reference's tree (whose leaves grow with the mesh, cpu:217)."""
-    rng = np.random.default_rng(11)
-    gx, gz = np.meshgrid(np.linspace(-18, 18, n), np.linspace(-14, 22, n), indexing="ij")
-    gy = -9.0 + 3.0 * np.sin(gx * 0.45) * np.cos(gz * 0.38) + 0.15 * rng.standard_normal((n, n))
-    v = np.stack([gx, gy, gz], -1).reshape(-1, 3).astype(np.float32)
-    i, j = np.meshgrid(np.arange(n - 1), np.arange(n - 1), indexing="ij")
-    a = (i * n + j).reshape(-1)
-    t = np.concatenate([np.stack([a, a + 1, a + n], 1), np.stack([a + 1, a + n + 1, a + n], 1)]).astype(np.int32)
+    v, t = _displaced_grid(n)
     first = hostlib.build_mesh(v, t, albedo=rt.scenes.CAT_ALBEDO, object_slot=6)
     ctx.scene_upload(rt.scenes.spheres("cpu"), first)
     W, H = 480, 270
@@ -156,6 +150,64 @@ def test_lbvh_large_mesh_bit_exact_and_much_less_work(ctx, oracle, n):
     assert work["tri_tests"] * 2 < work_ref["tri_tests"]
     assert diff.mean() <= 0.001
     assert st["device_build_ms"] < 50.0
+
+
+def _displaced_grid(n, seed=11):
+    rng = np.random.default_rng(seed)
+    gx, gz = np.meshgrid(np.linspace(-18, 18, n), np.linspace(-14, 22, n), indexing="ij")
+    gy = -9.0 + 3.0 * np.sin(gx * 0.45) * np.cos(gz * 0.38) + 0.15 * rng.standard_normal((n, n))
+    v = np.stack([gx, gy, gz], -1).reshape(-1, 3).astype(np.float32)
+    i, j = np.meshgrid(np.arange(n - 1), np.arange(n - 1), indexing="ij")
+    a = (i * n + j).reshape(-1)
+    t = np.concatenate([np.stack([a, a + 1, a + n], 1), np.stack([a + 1, a + n + 1, a + n], 1)]).astype(np.int32)
+    return v, t
+
+
+def test_lbvh_two_million_triangles_node_indices_beyond_2_pow_20(ctx, oracle):
+    """2 097 152 triangles (n = 1025): the LBVH has more than 2^21 nodes, so stack entries of wf_travq carry node indices that need all 22 bits of the
+    field (kQNodeShift = 10: the lowest node bit shares bit 10 with the seventh slot bit) and the BOX step reads the 16-bit fixed-point pairs (automatic
+    from 16 384 nodes).  Frame and work counters (binary instantiation) == the oracle walking the SAME tree at a small frame, and explicit rays aimed at
+    triangles all over the mesh -- in a breadth-first array most leaves sit at the deepest levels, i.e. at the highest indices -- through the production
+    traversal launches (rt_trace_rays) against the oracle's TriangleMesh::intersect.  Reference twin of the builder: global_launcher.cu:298-331."""
+    v, t = _displaced_grid(1025)
+    first = hostlib.build_mesh(v, t, albedo=rt.scenes.CAT_ALBEDO, object_slot=6)
+    ctx.scene_upload(rt.scenes.spheres("cpu"), first)
+    up = np.ascontiguousarray(first["indices"][:, :3])
+    arr, order = ctx.mesh_rebuild(len(up), mode="lbvh")
+    st = ctx.build_stats()
+    print(f"{len(up)} triangles: LBVH {st['n_nodes']} nodes (2^20 = {1 << 20}, 2^21 = {1 << 21}), depth {st['max_depth']}, {st['n_leaves']} leaves")
+    assert st["mode"] == 1 and st["n_nodes"] == len(arr) and st["n_nodes"] > (1 << 20)
+    om = oracle.Mesh.from_arrays(v, up)
+    om.set_bvh(arr, order)
+    osc = oracle.Scene.preset("cpu", om)
+    W, H = 320, 180
+    for b in (0, 2):
+        exp, _, cnt = osc.render(W, H, 1, b, want_rgb8=False)
+        p = rt.make_params(W, H, 1, b, **rt.scenes.CPU_LAUNCHER)
+        got = ctx.render(p)
+        assert values_equal(got[..., :3], exp[..., :3]).all(), b
+        np.testing.assert_array_equal(got[..., 3], exp[..., 3])
+        assert ctx.count_work(p) == {k: cnt[k] for k in KEYS}, b
+    # explicit rays: from above and from the sides towards triangles drawn uniformly from the uploaded order (every part of the node array), plus rays that miss
+    rng = np.random.default_rng(5)
+    n = 3000
+    tri = up[order[rng.integers(0, len(up), n)]]
+    target = v[tri].mean(axis=1) + rng.normal(scale=0.002, size=(n, 3)).astype(np.float32)
+    O = (target + np.float32([0, 25, 0]) + rng.uniform(-12, 12, (n, 3))).astype(np.float32)
+    u = (target - O).astype(np.float32)
+    u /= np.linalg.norm(u, axis=1, keepdims=True).astype(np.float32)
+    u[-300:] = rng.normal(size=(300, 3)).astype(np.float32)                    # arbitrary directions (unnormalised): most miss
+    rays = np.concatenate([O, u], axis=1).astype(np.float32)
+    exp = np.zeros((n, 5), np.float32)
+    for i in range(n):
+        h, tt, N = om.intersect(rays[i, :3], rays[i, 3:], 1e-4)
+        exp[i, 0] = 1.0 if h else 0.0
+        exp[i, 1] = tt; exp[i, 2:5] = N
+    got = ctx.trace_rays(rays, 1e-4, "wavefront_queue")
+    hit = exp[:, 0] != 0
+    np.testing.assert_array_equal(got[:, 0], exp[:, 0])
+    np.testing.assert_array_equal(got[hit].view(np.uint32), exp[hit].view(np.uint32))
+    assert hit.sum() > 2000 and (~hit).sum() > 50
 
 
 def test_lbvh_device_install_equals_host_install(oracle, cat_golden, monkeypatch):
