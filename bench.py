@@ -284,10 +284,30 @@ def static_counts():
         return None
 
 
-def travq_instructions(counts, sc):
+def qw_step_counts(rt, args, p):
+    """Step counters of the 4-wide traversal kernel (the production kernel for trees below 16 384 nodes): a context created under RT_TRAVQ_QW_COUNT=1
+    runs THAT kernel's counting instantiation in rt_count_work (the default counting run is the binary instantiation: the reference's own box / node
+    counts, which the algorithmic-bytes figure and the parity tests need)."""
+    old = os.environ.get("RT_TRAVQ_QW_COUNT")
+    os.environ["RT_TRAVQ_QW_COUNT"] = "1"
+    try:
+        c2 = rt.Context(int(os.environ.get("LOCAL_RANK", "0")) if not args.share_gpu else 0)
+    finally:
+        if old is None:
+            del os.environ["RT_TRAVQ_QW_COUNT"]
+        else:
+            os.environ["RT_TRAVQ_QW_COUNT"] = old
+    build_scene(rt, c2, args.scene)
+    out = c2.count_work(p, detail=True)
+    c2.close()
+    return out
+
+
+def travq_instructions(counts, sc, section="wf_travq"):
     """Vector / scalar wave-instructions of the frame's wf_travq launches: the step counters of the counting instantiation (this run)
-    x the static per-region counts of the production code object (tools/static_counts.py)."""
-    st, t = counts["steps"], sc["wf_travq"]
+    x the static per-region counts of the production code object (tools/static_counts.py).  section "wf_travq_qw": the 4-wide kernel, whose
+    leaf_push / leaf_push2 counters are the leaf / internal push blocks its BOX steps entered."""
+    st, t = counts["steps"], sc[section]
     weights = (("loop_head", st["iterations"]), ("retire", st["refill_passes"]), ("round", st["refill_rounds"]),
                ("fetch", st["fetches"]), ("tri", st["tri_steps"]), ("tdiv", st["tdiv_blocks"]), ("box", st["box_steps"]),
                ("lpush", st["leaf_push_blocks"]), ("lpush2", st["leaf_push2_blocks"]))
@@ -304,7 +324,7 @@ def roofline(rt, ctx, args, p, rows, local, stream, counts, world, W, H, kernel_
 
     wf_travq is bound by vector-instruction issue (HBM 9 % of peak, scene cache resident).  achieved = vector
     wave-instructions of one launch / that launch's duration (HIP events by the library on the stream the kernel runs on, in a
-    single-stream context: one launch owns the chip); peak = 1024 SIMDs x 2.4 GHz / 4 cycles.  The instruction count is the
+    single-stream context: one launch owns the chip); peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction.  The instruction count is the
     counting instantiation's step counters of THIS run x the static per-step counts of the production code object; it is checked
     against rocprofv3's SQ_INSTS_VALU in profiles/ (tools/round_profile.sh).  `traffic` quotes the measured HBM bytes of the same
     launch from the committed PMC summary when that summary was taken from this code (library hash), else null."""
@@ -331,7 +351,15 @@ def roofline(rt, ctx, args, p, rows, local, stream, counts, world, W, H, kernel_
     single_ms, single_launches, single_frame = (None, 0, None)
     if world == 1:
         single_ms, single_launches, single_frame = single_stream_launch_ms(rt, args, p, rows, local, stream)
-    ins = travq_instructions(counts, sc)
+    mode = st.get("travq_mode", 0)                                    # 2: the 4-wide BOX step is the production kernel (its own counting instantiation, its own static counts)
+    steps_of = counts
+    if mode == 2 and "wf_travq_qw" in sc:
+        steps_of = qw_step_counts(rt, args, p)
+        assert steps_of["rays"] == counts["rays"], (steps_of["rays"], counts["rays"])
+    ins = travq_instructions(steps_of, sc, "wf_travq_qw" if (mode == 2 and "wf_travq_qw" in sc) else "wf_travq")
+    kname = "rtk::wf_travq<false, 64, false, false, true, true> (4-wide BOX step on 16-bit fixed-point nodes)" if mode == 2 else \
+            "rtk::wf_travq<false, 64, false, false, true, false> (16-bit fixed-point sibling pairs)" if mode == 1 else "rtk::wf_travq<false, 64, false, false, false, false>"
+    boxes_per_step = 256.0 if mode == 2 else 128.0
     if single_ms:
         launches, k_ms = single_launches, single_ms
         out.update({"kernel_ms": round(single_ms, 4), "launches_per_frame": single_launches, "concurrent_launches": 1, "single_stream_frame_ms": round(single_frame, 4)})
@@ -343,22 +371,25 @@ def roofline(rt, ctx, args, p, rows, local, stream, counts, world, W, H, kernel_
     weighted_launch = ins["valu_weight"] / launches                   # in units of one full-rate instruction (2 cycles of one SIMD)
     ach = weighted_launch / (k_ms * 1e-3) / 1e9
     hbm_ach = trav_bytes / launches / (k_ms * 1e-3) / 1e9
-    out.update({"kernel": "rtk::wf_travq<false, 64, false, false>", "achieved": round(ach, 1), "frac": round(ach / VALU_PEAK_GINST, 4),
+    out.update({"kernel": kname, "achieved": round(ach, 1), "frac": round(ach / VALU_PEAK_GINST, 4),
                 "frac_is": "issue-cost-weighted vector wave-instructions of one launch (step counters of this run x static per-step counts of the code object; "
                            "weight 1 = fma / mul / add / logic, 1.75-2 = min / max / compare / cndmask / conversion / binary64, 4 = rcp / sqrt) / launch duration, "
-                           "over 1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction = 1228.8 G/s; what the kernel waits for the rest of the time is the CU's "
-                           "vector-memory path (profiles/round4/ab_pad_sensitivity.txt: +4 loads per BOX step cost +27 %, +32 vector instructions +7 %)",
+                           "over 1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction = 1228.8 G/s; the rest of a wave's time is s_waitcnt (vector-memory and LDS "
+                           "round trips of its dependent chain) and issue contention (profiles/round5/pmc_ab_wide_nodes.txt: with the 4-wide step 37 % of the wave-cycles "
+                           "wait for memory and 18 % for an issue slot; with the sibling pairs 49 % and 11 %)",
                 "achieved_unweighted": round(valu_launch / (k_ms * 1e-3) / 1e9, 1), "frac_unweighted": round(valu_launch / (k_ms * 1e-3) / 1e9 / VALU_PEAK_GINST, 4),
                 "valu_wave_insts_per_launch": int(valu_launch), "valu_weighted_insts_per_launch": int(weighted_launch), "salu_wave_insts_per_launch": int(ins["salu"] / launches),
-                "valu_by_region_per_frame": ins["by_region_valu"], "steps_per_frame": counts["steps"],
-                "box_step_lane_occupancy": round((counts["box_tests"] - counts["rays"]) / (128.0 * max(counts["steps"]["box_steps"], 1)), 4),   # the root-box test of every ray belongs to the uniform kernel
-                "tri_step_lane_occupancy": round(counts["tri_tests"] / (128.0 * max(counts["steps"]["tri_steps"], 1)), 4),
+                "valu_by_region_per_frame": ins["by_region_valu"], "steps_per_frame": steps_of["steps"],
+                "steps_are": "the production kernel's own counting instantiation" + (" (4-wide: box_steps = 64 quads of 4 boxes; leaf_push / leaf_push2 = leaf / internal push blocks entered); "
+                             "per_ray and the byte figures stay the reference-equivalent counts of the binary instantiation" if mode == 2 else ""),
+                "box_step_lane_occupancy": round((steps_of["box_tests"] - steps_of["rays"]) / (boxes_per_step * max(steps_of["steps"]["box_steps"], 1)), 4),   # the root-box test of every ray belongs to the uniform kernel
+                "tri_step_lane_occupancy": round(steps_of["tri_tests"] / (128.0 * max(steps_of["steps"]["tri_steps"], 1)), 4),
                 "literal_box_tests": counts["box_literal"], "literal_tri_tests": counts["tri_literal"],
                 "algorithmic_bytes_per_launch": int(trav_bytes / launches), "nominal_hbm_GBps": round(hbm_ach, 1), "nominal_hbm_frac": round(hbm_ach / HBM_PEAK_GBS, 4),
                 "nominal_hbm_frac_is": "SURVEY 8d: 24 B/box test + 16 B/node + 48 B/triangle test of a cache-resident scene over 8 TB/s; may exceed 1, NOT a utilisation"})
     # measured HBM traffic of the same launch: only from a PMC summary taken from THIS library
-    rnd = "round4"
-    for rnd in ("round4", "round3", "round2"):
+    rnd = "round5"
+    for rnd in ("round5", "round4", "round3", "round2"):
         spath = os.path.join(ROOT, "profiles", rnd, "summary.json")
         if os.path.exists(spath) and workload == "cat_1920x1080_spp1_b3":
             summ = json.load(open(spath))
@@ -477,7 +508,13 @@ def main():
     # dealt round-robin, every frame still rendered, gathered and assembled in full.  Measured on one MI355X for rank 0's share
     # (tools/share_scaling.py, profiles/round3/share_scaling.txt): 1/8 of 1080p 0.323 -> 0.234 ms, 1/8 of 3840x2160 0.620 -> 0.538 ms;
     # a share above ~1.3 Mpixel is faster as ONE frame with two sub-frames (two frames' path state would overflow the Infinity Cache).
+    # Round 5 (tools/share_frames.py, profiles/round5/share_frames.txt): a share below ~0.7 Mpixel wants FOUR frames in flight, and every lane's launches
+    # cut into fewer, fuller workgroups (RT_TRAV_MIN_GROUPS=64: 256 ray slots per wave instead of 64 -- a lone small launch is slower that way, four of them
+    # side by side fill the chip with waves whose stacks stay full): 1/8 of 1080p 0.204 -> 0.130 ms per frame and rank, 1/4 0.315 -> 0.248 ms.
+    # Five and more streams fall off the runtime's hardware queues (0.17 ms).
     SMALL_SHARE_PX = 1.3e6
+    TINY_SHARE_PX = 0.7e6
+    LANE_MIN_GROUPS = "64"
     ctx = None
     pools = {}                                                         # "full": [context with the default knobs]; "lanes": contexts with sub-frames off
 
@@ -485,10 +522,14 @@ def main():
         os.environ.setdefault("RT_PART_PRIO", "1")                    # this process will hold several contexts: keep their sub-frame streams off each other's hardware queues
 
     def pool(kind, n):
+        if kind in pools and len(pools[kind][0]) < n:                 # a later point wants more lanes: build the pool again
+            del pools[kind]
         if kind not in pools:
-            old_parts = os.environ.get("RT_PARTS")
+            old_parts, old_mg = os.environ.get("RT_PARTS"), os.environ.get("RT_TRAV_MIN_GROUPS")
             if kind == "lanes" and old_parts is None:
                 os.environ["RT_PARTS"] = "1"                          # knobs are read when a context is created
+            if kind == "lanes" and old_mg is None:
+                os.environ["RT_TRAV_MIN_GROUPS"] = LANE_MIN_GROUPS    # fuller workgroups for launches that run beside other frames' launches
             cs, ts = [], []
             for _ in range(n):
                 c = rt.Context(dev_index)
@@ -499,6 +540,8 @@ def main():
                 ts.append(torch.cuda.Stream(device=dev, priority=-1 if (len(ts) & 1) else 0))   # odd lanes in the high-priority queue pool: never the even lane's hardware queue
             if kind == "lanes" and old_parts is None:
                 del os.environ["RT_PARTS"]
+            if kind == "lanes" and old_mg is None:
+                del os.environ["RT_TRAV_MIN_GROUPS"]
             pools[kind] = (cs, ts)
         return pools[kind]
 
@@ -529,7 +572,8 @@ def main():
             self.W, self.H = W, H
             self.p = rt.make_params(W, H, args.spp, args.bounces, variant=args.variant, **rt.scenes.CPU_LAUNCHER)
             self.rows, self.idx = rt.interleaved_rows(H, TILE_ROWS, rank, world)
-            want = lanes if lanes > 0 else args.frames_in_flight if args.frames_in_flight > 0 else (2 if (world == 1 or self.rows.n_rows * W <= SMALL_SHARE_PX) else 1)
+            share_px = self.rows.n_rows * W
+            want = lanes if lanes > 0 else args.frames_in_flight if args.frames_in_flight > 0 else (2 if world == 1 else 4 if share_px <= TINY_SHARE_PX else 2 if share_px <= SMALL_SHARE_PX else 1)
             self.n_lanes = 1 if cpu_only else want
             # one GPU renders the whole frame: the frames in flight share ONE context and stream (two buffers, rt_ctx_set_pipelining);
             # a rank with a small share keeps one context per frame in flight
@@ -541,7 +585,11 @@ def main():
                     if hasattr(full[0][0], "set_pipelining"):
                         full[0][0].set_pipelining(self.pipelined)
                 else:
-                    self.ctxs, self.tstreams = pool("lanes", self.n_lanes) if self.n_lanes > 1 else pool("full", 1)
+                    if self.n_lanes > 1:
+                        cs_, ts_ = pool("lanes", self.n_lanes)
+                        self.ctxs, self.tstreams = cs_[:self.n_lanes], ts_[:self.n_lanes]
+                    else:
+                        self.ctxs, self.tstreams = pool("full", 1)
             self.lanes = [Lane(k, W, H) for k in range(self.n_lanes)]
             self.local = self.lanes[0].local
             self.frame = None
@@ -568,40 +616,45 @@ def main():
                 torch.cuda.current_stream().synchronize()
             self.frame = tiling.gather_frame(ln.xlocal, self.H, world, rank, ln.gathered)
 
-        def step(self, ev=None):
+        def step(self, ev=None, mode="both"):
+            """mode: "both" = the metric's step; "render" / "exchange" = one side only (the compute-side / exchange-side accounting after the timed region)."""
             ln = self.lanes[self.n % self.n_lanes]
             self.n += 1
             if cpu_only:
-                self.render(ln); self.exchange(ln)
+                if mode != "exchange":
+                    self.render(ln)
+                if mode != "render":
+                    self.exchange(ln)
                 return
             with torch.cuda.stream(self.tstreams[ln.k]):
                 if ev:
                     ev[0].record()
-                if not (args.gather_only and self.n > self.n_lanes):  # --gather-only: every lane's tiles are rendered once, then only exchanged
+                if mode != "exchange" and not (args.gather_only and self.n > self.n_lanes):  # --gather-only: every lane's tiles are rendered once, then only exchanged
                     self.render(ln)
                 if ev:
                     ev[1].record()
-                self.exchange(ln)
+                if mode != "render":
+                    self.exchange(ln)
 
     def sync():
         if not cpu_only:
             torch.cuda.synchronize()
 
-    def timed(pt, steps, warmup):
+    def timed(pt, steps, warmup, mode="both"):
         """W warm-up steps, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
         if not cpu_only and args.prewarm_ms > 0:                        # same count on every rank (the steps hold a collective)
             est_ms = max(pt.W * pt.H / 2.0e6 / world, 0.2)
             for _ in range(max(1, min(1000, int(args.prewarm_ms / est_ms)))):
                 pt.step()
         for _ in range(warmup):
-            pt.step()
+            pt.step(mode=mode)
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)] if not cpu_only else []
         if world > 1:
             dist.barrier()
         sync()
         t0 = time.perf_counter()
         for k in range(steps):
-            pt.step(ev[k] if ev else None)
+            pt.step(ev[k] if ev else None, mode)
         sync()
         if world > 1:
             dist.barrier()
@@ -634,6 +687,16 @@ def main():
         frame_ok = bool((got.view(np.uint32) == full.view(np.uint32)).all())
 
     elapsed, kernel_ms_max = timed(main_pt, args.steps, args.warmup)
+    sides = None
+    if world > 1 and not args.gather_only:
+        # the same steps once more with one side only, outside the timed region (same lanes, same buffers; every rank takes part: the exchange is collective):
+        # what the ranks' own shares cost (the compute side of the strong scaling) and what the gather costs when nothing is rendered beside it
+        pw, args.prewarm_ms = args.prewarm_ms, 0
+        e_r, _ = timed(main_pt, args.steps, 2, "render")
+        e_x, _ = timed(main_pt, args.steps, 2, "exchange")
+        args.prewarm_ms = pw
+        sides = {"compute_ms_per_step": round(1e3 * e_r / args.steps, 4), "exchange_ms_per_step": round(1e3 * e_x / args.steps, 4),
+                 "is": "the timed steps again with the exchange skipped / with the render skipped (max over ranks, same frames in flight): the two sides of ms_per_step, which overlaps them"}
 
     large = None
     if args.large_steps > 0 and args.scene == "cpu" and not cpu_only and (W, H) == (1920, 1080):
@@ -678,6 +741,8 @@ def main():
             res["config"]["frame_equals_single_device_frame"] = frame_ok
         if comm is not None:
             res["config"]["comm_plan"] = comm.last_plan
+        if sides is not None:
+            res["config"]["sides"] = sides
         if args.gather_only and world > 1:
             px_bytes = 3 if rgb8 else 16
             moved = W * H * px_bytes * (world - 1) / world               # bytes that cross the fabric into the root per gather

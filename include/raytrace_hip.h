@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 4
+#define RT_ABI_VERSION 5
 #define RT_MAX_SPHERES 16      /* reference: Geometry* objects[10], optimized.cu:663 */
 #define RT_MAX_SEGMENTS 16     /* reference: MAX_RAY_DEPTH 10, optimized.cu:22       */
 
@@ -147,6 +147,9 @@ typedef struct rt_stats {
     int32_t  adv_launches;         /* ... and the same for the uniform kernel (wf_advance, the launches after the first): */
     float    adv_ms;               /*     summed HIP-event time, launches, paths per launch (rt_stats_enable)             */
     int32_t  adv_paths;
+    int32_t  travq_mode;           /* work-stack traversal kernel of the last render: 0 = sibling pairs (64-byte float nodes), 1 = 16-bit fixed-point pairs,
+                                      2 = 4-wide fixed-point nodes (the default for trees below 16 384 nodes); -1 = another traversal kernel / no mesh */
+    int32_t  reserved;
 } rt_stats;
 
 /* --- device / context -------------------------------------------------------- */
@@ -194,6 +197,10 @@ typedef struct rt_work {
                                     * t-division blocks of the triangle tests (2 per TRI step at most), first and second leaf-queue
                                     * push of a BOX step; one reserved.  bench.py prices the vector-issue roofline with them. */
 } rt_work;
+/* The counters describe the REFERENCE-EQUIVALENT traversal (the binary instantiation of the kernel: every box the reference tests, cpu:284-293), whatever
+ * kernel produces the frames: with the 16-bit fixed-point pairs (RT_TRAVQ_Q16, automatic for trees of 16 384 nodes and more) or the 4-wide BOX step
+ * (RT_TRAVQ_QW) the production kernel enters a superset of the internal nodes and skips levels, and its own visits are not what box_tests / nodes
+ * report -- unless RT_TRAVQ_QW_COUNT=1 asks for the 4-wide kernel's own counting instantiation (experiments). */
 int rt_count_work(rt_ctx *ctx, const rt_params *p, int row_begin, int row_end, rt_work *out);
 
 int rt_synchronize(rt_ctx *ctx);

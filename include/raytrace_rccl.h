@@ -84,6 +84,8 @@ int rt_comm_tile_plan(int W, int H, int bytes_per_pixel, int tile_rows, int worl
  * RGB8 at world 8: 17 messages of 46 KB per peer become one of 783 KB).  AUTO (default) picks COALESCED when a full tile
  * (W * bytes_per_pixel * tile_rows) is smaller than coalesce_below_bytes (0 = RT_COMM_COALESCE_BELOW_DEFAULT).  Every rank of a
  * communicator must set the same plan and threshold: both sides of the exchange derive their message sizes from it.
+ * The staging area is ONE per communicator: a coalesced gather waits (stream-side, through an event) until the previous gather's placement
+ * kernel has read it, on whatever stream that one ran -- gathers of several frames in flight on different streams are ordered by the library.
  */
 typedef enum rt_comm_plan { RT_COMM_PLAN_AUTO = 0, RT_COMM_PLAN_PER_TILE = 1, RT_COMM_PLAN_COALESCED = 2 } rt_comm_plan;
 int rt_comm_set_plan(rt_comm *comm, int plan, uint64_t coalesce_below_bytes);

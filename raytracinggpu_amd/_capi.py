@@ -74,7 +74,7 @@ class Stats(C.Structure):
     _fields_ = [("kernel_ms", C.c_float), ("tonemap_ms", C.c_float), ("pixels", C.c_uint64), ("variant", C.c_int32),
                 ("lds_bytes", C.c_int32), ("block_threads", C.c_int32), ("grid_blocks", C.c_int32),
                 ("trav_ms", C.c_float), ("trav_launches", C.c_int32), ("parts", C.c_int32), ("adv_launches", C.c_int32),
-                ("adv_ms", C.c_float), ("adv_paths", C.c_int32)]
+                ("adv_ms", C.c_float), ("adv_paths", C.c_int32), ("travq_mode", C.c_int32), ("reserved", C.c_int32)]
 
 
 class BuildStats(C.Structure):
@@ -396,7 +396,7 @@ class Context:
 
     def mesh_rebuild(self, n_triangles, mode="reference"):
         """Device-side BVH build over the uploaded triangles and the current device vertices -> (bvh_arr10 [n_nodes, 10], order [n_triangles]).
-        mode "reference": TriangleMesh::buildBVH bit for bit; "lbvh": Morton sort + parallel hierarchy, leaves of at most four triangles."""
+        mode "reference": TriangleMesh::buildBVH bit for bit; "lbvh": Morton sort + parallel hierarchy, leaves cut by the surface-area heuristic (at most 32 triangles)."""
         arr = np.zeros(((2 * n_triangles + 2), 10), np.float32)
         order = np.zeros(n_triangles, np.int32)
         n = C.c_int32(0)

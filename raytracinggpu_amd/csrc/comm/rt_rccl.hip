@@ -25,6 +25,8 @@ struct rt_comm {
     uint64_t coalesce_below = RT_COMM_COALESCE_BELOW_DEFAULT;   // AUTO: a full tile smaller than this many bytes => the coalesced plan
     void *stage = nullptr;                   // root, coalesced plan: the peers' dense buffers side by side
     size_t stage_bytes = 0;
+    hipEvent_t stage_read = nullptr;         // root, coalesced plan: recorded behind the placement kernel that reads `stage`; the next gather -- on whatever stream --
+    bool stage_busy = false;                 // waits for it before a receive may overwrite the area (gathers of two frames in flight on two streams)
     std::string err;
 };
 
@@ -105,6 +107,7 @@ extern "C" int rt_comm_destroy(rt_comm *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->last_stream && c->last_stream != c->stream) (void)hipStreamSynchronize(c->last_stream);
     if (c->comm) (void)ncclCommDestroy(c->comm);
+    if (c->stage_read) { (void)hipEventSynchronize(c->stage_read); (void)hipEventDestroy(c->stage_read); }
     if (c->stage) (void)hipFree(c->stage);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -192,14 +195,19 @@ extern "C" int rt_comm_gather_tiles(rt_comm *c, const void *tiles_dev, int W, in
             if (last_peer == root) --last_peer;
             (void)rt_comm_peer_plan(W, H, bpp, tile_rows, c->world, root, last_peer, &last);
             const size_t need = (size_t)last.stage_offset + (size_t)((last.bytes + 255) / 256 * 256) + 256;
+            if (!c->stage_read) RC_HIP(c, hipEventCreateWithFlags(&c->stage_read, hipEventDisableTiming));
             if (c->stage_bytes < need) {
                 RC_HIP(c, hipStreamSynchronize(s));                      // an earlier gather may still read the old staging area
+                if (c->stage_busy) { RC_HIP(c, hipEventSynchronize(c->stage_read)); c->stage_busy = false; }   // ... also one issued on another stream
                 if (c->stage) (void)hipFree(c->stage);
                 c->stage = nullptr; c->stage_bytes = 0;
                 RC_HIP(c, hipMalloc(&c->stage, need));
                 c->stage_bytes = need;
             }
         }
+        // ONE staging area per communicator: this gather's receives must not land in it while the previous gather's placement kernel -- possibly on
+        // another stream: bench.py keeps two frames in flight on two streams -- still reads it (RCCL orders only its own kernels)
+        if (is_root && c->stage_busy) RC_HIP(c, hipStreamWaitEvent(s, c->stage_read, 0));
         RC_NCCL(c, ncclGroupStart());
         ncclResult_t r = ncclSuccess;
         SrcTable tab{};
@@ -230,6 +238,8 @@ extern "C" int rt_comm_gather_tiles(rt_comm *c, const void *tiles_dev, int W, in
             else if (ws == 4) hipLaunchKernelGGL(place_tiles_kernel<uint32_t>, grid, block, 0, s, tab, dst, n_words, tile_words, c->world);
             else hipLaunchKernelGGL(place_tiles_kernel<unsigned char>, grid, block, 0, s, tab, dst, n_words, tile_words, c->world);
             RC_HIP(c, hipGetLastError());
+            RC_HIP(c, hipEventRecord(c->stage_read, s));
+            c->stage_busy = true;
         }
         return RT_COMM_OK;
     }

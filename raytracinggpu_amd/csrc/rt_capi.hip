@@ -44,8 +44,9 @@ struct Knobs {
     int q16 = -1;              // RT_TRAVQ_Q16: the BOX step reads 16-bit fixed-point sibling pairs (32 bytes: two loads instead of four; rt_qnodes.hip.h) when the tree allows it.
                                // -1 (default) = for trees of at least kQ16AutoNodes nodes, 0 = never, 1 = always.  Bit-exact either way; on the cat (2 019 nodes, L1-resident) it measures
                                // +-0 once every leaf decision is exact (profiles/round4/ab_fixed_point_pairs.txt), on 55 000 / 533 000 nodes -8 % / -18 % per frame (big_mesh_bench.txt)
-    int qw = 0;                // RT_TRAVQ_QW: the BOX step is four boxes wide (fixed-point quads: the children of both nodes of a sibling pair in 64 bytes, every other level of the tree
-                               // skipped; exact leaf decisions in the TRI step; rt_travq.hip.h, QW).  0 = off, 1 = on where the tree allows the fixed-point format
+    int qw = -1;               // RT_TRAVQ_QW: the BOX step is four boxes wide (fixed-point quads: the children of both nodes of a sibling pair in 64 bytes, every other level of the tree
+                               // skipped; exact leaf decisions in the TRI step; rt_travq.hip.h, QW).  -1 (default) = 1 = on where the tree allows the format (boxes nest, leaves of
+                               // at most 127 triangles, fewer than 2^21 nodes), 0 = off.  Bit-exact either way; cat 1920x1080: 0.934 -> 0.887 ms per frame (profiles/round5/ab_wide_nodes.txt)
     int qw_count = 0;          // RT_TRAVQ_QW_COUNT=1: rt_count_work runs the 4-wide kernel's counting instantiation (its own step counters; the box / node counts then describe
                                // THAT kernel, not the reference's traversal)
     float lbvh_ct = 0.f;       // RT_LBVH_CT: cost of a triangle test relative to a box test in the LBVH's leaf cut (0 = kLbvhCt)
@@ -92,7 +93,7 @@ static Knobs read_knobs() {
     if (geti("RT_TRAVQ_MINFREE", v) && v >= 1 && v <= 64) k.q_minfree = v;
     if (const char *e = std::getenv("RT_LBVH_CT")) { const float f = (float)std::atof(e); if (f > 0.f && f < 100.f) k.lbvh_ct = f; }
     if (geti("RT_TRAVQ_Q16", v) && v >= -1 && v <= 1) k.q16 = v;
-    if (geti("RT_TRAVQ_QW", v) && v >= 0 && v <= 1) k.qw = v;
+    if (geti("RT_TRAVQ_QW", v) && v >= -1 && v <= 1) k.qw = v;
     if (geti("RT_TRAVQ_QW_COUNT", v)) k.qw_count = v != 0;
     if (geti("RT_PARTS", v) && v >= 1 && v <= 8) k.parts = v;
     if (getenv("RT_TRAVQ_BPC5")) k.bpc5 = 1;
@@ -142,7 +143,8 @@ struct rt_ctx {
     DevBuf nodesh, tri2leaf;                                        // 16-bit fixed-point sibling pairs and the triangle -> leaf table (rt_qnodes.hip.h)
     DevBuf nodesw, leafbox;                                         // 4-wide fixed-point nodes and the leaves' real boxes by first triangle (RT_TRAVQ_QW)
     int travq_blocks_per_cu_qw[2] = {0, 0};                         // [STATS]
-    unsigned chain_nonce = 0;                                       // launch chains started so far (WfState::nonce)
+    unsigned chain_nonce[8] = {};                                   // launch chains started so far, PER SUB-FRAME (WfState::nonce): every part owns its own region of the ray queue, so each
+                                                                    // region must cycle through all four values (one context-wide counter gave a part only two of them with two parts: ADVICE round 4)
     int q16_leaf_shift = 0;                                         // where a leaf's triangle count sits in its payload word (rtk::q16_leaf_shift), 0 = leaves too large
     bool q16_topo_ok = false;                                       // the tree's shape allows them (leaf sizes, node count, boxes nest)
     DevBuf node_lo, node_hi, nodes2, nodesq, nodesb, q2thr, tri, verts, tidx, scratch_rgba, scratch_rgb8, work, queue;
@@ -181,6 +183,7 @@ struct rt_ctx {
         // through HIP directly is invisible to the library: no run-time check can cover it.)
         struct Range { const uint8_t *lo, *hi; hipStream_t stream; };
         std::vector<Range> between;
+        bool between_overflow = false;     // more than 64 ranges came in between two render calls: treated as a hazard
     } pipe;
     bool trav_attr_set = false;
     bool stats_on = false;                                          // rt_stats_enable: bracket the traversal launches with timing events (production frames record none)
@@ -516,6 +519,7 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
     }
 
     ctx->stats.pixels = (uint64_t)rows->n_rows * p->width;
+    ctx->stats.travq_mode = -1;
     ctx->stats.variant = (want_ldsv || want_ldsn) ? variant_req : variant;
     if (rows->n_rows == 0) { ctx->stats.grid_blocks = 0; ctx->have_kernel_time = false; return RT_OK; }
     const int nseg = segs > 0 ? segs : 1;
@@ -688,7 +692,7 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
                     RT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, travq_fn(work_dev != nullptr, qR, false, false, true, true), tb, trav_lds));
                     nbq = nb > 0 ? nb : 1;
                 }
-                bpc = std::min(nbq, 16 / (tb / 64));
+                bpc = std::min(nbq, (kn.bpc5 ? 20 : 16) / (tb / 64));
             } else {
                 if (ctx->travq_blocks_per_cu[qi] == 0) {
                     int nb = 0;
@@ -797,6 +801,7 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
         ctx->stats.block_threads = tb;
         ctx->stats.grid_blocks = (int)pv[0].tblocks;
         ctx->stats.parts = parts;
+        ctx->stats.travq_mode = (queue && have_mesh) ? (qw ? 2 : (scn.nodesh != nullptr && !work_dev && qR == 64 && !qldsn && !ldsv) ? 1 : 0) : -1;
         if (int rs = need_part_streams(ctx, parts, own0); rs != RT_OK) return rs;
         if (rec_begin) RT_HIP(ctx, hipEventRecord(ctx->ev_k0, stream));
         // Where the chains start.  Chain 0 on the caller's stream, the others forked from it and joined back at the end (one chunk, no
@@ -812,7 +817,7 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
             if (!pl.fork2[0]) { RT_HIP(ctx, hipEventCreateWithFlags(&pl.fork2[0], hipEventDisableTiming)); RT_HIP(ctx, hipEventCreateWithFlags(&pl.fork2[1], hipEventDisableTiming)); }
             if (pl.call_chunk == 0) {
                 const bool disjoint = pl.call_hi <= pl.out_lo || pl.out_hi <= pl.call_lo;
-                bool hazard = false;                                     // a library call younger than the previous render call touches this frame's buffer
+                bool hazard = pl.between_overflow;                       // a library call younger than the previous render call touches this frame's buffer (or: too many to tell)
                 for (const rt_ctx::Pipe::Range &r : pl.between) if (r.stream == stream && r.lo < pl.call_hi && pl.call_lo < r.hi) hazard = true;
 #ifdef RT_DEBUG
                 if (pl.on && pl.prev_valid && pl.stream == stream && hazard)
@@ -831,16 +836,23 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
         } else if (fork) {
             RT_HIP(ctx, hipEventRecord(ctx->fork_ev, stream));
         }
+        // Every sub-frame's chain starts behind the fork; then the chains of ONE sample chunk are issued for all sub-frames before the next chunk's.
+        // (Rounds 2-4 issued all chunks of sub-frame 0 first: with hundreds of chains the host was still feeding stream 0 while stream 1 sat empty, the
+        // sub-frames ran one after the other instead of side by side, and a 256-sample 1080p frame cost 1.26 ms per sample against 0.94 at 32 samples --
+        // tools/spp_slope.py, profiles/round5/spp_slope.txt.)
         for (int j = 0; j < parts; ++j) {
-            Part &pt = pv[j];
             hipStream_t q = (j == 0 && !own0) ? stream : ctx->part_stream[j];
             if (fork && (j > 0 || own0)) RT_HIP(ctx, hipStreamWaitEvent(q, start_ev, 0));
             if (own0 && pl.call_chunk == 0 && pl.extra_wait) RT_HIP(ctx, hipStreamWaitEvent(q, pl.extra_wait, 0));
-            if (pt.st.n_paths == 0) { if (own0) RT_HIP(ctx, hipEventRecord(ctx->part_ev[j], q)); continue; }
-            for (int s = 0; s < fr.spp; s += chunk) {
+        }
+        for (int s = 0; s < fr.spp; s += chunk) {
+            for (int j = 0; j < parts; ++j) {
+                Part &pt = pv[j];
+                hipStream_t q = (j == 0 && !own0) ? stream : ctx->part_stream[j];
+                if (pt.st.n_paths == 0) continue;
                 pt.st.samp0 = s;
                 pt.st.epoch = 0;
-                pt.st.nonce = (int)(++ctx->chain_nonce & (unsigned)rtk::PQ_NONCE_MASK);
+                pt.st.nonce = (int)(++ctx->chain_nonce[j] & (unsigned)rtk::PQ_NONCE_MASK);
                 if (work_dev) hipLaunchKernelGGL((rtk::wf_advance<true, true>), dim3(pt.pblocks), dim3(kn.adv_block), 0, q, scn, pt.fr, pt.st);
                 else hipLaunchKernelGGL((rtk::wf_advance<false, true>), dim3(pt.pblocks), dim3(kn.adv_block), 0, q, scn, pt.fr, pt.st);
                 for (int it = 0; it < (segs > 0 ? segs + 1 : 0); ++it) {
@@ -874,6 +886,9 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
                     hipLaunchKernelGGL(rtk::path_reduce, dim3((unsigned)((pt.st.n_px + 255) / 256)), dim3(256), 0, q, pt.fr, pt.st.n_px, tiles_x, std::min(chunk, fr.spp - s),
                                        static_cast<const float4 *>(pt.st.samp_out), static_cast<float4 *>(ctx->wfT.p) + pt.pxbase, s == 0 ? 1 : 0, s + chunk >= fr.spp ? 1 : 0);
             }
+        }
+        for (int j = 0; j < parts; ++j) {
+            hipStream_t q = (j == 0 && !own0) ? stream : ctx->part_stream[j];
             if (j > 0 || own0) { RT_HIP(ctx, hipEventRecord(ctx->part_ev[j], q)); }
         }
         if (!own0) {
@@ -955,7 +970,7 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
     rt_ctx::Pipe &pl = ctx->pipe;
     pl.prev_valid = pl.valid; pl.valid = false;                          // every asynchronous user of the path state comes through here
     pl.call_chunk = 0; pl.call_chunks = 1; pl.open_parts = 0;
-    struct ClearBetween { rt_ctx::Pipe &p; ~ClearBetween() { p.between.clear(); } } clear_between{pl};   // the ranges describe the gap BEFORE this call: consumed by it
+    struct ClearBetween { rt_ctx::Pipe &p; ~ClearBetween() { p.between.clear(); p.between_overflow = false; } } clear_between{pl};   // the ranges describe the gap BEFORE this call: consumed by it
     pl.call_lo = static_cast<const uint8_t *>(out_dev);
     pl.call_hi = pl.call_lo + ((p && rows && p->width > 0 && rows->n_rows > 0) ? (size_t)rows->n_rows * p->width * sizeof(float4) : 0);
     if (!p || !rows || !wf || chunk_px <= 0 || p->width <= 0 || rows->tile_rows <= 0 || (int64_t)rows->n_rows * p->width <= chunk_px * 5 / 4) {
@@ -995,6 +1010,7 @@ int launch_tonemap(rt_ctx *ctx, const void *rgba_dev, int64_t npix, void *rgb8_d
     if (npix == 0) return RT_OK;
     RT_HIP(ctx, hipSetDevice(ctx->device));
     const int64_t quads = (npix + 3) / 4;
+    if (ctx->pipe.on && ctx->pipe.between.size() >= 64) ctx->pipe.between_overflow = true;   // more ranges than are kept: the next render call takes the full fork
     if (ctx->pipe.on && ctx->pipe.between.size() < 64) {              // (see Pipe::between)
         const uint8_t *a = static_cast<const uint8_t *>(rgba_dev), *b = static_cast<const uint8_t *>(rgb8_dev);
         ctx->pipe.between.push_back({a, a + (size_t)npix * sizeof(float4), stream});
@@ -1019,7 +1035,9 @@ constexpr int kQ16AutoNodes = 16384;                                 // RT_TRAVQ
 int requantize(rt_ctx *ctx, hipStream_t q) {
     rtk::Scene &sc = ctx->scene;
     sc.nodesh = nullptr; sc.tri2leaf = nullptr; sc.nodesw = nullptr; sc.leafbox = nullptr;
-    const bool want_qw = ctx->knobs.qw == 1 && ctx->q16_leaf_shift == 24 && sc.n_nodes + 2 < (1 << 21);   // the quad's payload word: leaves of <= 127 triangles, child << 10 positive
+    // (automatic only below kQ16AutoNodes: on trees that no longer sit in the caches the 4-wide step LOSES to the fixed-point pairs -- 358 503 nodes: 3.65 vs 2.77 ms per frame, the
+    // leaves' real boxes are one more scattered 32-byte gather per TRI-step entry: profiles/round5/ab_wide_nodes.txt)
+    const bool want_qw = (ctx->knobs.qw == 1 || (ctx->knobs.qw < 0 && sc.n_nodes < kQ16AutoNodes)) && ctx->q16_leaf_shift == 24 && sc.n_nodes + 2 < (1 << 21);   // the quad's payload word: leaves of <= 127 triangles, child << 10 positive
     if (!(ctx->knobs.q16 == 1 || (ctx->knobs.q16 < 0 && sc.n_nodes >= kQ16AutoNodes) || want_qw) || !ctx->q16_topo_ok || ctx->q16_leaf_shift == 0 || !ctx->travq_ok || !sc.fast_box || sc.mesh_slot < 0 || sc.n_nodes < 3 || sc.n_tris <= 0) return RT_OK;
     int rc;
     if ((rc = ensure(ctx, ctx->nodesh, ((size_t)sc.n_nodes + 2) * 16)) != RT_OK || (rc = ensure(ctx, ctx->tri2leaf, (size_t)sc.n_tris * sizeof(int))) != RT_OK) return rc;
@@ -1636,7 +1654,7 @@ static int rebuild_reference_tree(rt_ctx *ctx, const int nt, int &n_nodes_out) {
     return RT_OK;
 }
 
-// The LBVH builder (rt_lbvh.hip.h): Morton sort + parallel hierarchy emission, leaves of up to four triangles; same outputs
+// The LBVH builder (rt_lbvh.hip.h): Morton sort + parallel hierarchy emission, leaves cut by the surface-area heuristic (at most kLbvhLeaf = 32 triangles); same outputs
 static int rebuild_lbvh_tree(rt_ctx *ctx, const int nt, int &n_nodes_out) {
     RT_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t q = own_stream(ctx);

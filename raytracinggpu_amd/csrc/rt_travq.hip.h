@@ -56,7 +56,10 @@ constexpr int kQMaxLeaf = 1 << 20;           // triangles per leaf: count << 11 
 template <int R> struct QStackCap { static constexpr int value = R > 64 ? 800 : RT_TRAVQ_SCAP; };   // (R = 128: twice the rays, two pairs per lane and step)
 // 4-wide BOX step (QW, below): a step may append up to 256 stack entries and 256 leaf entries, but it knows how many before it writes one (the
 // masks are scalar registers): the carve stays the pair kernel's, and a step that would not fit walks its popped pairs serially instead
-constexpr int kQwStackCap = QStackCap<64>::value, kQwLeafCap = QLeafCap<64>::value;
+#ifndef RT_TRAVQ_SCAP_QW
+#define RT_TRAVQ_SCAP_QW RT_TRAVQ_SCAP
+#endif
+constexpr int kQwStackCap = RT_TRAVQ_SCAP_QW, kQwLeafCap = QLeafCap<64>::value;
 // payload word of a quad's child (qquads_kernel): > 0 internal = first child << kQNodeShift (a stack entry without its slot bits; trees below 2^21 nodes),
 // < 0 leaf = 1 << 31 | triangle count << 24 | first triangle (leaves of at most 127 triangles, 2^24 triangles), 0 = nothing there
 constexpr int kQwLeafShift = 24;
@@ -284,7 +287,7 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
     extern __shared__ __attribute__((aligned(16))) unsigned char travq_smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wib = tid >> 6;
+    const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: the carve's base address lives in a scalar register
     const int wpb = (int)(blockDim.x >> 6);
     unsigned char *const wl = travq_smem + wib * Carve::kBytes;
     int *const blk_cur = reinterpret_cast<int *>(travq_smem + wpb * Carve::kBytes);
@@ -468,8 +471,18 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
                         const f3 O = mk(r0.x, r0.y, r0.z), u = mk(r0.w, r1.x, r1.y);
                         const RayBoxC rb = ray_box_c(O, u, mk(sc.bmx, sc.bmy, sc.bmz), sc.fast_box != 0);
                         if (QN) {     // the same planes in grid units: k = fma(cq, r s, -(O - g) r)
-                            rowA(sbk) = make_float4(rb.rx * sc.qsx, rb.ry * sc.qsy, rb.rz * sc.qsz, 4.f * rb.c0);
-                            rowO(sbk) = make_float4((O.x - sc.qgx) * rb.rx, (O.y - sc.qgy) * rb.ry, (O.z - sc.qgz) * rb.rz, __int_as_float(work ? 1 : 0));
+                            const float qrx = rb.rx * sc.qsx, qry = rb.ry * sc.qsy, qrz = rb.rz * sc.qsz;
+                            const float qox = (O.x - sc.qgx) * rb.rx, qoy = (O.y - sc.qgy) * rb.ry, qoz = (O.z - sc.qgz) * rb.rz;
+                            float aw = 4.f * rb.c0;
+                            if (QW) {
+                                // ONE band per ray instead of one per box: every plane value of a box on the 16-bit grid is bounded by |o'| + (cq + hq) |r'| <= |o'| + 2^17 |r'|,
+                                // so B = 2 kRel Tm (1 + 2^-10) + 4 c0 with Tm = the largest such bound over the axes is at least cbox_dband's band for ANY box: d < -B excludes.
+                                // (About an eighth of a cell along the ray's steepest axis; the boxes carry three cells of slack.)
+                                const float tm = vmax3(fmaf(0x1p17f, fabsf(qrx), fabsf(qox)), fmaf(0x1p17f, fabsf(qry), fabsf(qoy)), fmaf(0x1p17f, fabsf(qrz), fabsf(qoz)));
+                                aw = fmaf(tm, 2.f * kRel * (1.f + 0x1p-10f), aw);
+                            }
+                            rowA(sbk) = make_float4(qrx, qry, qrz, aw);
+                            rowO(sbk) = make_float4(qox, qoy, qoz, __int_as_float(work ? 1 : 0));
                         } else {
                         rowA(sbk) = make_float4(rb.rx, rb.ry, rb.rz, rb.c0);
                         rowO(sbk) = make_float4(rb.ox, rb.oy, rb.oz, __int_as_float(work ? 1 : 0));      // .w: one outstanding entry
@@ -527,7 +540,7 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
                 WQ_CHECK((int)xf >= 0 && (int)xf < sc.n_tris, 2, (void)0);
                 xc = sc.leafbox[2 * (size_t)xf]; xh = sc.leafbox[2 * (size_t)xf + 1];      // (centre, half extent) of the real box, as the pair kernel's filter takes them
                 xC = rowC(E.y & kQSlotMask); xD = *reinterpret_cast<const float2 *>(&rowD(E.y & kQSlotMask));
-                xc0 = 0.25f * rowA(E.y & kQSlotMask).w;                                      // the slot's c0 (the row keeps 4 c0: exact)
+                xc0 = 0.25f * rowA(E.y & kQSlotMask).w;                                      // at least the slot's c0 (the row keeps 4 c0 + the ray's band term: a wider band decides less often, never wrongly)
             }
             const unsigned int c = QW ? (E.x >> kQwLeafShift) & 0x7fu : E.y >> kQLeafShift;               // >= 1 for queued entries, 0 beyond them (QW: the entry is (payload word, slot << 4 | decided))
             if (QW) E.x &= (1u << kQwLeafShift) - 1u;
@@ -675,9 +688,10 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
             auto child = [&](const uint4 q, const int j) {
                 const float4 cq = make_float4((float)(q.x & 0xffffu), (float)(q.x >> 16), (float)(q.y & 0xffffu), 0.f);
                 const float4 hq = make_float4((float)(q.y >> 16), (float)(q.z & 0xffffu), (float)(q.z >> 16), 0.f);
-                float d, band;
-                cbox_dband(cq, hq, A, Oo, d, band);
-                const unsigned long long g = mact & ~__ballot(d < -band);       // not excluded (a NaN is not excluded either)
+                const float kx = fmaf(cq.x, A.x, -Oo.x), ky = fmaf(cq.y, A.y, -Oo.y), kz = fmaf(cq.z, A.z, -Oo.z);
+                const float tn = vmax3(fmaf(-hq.x, fabsf(A.x), kx), fmaf(-hq.y, fabsf(A.y), ky), fmaf(-hq.z, fabsf(A.z), kz));
+                const float tf = vmin3(fmaf(hq.x, fabsf(A.x), kx), fmaf(hq.y, fabsf(A.y), ky), fmaf(hq.z, fabsf(A.z), kz));
+                const unsigned long long g = mact & ~__ballot(tf + A.w < tn);    // not excluded: the ray's own band (hand-off) covers every box; a NaN is not excluded either
                 p_[j] = q.w;                                                     // > 0 internal (the entry), < 0 leaf (count, first triangle), 0 nothing
                 mL[j] = g & __ballot((int)q.w < 0);
                 mI[j] = (j & 1) ? g & __ballot((int)q.w > 0) : g & ~mL[j];      // places 0 and 2 always hold a node (qquads_kernel): only 1 and 3 can be empty
@@ -698,10 +712,13 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
                 continue;
             }
             // pushes, child by child (the stack is a bag): position = entries before this child's + set lanes below
+            // (STATS: n_lpush2 / n_lpush count the internal / leaf push blocks entered -- a block runs only if some lane pushes that child)
             int base = top;
+            WQ_MARK("ipushw_begin");
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (mI[j] != 0ull) {
+                    if (STATS) n_lpush2++;
                     const int pos = base + lanes_below(mI[j]);
                     if (__builtin_amdgcn_inverse_ballot_w64(mI[j])) stack[pos] = p_[j] | sb;
                     base += __popcll(mI[j]);
@@ -709,16 +726,18 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
             }
             top = base;
             unsigned int lb = ltail;
-            if (STATS) n_lpush += nL != 0 ? 1u : 0u;
+            WQ_MARK("lpushw_begin");
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (mL[j] != 0ull) {
+                    if (STATS) n_lpush++;
                     const unsigned int pos = lb + (unsigned int)lanes_below(mL[j]);
-                    if (__builtin_amdgcn_inverse_ballot_w64(mL[j])) leafq[pos & (LCAP - 1)] = make_uint2(p_[j], sb);
+                    if (__builtin_amdgcn_inverse_ballot_w64(mL[j])) { unsigned int *const lq = reinterpret_cast<unsigned int *>(leafq + (pos & (LCAP - 1))); lq[0] = p_[j]; lq[1] = sb; }
                     lb += (unsigned int)__popcll(mL[j]);
                 }
             }
             ltail = lb;
+            WQ_MARK("lpushw_end");
             const int delta = lane_count8_minus(mI, mL, mact);
             if (delta != 0) atomicAdd(pend(sb), delta);
             WQ_CHECK(top >= 0 && top <= cap && top <= SCAP, 8, (void)0);

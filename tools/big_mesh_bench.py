@@ -33,7 +33,7 @@ for n in [int(x) for x in os.environ.get("BIG_N", "45,161,513,1025").split(",")]
     t0 = time.perf_counter(); arr, order = ctx.mesh_rebuild(len(t)); t_re = time.perf_counter() - t0
     print("%7d triangles, %6d nodes: host build %.2f s, upload %.2f s, frame %.3f ms = %.0f Mrays/s, per ray %.1f box tests / %.1f triangle tests; device rebuild %.2f s" %
           (len(t), len(mesh["bvh_arr10"]), t_build, t_up, ms, rays / ms / 1e3, w["box_tests"] / w["rays"], w["tri_tests"] / w["rays"], t_re), flush=True)
-    # the same mesh on the LBVH tree (rt_mesh_rebuild_mode(RT_BVH_LBVH): Morton sort + parallel hierarchy, leaves of at most four triangles)
+    # the same mesh on the LBVH tree (rt_mesh_rebuild_mode(RT_BVH_LBVH): Morton sort + parallel hierarchy, leaves cut by the surface-area heuristic: at most 32 triangles)
     t0 = time.perf_counter(); arr, order = ctx.mesh_rebuild(len(t), mode="lbvh"); t_lb = time.perf_counter() - t0
     st = ctx.build_stats()
     for _ in range(20):

@@ -124,6 +124,44 @@ def travq_counts(lines):
     return out
 
 
+def travq_qw_counts(lines):
+    """The 4-wide instantiation (wf_travq<.., QN, QW>): the same regions, its BOX step = the core (pop, four loads, unpack, four box tests, masks, the per-slot counter
+    update) + one block per child that some lane pushes as an internal node / as a leaf (counted per block entered: the step counters' leaf_push2 / leaf_push)."""
+    marks = regions(lines)
+    pos = {}
+    for i, name in marks:
+        pos.setdefault(name, []).append(i)
+    need = ("head", "refill_begin", "round_begin", "fetch_begin", "fetch_end", "round_end", "refill_end", "tri_begin", "tri_end", "boxw_begin", "ipushw_begin", "lpushw_begin", "lpushw_end", "boxw_end")
+    missing = [n for n in need if n not in pos]
+    if missing:
+        raise SystemExit(f"static_counts: markers missing from the 4-wide code object: {missing}")
+    one = {n: pos[n][0] for n in need}
+    reg = lambda a, b: count(lines[one[a]:one[b]])
+    inside = lambda name, a, b_: [(x, y) for x, y in zip(pos.get(name + "_begin", []), pos.get(name + "_end", [])) if one[a] < x < one[b_]]
+    span = lambda pairs: count([l for x, y in pairs for l in lines[x:y]])
+    trilit = span(inside("trilit", "tri_begin", "tri_end"))
+    tdivs = inside("tdiv", "tri_begin", "tri_end")
+    tdiv = span(tdivs)
+    n_tdiv = max(len(tdivs), 1)
+    quarter = lambda c: {k: v / 4.0 for k, v in c.items()}
+    def add(a, b):
+        return {k: a[k] + b[k] for k in a}
+    return {
+        "loop_head": reg("head", "refill_begin"),
+        "retire": sub(reg("refill_begin", "round_begin"), reg("fetch_begin", "fetch_end")),
+        "round": reg("round_begin", "round_end"),
+        "fetch": reg("fetch_begin", "fetch_end"),
+        "dispatch": reg("refill_end", "tri_begin"),
+        "tri": sub(sub(reg("tri_begin", "tri_end"), trilit), tdiv),
+        "tri_literal_blocks": trilit,
+        "tdiv": {k: v / n_tdiv for k, v in tdiv.items()},
+        "box": add(reg("boxw_begin", "ipushw_begin"), reg("lpushw_end", "boxw_end")),    # per BOX step (64 quads = 256 boxes) without the push blocks
+        "lpush2": quarter(reg("ipushw_begin", "lpushw_begin")),                            # per internal-child push block entered
+        "lpush": quarter(reg("lpushw_begin", "lpushw_end")),                               # per leaf-child push block entered
+        "whole_kernel": count(lines),
+    }
+
+
 def main():
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     sys.path.insert(0, ROOT)
@@ -132,10 +170,14 @@ def main():
     asm = subprocess.run([hipcc, *flags, "-S", "--cuda-device-only", "-o", "-", SRC], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True).stdout
     res = {"source": "hipcc -S --cuda-device-only of raytracinggpu_amd/csrc/rt_capi.hip with the flags of __graft_entry__.HIP_FLAGS",
            "weights": "valu_weight: 1 = full-rate instruction (2 SIMD cycles per wave64), 2 = half rate, 4 = quarter, 8 = binary64 transcendental"}
-    tq = kernel_text(asm, "_ZN3rtk8wf_travqILb0ELi64ELb0ELb0ELb0EEEvNS_5SceneENS_5FrameENS_7WfStateEiiii")
+    tq = kernel_text(asm, "_ZN3rtk8wf_travqILb0ELi64ELb0ELb0ELb0ELb0EEEvNS_5SceneENS_5FrameENS_7WfStateEiiii")
     if not tq:
         raise SystemExit("static_counts: wf_travq<false, 64, false, false> not found in the assembly")
     res["wf_travq"] = travq_counts(tq)
+    tw = kernel_text(asm, "_ZN3rtk8wf_travqILb0ELi64ELb0ELb0ELb1ELb1EEEvNS_5SceneENS_5FrameENS_7WfStateEiiii")
+    if not tw:
+        raise SystemExit("static_counts: wf_travq<false, 64, false, false, true, true> (the 4-wide BOX step) not found in the assembly")
+    res["wf_travq_qw"] = travq_qw_counts(tw)
     for name, mangled in (("wf_advance", "_ZN3rtk10wf_advanceILb0ELb0EEEvNS_5SceneENS_5FrameENS_7WfStateE"),
                           ("wf_advance_first", "_ZN3rtk10wf_advanceILb0ELb1EEEvNS_5SceneENS_5FrameENS_7WfStateE")):
         t = kernel_text(asm, mangled)
@@ -144,6 +186,9 @@ def main():
     m = re.search(r"\.name:\s+_ZN3rtk8wf_travqILb0ELi64ELb0ELb0EEE.*?\n(.*?)\.wavefront_size", asm, re.S)
     with open(OUT, "w") as f:
         json.dump(res, f, indent=1)
+    w = res["wf_travq_qw"]
+    print("static_counts: wf_travq 4-wide per step: BOX %d valu (weight %d) %d salu + %.1f per internal push block + %.1f per leaf push block | TRI %d (%d) %d | round %d | fetch %d" % (
+        w["box"]["valu"], w["box"]["valu_weight"], w["box"]["salu"], w["lpush2"]["valu"], w["lpush"]["valu"], w["tri"]["valu"], w["tri"]["valu_weight"], w["tri"]["salu"], w["round"]["valu"], w["fetch"]["valu"]))
     t = res["wf_travq"]
     print("static_counts: wf_travq per step: BOX %d valu (weight %d) %d salu + leaf pushes %d / %d | TRI %d (%d) %d + %.0f per t-division block | round %d (%d) %d | fetch %d | retire %d | head+dispatch %d" % (
         t["box"]["valu"], t["box"]["valu_weight"], t["box"]["salu"], t["lpush"]["valu"], t["lpush2"]["valu"], t["tri"]["valu"], t["tri"]["valu_weight"], t["tri"]["salu"], t["tdiv"]["valu"],
