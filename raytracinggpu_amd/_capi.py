@@ -472,6 +472,11 @@ class Context:
     def kat_mesh(self, rows, tri_tmin=1e-4, route=0):
         return self._kat(self._L.rt_kat_mesh, rows, 6, 5, C.c_float(tri_tmin), int(route))
 
+    def stats_after_render(self, params):
+        """Render one frame with `params` and return rt_get_stats of it (which traversal kernel ran: travq_mode)."""
+        self.render(params)
+        return self.stats()
+
     def stats(self):
         s = Stats()
         self._check(self._L.rt_get_stats(self._h, C.byref(s)))

@@ -136,24 +136,27 @@ def test_reference_mesh_vectors_through_the_production_traversal_kernels(ctx, va
 def test_reference_mesh_vectors_through_the_serial_drain(cat_golden, monkeypatch):
     """The same under RT_TRAVQ_CAP=128 (a context reads its knobs once): the work stack overflows and wf_travq drains popped pairs by
     the serial skip-pointer walk."""
-    monkeypatch.setenv("RT_TRAVQ_CAP", "128")
-    c = rt.Context(0)
-    monkeypatch.delenv("RT_TRAVQ_CAP")
     mesh = dict(vertices=cat_golden["vertices"], indices=cat_golden["tri_bvh_order"], bvh_arr10=cat_golden["bvh_arr10"], albedo=rt.scenes.CAT_ALBEDO, object_slot=6)
-    c.scene_upload(rt.scenes.spheres("cpu"), mesh)
     g = load_golden("kat.npz")
-    for variant in ("wavefront_queue", "path"):
-        _check_mesh_rows(c.trace_rays(g["mesh_in"], 1e-4, variant), g["mesh_out"])
-    drains = c.count_work(rt.make_params(640, 360, 1, 2, **rt.scenes.CPU_LAUNCHER), detail=True)["steps"]["serial_drains"]
-    assert drains > 0                                                  # the capacity really forces the drain on this mesh
-    c.close()
+    for qw in ("0", "1"):                                              # the sibling-pair kernel's drain, and the 4-wide step's (a step that predicts an overflow walks its pairs serially)
+        monkeypatch.setenv("RT_TRAVQ_CAP", "128"); monkeypatch.setenv("RT_TRAVQ_QW", qw); monkeypatch.setenv("RT_TRAVQ_QW_COUNT", qw)
+        c = rt.Context(0)
+        monkeypatch.delenv("RT_TRAVQ_CAP"); monkeypatch.delenv("RT_TRAVQ_QW"); monkeypatch.delenv("RT_TRAVQ_QW_COUNT")
+        c.scene_upload(rt.scenes.spheres("cpu"), mesh)
+        for variant in ("wavefront_queue", "path"):
+            _check_mesh_rows(c.trace_rays(g["mesh_in"], 1e-4, variant), g["mesh_out"])
+        p = rt.make_params(640, 360, 1, 2, **rt.scenes.CPU_LAUNCHER)
+        assert c.stats_after_render(p)["travq_mode"] == (2 if qw == "1" else 0)
+        drains = c.count_work(p, detail=True)["steps"]["serial_drains"]
+        assert drains > 0, qw                                          # the capacity really forces the drain on this mesh
+        c.close()
 
 
 def test_reference_mesh_vectors_through_the_fixed_point_box_step(cat_golden, monkeypatch):
     """RT_TRAVQ_Q16=1: the BOX step decides on 16-bit fixed-point boxes rounded outwards (a superset of the reference's visits), flags leaves it
     cannot be sure of and lets the reference's test of the leaf's real box decide when a triangle is accepted there (rt_qnodes.hip.h): the
     reference's 6 600 mesh vectors, bit for bit, and the frame of the default kernel."""
-    monkeypatch.setenv("RT_TRAVQ_Q16", "1")
+    monkeypatch.setenv("RT_TRAVQ_Q16", "1"); monkeypatch.setenv("RT_TRAVQ_QW", "0")
     c = rt.Context(0)
     monkeypatch.delenv("RT_TRAVQ_Q16")
     mesh = dict(vertices=cat_golden["vertices"], indices=cat_golden["tri_bvh_order"], bvh_arr10=cat_golden["bvh_arr10"], albedo=rt.scenes.CAT_ALBEDO, object_slot=6)
@@ -161,10 +164,37 @@ def test_reference_mesh_vectors_through_the_fixed_point_box_step(cat_golden, mon
     g = load_golden("kat.npz")
     hit = _check_mesh_rows(c.trace_rays(g["mesh_in"], 1e-4, "wavefront_queue"), g["mesh_out"])
     assert hit.sum() > 1500
-    d = rt.Context(0)
+    d = rt.Context(0)                                                  # RT_TRAVQ_QW=0 still set: the float sibling pairs
+    monkeypatch.delenv("RT_TRAVQ_QW")
     d.scene_upload(rt.scenes.spheres("cpu"), mesh)
     p = rt.make_params(960, 540, 1, 3, **rt.scenes.CPU_LAUNCHER)
     np.testing.assert_array_equal(c.render(p).view(np.uint32), d.render(p).view(np.uint32))
+    assert c.stats()["travq_mode"] == 1 and d.stats()["travq_mode"] == 0
+    c.close(); d.close()
+
+
+def test_reference_mesh_vectors_through_the_4_wide_box_step(ctx, cat_golden, monkeypatch):
+    """RT_TRAVQ_QW (round 5; the default for trees below 16 384 nodes, named here so that the test keeps meaning what it says): the BOX step tests the four boxes two
+    levels below a sibling pair's parent on 16-bit fixed-point records rounded outwards, skips every other level of the tree, and every leaf entry meets the reference's
+    test of its REAL box in the TRI step that consumes it (rt_travq.hip.h).  The reference's 6 600 mesh vectors bit for bit through the production launches, the frame of
+    the float sibling-pair kernel (RT_TRAVQ_QW=0) word for word at b = 3, and rt_stats says which kernel ran."""
+    mesh = dict(vertices=cat_golden["vertices"], indices=cat_golden["tri_bvh_order"], bvh_arr10=cat_golden["bvh_arr10"], albedo=rt.scenes.CAT_ALBEDO, object_slot=6)
+    monkeypatch.setenv("RT_TRAVQ_QW", "1")
+    c = rt.Context(0)
+    monkeypatch.setenv("RT_TRAVQ_QW", "0")
+    d = rt.Context(0)
+    monkeypatch.delenv("RT_TRAVQ_QW")
+    g = load_golden("kat.npz")
+    for x in (c, d):
+        x.scene_upload(rt.scenes.spheres("cpu"), mesh)
+        hit = _check_mesh_rows(x.trace_rays(g["mesh_in"], 1e-4, "wavefront_queue"), g["mesh_out"])
+        assert hit.sum() > 1500
+    p = rt.make_params(960, 540, 1, 3, **rt.scenes.CPU_LAUNCHER)
+    np.testing.assert_array_equal(c.render(p).view(np.uint32), d.render(p).view(np.uint32))
+    assert c.stats()["travq_mode"] == 2 and d.stats()["travq_mode"] == 0
+    ctx.scene_upload(rt.scenes.spheres("cpu"), mesh)                   # and the default IS the 4-wide step for this tree
+    ctx.render(p)
+    assert ctx.stats()["travq_mode"] == 2
     c.close(); d.close()
 
 
@@ -213,13 +243,16 @@ def test_degenerate_rays_through_the_production_traversal_kernels(ctx, oracle, o
 def test_degenerate_rays_through_the_fixed_point_box_step(oracle, oracle_cat, cat_golden, monkeypatch):
     """The same rays with RT_TRAVQ_Q16=1: the box test is not monotone for a ray with a zero / denormal / huge component, so such a ray never meets the
     fixed-point pairs -- it is walked serially with the literal test when it is handed its slot (rt_qnodes.hip.h) -- while the rest of the batch does."""
-    monkeypatch.setenv("RT_TRAVQ_Q16", "1")
-    c = rt.Context(0)
-    monkeypatch.delenv("RT_TRAVQ_Q16")
     mesh = dict(vertices=cat_golden["vertices"], indices=cat_golden["tri_bvh_order"], bvh_arr10=cat_golden["bvh_arr10"], albedo=rt.scenes.CAT_ALBEDO, object_slot=6)
-    c.scene_upload(rt.scenes.spheres("cpu"), mesh)
-    _check_degenerate(c, oracle_cat, "wavefront_queue")
-    c.close()
+    for env in ({"RT_TRAVQ_Q16": "1", "RT_TRAVQ_QW": "0"}, {"RT_TRAVQ_QW": "1"}, {"RT_TRAVQ_QW": "0"}):   # fixed-point pairs, the 4-wide step (same rule: such rays are walked serially), float pairs
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = rt.Context(0)
+        for k in env:
+            monkeypatch.delenv(k)
+        c.scene_upload(rt.scenes.spheres("cpu"), mesh)
+        _check_degenerate(c, oracle_cat, "wavefront_queue")
+        c.close()
 
 
 def test_trace_rays_error_paths_and_empty_scene(ctx):
