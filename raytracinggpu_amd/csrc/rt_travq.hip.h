@@ -717,11 +717,7 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
             WQ_MARK("ipushw_begin");
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-#ifdef RT_QW_NOBRANCH
-                {
-#else
-                if (mI[j] != 0ull) {
-#endif
+                if (mI[j] != 0ull) {                  // (a block without the test measured the same: profiles/round5/ab_wide_nodes.txt)
                     if (STATS) n_lpush2++;
                     const int pos = base + lanes_below(mI[j]);
                     if (__builtin_amdgcn_inverse_ballot_w64(mI[j])) stack[pos] = p_[j] | sb;
