@@ -271,9 +271,9 @@ __device__ __forceinline__ bool qtri_test(const float4 q0, const float4 q1, cons
 // loads a step of the float pairs issues -- tests the four boxes and pushes one entry per hit internal grandchild: every other level of the tree is
 // never tested, a ray's chain of dependent steps is half as long and a frame runs half as many BOX steps.  Exactness: the fixed-point boxes contain the
 // real ones and the reference's test is monotone along nested boxes (rt_qnodes.hip.h), so the leaves the reference reaches are exactly the leaves whose
-// OWN box its test hits; here every leaf entry meets the reference's test of its real box (sc.leafbox, indexed by the leaf's first triangle; slab_filtered)
-// in the TRI step that consumes it -- one test per ENTRY, beside the triangle loads, for every entry: no flags, no second threshold in the BOX step -- and a
-// triangle accepted in a leaf counts only if that test says hit.  Work counters of this instantiation differ from the oracle's by construction (no test
+// OWN box its test hits; here every leaf entry meets the reference's test of its real box (sc.leafbox, indexed by the leaf's first triangle: cbox_filter, the
+// literal slab behind a vote) in the TRI step that consumes it -- one test per ENTRY, beside the triangle loads, for every entry: no flags, no second threshold in
+// the BOX step -- and a triangle accepted in a leaf counts only if that test says hit.  Work counters of this instantiation differ from the oracle's by construction (no test
 // of the skipped level, a superset of internal nodes entered): the counter tests use the binary instantiation, this one is held to frames and ray counts.
 template <bool STATS, int R, bool LDSN, bool LDSV, bool QN = false, bool QW = false>
 __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || kQBlock != 256 || QPairs<R>::value > 1) ? 4 : 5) void wf_travq(const Scene sc, const Frame fr, const WfState st, const int cap, const int n_lds, const int kLow, const int kMinFree) {
