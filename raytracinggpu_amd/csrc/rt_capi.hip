@@ -369,7 +369,7 @@ TravqFn travq_fn(bool stats, int R, bool ldsn, bool ldsv = false, bool qn = fals
     return R == 32 ? travq_pick<false, 32>(ldsn, ldsv) : R == 128 ? travq_pick<false, 128>(ldsn, ldsv) : travq_pick<false, 64>(ldsn, ldsv);
 }
 size_t travq_carve_bytes(int R, bool qw = false) {
-    if (qw) return (size_t)rtk::QCarve<64, rtk::kQwStackCap, rtk::kQwLeafCap>::kBytes;
+    if (qw) return (size_t)rtk::QCarve<64, rtk::kQwStackCap, rtk::kQwLeafCap, rtk::kQwTris>::kBytes;
     return R == 128 ? (size_t)rtk::QCarve<128, rtk::QStackCap<128>::value, rtk::QLeafCap<128>::value>::kBytes
          : R == 64 ? (size_t)rtk::QCarve<64, rtk::QStackCap<64>::value, rtk::QLeafCap<64>::value>::kBytes : (size_t)rtk::QCarve<32, rtk::QStackCap<32>::value, rtk::QLeafCap<32>::value>::kBytes;
 }

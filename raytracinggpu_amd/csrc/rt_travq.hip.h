@@ -63,6 +63,10 @@ constexpr int kQwStackCap = RT_TRAVQ_SCAP_QW, kQwLeafCap = QLeafCap<64>::value;
 // payload word of a quad's child (qquads_kernel): > 0 internal = first child << kQNodeShift (a stack entry without its slot bits; trees below 2^21 nodes),
 // < 0 leaf = 1 << 31 | triangle count << 24 | first triangle (leaves of at most 127 triangles, 2^24 triangles), 0 = nothing there
 constexpr int kQwLeafShift = 24;
+#ifndef RT_TRAVQ_QW_TRIS
+#define RT_TRAVQ_QW_TRIS 2
+#endif
+constexpr int kQwTris = RT_TRAVQ_QW_TRIS;      // triangles per lane and TRI step of the 4-wide kernel
 
 // Per-wave LDS carve.  Four tables of 16-byte rows indexed by ray slot, so that ONE address register (wave base + slot * 16)
 // reaches everything a step needs about a ray through the instructions' immediate offsets:
@@ -70,13 +74,13 @@ constexpr int kQwLeafShift = 24;
 //   O = (fl(O.x / u.x) .., int: outstanding stack + leaf-queue entries)      BOX step (the counter shares the row: no address arithmetic)
 //   C = (O.xyz, u.x)                                                         TRI step, literal box test
 //   D = (u.y, u.z, u64: nearest accepted hit)                                TRI step
-template <int R, int SCAP, int LCAP> struct QCarve {
+template <int R, int SCAP, int LCAP, int NT = 2> struct QCarve {
     static constexpr int kTabA = 0;
     static constexpr int kTabO = kTabA + 16 * R;
     static constexpr int kTabC = kTabO + 16 * R;
     static constexpr int kTabD = kTabC + 16 * R;
-    static constexpr int kMarks = kTabD + 16 * R;         // u8[128]: TRI-step expansion marks (all zero between steps)
-    static constexpr int kStack = kMarks + 128;           // u32[SCAP]
+    static constexpr int kMarks = kTabD + 16 * R;         // u8[64 NT]: TRI-step expansion marks (all zero between steps)
+    static constexpr int kStack = kMarks + 64 * NT;       // u32[SCAP]
     static constexpr int kLeaf = kStack + 4 * SCAP;       // uint2[LCAP]: (first triangle, count << 11 | slot << 4 | flag)
     static constexpr int kStage = kLeaf + 8 * LCAP;       // u8[64]: lanes whose registers hold a fetched ray record that has no slot yet
     static constexpr int kBytes = kStage + 64;
@@ -276,13 +280,14 @@ __device__ __forceinline__ bool qtri_test(const float4 q0, const float4 q1, cons
 // the BOX step -- and a triangle accepted in a leaf counts only if that test says hit.  Work counters of this instantiation differ from the oracle's by construction (no test
 // of the skipped level, a superset of internal nodes entered): the counter tests use the binary instantiation, this one is held to frames and ray counts.
 template <bool STATS, int R, bool LDSN, bool LDSV, bool QN = false, bool QW = false>
-__global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || kQBlock != 256 || QPairs<R>::value > 1) ? 4 : 5) void wf_travq(const Scene sc, const Frame fr, const WfState st, const int cap, const int n_lds, const int kLow, const int kMinFree) {
+__global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || kQBlock != 256 || QPairs<R>::value > 1 || (QW && kQwTris > 2)) ? 4 : 5) void wf_travq(const Scene sc, const Frame fr, const WfState st, const int cap, const int n_lds, const int kLow, const int kMinFree) {
     // kLow: refill while the stack holds fewer entries (sibling pairs) than this (default 48); kMinFree: ... and at least this
     // many slots are free, or the stack is short (default R / 4)
     static_assert(!QW || (QN && R == 64 && !LDSN && !LDSV), "the 4-wide step reads fixed-point quads through L1 / L2, one ray slot per lane");
     constexpr int SCAP = QW ? kQwStackCap : QStackCap<R>::value, LCAP = QW ? kQwLeafCap : QLeafCap<R>::value;
     constexpr int NB = R > 64 ? 2 : 1;                      // ray slots per lane ("banks"): lane l owns slots l and, with 128 resident rays, l + 64
-    using Carve = QCarve<R, SCAP, LCAP>;
+    constexpr int NT = QW ? kQwTris : 2;                    // triangles per lane and TRI step
+    using Carve = QCarve<R, SCAP, LCAP, NT>;
     static_assert(R <= 128 && (R & (R - 1)) == 0, "ray slots are owned by lanes: one per lane, or two");
     extern __shared__ __attribute__((aligned(16))) unsigned char travq_smem[];
     const int tid = threadIdx.x;
@@ -306,7 +311,7 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
     auto best = [&](unsigned int sb) -> unsigned long long * { return reinterpret_cast<unsigned long long *>(wl + Carve::kTabD + sb + 8); };
     const unsigned int my_sb0 = (unsigned int)lane << 4;           // lane l owns ray slot l (bank 0) and l + 64 (bank 1, R = 128): row offsets
     if (tid == 0) *blk_cur = 0;
-    marks[lane] = 0; marks[lane + 64] = 0;
+    for (int k = 0; k < NT; ++k) marks[lane + 64 * k] = 0;
     for (int b = 0; b < NB; ++b) if (lane + 64 * b < R) *pend(my_sb0 + 1024u * b) = 0;
     if (LDSN) for (int k = tid; k < 2 * n_lds; k += (int)blockDim.x) lnodes[k] = sc.nodesb[k];
     if (LDSV) for (int k = tid; k < sc.n_verts; k += (int)blockDim.x) lverts[k] = sc.verts[k];
@@ -524,11 +529,16 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
         }
         WQ_STAMP(cy_srv);
         WQ_MARK("refill_end");
-        // =============================== TRI step: two triangles per lane ===============================
+        // =============================== TRI step: NT triangles per lane ===============================
+        // NT = 2 (128 triangles per step).  -DRT_TRAVQ_QW_TRIS=4 gives the 4-wide kernel 256: its exact leaf-box test runs once per STEP on all 64 lanes whatever the number of
+        // entries the step consumes, and 128 triangles are only ~33 entries; with 256 the 64 entries a step reads are the 64 it consumes and TRI steps fall from 736 K to 425 K per
+        // frame -- measured SLOWER (profiles/round5/ab_wide_nodes.txt): twelve triangle records per lane need 127 registers, the launch owns the register file and the other
+        // sub-frame's wf_advance no longer fits beside it (frame 0.887 -> 1.016 ms; the launch alone 0.174 -> 0.175 ms: nothing gained even then).
         const unsigned int lcount = ltail - lhead;
         if (lcount >= 64u || (top == 0 && lcount > 0u)) {
             if (STATS) n_tri++;
             WQ_MARK("tri_begin");
+            constexpr unsigned int LIM = 64u * NT;                   // triangles a step takes
             const unsigned int m = lcount < 64u ? lcount : 64u;
             uint2 E = make_uint2(0u, 0u);
             if ((unsigned int)lane < m) E = leafq[(lhead + (unsigned int)lane) & (LCAP - 1)];
@@ -546,55 +556,64 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
             if (QW) E.x &= (1u << kQwLeafShift) - 1u;
             const unsigned int incl = wave_incl_scan(c);
             const unsigned int P = incl - c;                         // position of this entry's first triangle
-            const bool part = c > 0u && P < 128u;
+            const bool part = c > 0u && P < LIM;
             const unsigned int all = (unsigned int)__builtin_amdgcn_readlane((int)incl, 63);
-            const unsigned int total = all < 128u ? all : 128u;
+            const unsigned int total = all < LIM ? all : LIM;
             if (part) marks[P] = 1;
             __builtin_amdgcn_wave_barrier();
-            const unsigned int mk0 = marks[lane], mk1 = marks[lane + 64];
-            const unsigned long long B0 = __ballot(mk0 != 0u), B1 = __ballot(mk1 != 0u);
+            unsigned int mk_[NT];
+            unsigned long long B_[NT];
+#pragma unroll
+            for (int k = 0; k < NT; ++k) { mk_[k] = marks[lane + 64 * k]; B_[k] = __ballot(mk_[k] != 0u); }
             __builtin_amdgcn_wave_barrier();
             if (part) marks[P] = 0;
-            // entry whose triangle range covers position lane (j0) and position lane + 64 (j1): marks at or below the position, minus one
-            // (a mark byte is the lane's own bit of B0 / B1); ds_bpermute takes the source lane as a byte address
-            const int j0 = (lanes_below(B0) + (int)mk0 - 1) << 2;
-            const int j1 = (__popcll(B0) + lanes_below(B1) + (int)mk1 - 1) << 2;
-            const unsigned int f0 = (unsigned int)__builtin_amdgcn_ds_bpermute(j0, (int)E.x), y0 = (unsigned int)__builtin_amdgcn_ds_bpermute(j0, (int)E.y), P0 = (unsigned int)__builtin_amdgcn_ds_bpermute(j0, (int)P);
-            const unsigned int f1 = (unsigned int)__builtin_amdgcn_ds_bpermute(j1, (int)E.x), y1 = (unsigned int)__builtin_amdgcn_ds_bpermute(j1, (int)E.y), P1 = (unsigned int)__builtin_amdgcn_ds_bpermute(j1, (int)P);
-            const bool t0 = (unsigned int)lane < total, t1 = (unsigned int)lane + 64u < total;
-            const unsigned int o0 = y0 & kQSlotMask, o1 = y1 & kQSlotMask;      // the owners' table rows (positions beyond `total` read some entry's row: harmless)
-            int i0 = t0 ? (int)(f0 + ((unsigned int)lane - P0)) : 0, i1 = t1 ? (int)(f1 + ((unsigned int)lane + 64u - P1)) : 0;
-            WQ_CHECK(i0 >= 0 && i0 < sc.n_tris && i1 >= 0 && i1 < sc.n_tris, 2, (i0 = 0, i1 = 0));
+            // entry whose triangle range covers position lane + 64 k: marks at or below the position, minus one (a mark byte is the lane's own bit of B_[k]);
+            // ds_bpermute takes the source lane as a byte address
+            int j_[NT], i_[NT];
+            unsigned int y_[NT], o_[NT];
+            bool t_[NT];
+            int before = 0;
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                j_[k] = (before + lanes_below(B_[k]) + (int)mk_[k] - 1) << 2;
+                before += __popcll(B_[k]);
+                const unsigned int fk = (unsigned int)__builtin_amdgcn_ds_bpermute(j_[k], (int)E.x), Pk = (unsigned int)__builtin_amdgcn_ds_bpermute(j_[k], (int)P);
+                y_[k] = (unsigned int)__builtin_amdgcn_ds_bpermute(j_[k], (int)E.y);
+                t_[k] = (unsigned int)lane + 64u * k < total;
+                o_[k] = y_[k] & kQSlotMask;                           // the owner's table row (positions beyond `total` read some entry's row: harmless)
+                i_[k] = t_[k] ? (int)(fk + ((unsigned int)lane + 64u * k - Pk)) : 0;
+                WQ_CHECK(i_[k] >= 0 && i_[k] < sc.n_tris, 2, i_[k] = 0);
+            }
             WQ_CHECK(ltail - lhead <= (unsigned int)LCAP, 16, (void)0);
-            float4 a0, a1, a2, b0, b1, b2;
-            if (LDSV) {
-                const int4 ia = sc.tidx[i0], ib = sc.tidx[i1];
-                auto record = [&](const int4 ix, float4 &q0, float4 &q1, float4 &q2) {
+            float4 q0_[NT], q1_[NT], q2_[NT];
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                if (LDSV) {
+                    const int4 ix = sc.tidx[i_[k]];
                     const float4 va = lverts[ix.x], vb = lverts[ix.y], vc = lverts[ix.z];
                     const f3 A = mk(va.x, va.y, va.z);
                     const f3 e1 = mk(vb.x, vb.y, vb.z) - A, e2 = mk(vc.x, vc.y, vc.z) - A, N = cross(e1, e2);   // cpu:227-229
-                    q0 = make_float4(A.x, A.y, A.z, e1.x); q1 = make_float4(e1.y, e1.z, e2.x, e2.y); q2 = make_float4(e2.z, N.x, N.y, N.z);
-                };
-                record(ia, a0, a1, a2);
-                record(ib, b0, b1, b2);
-            } else {
-                // 32-bit byte offsets: the loads take the scalar base + vector offset form (n_tris * 48 < 2^32 is checked by the upload)
-                const unsigned char *tb = reinterpret_cast<const unsigned char *>(sc.tri);
-                const float4 *tp0 = reinterpret_cast<const float4 *>(tb + (unsigned int)i0 * 48u), *tp1 = reinterpret_cast<const float4 *>(tb + (unsigned int)i1 * 48u);
-                a0 = tp0[0]; a1 = tp0[1]; a2 = tp0[2];
-                b0 = tp1[0]; b1 = tp1[1]; b2 = tp1[2];
+                    q0_[k] = make_float4(A.x, A.y, A.z, e1.x); q1_[k] = make_float4(e1.y, e1.z, e2.x, e2.y); q2_[k] = make_float4(e2.z, N.x, N.y, N.z);
+                } else {
+                    // 32-bit byte offsets: the loads take the scalar base + vector offset form (n_tris * 48 < 2^32 is checked by the upload)
+                    const float4 *tp = reinterpret_cast<const float4 *>(reinterpret_cast<const unsigned char *>(sc.tri) + (unsigned int)i_[k] * 48u);
+                    q0_[k] = tp[0]; q1_[k] = tp[1]; q2_[k] = tp[2];
+                }
             }
-            const float4 C0 = rowC(o0), C1 = rowC(o1);
-            const float2 D0 = *reinterpret_cast<const float2 *>(&rowD(o0)), D1 = *reinterpret_cast<const float2 *>(&rowD(o1));
-            float ta, tb_;
-            int how0, how1;
-            const bool ok0 = qtri_test(a0, a1, a2, mk(C0.x, C0.y, C0.z), mk(C0.w, D0.x, D0.y), fr.tri_tmin, ta, how0, t0);
-            const bool ok1 = qtri_test(b0, b1, b2, mk(C1.x, C1.y, C1.z), mk(C1.w, D1.x, D1.y), fr.tri_tmin, tb_, how1, t1);
-            if (STATS) {
-                wk.lit_tri += ((t0 && (how0 & 3) == 2) ? 1u : 0u) + ((t1 && (how1 & 3) == 2) ? 1u : 0u);
-                n_tdiv += (__ballot((how0 & 4) != 0) != 0ull ? 1u : 0u) + (__ballot((how1 & 4) != 0) != 0ull ? 1u : 0u);   // division blocks some lane entered
+            float tt_[NT];
+            bool ok_[NT];
+            float4 C_[NT]; float2 D_[NT];
+#pragma unroll
+            for (int k = 0; k < NT; ++k) { C_[k] = rowC(o_[k]); D_[k] = *reinterpret_cast<const float2 *>(&rowD(o_[k])); }
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                int how;
+                ok_[k] = qtri_test(q0_[k], q1_[k], q2_[k], mk(C_[k].x, C_[k].y, C_[k].z), mk(C_[k].w, D_[k].x, D_[k].y), fr.tri_tmin, tt_[k], how, t_[k]);
+                if (STATS) {
+                    wk.lit_tri += (t_[k] && (how & 3) == 2) ? 1u : 0u;
+                    n_tdiv += __ballot((how & 4) != 0) != 0ull ? 1u : 0u;   // division blocks some lane entered
+                }
             }
-            bool ok0_ = ok0, ok1_ = ok1;
             bool xok = true;
             if (QW) {       // a triangle counts only if the reference's test of its leaf's real box says hit: the entry's lane decides, the triangle's lane looks the bit up
                 // cbox_filter on the values ray_box_c formed at hand-off (v_rcp_f32 and the products are deterministic: recomputed, not stored); an undecided
@@ -612,21 +631,24 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
                     }
                 }
                 const unsigned long long mok = __ballot(xok);
-                ok0_ = ok0 && ((mok >> ((unsigned int)(j0 >> 2) & 63u)) & 1ull) != 0ull;
-                ok1_ = ok1 && ((mok >> ((unsigned int)(j1 >> 2) & 63u)) & 1ull) != 0ull;
+#pragma unroll
+                for (int k = 0; k < NT; ++k) ok_[k] = ok_[k] && ((mok >> ((unsigned int)(j_[k] >> 2) & 63u)) & 1ull) != 0ull;
             }
             if (QN && !QW) {       // a triangle accepted in a flagged leaf counts only if the reference's test of the leaf's real box says hit (rare: behind a vote)
-                const bool ch0 = ok0 && (y0 & 1u) != 0u, ch1 = ok1 && (y1 & 1u) != 0u;
-                if (__builtin_expect(__ballot(ch0 || ch1) != 0ull, 0)) {
-                    if (ch0) { const int lf = sc.tri2leaf[i0]; const f3 Or = mk(C0.x, C0.y, C0.z), ur = mk(C0.w, D0.x, D0.y); ok0_ = slab_filtered(sc.nodesq[2 * (size_t)lf], sc.nodesq[2 * (size_t)lf + 1], Or, ur, ray_inv(ur)); }
-                    if (ch1) { const int lf = sc.tri2leaf[i1]; const f3 Or = mk(C1.x, C1.y, C1.z), ur = mk(C1.w, D1.x, D1.y); ok1_ = slab_filtered(sc.nodesq[2 * (size_t)lf], sc.nodesq[2 * (size_t)lf + 1], Or, ur, ray_inv(ur)); }
+                bool ch_[NT], any = false;
+#pragma unroll
+                for (int k = 0; k < NT; ++k) { ch_[k] = ok_[k] && (y_[k] & 1u) != 0u; any = any || ch_[k]; }
+                if (__builtin_expect(__ballot(any) != 0ull, 0)) {
+#pragma unroll
+                    for (int k = 0; k < NT; ++k)
+                        if (ch_[k]) { const int lf = sc.tri2leaf[i_[k]]; const f3 Or = mk(C_[k].x, C_[k].y, C_[k].z), ur = mk(C_[k].w, D_[k].x, D_[k].y); ok_[k] = slab_filtered(sc.nodesq[2 * (size_t)lf], sc.nodesq[2 * (size_t)lf + 1], Or, ur, ray_inv(ur)); }
                 }
             }
-            if (ok0_) atomicMin(best(o0), (unsigned long long)__float_as_uint(ta) << 32 | (unsigned int)i0);
-            if (ok1_) atomicMin(best(o1), (unsigned long long)__float_as_uint(tb_) << 32 | (unsigned int)i1);
-            const bool full = part && (P + c <= 128u || (QW && !xok));   // (QW: a leaf whose real box is missed is done, whatever part of it this step took)
-            if (part && !full) {                                     // at most one entry straddles position 127: keep its rest
-                const unsigned int took = 128u - P;
+#pragma unroll
+            for (int k = 0; k < NT; ++k) if (ok_[k]) atomicMin(best(o_[k]), (unsigned long long)__float_as_uint(tt_[k]) << 32 | (unsigned int)i_[k]);
+            const bool full = part && (P + c <= LIM || (QW && !xok));   // (QW: a leaf whose real box is missed is done, whatever part of it this step took)
+            if (part && !full) {                                     // at most one entry straddles position LIM - 1: keep its rest
+                const unsigned int took = LIM - P;
                 if (QW) leafq[(lhead + (unsigned int)lane) & (LCAP - 1)] = make_uint2(0x80000000u | (c - took) << kQwLeafShift | (E.x + took), (E.y & kQSlotMask) | 1u);
                 else leafq[(lhead + (unsigned int)lane) & (LCAP - 1)] = make_uint2(E.x + took, (E.y & (kQSlotMask | 1u)) | (c - took) << kQLeafShift);
             }
