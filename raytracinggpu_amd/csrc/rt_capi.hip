@@ -36,8 +36,9 @@ struct DevBuf {
 // Tuning / test knobs: environment variables read ONCE, when the context is created (rt_ctx_create).  Defaults are the
 // measured optimum on MI355X; tests create a context under a modified environment to reach the rare code paths.
 struct Knobs {
-    int travq_R = 64;          // RT_TRAVQ_R: ray slots per wave of the work-stack kernel (32 | 64 | 128: two slots per lane, two sibling pairs per lane and BOX step;
-                               // measured 19 % slower per frame than 64 -- 10 waves per CU instead of 16: profiles/round4/ab_128_rays_per_wave.txt)
+    int travq_R = 64;          // RT_TRAVQ_R: ray slots per wave of the work-stack kernel (32 | 64).  (128 -- two slots per lane, two sibling pairs per lane and BOX step -- measured 19 % slower
+                               // per frame: 10 waves per CU instead of 16, profiles/round4/ab_128_rays_per_wave.txt; its instantiations left the library in round 5, the kernel source still
+                               // carries the two-bank form behind R > 64)
     int travq_cap = 0;         // RT_TRAVQ_CAP: stack capacity (>= 128; tests force the serial drain); 0 = the carve's capacity
     int travq_lds = 0;         // RT_TRAVQ_LDS: waves of the ONE workgroup per CU that stages the top of the BVH in LDS; 0 = nodes through L1/L2
     int q_low = 48;            // RT_TRAVQ_LOW: refill while the stack holds fewer sibling pairs than this (measured 1.19 / 1.21 / 1.25 ms per frame for 48 / 64 / 96)
@@ -86,7 +87,7 @@ static Knobs read_knobs() {
     Knobs k;
     auto geti = [](const char *name, int &out) { const char *e = getenv(name); if (e && *e) { out = atoi(e); return true; } return false; };
     int v;
-    if (geti("RT_TRAVQ_R", v) && (v == 32 || v == 64 || v == 128)) k.travq_R = v;
+    if (geti("RT_TRAVQ_R", v) && (v == 32 || v == 64)) k.travq_R = v;
     if (geti("RT_TRAVQ_CAP", v) && v >= 128) k.travq_cap = v;
     if (geti("RT_TRAVQ_LDS", v) && v >= 1 && v <= 16) k.travq_lds = v;
     if (geti("RT_TRAVQ_LOW", v) && v >= 32 && v <= 320) k.q_low = v;
@@ -365,17 +366,15 @@ template <bool S, int R> TravqFn travq_pick(bool ldsn, bool ldsv) {
 TravqFn travq_fn(bool stats, int R, bool ldsn, bool ldsv = false, bool qn = false, bool qw = false) {
     if (qw && R == 64 && !ldsn && !ldsv) return stats ? rtk::wf_travq<true, 64, false, false, true, true> : rtk::wf_travq<false, 64, false, false, true, true>;
     if (qn && !stats && R == 64 && !ldsn && !ldsv) return rtk::wf_travq<false, 64, false, false, true>;
-    if (stats) return R == 32 ? travq_pick<true, 32>(ldsn, ldsv) : R == 128 ? travq_pick<true, 128>(ldsn, ldsv) : travq_pick<true, 64>(ldsn, ldsv);
-    return R == 32 ? travq_pick<false, 32>(ldsn, ldsv) : R == 128 ? travq_pick<false, 128>(ldsn, ldsv) : travq_pick<false, 64>(ldsn, ldsv);
+    if (stats) return R == 32 ? travq_pick<true, 32>(ldsn, ldsv) : travq_pick<true, 64>(ldsn, ldsv);
+    return R == 32 ? travq_pick<false, 32>(ldsn, ldsv) : travq_pick<false, 64>(ldsn, ldsv);
 }
 size_t travq_carve_bytes(int R, bool qw = false) {
     if (qw) return (size_t)rtk::QCarve<64, rtk::kQwStackCap, rtk::kQwLeafCap, rtk::kQwTris>::kBytes;
-    return R == 128 ? (size_t)rtk::QCarve<128, rtk::QStackCap<128>::value, rtk::QLeafCap<128>::value>::kBytes
-         : R == 64 ? (size_t)rtk::QCarve<64, rtk::QStackCap<64>::value, rtk::QLeafCap<64>::value>::kBytes : (size_t)rtk::QCarve<32, rtk::QStackCap<32>::value, rtk::QLeafCap<32>::value>::kBytes;
+    return R == 64 ? (size_t)rtk::QCarve<64, rtk::QStackCap<64>::value, rtk::QLeafCap<64>::value>::kBytes : (size_t)rtk::QCarve<32, rtk::QStackCap<32>::value, rtk::QLeafCap<32>::value>::kBytes;
 }
-int travq_stack_cap(int R, bool qw = false) { return qw ? rtk::kQwStackCap : R == 128 ? rtk::QStackCap<128>::value : R == 64 ? rtk::QStackCap<64>::value : rtk::QStackCap<32>::value; }
-int travq_block_threads(int R) { return R == 128 ? 128 : rtk::kQBlock;   // 128 resident rays per wave: 16 KB of LDS per wave, two-wave workgroups (five fit a CU)
-}
+int travq_stack_cap(int R, bool qw = false) { return qw ? rtk::kQwStackCap : R == 64 ? rtk::QStackCap<64>::value : rtk::QStackCap<32>::value; }
+int travq_block_threads(int) { return rtk::kQBlock; }
 
 // Camera::rotate(), realtime_render.cu:823-846 (host code there too: float cos/sin/sqrt)
 void camera_basis(float yaw, float pitch, float bx[3], float by[3], float bz[3]) {

@@ -331,7 +331,7 @@ def test_config2_spheres_only_full_size(ctx, oracle, cat_golden):
     assert int(got[..., 3].astype(np.float64).sum()) == cnt["rays"]
 
 
-@pytest.mark.parametrize("env", [{"RT_TRAVQ_CAP": "128"}, {"RT_TRAVQ_R": "32"}, {"RT_TRAVQ_R": "32", "RT_TRAVQ_CAP": "128"}, {"RT_TRAVQ_R": "128"}, {"RT_TRAVQ_R": "128", "RT_TRAVQ_CAP": "256"},
+@pytest.mark.parametrize("env", [{"RT_TRAVQ_CAP": "128"}, {"RT_TRAVQ_R": "32"}, {"RT_TRAVQ_R": "32", "RT_TRAVQ_CAP": "128"},
                                  {"RT_TRAVQ_LDS": "12"}, {"RT_TRAVQ_LDS": "12", "RT_TRAVQ_R": "32"}, {"RT_TRAVQ_LDS": "16"},
                                  {"RT_TRAVQ_LDS": "8", "RT_TRAVQ_CAP": "128"}, {"RT_TRAVQ_QW": "0", "RT_TRAVQ_Q16": "1"}, {"RT_TRAVQ_QW": "0", "RT_TRAVQ_Q16": "1", "RT_TRAVQ_CAP": "128"},
                                  {"RT_TRAVQ_QW": "0"}, {"RT_TRAVQ_QW": "0", "RT_TRAVQ_CAP": "128"}, {"RT_TRAVQ_QW": "1"}, {"RT_TRAVQ_QW": "1", "RT_TRAVQ_CAP": "128"}])
