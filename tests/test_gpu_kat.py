@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 import raytracinggpu_amd as rt
+from raytracinggpu_amd import hostlib
 from .conftest import load_golden
 
 pytestmark = pytest.mark.gpu
@@ -253,6 +254,60 @@ def test_degenerate_rays_through_the_fixed_point_box_step(oracle, oracle_cat, ca
         c.scene_upload(rt.scenes.spheres("cpu"), mesh)
         _check_degenerate(c, oracle_cat, "wavefront_queue")
         c.close()
+
+
+def _grazing_rays(arr, rng, n):
+    """Rays aimed at points ON the faces, edges and corners of leaf boxes (exact float coordinates of the tree's own bounds), from origins all around: the rays for which a box test
+    decides by its last bits -- where a fixed-point box rounded outwards and the reference's test of the real box part company.  Half of them are normalised, the others are not."""
+    leaves = arr[arr[:, 0] < 0]
+    pick = leaves[rng.integers(0, len(leaves), n)]
+    lo, hi = pick[:, 2:5], pick[:, 5:8]
+    w = rng.integers(0, 3, (n, 3))                                     # per axis: 0 = lo face, 1 = hi face, 2 = somewhere between
+    tt = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    target = np.where(w == 0, lo, np.where(w == 1, hi, lo + tt * (hi - lo))).astype(np.float32)
+    O = (target + rng.normal(size=(n, 3)).astype(np.float32) * np.float32(25.0)).astype(np.float32)
+    u = (target - O).astype(np.float32)
+    nrm = np.linalg.norm(u, axis=1, keepdims=True).astype(np.float32)
+    u[: n // 2] = (u[: n // 2] / nrm[: n // 2]).astype(np.float32)
+    k = rng.integers(0, 3, n // 8)                                     # some exactly axis-parallel ones along a face
+    idx = rng.integers(0, n, n // 8)
+    u[idx, k] = 0.0
+    return np.concatenate([O, u], axis=1).astype(np.float32)
+
+
+@pytest.mark.parametrize("kind", ["cat", "soup", "axis_aligned_quads", "geometric_chain"])
+def test_rays_grazing_leaf_boxes_through_every_box_step_form(oracle, cat_golden, monkeypatch, kind):
+    """The 4-wide BOX step and the fixed-point pairs decide internal nodes on boxes rounded OUTWARDS and leaves by the reference's own test of the real box (round 5: per leaf entry in the
+    TRI step; round 4: per accepted triangle of a flagged leaf).  4 000 rays through points on the faces, edges and corners of the tree's own leaf boxes -- the band in which the two box
+    tests disagree -- must give the oracle's TriangleMesh::intersect bit for bit through the production launches of all three forms (and the float pairs, which have no such band)."""
+    from .test_gpu_parity import _synthetic_mesh
+    rng = np.random.default_rng(77)
+    if kind == "cat":
+        v, t = np.array(cat_golden["vertices"], np.float32), np.array(cat_golden["tri_obj_order"], np.int32)
+    else:
+        v, t = _synthetic_mesh(kind, rng)
+    mesh = hostlib.build_mesh(v, t, albedo=rt.scenes.CAT_ALBEDO, object_slot=6)
+    om = oracle.Mesh.from_arrays(v, t).build_bvh()
+    rays = _grazing_rays(np.asarray(mesh["bvh_arr10"], np.float32), rng, 4000)
+    exp = np.zeros((len(rays), 5), np.float32)
+    for i in range(len(rays)):
+        h, tt, N = om.intersect(rays[i, :3], rays[i, 3:], 1e-4)
+        exp[i, 0] = 1.0 if h else 0.0
+        exp[i, 1] = tt; exp[i, 2:5] = N
+    modes = {}
+    for env, want in (({"RT_TRAVQ_QW": "1"}, 2), ({"RT_TRAVQ_QW": "0", "RT_TRAVQ_Q16": "1"}, 1), ({"RT_TRAVQ_QW": "0", "RT_TRAVQ_Q16": "0"}, 0)):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        c = rt.Context(0)
+        for k_ in env:
+            monkeypatch.delenv(k_)
+        c.scene_upload(rt.scenes.spheres("cpu"), mesh)
+        hit = _check_mesh_rows(c.trace_rays(rays, 1e-4, "wavefront_queue"), exp)
+        modes[want] = c.stats_after_render(rt.make_params(64, 64, 1, 0, **rt.scenes.CPU_LAUNCHER))["travq_mode"]
+        c.close()
+    assert hit.sum() > 50 and (~hit).sum() > 50
+    if kind == "cat":
+        assert modes == {2: 2, 1: 1, 0: 0}                              # the cat's tree takes every form (trees that do not nest, or with leaves above 127 triangles, fall back to the pairs)
 
 
 def test_trace_rays_error_paths_and_empty_scene(ctx):
