@@ -74,7 +74,7 @@ constexpr int kQwTris = RT_TRAVQ_QW_TRIS;      // triangles per lane and TRI ste
 //   O = (fl(O.x / u.x) .., int: outstanding stack + leaf-queue entries)      BOX step (the counter shares the row: no address arithmetic)
 //   C = (O.xyz, u.x)                                                         TRI step, literal box test
 //   D = (u.y, u.z, u64: nearest accepted hit)                                TRI step
-template <int R, int SCAP, int LCAP, int NT = 2> struct QCarve {
+template <int R, int SCAP, int LCAP, int NT = 2, bool TABE = false> struct QCarve {
     static constexpr int kTabA = 0;
     static constexpr int kTabO = kTabA + 16 * R;
     static constexpr int kTabC = kTabO + 16 * R;
@@ -83,7 +83,8 @@ template <int R, int SCAP, int LCAP, int NT = 2> struct QCarve {
     static constexpr int kStack = kMarks + 64 * NT;       // u32[SCAP]
     static constexpr int kLeaf = kStack + 4 * SCAP;       // uint2[LCAP]: (first triangle, count << 11 | slot << 4 | flag)
     static constexpr int kStage = kLeaf + 8 * LCAP;       // u8[64]: lanes whose registers hold a fetched ray record that has no slot yet
-    static constexpr int kBytes = kStage + 64;
+    static constexpr int kTabE = kStage + 64;             // QW: a fifth table, (1/u.xyz by v_rcp_f32, c0) in WORLD units: what the exact leaf test of a TRI step takes (tables A / O are in grid units)
+    static constexpr int kBytes = kTabE + (TABE ? 16 * R : 0);
     static_assert(kBytes % 16 == 0 && kLeaf % 8 == 0 && kStack % 4 == 0, "the next wave's float4 tables start at kBytes");
 };
 
@@ -287,7 +288,7 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
     constexpr int SCAP = QW ? kQwStackCap : QStackCap<R>::value, LCAP = QW ? kQwLeafCap : QLeafCap<R>::value;
     constexpr int NB = R > 64 ? 2 : 1;                      // ray slots per lane ("banks"): lane l owns slots l and, with 128 resident rays, l + 64
     constexpr int NT = QW ? kQwTris : 2;                    // triangles per lane and TRI step
-    using Carve = QCarve<R, SCAP, LCAP, NT>;
+    using Carve = QCarve<R, SCAP, LCAP, NT, QW>;
     static_assert(R <= 128 && (R & (R - 1)) == 0, "ray slots are owned by lanes: one per lane, or two");
     extern __shared__ __attribute__((aligned(16))) unsigned char travq_smem[];
     const int tid = threadIdx.x;
@@ -307,6 +308,7 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
     auto rowO = [&](unsigned int sb) -> float4 & { return *reinterpret_cast<float4 *>(wl + Carve::kTabO + sb); };
     auto rowC = [&](unsigned int sb) -> float4 & { return *reinterpret_cast<float4 *>(wl + Carve::kTabC + sb); };
     auto rowD = [&](unsigned int sb) -> float4 & { return *reinterpret_cast<float4 *>(wl + Carve::kTabD + sb); };
+    auto rowE = [&](unsigned int sb) -> float4 & { return *reinterpret_cast<float4 *>(wl + Carve::kTabE + sb); };
     auto pend = [&](unsigned int sb) -> int * { return reinterpret_cast<int *>(wl + Carve::kTabO + sb + 12); };
     auto best = [&](unsigned int sb) -> unsigned long long * { return reinterpret_cast<unsigned long long *>(wl + Carve::kTabD + sb + 8); };
     const unsigned int my_sb0 = (unsigned int)lane << 4;           // lane l owns ray slot l (bank 0) and l + 64 (bank 1, R = 128): row offsets
@@ -486,6 +488,7 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
                                 const float tm = vmax3(fmaf(0x1p17f, fabsf(qrx), fabsf(qox)), fmaf(0x1p17f, fabsf(qry), fabsf(qoy)), fmaf(0x1p17f, fabsf(qrz), fabsf(qoz)));
                                 aw = fmaf(tm, 2.f * kRel * (1.f + 0x1p-10f), aw);
                             }
+                            if (QW) rowE(sbk) = make_float4(rb.rx, rb.ry, rb.rz, rb.c0);
                             rowA(sbk) = make_float4(qrx, qry, qrz, aw);
                             rowO(sbk) = make_float4(qox, qoy, qoz, __int_as_float(work ? 1 : 0));
                         } else {
@@ -544,13 +547,12 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
             if ((unsigned int)lane < m) E = leafq[(lhead + (unsigned int)lane) & (LCAP - 1)];
             // QW: the reference's test of the entry's REAL leaf box (one entry per lane, loads in flight beside the triangle loads below); bit 0 of the
             // entry = already decided (the rest of a leaf an earlier step cut in two)
-            float4 xc = make_float4(0, 0, 0, 0), xh = xc, xC = xc; float2 xD = make_float2(0, 0); float xc0 = 0.f;
+            float4 xc = make_float4(0, 0, 0, 0), xh = xc, xC = xc, xR = xc;
             if (QW) {
                 const unsigned int xf = E.x & ((1u << kQwLeafShift) - 1u);
                 WQ_CHECK((int)xf >= 0 && (int)xf < sc.n_tris, 2, (void)0);
                 xc = sc.leafbox[2 * (size_t)xf]; xh = sc.leafbox[2 * (size_t)xf + 1];      // (centre, half extent) of the real box, as the pair kernel's filter takes them
-                xC = rowC(E.y & kQSlotMask); xD = *reinterpret_cast<const float2 *>(&rowD(E.y & kQSlotMask));
-                xc0 = 0.25f * rowA(E.y & kQSlotMask).w;                                      // at least the slot's c0 (the row keeps 4 c0 + the ray's band term: a wider band decides less often, never wrongly)
+                xC = rowC(E.y & kQSlotMask); xR = rowE(E.y & kQSlotMask);                    // the slot's (O, u.x) and (1 / u, c0): what ray_box_c formed at hand-off
             }
             const unsigned int c = QW ? (E.x >> kQwLeafShift) & 0x7fu : E.y >> kQLeafShift;               // >= 1 for queued entries, 0 beyond them (QW: the entry is (payload word, slot << 4 | decided))
             if (QW) E.x &= (1u << kQwLeafShift) - 1u;
@@ -618,21 +620,21 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
             if (QW) {       // a triangle counts only if the reference's test of its leaf's real box says hit: the entry's lane decides, the triangle's lane looks the bit up
                 // cbox_filter on the values ray_box_c formed at hand-off (v_rcp_f32 and the products are deterministic: recomputed, not stored); an undecided
                 // lane -- almost never -- takes the literal test on the (lo, hi) copy of its leaf
-                const float xrx = __builtin_amdgcn_rcpf(xC.w), xry = __builtin_amdgcn_rcpf(xD.x), xrz = __builtin_amdgcn_rcpf(xD.y);
                 bool xhit, xmiss;
-                cbox_filter(xc, xh, make_float4(xrx, xry, xrz, xc0), make_float4(xC.x * xrx, xC.y * xry, xC.z * xrz, 0.f), xhit, xmiss);
+                cbox_filter(xc, xh, xR, make_float4(xC.x * xR.x, xC.y * xR.y, xC.z * xR.z, 0.f), xhit, xmiss);   // o = fl(O r): the product ray_box_c formed
                 const bool xdone = (E.y & 1u) != 0u;
                 xok = xdone || xhit;
                 if (__builtin_expect(__ballot((unsigned int)lane < m && !xdone && !xhit && !xmiss) != 0ull, 0)) {
                     if ((unsigned int)lane < m && !xdone && !xhit && !xmiss) {
                         const int lf = sc.tri2leaf[E.x];
+                        const float4 xD = rowD(E.y & kQSlotMask);
                         xok = slab(sc.nodesq[2 * (size_t)lf], sc.nodesq[2 * (size_t)lf + 1], mk(xC.x, xC.y, xC.z), mk(xC.w, xD.x, xD.y));
                         if (STATS) wk.lit_box++;
                     }
                 }
-                const unsigned long long mok = __ballot(xok);
+                const int xbit = xok ? 1 : 0;                        // handed to the triangles' lanes the way their entry's words were: one LDS permute each
 #pragma unroll
-                for (int k = 0; k < NT; ++k) ok_[k] = ok_[k] && ((mok >> ((unsigned int)(j_[k] >> 2) & 63u)) & 1ull) != 0ull;
+                for (int k = 0; k < NT; ++k) { const int xb = __builtin_amdgcn_ds_bpermute(j_[k], xbit); ok_[k] = ok_[k] && xb != 0; }   // (the permute with every lane active: a masked-off source lane reads as 0)
             }
             if (QN && !QW) {       // a triangle accepted in a flagged leaf counts only if the reference's test of the leaf's real box says hit (rare: behind a vote)
                 bool ch_[NT], any = false;
