@@ -46,8 +46,8 @@ struct Knobs {
                                // -1 (default) = for trees of at least kQ16AutoNodes nodes, 0 = never, 1 = always.  Bit-exact either way; on the cat (2 019 nodes, L1-resident) it measures
                                // +-0 once every leaf decision is exact (profiles/round4/ab_fixed_point_pairs.txt), on 55 000 / 533 000 nodes -8 % / -18 % per frame (big_mesh_bench.txt)
     int qw = -1;               // RT_TRAVQ_QW: the BOX step is four boxes wide (fixed-point quads: the children of both nodes of a sibling pair in 64 bytes, every other level of the tree
-                               // skipped; exact leaf decisions in the TRI step; rt_travq.hip.h, QW).  -1 (default) = 1 = on where the tree allows the format (boxes nest, leaves of
-                               // at most 127 triangles, fewer than 2^21 nodes), 0 = off.  Bit-exact either way; cat 1920x1080: 0.934 -> 0.887 ms per frame (profiles/round5/ab_wide_nodes.txt)
+                               // skipped; leaves flagged and decided as the fixed-point pairs decide them; rt_travq.hip.h, QW).  -1 (default) = 1 = on where the tree allows the format (boxes nest, leaves of
+                               // at most 127 triangles, fewer than 2^21 nodes), 0 = off.  Bit-exact either way; cat 1920x1080: 0.934 -> 0.861 ms per frame (profiles/round5/ab_wide_nodes.txt)
     int qw_count = 0;          // RT_TRAVQ_QW_COUNT=1: rt_count_work runs the 4-wide kernel's counting instantiation (its own step counters; the box / node counts then describe
                                // THAT kernel, not the reference's traversal)
     float lbvh_ct = 0.f;       // RT_LBVH_CT: cost of a triangle test relative to a box test in the LBVH's leaf cut (0 = kLbvhCt)
@@ -142,7 +142,7 @@ struct rt_ctx {
     rt_build_stats build{};                                          // what the last rt_mesh_rebuild_mode did
     int n_levels = 0;
     DevBuf nodesh, tri2leaf;                                        // 16-bit fixed-point sibling pairs and the triangle -> leaf table (rt_qnodes.hip.h)
-    DevBuf nodesw, leafbox;                                         // 4-wide fixed-point nodes and the leaves' real boxes by first triangle (RT_TRAVQ_QW)
+    DevBuf nodesw;                                                  // 4-wide fixed-point nodes (RT_TRAVQ_QW)
     int travq_blocks_per_cu_qw[2] = {0, 0};                         // [STATS]
     unsigned chain_nonce[8] = {};                                   // launch chains started so far, PER SUB-FRAME (WfState::nonce): every part owns its own region of the ray queue, so each
                                                                     // region must cycle through all four values (one context-wide counter gave a part only two of them with two parts: ADVICE round 4)
@@ -370,7 +370,7 @@ TravqFn travq_fn(bool stats, int R, bool ldsn, bool ldsv = false, bool qn = fals
     return R == 32 ? travq_pick<false, 32>(ldsn, ldsv) : travq_pick<false, 64>(ldsn, ldsv);
 }
 size_t travq_carve_bytes(int R, bool qw = false) {
-    if (qw) return (size_t)rtk::QCarve<64, rtk::kQwStackCap, rtk::kQwLeafCap, rtk::kQwTris, true>::kBytes;
+    if (qw) return (size_t)rtk::QCarve<64, rtk::kQwStackCap, rtk::kQwLeafCap, rtk::kQwTris>::kBytes;
     return R == 64 ? (size_t)rtk::QCarve<64, rtk::QStackCap<64>::value, rtk::QLeafCap<64>::value>::kBytes : (size_t)rtk::QCarve<32, rtk::QStackCap<32>::value, rtk::QLeafCap<32>::value>::kBytes;
 }
 int travq_stack_cap(int R, bool qw = false) { return qw ? rtk::kQwStackCap : R == 64 ? rtk::QStackCap<64>::value : rtk::QStackCap<32>::value; }
@@ -1033,30 +1033,25 @@ constexpr int kQ16AutoNodes = 16384;                                 // RT_TRAVQ
 // get later, profiles/round3/ab_hw_queues_parts.log), joined before returning.  ctx->scene must be final (root box, node arrays); trees the format does not fit keep scene.nodesh = nullptr.
 int requantize(rt_ctx *ctx, hipStream_t q) {
     rtk::Scene &sc = ctx->scene;
-    sc.nodesh = nullptr; sc.tri2leaf = nullptr; sc.nodesw = nullptr; sc.leafbox = nullptr;
-    // (automatic only below kQ16AutoNodes: on trees that no longer sit in the caches the 4-wide step LOSES to the fixed-point pairs -- 358 503 nodes: 3.65 vs 2.77 ms per frame, the
-    // leaves' real boxes are one more scattered 32-byte gather per TRI-step entry: profiles/round5/ab_wide_nodes.txt)
-    const bool want_qw = (ctx->knobs.qw == 1 || (ctx->knobs.qw < 0 && sc.n_nodes < kQ16AutoNodes)) && ctx->q16_leaf_shift == 24 && sc.n_nodes + 2 < (1 << 21);   // the quad's payload word: leaves of <= 127 triangles, child << 10 positive
+    sc.nodesh = nullptr; sc.tri2leaf = nullptr; sc.nodesw = nullptr;
+    // (wherever the format fits: with flagged leaves the 4-wide step beats the fixed-point pairs on every tree measured -- 2 019 nodes -8 %, 32 889 -9 %, 358 503 -12 %: profiles/round5/ab_wide_nodes.txt)
+    const bool want_qw = ctx->knobs.qw != 0 && ctx->q16_leaf_shift == 24 && sc.n_nodes + 2 < (1 << 21);   // the quad's payload word: leaves of <= 127 triangles, child << 10 positive
     if (!(ctx->knobs.q16 == 1 || (ctx->knobs.q16 < 0 && sc.n_nodes >= kQ16AutoNodes) || want_qw) || !ctx->q16_topo_ok || ctx->q16_leaf_shift == 0 || !ctx->travq_ok || !sc.fast_box || sc.mesh_slot < 0 || sc.n_nodes < 3 || sc.n_tris <= 0) return RT_OK;
     int rc;
     if ((rc = ensure(ctx, ctx->nodesh, ((size_t)sc.n_nodes + 2) * 16)) != RT_OK || (rc = ensure(ctx, ctx->tri2leaf, (size_t)sc.n_tris * sizeof(int))) != RT_OK) return rc;
     const rtk::QGrid g = rtk::q16_grid(sc.root_lo, sc.root_hi);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipMemsetAsync(ctx->nodesh.p, 0, 32, q));            // nodes 0 (padding) and 1 (the root: tested when a ray is emitted)
-    if (want_qw) {
-        if ((rc = ensure(ctx, ctx->nodesw, ((size_t)sc.n_nodes + 4) * 32)) != RT_OK || (rc = ensure(ctx, ctx->leafbox, (size_t)sc.n_tris * 32)) != RT_OK) return rc;
-        RT_HIP(ctx, hipMemsetAsync(ctx->leafbox.p, 0, (size_t)sc.n_tris * 32, q));
-    }
+    if (want_qw && (rc = ensure(ctx, ctx->nodesw, ((size_t)sc.n_nodes + 4) * 32)) != RT_OK) return rc;
     hipLaunchKernelGGL(rtk::qnodes_kernel, dim3((unsigned)((sc.n_nodes + 255) / 256)), dim3(256), 0, q, sc.nodesq, sc.nodesb, sc.n_nodes, g,
-                       static_cast<uint4 *>(ctx->nodesh.p), static_cast<int *>(ctx->tri2leaf.p), sc.n_tris, rtk::kQLeafShift, ctx->q16_leaf_shift,
-                       want_qw ? static_cast<float4 *>(ctx->leafbox.p) : nullptr);
+                       static_cast<uint4 *>(ctx->nodesh.p), static_cast<int *>(ctx->tri2leaf.p), sc.n_tris, rtk::kQLeafShift, ctx->q16_leaf_shift);
     if (want_qw)
         hipLaunchKernelGGL(rtk::qquads_kernel, dim3((unsigned)((sc.n_nodes / 2 + 1 + 255) / 256)), dim3(256), 0, q, static_cast<const uint4 *>(ctx->nodesh.p), sc.n_nodes,
                            rtk::kQNodeShift, ctx->q16_leaf_shift, static_cast<uint4 *>(ctx->nodesw.p));
     RT_HIP(ctx, hipGetLastError());
     RT_HIP(ctx, hipStreamSynchronize(q));
     sc.nodesh = static_cast<const uint4 *>(ctx->nodesh.p); sc.tri2leaf = static_cast<const int *>(ctx->tri2leaf.p);
-    if (want_qw) { sc.nodesw = static_cast<const uint4 *>(ctx->nodesw.p); sc.leafbox = static_cast<const float4 *>(ctx->leafbox.p); }
+    if (want_qw) sc.nodesw = static_cast<const uint4 *>(ctx->nodesw.p);
     sc.qgx = g.gx; sc.qgy = g.gy; sc.qgz = g.gz; sc.qsx = g.sx; sc.qsy = g.sy; sc.qsz = g.sz; sc.qleaf_shift = ctx->q16_leaf_shift;
     return RT_OK;
 }
@@ -1321,7 +1316,7 @@ int rt_ctx_destroy(rt_ctx *ctx) {
         if (ctx->slot_rendered[k]) (void)hipEventDestroy(ctx->slot_rendered[k]);
         if (ctx->slot_done[k]) (void)hipEventDestroy(ctx->slot_done[k]);
     }
-    ctx->node_lo.release(); ctx->node_hi.release(); ctx->nodes2.release(); ctx->nodesq.release(); ctx->nodesb.release(); ctx->nodesh.release(); ctx->tri2leaf.release(); ctx->nodesw.release(); ctx->leafbox.release(); ctx->q2thr.release(); ctx->left_dev.release(); ctx->lvl_nodes.release(); ctx->lvl_off.release(); ctx->nrm.release(); ctx->tri.release(); ctx->verts.release(); ctx->tidx.release();
+    ctx->node_lo.release(); ctx->node_hi.release(); ctx->nodes2.release(); ctx->nodesq.release(); ctx->nodesb.release(); ctx->nodesh.release(); ctx->tri2leaf.release(); ctx->nodesw.release(); ctx->q2thr.release(); ctx->left_dev.release(); ctx->lvl_nodes.release(); ctx->lvl_off.release(); ctx->nrm.release(); ctx->tri.release(); ctx->verts.release(); ctx->tidx.release();
     ctx->scratch_rgba.release(); ctx->scratch_rgb8.release(); ctx->work.release(); ctx->queue.release();
     ctx->wfM.release(); ctx->wfT.release(); ctx->wfLS.release(); ctx->wfSID.release(); ctx->wfSamp.release();
     ctx->wfQR.release(); ctx->accum.release(); ctx->dbgbuf.release();

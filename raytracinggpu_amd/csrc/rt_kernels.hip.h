@@ -61,7 +61,6 @@ struct Scene {
     const int *tri2leaf;      // triangle (visit order) -> breadth-first index of its leaf (the exact box of a flagged leaf: rt_qnodes.hip.h)
     const uint4 *nodesw;      // 4-wide fixed-point nodes (rt_travq.hip.h, QW): for the sibling pair (c, c + 1) the 64 bytes at byte offset 32 c hold the nodesh records of
                               // c's children and (c + 1)'s children (a leaf of the pair stands for itself, the free place is an empty leaf); nullptr = not in use
-    const float4 *leafbox;    // QW: (centre, half extent) of a leaf -- its nodesb record -- at [2 f], [2 f + 1], f = the leaf's first triangle (visit order): the exact box test of a leaf entry needs no index but the entry's own
     float qgx, qgy, qgz;      // grid origin (the root box's lower corner) and cell size per axis
     float qsx, qsy, qsz;
     int qleaf_shift;          // a leaf's payload word in nodesh = 1 << 31 | count << qleaf_shift | first triangle (20 or 24: rt_qnodes.hip.h)

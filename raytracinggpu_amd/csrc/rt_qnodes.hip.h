@@ -56,8 +56,7 @@ __device__ __forceinline__ void q16_axis(float lo, float hi, float g, float s, u
 
 // one thread per breadth-first node b in [1, n_bfs]: nodesq[2b], [2b+1] = (lo, hi) of the node, nodesb[2b].w / [2b+1].w = payload / kind as wf_travq carries them
 __global__ __launch_bounds__(256) void qnodes_kernel(const float4 *__restrict__ nodesq, const float4 *__restrict__ nodesb, int n_bfs, QGrid g,
-                                                     uint4 *__restrict__ nodesh, int *__restrict__ tri2leaf, int n_tris, int leaf_kind_shift, int leaf_shift,
-                                                     float4 *__restrict__ leafbox) {
+                                                     uint4 *__restrict__ nodesh, int *__restrict__ tri2leaf, int n_tris, int leaf_kind_shift, int leaf_shift) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x + 1;
     if (b > n_bfs) return;
     const float4 lo = nodesq[2 * (size_t)b], hi = nodesq[2 * (size_t)b + 1];
@@ -73,7 +72,6 @@ __global__ __launch_bounds__(256) void qnodes_kernel(const float4 *__restrict__ 
         const int cnt = kind >> leaf_kind_shift, first = (int)payload;
         pay = 0x80000000u | (unsigned int)cnt << leaf_shift | (unsigned int)first;
         for (int t = 0; t < cnt; ++t) if (first + t < n_tris) tri2leaf[first + t] = b;
-        if (leafbox && cnt > 0 && first >= 0 && first < n_tris) { leafbox[2 * (size_t)first] = nodesb[2 * (size_t)b]; leafbox[2 * (size_t)first + 1] = nodesb[2 * (size_t)b + 1]; }   // QW: the real box (centre, half extent), by first triangle
     }
     nodesh[b] = make_uint4(cx | cy << 16, cz | hx << 16, hy | hz << 16, pay);
 }

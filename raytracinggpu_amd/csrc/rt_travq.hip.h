@@ -74,7 +74,7 @@ constexpr int kQwTris = RT_TRAVQ_QW_TRIS;      // triangles per lane and TRI ste
 //   O = (fl(O.x / u.x) .., int: outstanding stack + leaf-queue entries)      BOX step (the counter shares the row: no address arithmetic)
 //   C = (O.xyz, u.x)                                                         TRI step, literal box test
 //   D = (u.y, u.z, u64: nearest accepted hit)                                TRI step
-template <int R, int SCAP, int LCAP, int NT = 2, bool TABE = false> struct QCarve {
+template <int R, int SCAP, int LCAP, int NT = 2> struct QCarve {
     static constexpr int kTabA = 0;
     static constexpr int kTabO = kTabA + 16 * R;
     static constexpr int kTabC = kTabO + 16 * R;
@@ -83,8 +83,7 @@ template <int R, int SCAP, int LCAP, int NT = 2, bool TABE = false> struct QCarv
     static constexpr int kStack = kMarks + 64 * NT;       // u32[SCAP]
     static constexpr int kLeaf = kStack + 4 * SCAP;       // uint2[LCAP]: (first triangle, count << 11 | slot << 4 | flag)
     static constexpr int kStage = kLeaf + 8 * LCAP;       // u8[64]: lanes whose registers hold a fetched ray record that has no slot yet
-    static constexpr int kTabE = kStage + 64;             // QW: a fifth table, (1/u.xyz by v_rcp_f32, c0) in WORLD units: what the exact leaf test of a TRI step takes (tables A / O are in grid units)
-    static constexpr int kBytes = kTabE + (TABE ? 16 * R : 0);
+    static constexpr int kBytes = kStage + 64;
     static_assert(kBytes % 16 == 0 && kLeaf % 8 == 0 && kStack % 4 == 0, "the next wave's float4 tables start at kBytes");
 };
 
@@ -115,6 +114,13 @@ __device__ __forceinline__ int lane_count4_minus(unsigned long long m0, unsigned
         "v_addc_co_u32_e64 %0, vcc, 0, %0, %3\n\tv_addc_co_u32_e64 %0, vcc, 0, %0, %4"
         : "=&v"(d) : "s"(m0), "s"(m1), "s"(m2), "s"(m3), "s"(act) : "vcc");
     return d;
+}
+
+// x | 1 in the lanes of m (bit 0 of x clear): the mask enters as the carry-in of one add
+__device__ __forceinline__ unsigned int or_bit0(unsigned int x, unsigned long long m) {
+    unsigned int r;
+    asm("v_addc_co_u32_e64 %0, vcc, 0, %1, %2" : "=v"(r) : "v"(x), "s"(m) : "vcc");
+    return r;
 }
 
 // the same over eight masks (the 4-wide BOX step: four internal and four leaf masks)
@@ -276,10 +282,12 @@ __device__ __forceinline__ bool qtri_test(const float4 q0, const float4 q1, cons
 // loads a step of the float pairs issues -- tests the four boxes and pushes one entry per hit internal grandchild: every other level of the tree is
 // never tested, a ray's chain of dependent steps is half as long and a frame runs half as many BOX steps.  Exactness: the fixed-point boxes contain the
 // real ones and the reference's test is monotone along nested boxes (rt_qnodes.hip.h), so the leaves the reference reaches are exactly the leaves whose
-// OWN box its test hits; here every leaf entry meets the reference's test of its real box (sc.leafbox, indexed by the leaf's first triangle: cbox_filter, the
-// literal slab behind a vote) in the TRI step that consumes it -- one test per ENTRY, beside the triangle loads, for every entry: no flags, no second threshold in
-// the BOX step -- and a triangle accepted in a leaf counts only if that test says hit.  Work counters of this instantiation differ from the oracle's by construction (no test
-// of the skipped level, a superset of internal nodes entered): the counter tests use the binary instantiation, this one is held to frames and ray counts.
+// OWN box its test hits.  Leaves are decided as the fixed-point pairs decide them: a leaf hit by more than the boxes' enlargement (one threshold per RAY: its band + six
+// cells along its steepest axis) is hit by the reference; a leaf in between is queued with a flag, and a triangle ACCEPTED in a flagged leaf counts only if the
+// reference's own test of the leaf's real box (slab_filtered on its (lo, hi) record, behind a vote: a few steps in a hundred) says hit.  (The first versions tested the
+// real box of EVERY leaf entry in the TRI step, two gathers and 26 vector instructions per step: 8 % of the cat's frame and a third of a frame of 524 288 triangles,
+// profiles/round5/ab_wide_nodes.txt.)  Work counters of this instantiation differ from the oracle's by construction (no test of the skipped level, a superset of
+// internal nodes entered): the counter tests use the binary instantiation, this one is held to frames and ray counts.
 template <bool STATS, int R, bool LDSN, bool LDSV, bool QN = false, bool QW = false>
 __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || kQBlock != 256 || QPairs<R>::value > 1 || (QW && kQwTris > 2)) ? 4 : 5) void wf_travq(const Scene sc, const Frame fr, const WfState st, const int cap, const int n_lds, const int kLow, const int kMinFree) {
     // kLow: refill while the stack holds fewer entries (sibling pairs) than this (default 48); kMinFree: ... and at least this
@@ -288,7 +296,7 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
     constexpr int SCAP = QW ? kQwStackCap : QStackCap<R>::value, LCAP = QW ? kQwLeafCap : QLeafCap<R>::value;
     constexpr int NB = R > 64 ? 2 : 1;                      // ray slots per lane ("banks"): lane l owns slots l and, with 128 resident rays, l + 64
     constexpr int NT = QW ? kQwTris : 2;                    // triangles per lane and TRI step
-    using Carve = QCarve<R, SCAP, LCAP, NT, QW>;
+    using Carve = QCarve<R, SCAP, LCAP, NT>;
     static_assert(R <= 128 && (R & (R - 1)) == 0, "ray slots are owned by lanes: one per lane, or two");
     extern __shared__ __attribute__((aligned(16))) unsigned char travq_smem[];
     const int tid = threadIdx.x;
@@ -308,7 +316,6 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
     auto rowO = [&](unsigned int sb) -> float4 & { return *reinterpret_cast<float4 *>(wl + Carve::kTabO + sb); };
     auto rowC = [&](unsigned int sb) -> float4 & { return *reinterpret_cast<float4 *>(wl + Carve::kTabC + sb); };
     auto rowD = [&](unsigned int sb) -> float4 & { return *reinterpret_cast<float4 *>(wl + Carve::kTabD + sb); };
-    auto rowE = [&](unsigned int sb) -> float4 & { return *reinterpret_cast<float4 *>(wl + Carve::kTabE + sb); };
     auto pend = [&](unsigned int sb) -> int * { return reinterpret_cast<int *>(wl + Carve::kTabO + sb + 12); };
     auto best = [&](unsigned int sb) -> unsigned long long * { return reinterpret_cast<unsigned long long *>(wl + Carve::kTabD + sb + 8); };
     const unsigned int my_sb0 = (unsigned int)lane << 4;           // lane l owns ray slot l (bank 0) and l + 64 (bank 1, R = 128): row offsets
@@ -488,7 +495,6 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
                                 const float tm = vmax3(fmaf(0x1p17f, fabsf(qrx), fabsf(qox)), fmaf(0x1p17f, fabsf(qry), fabsf(qoy)), fmaf(0x1p17f, fabsf(qrz), fabsf(qoz)));
                                 aw = fmaf(tm, 2.f * kRel * (1.f + 0x1p-10f), aw);
                             }
-                            if (QW) rowE(sbk) = make_float4(rb.rx, rb.ry, rb.rz, rb.c0);
                             rowA(sbk) = make_float4(qrx, qry, qrz, aw);
                             rowO(sbk) = make_float4(qox, qoy, qoz, __int_as_float(work ? 1 : 0));
                         } else {
@@ -517,7 +523,7 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
                     } else {                           // the root is a leaf
                         if (cnt > 0) {
                             if (got) {
-                                leafq[(ltail + (unsigned int)lanes_below(gm)) & (LCAP - 1)] = QW ? make_uint2(0x80000000u | (unsigned int)cnt << kQwLeafShift | (unsigned int)first, sbk | 1u)
+                                leafq[(ltail + (unsigned int)lanes_below(gm)) & (LCAP - 1)] = QW ? make_uint2(0x80000000u | (unsigned int)cnt << kQwLeafShift | (unsigned int)first, sbk)
                                                                                                  : make_uint2((unsigned int)first, (unsigned int)cnt << kQLeafShift | sbk);
                                 if (STATS) wk.tris += (uint32_t)cnt;
                             }
@@ -545,16 +551,7 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
             const unsigned int m = lcount < 64u ? lcount : 64u;
             uint2 E = make_uint2(0u, 0u);
             if ((unsigned int)lane < m) E = leafq[(lhead + (unsigned int)lane) & (LCAP - 1)];
-            // QW: the reference's test of the entry's REAL leaf box (one entry per lane, loads in flight beside the triangle loads below); bit 0 of the
-            // entry = already decided (the rest of a leaf an earlier step cut in two)
-            float4 xc = make_float4(0, 0, 0, 0), xh = xc, xC = xc, xR = xc;
-            if (QW) {
-                const unsigned int xf = E.x & ((1u << kQwLeafShift) - 1u);
-                WQ_CHECK((int)xf >= 0 && (int)xf < sc.n_tris, 2, (void)0);
-                xc = sc.leafbox[2 * (size_t)xf]; xh = sc.leafbox[2 * (size_t)xf + 1];      // (centre, half extent) of the real box, as the pair kernel's filter takes them
-                xC = rowC(E.y & kQSlotMask); xR = rowE(E.y & kQSlotMask);                    // the slot's (O, u.x) and (1 / u, c0): what ray_box_c formed at hand-off
-            }
-            const unsigned int c = QW ? (E.x >> kQwLeafShift) & 0x7fu : E.y >> kQLeafShift;               // >= 1 for queued entries, 0 beyond them (QW: the entry is (payload word, slot << 4 | decided))
+            const unsigned int c = QW ? (E.x >> kQwLeafShift) & 0x7fu : E.y >> kQLeafShift;               // >= 1 for queued entries, 0 beyond them (QW: the entry is (payload word, slot << 4 | flag))
             if (QW) E.x &= (1u << kQwLeafShift) - 1u;
             const unsigned int incl = wave_incl_scan(c);
             const unsigned int P = incl - c;                         // position of this entry's first triangle
@@ -616,27 +613,7 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
                     n_tdiv += __ballot((how & 4) != 0) != 0ull ? 1u : 0u;   // division blocks some lane entered
                 }
             }
-            bool xok = true;
-            if (QW) {       // a triangle counts only if the reference's test of its leaf's real box says hit: the entry's lane decides, the triangle's lane looks the bit up
-                // cbox_filter on the values ray_box_c formed at hand-off (v_rcp_f32 and the products are deterministic: recomputed, not stored); an undecided
-                // lane -- almost never -- takes the literal test on the (lo, hi) copy of its leaf
-                bool xhit, xmiss;
-                cbox_filter(xc, xh, xR, make_float4(xC.x * xR.x, xC.y * xR.y, xC.z * xR.z, 0.f), xhit, xmiss);   // o = fl(O r): the product ray_box_c formed
-                const bool xdone = (E.y & 1u) != 0u;
-                xok = xdone || xhit;
-                if (__builtin_expect(__ballot((unsigned int)lane < m && !xdone && !xhit && !xmiss) != 0ull, 0)) {
-                    if ((unsigned int)lane < m && !xdone && !xhit && !xmiss) {
-                        const int lf = sc.tri2leaf[E.x];
-                        const float4 xD = rowD(E.y & kQSlotMask);
-                        xok = slab(sc.nodesq[2 * (size_t)lf], sc.nodesq[2 * (size_t)lf + 1], mk(xC.x, xC.y, xC.z), mk(xC.w, xD.x, xD.y));
-                        if (STATS) wk.lit_box++;
-                    }
-                }
-                const int xbit = xok ? 1 : 0;                        // handed to the triangles' lanes the way their entry's words were: one LDS permute each
-#pragma unroll
-                for (int k = 0; k < NT; ++k) { const int xb = __builtin_amdgcn_ds_bpermute(j_[k], xbit); ok_[k] = ok_[k] && xb != 0; }   // (the permute with every lane active: a masked-off source lane reads as 0)
-            }
-            if (QN && !QW) {       // a triangle accepted in a flagged leaf counts only if the reference's test of the leaf's real box says hit (rare: behind a vote)
+            if (QN) {              // a triangle accepted in a flagged leaf counts only if the reference's test of the leaf's real box says hit (rare: behind a vote)
                 bool ch_[NT], any = false;
 #pragma unroll
                 for (int k = 0; k < NT; ++k) { ch_[k] = ok_[k] && (y_[k] & 1u) != 0u; any = any || ch_[k]; }
@@ -648,10 +625,10 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
             }
 #pragma unroll
             for (int k = 0; k < NT; ++k) if (ok_[k]) atomicMin(best(o_[k]), (unsigned long long)__float_as_uint(tt_[k]) << 32 | (unsigned int)i_[k]);
-            const bool full = part && (P + c <= LIM || (QW && !xok));   // (QW: a leaf whose real box is missed is done, whatever part of it this step took)
+            const bool full = part && P + c <= LIM;
             if (part && !full) {                                     // at most one entry straddles position LIM - 1: keep its rest
                 const unsigned int took = LIM - P;
-                if (QW) leafq[(lhead + (unsigned int)lane) & (LCAP - 1)] = make_uint2(0x80000000u | (c - took) << kQwLeafShift | (E.x + took), (E.y & kQSlotMask) | 1u);
+                if (QW) leafq[(lhead + (unsigned int)lane) & (LCAP - 1)] = make_uint2(0x80000000u | (c - took) << kQwLeafShift | (E.x + took), E.y & (kQSlotMask | 1u));
                 else leafq[(lhead + (unsigned int)lane) & (LCAP - 1)] = make_uint2(E.x + took, (E.y & (kQSlotMask | 1u)) | (c - took) << kQLeafShift);
             }
             lhead += (unsigned int)__popcll(__ballot(full));
@@ -707,7 +684,8 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
             const uint4 *qp = reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(sc.nodesw) + off);
             const uint4 q0 = qp[0], q1 = qp[1], q2 = qp[2], q3 = qp[3];
             const unsigned long long mact = __ballot(act);
-            unsigned long long mI[4], mL[4];
+            unsigned long long mI[4], mL[4], mF[4];
+            const float W = fmaf(6.f, vmax3abs(A.x, A.y, A.z), A.w);   // band + the fixed-point boxes' enlargement (three cells per face, rt_qnodes.hip.h) in the ray's parameter: a hit by more than this is a hit of the REAL box
             unsigned int p_[4];
             auto child = [&](const uint4 q, const int j) {
                 const float4 cq = make_float4((float)(q.x & 0xffffu), (float)(q.x >> 16), (float)(q.y & 0xffffu), 0.f);
@@ -715,9 +693,11 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
                 const float kx = fmaf(cq.x, A.x, -Oo.x), ky = fmaf(cq.y, A.y, -Oo.y), kz = fmaf(cq.z, A.z, -Oo.z);
                 const float tn = vmax3(fmaf(-hq.x, fabsf(A.x), kx), fmaf(-hq.y, fabsf(A.y), ky), fmaf(-hq.z, fabsf(A.z), kz));
                 const float tf = vmin3(fmaf(hq.x, fabsf(A.x), kx), fmaf(hq.y, fabsf(A.y), ky), fmaf(hq.z, fabsf(A.z), kz));
-                const unsigned long long g = mact & ~__ballot(tf + A.w < tn);    // not excluded: the ray's own band (hand-off) covers every box; a NaN is not excluded either
+                const float d = tf - tn;
+                const unsigned long long g = mact & ~__ballot(d < -A.w);         // not excluded: the ray's own band (hand-off) covers every box; a NaN is not excluded either
                 p_[j] = q.w;                                                     // > 0 internal (the entry), < 0 leaf (count, first triangle), 0 nothing
                 mL[j] = g & __ballot((int)q.w < 0);
+                mF[j] = mL[j] & ~__ballot(d > W);                                // leaves hit by less than the enlargement: flagged (their real box is tested when a triangle is accepted)
                 mI[j] = (j & 1) ? g & __ballot((int)q.w > 0) : g & ~mL[j];      // places 0 and 2 always hold a node (qquads_kernel): only 1 and 3 can be empty
                 if (STATS) {
                     wk.box += act ? 1u : 0u;
@@ -756,7 +736,7 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
                 if (mL[j] != 0ull) {
                     if (STATS) n_lpush++;
                     const unsigned int pos = lb + (unsigned int)lanes_below(mL[j]);
-                    if (__builtin_amdgcn_inverse_ballot_w64(mL[j])) { unsigned int *const lq = reinterpret_cast<unsigned int *>(leafq + (pos & (LCAP - 1))); lq[0] = p_[j]; lq[1] = sb; }
+                    if (__builtin_amdgcn_inverse_ballot_w64(mL[j])) { unsigned int *const lq = reinterpret_cast<unsigned int *>(leafq + (pos & (LCAP - 1))); lq[0] = p_[j]; lq[1] = or_bit0(sb, mF[j]); }
                     lb += (unsigned int)__popcll(mL[j]);
                 }
             }
