@@ -618,9 +618,21 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
 #pragma unroll
                 for (int k = 0; k < NT; ++k) { ch_[k] = ok_[k] && (y_[k] & 1u) != 0u; any = any || ch_[k]; }
                 if (__builtin_expect(__ballot(any) != 0ull, 0)) {
+                    if (STATS) n_lit++;                              // (the counter of the float pairs' literal-box blocks: they never run in this instantiation)
+                    if (any) {                                       // one region for the lane's triangles: the table lookups, then the boxes, of all of them in flight together
+                        int lf_[NT];
+                        float4 lo_[NT], hi_[NT];
 #pragma unroll
-                    for (int k = 0; k < NT; ++k)
-                        if (ch_[k]) { const int lf = sc.tri2leaf[i_[k]]; const f3 Or = mk(C_[k].x, C_[k].y, C_[k].z), ur = mk(C_[k].w, D_[k].x, D_[k].y); ok_[k] = slab_filtered(sc.nodesq[2 * (size_t)lf], sc.nodesq[2 * (size_t)lf + 1], Or, ur, ray_inv(ur)); }
+                        for (int k = 0; k < NT; ++k) lf_[k] = sc.tri2leaf[ch_[k] ? i_[k] : 0];
+#pragma unroll
+                        for (int k = 0; k < NT; ++k) { lo_[k] = sc.nodesq[2 * (size_t)lf_[k]]; hi_[k] = sc.nodesq[2 * (size_t)lf_[k] + 1]; }
+#pragma unroll
+                        for (int k = 0; k < NT; ++k) {
+                            const f3 Or = mk(C_[k].x, C_[k].y, C_[k].z), ur = mk(C_[k].w, D_[k].x, D_[k].y);
+                            const bool hitk = slab_filtered(lo_[k], hi_[k], Or, ur, ray_inv(ur));
+                            if (ch_[k]) ok_[k] = hitk;
+                        }
+                    }
                 }
             }
 #pragma unroll
