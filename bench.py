@@ -311,6 +311,8 @@ def travq_instructions(counts, sc, section="wf_travq"):
     weights = (("loop_head", st["iterations"]), ("retire", st["refill_passes"]), ("round", st["refill_rounds"]),
                ("fetch", st["fetches"]), ("tri", st["tri_steps"]), ("tdiv", st["tdiv_blocks"]), ("box", st["box_steps"]),
                ("lpush", st["leaf_push_blocks"]), ("lpush2", st["leaf_push2_blocks"]))
+    if section == "wf_travq_qw" and "lflag" in t:    # the 4-wide kernel counts the flagged-leaf check blocks its TRI steps entered where the float pairs count their literal box blocks
+        weights += (("lflag", st["literal_box_fallbacks"]),)
     out = {k: int(sum(t[r][k] * n for r, n in weights)) for k in ("valu", "valu_weight", "salu")}
     # the step dispatch between the refill and the steps: scalar instructions every iteration, its vector ones only in front of a TRI step
     out["salu"] += int(t["dispatch"]["salu"] * st["iterations"])

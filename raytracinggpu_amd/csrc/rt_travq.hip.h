@@ -543,6 +543,7 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
         // entries the step consumes, and 128 triangles are only ~33 entries; with 256 the 64 entries a step reads are the 64 it consumes and TRI steps fall from 736 K to 425 K per
         // frame -- measured SLOWER (profiles/round5/ab_wide_nodes.txt): twelve triangle records per lane need 127 registers, the launch owns the register file and the other
         // sub-frame's wf_advance no longer fits beside it (frame 0.887 -> 1.016 ms; the launch alone 0.174 -> 0.175 ms: nothing gained even then).
+        // Again without the per-entry leaf test: NT = 3 wants 101 registers, NT = 4 124 (68 spills at a 64-register limit): the launch alone 0.173 -> 0.167 ms, the frame 0.866 -> 0.882 / 0.953 ms.
         const unsigned int lcount = ltail - lhead;
         if (lcount >= 64u || (top == 0 && lcount > 0u)) {
             if (STATS) n_tri++;
@@ -620,6 +621,7 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
                 if (__builtin_expect(__ballot(any) != 0ull, 0)) {
                     if (STATS) n_lit++;                              // (the counter of the float pairs' literal-box blocks: they never run in this instantiation)
                     if (any) {                                       // one region for the lane's triangles: the table lookups, then the boxes, of all of them in flight together
+                        WQ_MARK("lflag_begin");
                         int lf_[NT];
                         float4 lo_[NT], hi_[NT];
 #pragma unroll
@@ -632,6 +634,7 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
                             const bool hitk = slab_filtered(lo_[k], hi_[k], Or, ur, ray_inv(ur));
                             if (ch_[k]) ok_[k] = hitk;
                         }
+                        WQ_MARK("lflag_end");
                     }
                 }
             }

@@ -98,6 +98,7 @@ def travq_counts(lines):
     tdivs = inside("tdiv", "tri_begin", "tri_end")                   # the two inlined triangle tests of a TRI step: t = dot(AO, N) / det, entered when some lane accepted
     tdiv = span(tdivs)
     n_tdiv = max(len(tdivs), 1)
+    lflag = span(inside("lflag", "tri_begin", "tri_end"))            # fixed-point instantiations: the real-box check of accepted triangles in flagged leaves (behind a vote)
     lp = [x for x in pos.get("lpush_begin", []) if one["box_begin"] < x < one["box_end"]]
     lp2 = [x for x in pos.get("lpush2_begin", []) if one["box_begin"] < x < one["box_end"]]
     lpe = [x for x in pos.get("lpush_end", []) if one["box_begin"] < x < one["box_end"]]
@@ -113,8 +114,9 @@ def travq_counts(lines):
         "fetch": reg("fetch_begin", "fetch_end"),                       # per queue fetch (64 slots)
         "dispatch": reg("refill_end", "tri_begin"),                     # which step runs next: scalar, per loop iteration; its few vector instructions are the TRI
                                                                         # step's first ones, placed in front of the label (priced per TRI step)
-        "tri": sub(sub(reg("tri_begin", "tri_end"), trilit), tdiv),     # per TRI step (128 triangle tests) without the blocks below
-        "tri_literal_blocks": trilit,                                   # literal beta / gamma divisions: rare, not priced
+        "tri": sub(sub(sub(reg("tri_begin", "tri_end"), trilit), tdiv), lflag),     # per TRI step (128 triangle tests) without the blocks below
+        "tri_literal_blocks": trilit,
+        "lflag": lflag,                                   # literal beta / gamma divisions: rare, not priced
         "tdiv": {k: v / n_tdiv for k, v in tdiv.items()},               # per t-division block entered (a TRI step has two)
         "box": sub(sub(reg("box_begin", "box_end"), lpush1), lpush2),   # per BOX step (64 sibling pairs) without the leaf-queue pushes
         "lpush": lpush1, "lpush2": lpush2,                              # per first / second leaf-queue push entered
@@ -143,6 +145,7 @@ def travq_qw_counts(lines):
     tdivs = inside("tdiv", "tri_begin", "tri_end")
     tdiv = span(tdivs)
     n_tdiv = max(len(tdivs), 1)
+    lflag = span(inside("lflag", "tri_begin", "tri_end"))            # the real-box check of accepted triangles in flagged leaves: behind a vote, counted per block entered (literal_box_fallbacks)
     quarter = lambda c: {k: v / 4.0 for k, v in c.items()}
     def add(a, b):
         return {k: a[k] + b[k] for k in a}
@@ -152,8 +155,9 @@ def travq_qw_counts(lines):
         "round": reg("round_begin", "round_end"),
         "fetch": reg("fetch_begin", "fetch_end"),
         "dispatch": reg("refill_end", "tri_begin"),
-        "tri": sub(sub(reg("tri_begin", "tri_end"), trilit), tdiv),
+        "tri": sub(sub(sub(reg("tri_begin", "tri_end"), trilit), tdiv), lflag),
         "tri_literal_blocks": trilit,
+        "lflag": lflag,
         "tdiv": {k: v / n_tdiv for k, v in tdiv.items()},
         "box": add(reg("boxw_begin", "ipushw_begin"), reg("lpushw_end", "boxw_end")),    # per BOX step (64 quads = 256 boxes) without the push blocks
         "lpush2": quarter(reg("ipushw_begin", "lpushw_begin")),                            # per internal-child push block entered
