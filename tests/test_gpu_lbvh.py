@@ -163,18 +163,24 @@ def _displaced_grid(n, seed=11):
     return v, t
 
 
-def test_lbvh_two_million_triangles_node_indices_beyond_2_pow_20(ctx, oracle):
-    """2 097 152 triangles (n = 1025): the LBVH has more than 2^21 nodes, so stack entries of wf_travq carry node indices that need all 22 bits of the
-    field (kQNodeShift = 10: the lowest node bit shares bit 10 with the seventh slot bit) and the BOX step reads the 16-bit fixed-point pairs (automatic
-    from 16 384 nodes).  Frame and work counters (binary instantiation) == the oracle walking the SAME tree at a small frame, and explicit rays aimed at
+@pytest.mark.parametrize("qw", ["default", "0"])
+def test_lbvh_two_million_triangles_node_indices_beyond_2_pow_20(oracle, monkeypatch, qw):
+    """2 097 152 triangles (n = 1025): the LBVH has more than 2^20 nodes, so stack entries of wf_travq carry node indices that need the top bits of their
+    22-bit field (kQNodeShift = 10: the lowest node bit shares bit 10 with the seventh slot bit).  Twice: with the BOX step the library chooses (the 4-wide
+    step on fixed-point quads: the tree has fewer than 2^21 nodes) and with RT_TRAVQ_QW=0 (the 16-bit fixed-point sibling pairs, automatic from 16 384
+    nodes).  Frame and work counters (binary instantiation) == the oracle walking the SAME tree at a small frame, and explicit rays aimed at
     triangles all over the mesh -- in a breadth-first array most leaves sit at the deepest levels, i.e. at the highest indices -- through the production
     traversal launches (rt_trace_rays) against the oracle's TriangleMesh::intersect.  Reference twin of the builder: global_launcher.cu:298-331."""
+    if qw != "default":
+        monkeypatch.setenv("RT_TRAVQ_QW", qw)
+    ctx = rt.Context(0)                                   # knobs are read when the context is created
     v, t = _displaced_grid(1025)
     first = hostlib.build_mesh(v, t, albedo=rt.scenes.CAT_ALBEDO, object_slot=6)
     ctx.scene_upload(rt.scenes.spheres("cpu"), first)
     up = np.ascontiguousarray(first["indices"][:, :3])
     arr, order = ctx.mesh_rebuild(len(up), mode="lbvh")
     st = ctx.build_stats()
+    assert ctx.stats_after_render(rt.make_params(64, 64, 1, 0, **rt.scenes.CPU_LAUNCHER))["travq_mode"] == (2 if qw == "default" else 1)
     print(f"{len(up)} triangles: LBVH {st['n_nodes']} nodes (2^20 = {1 << 20}, 2^21 = {1 << 21}), depth {st['max_depth']}, {st['n_leaves']} leaves")
     assert st["mode"] == 1 and st["n_nodes"] == len(arr) and st["n_nodes"] > (1 << 20)
     om = oracle.Mesh.from_arrays(v, up)
@@ -208,6 +214,7 @@ def test_lbvh_two_million_triangles_node_indices_beyond_2_pow_20(ctx, oracle):
     np.testing.assert_array_equal(got[:, 0], exp[:, 0])
     np.testing.assert_array_equal(got[hit].view(np.uint32), exp[hit].view(np.uint32))
     assert hit.sum() > 2000 and (~hit).sum() > 50
+    ctx.close()
 
 
 def test_lbvh_device_install_equals_host_install(oracle, cat_golden, monkeypatch):
