@@ -48,6 +48,7 @@ struct Knobs {
     int qw = -1;               // RT_TRAVQ_QW: the BOX step is four boxes wide (fixed-point quads: the children of both nodes of a sibling pair in 64 bytes, every other level of the tree
                                // skipped; leaves flagged and decided as the fixed-point pairs decide them; rt_travq.hip.h, QW).  -1 (default) = 1 = on where the tree allows the format (boxes nest, leaves of
                                // at most 127 triangles, fewer than 2^21 nodes), 0 = off.  Bit-exact either way; cat 1920x1080: 0.934 -> 0.861 ms per frame (profiles/round5/ab_wide_nodes.txt)
+    int auto_lockstep = 1;     // RT_AUTO_LOCKSTEP=0: RT_VARIANT_AUTO stays the wavefront pipeline for scenes without a mesh (A/B; default: the lock-step kernel renders them)
     int qw_count = 0;          // RT_TRAVQ_QW_COUNT=1: rt_count_work runs the 4-wide kernel's counting instantiation (its own step counters; the box / node counts then describe
                                // THAT kernel, not the reference's traversal)
     float lbvh_ct = 0.f;       // RT_LBVH_CT: cost of a triangle test relative to a box test in the LBVH's leaf cut (0 = kLbvhCt)
@@ -96,6 +97,7 @@ static Knobs read_knobs() {
     if (geti("RT_TRAVQ_Q16", v) && v >= -1 && v <= 1) k.q16 = v;
     if (geti("RT_TRAVQ_QW", v) && v >= -1 && v <= 1) k.qw = v;
     if (geti("RT_TRAVQ_QW_COUNT", v)) k.qw_count = v != 0;
+    if (geti("RT_AUTO_LOCKSTEP", v)) k.auto_lockstep = v != 0;
     if (geti("RT_PARTS", v) && v >= 1 && v <= 8) k.parts = v;
     if (getenv("RT_TRAVQ_BPC5")) k.bpc5 = 1;
     if (geti("RT_TRAV_WAVES", v) && v >= 1) k.trav_waves = v;
@@ -453,6 +455,11 @@ int need_copy_streams(rt_ctx *ctx, bool second) {
     return RT_OK;
 }
 
+// RT_VARIANT_AUTO for a scene without a mesh: the lock-step kernel (launch_render_chunk says why)
+inline bool auto_is_lockstep(const rt_ctx *ctx, const rt_camera_pose *pose) {
+    return ctx->knobs.auto_lockstep != 0 && ctx->have_scene && ctx->scene.mesh_slot < 0 && ctx->scene.nrm == nullptr && pose == nullptr;
+}
+
 int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *out_dev, hipStream_t stream,
                         unsigned long long *work_dev, const rt_camera_pose *pose, bool rec_begin, bool rec_end) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
@@ -474,7 +481,10 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
     int variant = p->variant;
     // measured on MI355X (cat, 1080p): the work-stack traversal (1.67 ms/frame) beats the per-lane stackless walk
     // (2.48 ms/frame; with LDS-staged nodes 2.65), so AUTO is the work-stack variant
-    if (variant == RT_VARIANT_AUTO) variant = RT_VARIANT_WAVEFRONT_QUEUE;
+    // ... when there is a mesh.  A scene of spheres alone has no traversal to feed and no divergence to sort out: one lane per pixel for the whole frame (the reference's
+    // own structure, the lock-step kernel) keeps a path in registers instead of streaming it through HBM once per bounce -- BASELINE config 2, 1920x1080 b 3: 0.198 against
+    // 0.220 ms per frame (profiles/round5/ab_spheres_only.txt).  A posed camera exists in the wavefront family only.
+    if (variant == RT_VARIANT_AUTO) variant = auto_is_lockstep(ctx, pose) ? RT_VARIANT_LOCKSTEP : RT_VARIANT_WAVEFRONT_QUEUE;
     // BASELINE config 4 / north star: "hot triangle vertices and top BVH levels staged in LDS" = the work-stack traversal kernel
     // with the vertex array (LDS_VERTS), the breadth-first top of the node array (LDS_TOP) or both (LDS_ALL) staged per workgroup
     const int variant_req = variant;
@@ -964,7 +974,7 @@ int launch_render(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *ou
     const int v = p ? p->variant : 0;
     // (the work-stack pipeline and its LDS-staged variants; the per-lane-walk variants with one big workgroup per CU lose more to the
     // smaller launches than the cache gives back: wavefront_lds 7.9 -> 9.1 ms at 3840x2160)
-    const bool wf = v == RT_VARIANT_AUTO || v == RT_VARIANT_WAVEFRONT_QUEUE || v == RT_VARIANT_LDS_VERTS || v == RT_VARIANT_LDS_TOP || v == RT_VARIANT_LDS_ALL;
+    const bool wf = (v == RT_VARIANT_AUTO && !auto_is_lockstep(ctx, pose)) || v == RT_VARIANT_WAVEFRONT_QUEUE || v == RT_VARIANT_LDS_VERTS || v == RT_VARIANT_LDS_TOP || v == RT_VARIANT_LDS_ALL;
     const int64_t chunk_px = (int64_t)(ctx->knobs.chunk_mpx * 1e6);
     rt_ctx::Pipe &pl = ctx->pipe;
     pl.prev_valid = pl.valid; pl.valid = false;                          // every asynchronous user of the path state comes through here
