@@ -45,7 +45,8 @@ typedef enum rt_status {
 
 /* kernel variants (BASELINE.json configs 3/4); all produce bit-identical results */
 typedef enum rt_variant {
-    RT_VARIANT_AUTO = 0,       /* the fastest measured variant: RT_VARIANT_WAVEFRONT_QUEUE          */
+    RT_VARIANT_AUTO = 0,       /* the fastest measured variant: RT_VARIANT_WAVEFRONT_QUEUE; for a scene
+                                  without a mesh (and no pose / smooth normals): RT_VARIANT_LOCKSTEP   */
     RT_VARIANT_GLOBAL = 1,     /* persistent lanes (micro-op scheduler); SoA nodes + packed
                                   triangles read from HBM through L2/L1                             */
     RT_VARIANT_LDS_VERTS = 2,  /* work-stack traversal (as 8) with the vertex array staged in LDS by a
