@@ -3,8 +3,10 @@
 // wf_travq's BOX step is bound by the NUMBER of vector-memory instructions it issues (profiles/round4/ab_load_cost_model.txt): a pair of
 // (centre, half extent, payload, kind) nodes is 64 bytes = four 16-byte loads per lane.  Here a node is 16 bytes -- centre and half
 // extent of each axis as unsigned 16-bit numbers on a grid laid over the root box, and one payload word -- so a pair is TWO loads.
-// Every face is rounded OUTWARDS: the fixed-point box contains the real one, and no face is further than three cells from the real one:
-//     cq = round((c - g) / s),   hq = ceil((h + |c - (g + cq s)|) / s) + 1          (binary64; c, h = exact centre / half extent of lo, hi)
+// Every face is rounded OUTWARDS: the fixed-point box contains the real one, and no face is further than TWO cells from the real one (kQ16FaceCells in rt_travq.hip.h):
+//     cq = round((c - g) / s),   hq = the least integer with hq s >= h + |c - (g + cq s)|          (binary64; c, h = exact centre / half extent of lo, hi)
+// -- a face sits at most one cell (the ceiling) + 2 |c - (g + cq s)| <= one more cell outside.  (Rounds 4-5 added a spare cell to hq against the rounding of the quotient; the
+// comparison below makes the containment hold without it, and the kernels' flag threshold shrank from six cells to four: profiles/round5/ab_wide_nodes.txt.)
 // The kernel (wf_travq<.., QN = true>) uses the fixed-point box in two ways, both conservative with respect to BoundingBox::intersect
 // (cpu_launcher.cpp:146-157) on the real box:
 //   * a box the ray misses even enlarged is missed by the reference (no entry pushed, no triangle tested);
@@ -49,7 +51,9 @@ __device__ __forceinline__ void q16_axis(float lo, float hi, float g, float s, u
     double ci = floor((c - (double)g) / (double)s + 0.5);
     ci = ci < 0.0 ? 0.0 : (ci > 65535.0 ? 65535.0 : ci);
     const double cw = (double)g + ci * (double)s;
-    double hi_ = ceil((h + fabs(c - cw)) / (double)s) + 1.0;
+    const double need = (h + fabs(c - cw)) * (1.0 + 0x1p-50);            // (the sum may have rounded down by half an ulp)
+    double hi_ = ceil(need / (double)s);
+    if (hi_ * (double)s < need) hi_ += 1.0;                              // the quotient rounded down across an integer: hi_ s is exact (16 x 24 bits)
     hi_ = hi_ > 65535.0 ? 65535.0 : (hi_ >= 1.0 ? hi_ : 65535.0);       // NaN or an out-of-range box: the widest box (never excluded)
     cq = (unsigned int)ci; hq = (unsigned int)hi_;
 }

@@ -44,6 +44,7 @@ constexpr int kQLeafCap = QLeafCap<64>::value;
 // that issue at half rate on gfx950 (tools/ubench/issue_table: v_lshlrev_b32, v_lshl_add_u32, v_and_or_b32 ... take twice the
 // issue time of v_and_b32 / v_lshrrev_b32 / v_add_u32 / v_fma_f32).
 constexpr int kQNodeShift = 10, kQNodeBits = 22;   // stack entry = node << 10 | slot << 4: the node of an entry is EVEN (a sibling pair), so its lowest bit may share bit 10 with the seventh slot bit (128 resident rays)
+constexpr float kQ16FaceCells = 2.f;                // how far outside its real face a fixed-point face can sit, in cells (the quantiser of rt_qnodes.hip.h guarantees it)
 constexpr int kQLeafShift = 11;                    // leaf-queue entry / a leaf's kind word = triangle count << 11 | slot << 4 (| flag): counts may be odd, they start above the slot bits
 constexpr unsigned int kQSlotMask = 0x7f0u;
 constexpr int kQMaxLeaf = 1 << 20;           // triangles per leaf: count << 11 must stay a positive int (the sign says "internal")
@@ -282,7 +283,7 @@ __device__ __forceinline__ bool qtri_test(const float4 q0, const float4 q1, cons
 // loads a step of the float pairs issues -- tests the four boxes and pushes one entry per hit internal grandchild: every other level of the tree is
 // never tested, a ray's chain of dependent steps is half as long and a frame runs half as many BOX steps.  Exactness: the fixed-point boxes contain the
 // real ones and the reference's test is monotone along nested boxes (rt_qnodes.hip.h), so the leaves the reference reaches are exactly the leaves whose
-// OWN box its test hits.  Leaves are decided as the fixed-point pairs decide them: a leaf hit by more than the boxes' enlargement (one threshold per RAY: its band + six
+// OWN box its test hits.  Leaves are decided as the fixed-point pairs decide them: a leaf hit by more than the boxes' enlargement (one threshold per RAY: its band + four
 // cells along its steepest axis) is hit by the reference; a leaf in between is queued with a flag, and a triangle ACCEPTED in a flagged leaf counts only if the
 // reference's own test of the leaf's real box (slab_filtered on its (lo, hi) record, behind a vote: a few steps in a hundred) says hit.  (The first versions tested the
 // real box of EVERY leaf entry in the TRI step, two gathers and 26 vector instructions per step: 8 % of the cat's frame and a third of a frame of 524 288 triangles,
@@ -491,7 +492,7 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
                             if (QW) {
                                 // ONE band per ray instead of one per box: every plane value of a box on the 16-bit grid is bounded by |o'| + (cq + hq) |r'| <= |o'| + 2^17 |r'|,
                                 // so B = 2 kRel Tm (1 + 2^-10) + 4 c0 with Tm = the largest such bound over the axes is at least cbox_dband's band for ANY box: d < -B excludes.
-                                // (About an eighth of a cell along the ray's steepest axis; the boxes carry three cells of slack.)
+                                // (About an eighth of a cell along the ray's steepest axis; the boxes carry up to two cells of slack per face.)
                                 const float tm = vmax3(fmaf(0x1p17f, fabsf(qrx), fabsf(qox)), fmaf(0x1p17f, fabsf(qry), fabsf(qoy)), fmaf(0x1p17f, fabsf(qrz), fabsf(qoz)));
                                 aw = fmaf(tm, 2.f * kRel * (1.f + 0x1p-10f), aw);
                             }
@@ -539,11 +540,9 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
         WQ_STAMP(cy_srv);
         WQ_MARK("refill_end");
         // =============================== TRI step: NT triangles per lane ===============================
-        // NT = 2 (128 triangles per step).  -DRT_TRAVQ_QW_TRIS=4 gives the 4-wide kernel 256: its exact leaf-box test runs once per STEP on all 64 lanes whatever the number of
-        // entries the step consumes, and 128 triangles are only ~33 entries; with 256 the 64 entries a step reads are the 64 it consumes and TRI steps fall from 736 K to 425 K per
-        // frame -- measured SLOWER (profiles/round5/ab_wide_nodes.txt): twelve triangle records per lane need 127 registers, the launch owns the register file and the other
-        // sub-frame's wf_advance no longer fits beside it (frame 0.887 -> 1.016 ms; the launch alone 0.174 -> 0.175 ms: nothing gained even then).
-        // Again without the per-entry leaf test: NT = 3 wants 101 registers, NT = 4 124 (68 spills at a 64-register limit): the launch alone 0.173 -> 0.167 ms, the frame 0.866 -> 0.882 / 0.953 ms.
+        // NT = 2 (128 triangles per step).  -DRT_TRAVQ_QW_TRIS=3 / 4 give the 4-wide kernel 192 / 256: with 256 the 64 entries a step reads are the 64 it consumes and TRI steps fall
+        // from 736 K to 425 K per frame -- measured SLOWER twice (profiles/round5/ab_wide_nodes.txt): nine / twelve triangle records per lane want 101 / 124 registers (68 spills at a
+        // 64-register limit), the launch owns the register file and the other sub-frame's wf_advance no longer fits beside it: the launch alone 0.173 -> 0.167 ms, the frame 0.866 -> 0.882 / 0.953 ms.
         const unsigned int lcount = ltail - lhead;
         if (lcount >= 64u || (top == 0 && lcount > 0u)) {
             if (STATS) n_tri++;
@@ -700,7 +699,7 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
             const uint4 q0 = qp[0], q1 = qp[1], q2 = qp[2], q3 = qp[3];
             const unsigned long long mact = __ballot(act);
             unsigned long long mI[4], mL[4], mF[4];
-            const float W = fmaf(6.f, vmax3abs(A.x, A.y, A.z), A.w);   // band + the fixed-point boxes' enlargement (three cells per face, rt_qnodes.hip.h) in the ray's parameter: a hit by more than this is a hit of the REAL box
+            const float W = fmaf(2.f * kQ16FaceCells * (1.f + 0x1p-12f), vmax3abs(A.x, A.y, A.z), A.w);   // band + the fixed-point boxes' enlargement (two cells per face, rt_qnodes.hip.h) in the ray's parameter: a hit by more than this is a hit of the REAL box
             unsigned int p_[4];
             auto child = [&](const uint4 q, const int j) {
                 const float4 cq = make_float4((float)(q.x & 0xffffu), (float)(q.x >> 16), (float)(q.y & 0xffffu), 0.f);
@@ -857,11 +856,11 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
             const unsigned long long mact = __ballot(act);
             unsigned long long mflag0 = 0ull, mflag1 = 0ull;   // QN: leaves hit by less than the fixed-point box's enlargement (their real box is tested when a triangle is accepted)
             if (QN) {
-                // the fixed-point box contains the real one and no face is further than 3 cells from the real face (rt_qnodes.hip.h): in the
-                // ray's parameter that is 3 max|r'| per face, 6 for d = far - near.  `miss` (d < -band) therefore holds for the real box too, and so
-                // does a hit by more than band + 6 max|r'|; what lies between enters internal nodes (a superset of the reference's visits: harmless,
+                // the fixed-point box contains the real one and no face is further than 2 cells from the real face (rt_qnodes.hip.h): in the
+                // ray's parameter that is 2 max|r'| per face, 4 for d = far - near.  `miss` (d < -band) therefore holds for the real box too, and so
+                // does a hit by more than band + 4 max|r'|; what lies between enters internal nodes (a superset of the reference's visits: harmless,
                 // its box test is monotone along a path of nested boxes) and flags leaves
-                const float slack = 6.f * vmax3abs(A.x, A.y, A.z);
+                const float slack = 2.f * kQ16FaceCells * (1.f + 0x1p-12f) * vmax3abs(A.x, A.y, A.z);
                 float d0, d1, band0, band1;
                 cbox_dband(c0, h0, A, Oo, d0, band0);
                 cbox_dband(c1, h1, A, Oo, d1, band1);
