@@ -76,16 +76,18 @@ constexpr int kQwTris = RT_TRAVQ_QW_TRIS;      // triangles per lane and TRI ste
 //   C = (O.xyz, u.x)                                                         TRI step, literal box test
 //   D = (u.y, u.z, u64: nearest accepted hit)                                TRI step
 template <int R, int SCAP, int LCAP, int NT = 2> struct QCarve {
-    static constexpr int kTabA = 0;
+    // the leaf ring FIRST: its pushes are ds_write2_b32, whose immediate offsets reach 1 KB only -- at the carve's base the ring's address is index * 8 + the wave's base and no
+    // vector add is left (the tables and the stack are reached through 16-bit offsets wherever they lie)
+    static constexpr int kLeaf = 0;                       // uint2[LCAP]: (first triangle, count << 11 | slot << 4 | flag); QW: (payload word, slot << 4 | flag)
+    static constexpr int kTabA = kLeaf + 8 * LCAP;
     static constexpr int kTabO = kTabA + 16 * R;
     static constexpr int kTabC = kTabO + 16 * R;
     static constexpr int kTabD = kTabC + 16 * R;
     static constexpr int kMarks = kTabD + 16 * R;         // u8[64 NT]: TRI-step expansion marks (all zero between steps)
     static constexpr int kStack = kMarks + 64 * NT;       // u32[SCAP]
-    static constexpr int kLeaf = kStack + 4 * SCAP;       // uint2[LCAP]: (first triangle, count << 11 | slot << 4 | flag)
-    static constexpr int kStage = kLeaf + 8 * LCAP;       // u8[64]: lanes whose registers hold a fetched ray record that has no slot yet
+    static constexpr int kStage = kStack + 4 * SCAP;      // u8[64]: lanes whose registers hold a fetched ray record that has no slot yet
     static constexpr int kBytes = kStage + 64;
-    static_assert(kBytes % 16 == 0 && kLeaf % 8 == 0 && kStack % 4 == 0, "the next wave's float4 tables start at kBytes");
+    static_assert(kBytes % 16 == 0 && kTabA % 16 == 0 && kStack % 4 == 0, "the next wave's ring and float4 tables start at kBytes");
 };
 
 // wave64 inclusive prefix sum by DPP (row_shr 1,2,4,8 inside the 16-lane rows, then row_bcast:15 / row_bcast:31).
