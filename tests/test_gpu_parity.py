@@ -331,6 +331,19 @@ def test_config2_spheres_only_full_size(ctx, oracle, cat_golden):
     assert int(got[..., 3].astype(np.float64).sum()) == cnt["rays"]
 
 
+def test_auto_variant_is_the_lock_step_kernel_without_a_mesh_and_the_work_stack_pipeline_with_one(ctx, cat_golden):
+    """RT_VARIANT_AUTO (round 5): a scene without a mesh has no traversal to feed, so one lane per pixel for the whole frame (variant 5) renders it; a scene with
+    a mesh, or a posed camera (the wavefront family only), takes the wavefront pipeline with the work-stack traversal (8).  Both are checked against the oracle by the
+    tests above; this one pins which kernel AUTO means (rt_stats.variant)."""
+    small = rt.make_params(96, 64, 1, 2, **rt.scenes.CPU_LAUNCHER)
+    upload(ctx, "demo10", cat_golden)
+    assert ctx.stats_after_render(small)["variant"] == rt._capi.VARIANTS["lockstep"]
+    ctx.render_pose(small, rt.make_pose(yaw=0.2))
+    assert ctx.stats()["variant"] == rt._capi.VARIANTS["wavefront_queue"]
+    upload(ctx, "cpu", cat_golden)
+    assert ctx.stats_after_render(small)["variant"] == rt._capi.VARIANTS["wavefront_queue"]
+
+
 @pytest.mark.parametrize("env", [{"RT_TRAVQ_CAP": "128"}, {"RT_TRAVQ_R": "32"}, {"RT_TRAVQ_R": "32", "RT_TRAVQ_CAP": "128"},
                                  {"RT_TRAVQ_LDS": "12"}, {"RT_TRAVQ_LDS": "12", "RT_TRAVQ_R": "32"}, {"RT_TRAVQ_LDS": "16"},
                                  {"RT_TRAVQ_LDS": "8", "RT_TRAVQ_CAP": "128"}, {"RT_TRAVQ_QW": "0", "RT_TRAVQ_Q16": "1"}, {"RT_TRAVQ_QW": "0", "RT_TRAVQ_Q16": "1", "RT_TRAVQ_CAP": "128"},
