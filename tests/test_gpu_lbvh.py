@@ -130,7 +130,7 @@ def test_lbvh_after_device_transform_and_refit(ctx, oracle, cat_golden):
 
 
 @pytest.mark.parametrize("n", [513])
-def test_lbvh_large_mesh_bit_exact_and_much_less_work(ctx, oracle, n):
+def test_lbvh_large_mesh_bit_exact_and_much_less_work(ctx, oracle, n, monkeypatch):
     """524 288 triangles (the displaced grid of test_large_mesh_bit_exact): frame and work counters == the oracle on the LBVH tree; the
     triangle tests per ray fall by an order of magnitude against the reference's tree (whose leaves grow with the mesh, cpu:217)."""
     v, t = _displaced_grid(n)
@@ -150,6 +150,16 @@ def test_lbvh_large_mesh_bit_exact_and_much_less_work(ctx, oracle, n):
     assert work["tri_tests"] * 2 < work_ref["tri_tests"]
     assert diff.mean() <= 0.001
     assert st["device_build_ms"] < 50.0
+    # the 4-wide kernel's OWN counting instantiation on this tree (RT_TRAVQ_QW_COUNT=1: every index that reaches an address is checked, rt_count_work fails if one is out of range):
+    # the rays it retires are the frame's, its BOX steps are four boxes wide (fewer than a quarter of the reference-equivalent box tests per 64 lanes), nothing was walked serially
+    monkeypatch.setenv("RT_TRAVQ_QW_COUNT", "1")
+    c2 = rt.Context(0)
+    c2.scene_upload(rt.scenes.spheres("cpu"), first)
+    c2.mesh_rebuild(len(up), mode="lbvh")
+    own = c2.count_work(p0, detail=True)
+    c2.close()
+    assert own["rays"] == work["rays"] and own["tri_tests"] >= work["tri_tests"]
+    assert 0 < own["steps"]["box_steps"] * 64 * 4 < 2 * work["box_tests"] and own["steps"]["serial_drains"] == 0
 
 
 def _displaced_grid(n, seed=11):
