@@ -54,17 +54,17 @@ struct Knobs {
     float lbvh_ct = 0.f;       // RT_LBVH_CT: cost of a triangle test relative to a box test in the LBVH's leaf cut (0 = kLbvhCt)
     int q_minfree = 0;         // RT_TRAVQ_MINFREE: ... and at least this many slots are free (0 = R / 4)
     int parts = 2;             // RT_PARTS: concurrent sub-frames of the wavefront pipeline
-    int bpc5 = 0;              // RT_TRAVQ_BPC5: allow a fifth workgroup per CU
+    int bpc5 = 0;              // (fixed; RT_TRAVQ_BPC5 was an environment knob until round 5) allow a fifth workgroup per CU
     int trav_waves = 0;        // RT_TRAV_WAVES: cap on traversal workgroups per CU
     int oversub = 2;           // RT_TRAVQ_OVERSUB: grid oversubscription of the work-stack kernel
-    int oversub_min = 0;       // RT_TRAVQ_OVERSUB_MIN
+    int oversub_min = 0;       // (fixed; RT_TRAVQ_OVERSUB_MIN was an environment knob until round 5)
     int min_groups = 16;       // RT_TRAV_MIN_GROUPS: ray groups per wave below which a launch uses fewer workgroups
     int log2S = -1;            // RT_TRAV_LOG2S: cap on the scramble period (experiment)
-    int path_low = 96;         // RT_PATH_LOW: wf_path runs a SHADE step only while the stack holds fewer sibling pairs than this
-    int path_shade_min = 32;   // RT_PATH_SHADE_MIN: ... and at least this many of the wave's 64 paths are ready (or nothing else is left to do)
-    int path_oversub = 2;      // RT_PATH_OVERSUB: grid oversubscription of wf_path
-    int path_bpc = 4;          // RT_PATH_BPC: workgroups (4 waves) per CU
-    int path_parts = 1;        // RT_PATH_PARTS: concurrent sub-frames (launches on separate streams)
+    int path_low = 96;         // (fixed; RT_PATH_LOW was an environment knob until round 5) wf_path runs a SHADE step only while the stack holds fewer sibling pairs than this
+    int path_shade_min = 32;   // (fixed; RT_PATH_SHADE_MIN was an environment knob until round 5) ... and at least this many of the wave's 64 paths are ready (or nothing else is left to do)
+    int path_oversub = 2;      // (fixed; RT_PATH_OVERSUB was an environment knob until round 5) grid oversubscription of wf_path
+    int path_bpc = 4;          // (fixed; RT_PATH_BPC was an environment knob until round 5) workgroups (4 waves) per CU
+    int path_parts = 1;        // (fixed; RT_PATH_PARTS was an environment knob until round 5) concurrent sub-frames (launches on separate streams)
     long long path_samp_bytes = 400ll << 20; // RT_PATH_SAMP_MB: state of the samples traced together (frames with num_rays > 1; ~130 B per sample and pixel slot).
                                              // Measured: a chain is fastest while its state stays near the 256 MB Infinity Cache -- 512x512, 64 samples: 23.5 / 8.8 / 8.0 /
                                              // 8.8 ms for 30 / 192 / 400 / 4096 MB; 1920x1080 (277 MB per sample): one sample per chain is best (71.5 vs 76.9 ms at 13)
@@ -75,11 +75,11 @@ struct Knobs {
                                // 7680x4320: 2.7 instead of 2.0 ms).  Off by default: a lone context is 1 % faster with both sub-frames at equal priority.
     int adv_block = 64;        // RT_ADV_BLOCK: threads per workgroup of wf_advance (64 / 128 / 256).  One-wave workgroups slip into the wave slots the traversal
                                // kernel of the other sub-frame frees one by one: 0.970 -> 0.957 ms per frame (128: 0.963; profiles/round3/ab_advance_block.log)
-    int copy_prio = 1;         // RT_COPY_PRIO: the copy streams of rt_render_async in the low-priority class (1, default), the normal one (0) or the high one (-1).  The
+    int copy_prio = 1;         // (fixed; RT_COPY_PRIO was an environment knob until round 5) the copy streams of rt_render_async in the low-priority class (1, default), the normal one (0) or the high one (-1).  The
                                // runtime keeps a pool of hardware queues per class; in the normal class the copy stream can share a queue with one of the
                                // sub-frame streams and the copy then waits behind kernels (pipelined float4 frames 1.72 instead of 1.19 ms)
     int async_pipeline = 1;    // RT_ASYNC_PIPELINE=0: rt_render_async joins the sub-frames of frame k before frame k+1 starts (as rt_render_device does without rt_ctx_set_pipelining)
-    int copy_split = 0;        // RT_COPY_SPLIT=1: rt_render_async sends the two halves of a big frame through two copy streams (measured SLOWER: 1.62 vs 1.48 ms per
+    int copy_split = 0;        // (fixed; RT_COPY_SPLIT=1 was an environment knob until round 5) rt_render_async sends the two halves of a big frame through two copy streams (measured SLOWER: 1.62 vs 1.48 ms per
                                // pipelined 1080p float4 frame -- one DMA already runs at the rate the PCIe link gives, two share it and add an event hop)
     int debug_trav = -2;       // RT_DEBUG_TRAV: traversal launch whose per-wave records are dumped (-DRT_DEBUG builds only)
 };
@@ -99,22 +99,13 @@ static Knobs read_knobs() {
     if (geti("RT_TRAVQ_QW_COUNT", v)) k.qw_count = v != 0;
     if (geti("RT_AUTO_LOCKSTEP", v)) k.auto_lockstep = v != 0;
     if (geti("RT_PARTS", v) && v >= 1 && v <= 8) k.parts = v;
-    if (getenv("RT_TRAVQ_BPC5")) k.bpc5 = 1;
     if (geti("RT_TRAV_WAVES", v) && v >= 1) k.trav_waves = v;
     if (geti("RT_TRAVQ_OVERSUB", v) && v >= 1 && v <= 16) k.oversub = v;
-    if (geti("RT_TRAVQ_OVERSUB_MIN", v) && v >= 0) k.oversub_min = v;
     if (geti("RT_TRAV_MIN_GROUPS", v) && v >= 4) k.min_groups = v;
     if (geti("RT_TRAV_LOG2S", v) && v >= 0) k.log2S = v;
-    if (geti("RT_PATH_LOW", v) && v >= 32 && v <= 320) k.path_low = v;
-    if (geti("RT_PATH_SHADE_MIN", v) && v >= 1 && v <= 64) k.path_shade_min = v;
-    if (geti("RT_PATH_OVERSUB", v) && v >= 1 && v <= 64) k.path_oversub = v;
-    if (geti("RT_PATH_BPC", v) && v >= 1 && v <= 8) k.path_bpc = v;
-    if (geti("RT_PATH_PARTS", v) && v >= 1 && v <= 8) k.path_parts = v;
-    if (geti("RT_COPY_SPLIT", v)) k.copy_split = v != 0;
     if (geti("RT_PART_PRIO", v)) k.part_prio = v != 0;
     { const char *e = getenv("RT_CHUNK_MPX"); if (e && *e) { const double d = atof(e); if (d >= 0 && d < 1e4) k.chunk_mpx = d; } }
     if (geti("RT_ASYNC_PIPELINE", v)) k.async_pipeline = v != 0;
-    if (geti("RT_COPY_PRIO", v)) k.copy_prio = v;
     if (geti("RT_ADV_BLOCK", v) && (v == 64 || v == 128 || v == 256)) k.adv_block = v;
     if (geti("RT_PATH_SAMP_MB", v) && v >= 1) k.path_samp_bytes = (long long)v << 20;
 #ifdef RT_DEBUG
@@ -449,7 +440,7 @@ int need_part_streams(rt_ctx *ctx, int parts, bool chain0 = false) {
 int need_copy_streams(rt_ctx *ctx, bool second) {
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    const int pr = ctx->knobs.copy_prio > 0 ? lo : ctx->knobs.copy_prio < 0 ? hi : 0;   // RT_COPY_PRIO: 1 = the low-priority class' queue pool, -1 = the high one
+    const int pr = ctx->knobs.copy_prio > 0 ? lo : ctx->knobs.copy_prio < 0 ? hi : 0;   // (fixed; RT_COPY_PRIO was an environment knob until round 5) 1 = the low-priority class' queue pool, -1 = the high one
     if (!ctx->copy_stream) RT_HIP(ctx, hipStreamCreateWithPriority(&ctx->copy_stream, hipStreamNonBlocking, pr));
     if (second && !ctx->copy_stream2) RT_HIP(ctx, hipStreamCreateWithPriority(&ctx->copy_stream2, hipStreamNonBlocking, pr));
     return RT_OK;
