@@ -285,7 +285,7 @@ def static_counts():
 
 
 def qw_step_counts(rt, args, p):
-    """Step counters of the 4-wide traversal kernel (the production kernel for trees below 16 384 nodes): a context created under RT_TRAVQ_QW_COUNT=1
+    """Step counters of the 4-wide traversal kernel (the production kernel wherever its node format fits): a context created under RT_TRAVQ_QW_COUNT=1
     runs THAT kernel's counting instantiation in rt_count_work (the default counting run is the binary instantiation: the reference's own box / node
     counts, which the algorithmic-bytes figure and the parity tests need)."""
     old = os.environ.get("RT_TRAVQ_QW_COUNT")

@@ -175,9 +175,9 @@ def test_reference_mesh_vectors_through_the_fixed_point_box_step(cat_golden, mon
 
 
 def test_reference_mesh_vectors_through_the_4_wide_box_step(ctx, cat_golden, monkeypatch):
-    """RT_TRAVQ_QW (round 5; the default for trees below 16 384 nodes, named here so that the test keeps meaning what it says): the BOX step tests the four boxes two
-    levels below a sibling pair's parent on 16-bit fixed-point records rounded outwards, skips every other level of the tree, and every leaf entry meets the reference's
-    test of its REAL box in the TRI step that consumes it (rt_travq.hip.h).  The reference's 6 600 mesh vectors bit for bit through the production launches, the frame of
+    """RT_TRAVQ_QW (round 5; the default wherever its node format fits, named here so that the test keeps meaning what it says): the BOX step tests the four boxes two
+    levels below a sibling pair's parent on 16-bit fixed-point records rounded outwards, skips every other level of the tree, flags the leaves it hits by less than the
+    boxes' enlargement, and a triangle accepted in a flagged leaf meets the reference's test of the leaf's REAL box (rt_travq.hip.h).  The reference's 6 600 mesh vectors bit for bit through the production launches, the frame of
     the float sibling-pair kernel (RT_TRAVQ_QW=0) word for word at b = 3, and rt_stats says which kernel ran."""
     mesh = dict(vertices=cat_golden["vertices"], indices=cat_golden["tri_bvh_order"], bvh_arr10=cat_golden["bvh_arr10"], albedo=rt.scenes.CAT_ALBEDO, object_slot=6)
     monkeypatch.setenv("RT_TRAVQ_QW", "1")
