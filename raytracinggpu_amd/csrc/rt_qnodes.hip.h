@@ -83,7 +83,9 @@ __global__ __launch_bounds__(256) void qnodes_kernel(const float4 *__restrict__ 
 // The 4-wide nodes of wf_travq<.., QW> (rt_travq.hip.h): one thread per sibling pair c = 2, 4, .. of the breadth-first array.  The quad of the pair (c, c + 1), at
 // uint4 index 2 c, is the nodesh records of the children of c and of c + 1 -- the boxes a ray meets two levels below the pair's parent -- where a LEAF of the pair
 // stands for itself next to an empty place.  Index 0 (what an idle lane's zero entry addresses) is four empty places.
-__global__ __launch_bounds__(256) void qquads_kernel(const uint4 *__restrict__ nodesh, int n_bfs, int node_shift, int leaf_shift, uint4 *__restrict__ nodesw) {
+// sel (optional): for the pair at uint4 index 2 c, sel[c / 2] = the breadth-first indices of the up to four nodes its quad holds instead (0 = empty place; places 0 and 2 are never
+// empty) -- ANY cut of the subtree below the pair's parent is exact; the host picks the one a surface-area model likes best (install_scene in rt_capi.hip).
+__global__ __launch_bounds__(256) void qquads_kernel(const uint4 *__restrict__ nodesh, int n_bfs, int node_shift, int leaf_shift, const int4 *__restrict__ sel, uint4 *__restrict__ nodesw) {
     const int c = 2 * (blockIdx.x * blockDim.x + threadIdx.x);
     if (c > n_bfs) return;
     uint4 *out = nodesw + 2 * (size_t)c;
@@ -98,6 +100,14 @@ __global__ __launch_bounds__(256) void qquads_kernel(const uint4 *__restrict__ n
         r.w = 0x80000000u | cnt << 24 | first;
         return r;
     };
+    if (sel) {
+        const int4 q = sel[c / 2];
+        const int ids[4] = {q.x, q.y, q.z, q.w};
+        if (q.x > 0 && q.z > 0) {
+            for (int j = 0; j < 4; ++j) out[j] = (ids[j] > 0 && ids[j] <= n_bfs) ? conv(nodesh[ids[j]]) : none;
+            return;
+        }
+    }
     for (int s = 0; s < 2; ++s) {
         const int x = c + s;
         const uint4 rec = x <= n_bfs ? nodesh[x] : make_uint4(0u, 0u, 0u, 0x80000000u);
