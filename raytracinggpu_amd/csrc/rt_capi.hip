@@ -48,7 +48,7 @@ struct Knobs {
     int qw = -1;               // RT_TRAVQ_QW: the BOX step is four boxes wide (fixed-point quads: the children of both nodes of a sibling pair in 64 bytes, every other level of the tree
                                // skipped; leaves flagged and decided as the fixed-point pairs decide them; rt_travq.hip.h, QW).  -1 (default) = 1 = on where the tree allows the format (boxes nest, leaves of
                                // at most 127 triangles, fewer than 2^21 nodes), 0 = off.  Bit-exact either way; cat 1920x1080: 0.934 -> 0.861 ms per frame (profiles/round5/ab_wide_nodes.txt)
-    int quad_sel = 1;          // RT_TRAVQ_QSEL=0: the quads of the 4-wide step take every other level of the tree (A/B; default: the four nodes a surface-area DP picks, host uploads only)
+    int quad_sel = 1;          // RT_TRAVQ_QSEL=0: the quads of the 4-wide step take every other level of the tree (A/B; default: the four nodes a surface-area DP picks, rt_qnodes.hip.h)
     int auto_lockstep = 1;     // RT_AUTO_LOCKSTEP=0: RT_VARIANT_AUTO stays the wavefront pipeline for scenes without a mesh (A/B; default: the lock-step kernel renders them)
     int qw_count = 0;          // RT_TRAVQ_QW_COUNT=1: rt_count_work runs the 4-wide kernel's counting instantiation (its own step counters; the box / node counts then describe
                                // THAT kernel, not the reference's traversal)
@@ -137,8 +137,7 @@ struct rt_ctx {
     rt_build_stats build{};                                          // what the last rt_mesh_rebuild_mode did
     int n_levels = 0;
     DevBuf nodesh, tri2leaf;                                        // 16-bit fixed-point sibling pairs and the triangle -> leaf table (rt_qnodes.hip.h)
-    DevBuf nodesw, quadsel;                                         // 4-wide fixed-point nodes (RT_TRAVQ_QW); which four nodes below a sibling pair's parent its quad holds (host uploads: chosen by a surface-area DP)
-    bool quadsel_ok = false;                                        // quadsel describes the tree the scene holds (false after a device-side build: the quads then take every other level)
+    DevBuf nodesw, qdp_parent, qdp_cnt, qdp_g, qdp_ch;              // 4-wide fixed-point nodes (RT_TRAVQ_QW) and the scratch of the DP that picks which four nodes a quad holds (rt_qnodes.hip.h)
     int travq_blocks_per_cu_qw[2] = {0, 0};                         // [STATS]
     unsigned chain_nonce[8] = {};                                   // launch chains started so far, PER SUB-FRAME (WfState::nonce): every part owns its own region of the ray queue, so each
                                                                     // region must cycle through all four values (one context-wide counter gave a part only two of them with two parts: ADVICE round 4)
@@ -1049,9 +1048,26 @@ int requantize(rt_ctx *ctx, hipStream_t q) {
     if (want_qw && (rc = ensure(ctx, ctx->nodesw, ((size_t)sc.n_nodes + 4) * 32)) != RT_OK) return rc;
     hipLaunchKernelGGL(rtk::qnodes_kernel, dim3((unsigned)((sc.n_nodes + 255) / 256)), dim3(256), 0, q, sc.nodesq, sc.nodesb, sc.n_nodes, g,
                        static_cast<uint4 *>(ctx->nodesh.p), static_cast<int *>(ctx->tri2leaf.p), sc.n_tris, rtk::kQLeafShift, ctx->q16_leaf_shift);
-    if (want_qw)
+    if (want_qw) {
+        const bool dp = ctx->knobs.quad_sel != 0;
+        if (dp) {
+            const size_t nn = (size_t)sc.n_nodes + 2;
+            if ((rc = ensure(ctx, ctx->qdp_parent, nn * 4)) != RT_OK || (rc = ensure(ctx, ctx->qdp_cnt, nn * 4)) != RT_OK || (rc = ensure(ctx, ctx->qdp_g, nn * 16)) != RT_OK ||
+                (rc = ensure(ctx, ctx->qdp_ch, nn * 4)) != RT_OK) return rc;
+            rtk::QdpArgs a{};
+            a.nodesh = static_cast<const uint4 *>(ctx->nodesh.p); a.n_bfs = sc.n_nodes; a.node_shift = rtk::kQNodeShift;
+            a.sx = g.sx; a.sy = g.sy; a.sz = g.sz;
+            a.parent = static_cast<int *>(ctx->qdp_parent.p); a.cnt = static_cast<int *>(ctx->qdp_cnt.p);
+            a.g = static_cast<float4 *>(ctx->qdp_g.p); a.ch = static_cast<uchar4 *>(ctx->qdp_ch.p);
+            RT_HIP(ctx, hipMemsetAsync(ctx->qdp_ch.p, 0, nn * 4, q));
+            const dim3 grid((unsigned)((sc.n_nodes + 255) / 256));
+            hipLaunchKernelGGL(rtk::qdp_init_kernel, grid, dim3(256), 0, q, a);
+            hipLaunchKernelGGL(rtk::qdp_up_kernel, grid, dim3(256), 0, q, a);
+        }
         hipLaunchKernelGGL(rtk::qquads_kernel, dim3((unsigned)((sc.n_nodes / 2 + 1 + 255) / 256)), dim3(256), 0, q, static_cast<const uint4 *>(ctx->nodesh.p), sc.n_nodes,
-                           rtk::kQNodeShift, ctx->q16_leaf_shift, ctx->quadsel_ok ? static_cast<const int4 *>(ctx->quadsel.p) : nullptr, static_cast<uint4 *>(ctx->nodesw.p));
+                           rtk::kQNodeShift, ctx->q16_leaf_shift, dp ? static_cast<const int *>(ctx->qdp_parent.p) : nullptr, dp ? static_cast<const uchar4 *>(ctx->qdp_ch.p) : nullptr,
+                           static_cast<uint4 *>(ctx->nodesw.p));
+    }
     RT_HIP(ctx, hipGetLastError());
     RT_HIP(ctx, hipStreamSynchronize(q));
     sc.nodesh = static_cast<const uint4 *>(ctx->nodesh.p); sc.tri2leaf = static_cast<const int *>(ctx->tri2leaf.p);
@@ -1179,62 +1195,16 @@ int install_scene(rt_ctx *ctx, rtk::Scene sc, const rt_mesh *mesh) {
             qb[2 * (k + 1)] = cb; qb[2 * (k + 1) + 1] = hb;
         }
         if ((rc = upload(ctx, ctx->nodesb, qb.data(), qb.size() * sizeof(float4))) != RT_OK) return rc;
-        ctx->quadsel_ok = false;
-        if (ctx->knobs.quad_sel && order.size() >= 3) {
-            // Which four nodes stand in the quad of a sibling pair's parent P (rt_qnodes.hip.h, qquads_kernel)?  Any cut of P's subtree of at most four nodes is exact (the
-            // boxes nest; only the leaves' own boxes decide what the reference reaches); taking every other level is one choice.  Here: the cut that minimises the
-            // expected number of stack entries below P under the surface-area model (an internal node y in a cut costs area(y) + the best cost below y) -- a
-            // bottom-up DP over g(x, k) = the least cost of covering x's subtree with at most k nodes (breadth-first order: children have larger indices).
-            const size_t nb = order.size() + 1;
-            std::vector<int> fc(nb, 0);                                // first child (breadth-first index), 0 = leaf
-            std::vector<double> area(nb, 0.0), tot(nb, 0.0);
-            std::vector<double> g(nb * 4, 0.0);                        // g[4 b + k], k = 1..3
-            std::vector<unsigned char> cg(nb * 4, 0), ct(nb, 0);       // argmin: 0 = the node itself, k1 = nodes given to the first child
-            for (size_t k = 0; k < order.size(); ++k) {
-                const int x = order[k];
-                const double ex = (double)hi[x].x - lo[x].x, ey = (double)hi[x].y - lo[x].y, ez = (double)hi[x].z - lo[x].z;
-                area[k + 1] = ex * ey + ey * ez + ex * ez;
-                fc[k + 1] = left_of[x] >= 0 ? bfs_of[x + 1] + 1 : 0;
-            }
-            for (size_t b = nb - 1; b >= 1; --b) {
-                if (!fc[b]) continue;                                  // leaf: g = 0 for every k
-                const int l = fc[b], r = fc[b] + 1;
-                double best = 1e300; int bk = 1;
-                for (int k1 = 1; k1 <= 3; ++k1) { const double v = g[4 * l + k1] + g[4 * r + (4 - k1)]; if (v < best) { best = v; bk = k1; } }
-                tot[b] = best; ct[b] = (unsigned char)bk;
-                g[4 * b + 1] = area[b] + tot[b]; cg[4 * b + 1] = 0;
-                for (int k = 2; k <= 3; ++k) {
-                    double bv = g[4 * b + 1]; int bc = 0;
-                    for (int k1 = 1; k1 < k; ++k1) { const double v = g[4 * l + k1] + g[4 * r + (k - k1)]; if (v < bv) { bv = v; bc = k1; } }
-                    g[4 * b + k] = bv; cg[4 * b + k] = (unsigned char)bc;
-                }
-            }
-            std::vector<int4> sel(nb / 2 + 1, make_int4(0, 0, 0, 0));
-            for (size_t b = 1; b < nb; ++b) {
-                if (!fc[b]) continue;
-                int cut[4], nc = 0;
-                struct Item { int x, k; } st[8];
-                int sp = 0;
-                st[sp++] = {fc[b] + 1, 4 - ct[b]}; st[sp++] = {fc[b], ct[b]};          // first child's part comes out first
-                while (sp > 0) {
-                    const Item it = st[--sp];
-                    const int c1 = (fc[it.x] && it.k >= 2) ? cg[4 * it.x + (it.k > 3 ? 3 : it.k)] : 0;
-                    if (!fc[it.x] || it.k < 2 || c1 == 0) { if (nc < 4) cut[nc++] = it.x; continue; }
-                    st[sp++] = {fc[it.x] + 1, it.k - c1}; st[sp++] = {fc[it.x], c1};
-                }
-                // internal nodes first, leaves last: a BOX step runs one push block per place and kind that SOME lane needs, so kinds that keep to their places mean fewer blocks
-                std::stable_partition(cut, cut + nc, [&](int x) { return fc[x] != 0; });
-                // the 4-wide step assumes places 0 and 2 hold a node: two nodes sit at 0 and 2, three at 0, 1, 2
-                sel[fc[b] / 2] = nc == 2 ? make_int4(cut[0], 0, cut[1], 0) : nc == 3 ? make_int4(cut[0], cut[1], cut[2], 0) : make_int4(cut[0], cut[1], cut[2], cut[3]);
-            }
-            if ((rc = upload(ctx, ctx->quadsel, sel.data(), sel.size() * sizeof(int4))) != RT_OK) return rc;
-            ctx->quadsel_ok = true;
-        }
         {   // may this tree use the 16-bit fixed-point pairs (rt_qnodes.hip.h)?  Leaf sizes and counts fit the payload word, and every box nests inside its parent's
             bool topo = order.size() >= 3;
             int max_leaf = 0;
             for (size_t x = 0; topo && x < n; ++x) {
-                if (left_of[x] < 0) { max_leaf = std::max(max_leaf, __builtin_bit_cast(int, hi[x].w) - __builtin_bit_cast(int, lo[x].w)); continue; }
+                if (left_of[x] < 0) {
+                    const int cnt = __builtin_bit_cast(int, hi[x].w) - __builtin_bit_cast(int, lo[x].w);
+                    max_leaf = std::max(max_leaf, cnt);
+                    if (cnt <= 0) topo = false;                       // an empty leaf: the quads' places 0 and 2 must hold a node (the float pairs cope with it)
+                    continue;
+                }
                 for (const int c : {(int)x + 1, left_of[x]}) {
                     const float4 cl = lo[c], ch = hi[c], pl = lo[x], ph = hi[x];
                     if (!(cl.x >= pl.x && cl.y >= pl.y && cl.z >= pl.z && ch.x <= ph.x && ch.y <= ph.y && ch.z <= ph.z)) topo = false;   // also false for NaN
@@ -1371,7 +1341,7 @@ int rt_ctx_destroy(rt_ctx *ctx) {
         if (ctx->slot_rendered[k]) (void)hipEventDestroy(ctx->slot_rendered[k]);
         if (ctx->slot_done[k]) (void)hipEventDestroy(ctx->slot_done[k]);
     }
-    ctx->node_lo.release(); ctx->node_hi.release(); ctx->nodes2.release(); ctx->nodesq.release(); ctx->nodesb.release(); ctx->nodesh.release(); ctx->tri2leaf.release(); ctx->nodesw.release(); ctx->quadsel.release(); ctx->q2thr.release(); ctx->left_dev.release(); ctx->lvl_nodes.release(); ctx->lvl_off.release(); ctx->nrm.release(); ctx->tri.release(); ctx->verts.release(); ctx->tidx.release();
+    ctx->node_lo.release(); ctx->node_hi.release(); ctx->nodes2.release(); ctx->nodesq.release(); ctx->nodesb.release(); ctx->nodesh.release(); ctx->tri2leaf.release(); ctx->nodesw.release(); ctx->qdp_parent.release(); ctx->qdp_cnt.release(); ctx->qdp_g.release(); ctx->qdp_ch.release(); ctx->q2thr.release(); ctx->left_dev.release(); ctx->lvl_nodes.release(); ctx->lvl_off.release(); ctx->nrm.release(); ctx->tri.release(); ctx->verts.release(); ctx->tidx.release();
     ctx->scratch_rgba.release(); ctx->scratch_rgb8.release(); ctx->work.release(); ctx->queue.release();
     ctx->wfM.release(); ctx->wfT.release(); ctx->wfLS.release(); ctx->wfSID.release(); ctx->wfSamp.release();
     ctx->wfQR.release(); ctx->accum.release(); ctx->dbgbuf.release();
@@ -1875,7 +1845,6 @@ static int install_lbvh_device(rt_ctx *ctx, const rtk::Scene &old, const int n_n
     ctx->host_mesh_stale = true;                                                 // tri_perm / up_indices: on the device now (perm_dev, tidx_up)
     ctx->have_scene = true;
     ctx->q16_topo_ok = true;                                                     // boxes are unions, bottom-up: they nest
-    ctx->quadsel_ok = false;                                                     // (a tree built on the device: its quads take every other level)
     ctx->q16_leaf_shift = rtk::q16_leaf_shift(rtk::kLbvhLeaf, n);                // leaves of at most kLbvhLeaf triangles
     return requantize(ctx, q);
 }

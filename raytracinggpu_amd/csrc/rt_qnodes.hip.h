@@ -83,9 +83,70 @@ __global__ __launch_bounds__(256) void qnodes_kernel(const float4 *__restrict__ 
 // The 4-wide nodes of wf_travq<.., QW> (rt_travq.hip.h): one thread per sibling pair c = 2, 4, .. of the breadth-first array.  The quad of the pair (c, c + 1), at
 // uint4 index 2 c, is the nodesh records of the children of c and of c + 1 -- the boxes a ray meets two levels below the pair's parent -- where a LEAF of the pair
 // stands for itself next to an empty place.  Index 0 (what an idle lane's zero entry addresses) is four empty places.
-// sel (optional): for the pair at uint4 index 2 c, sel[c / 2] = the breadth-first indices of the up to four nodes its quad holds instead (0 = empty place; places 0 and 2 are never
-// empty) -- ANY cut of the subtree below the pair's parent is exact; the host picks the one a surface-area model likes best (install_scene in rt_capi.hip).
-__global__ __launch_bounds__(256) void qquads_kernel(const uint4 *__restrict__ nodesh, int n_bfs, int node_shift, int leaf_shift, const int4 *__restrict__ sel, uint4 *__restrict__ nodesw) {
+// WHICH four nodes a quad holds.  Any cut of at most four nodes of the subtree below a sibling pair's parent P is exact (the boxes nest; only the leaves' own boxes decide what the
+// reference reaches); "the children of c and of c + 1" is one choice.  The three kernels below pick, for every P, the cut that minimises the expected number of stack entries below
+// P under the surface-area model -- an internal node y in a cut costs area(y) + the best cost below y -- by a bottom-up DP over
+//     g(x, k) = the least cost of covering x's subtree with at most k nodes          (k = 1, 2, 3;  a leaf costs nothing;  tot(x) = min over k1 + k2 = 4 of g(l, k1) + g(r, k2))
+// one thread per leaf climbing towards the root, the second arrival at a node computing it (the first one's values are behind a fence; a stale value could only cost optimality:
+// every recorded choice describes a valid cut whatever the numbers were).  On the cat the model says 7.05 -> 6.69 entries per root hit; measured: BOX steps -3.3 %, frame -1.0 %
+// (profiles/round5/ab_wide_nodes.txt).  Areas are taken from the fixed-point half extents (a model needs no more).
+struct QdpArgs {
+    const uint4 *nodesh; int n_bfs, node_shift;
+    float sx, sy, sz;
+    int *parent, *cnt;          // [n_bfs + 2]
+    float4 *g;                  // (g1, g2, g3, tot)
+    uchar4 *ch;                 // (first child's share of g2's split or 0 = the node itself, the same for g3, the first child's share of tot's four, -)
+};
+__device__ __forceinline__ int qdp_first_child(uint4 rec, int node_shift) { return (int)rec.w > 0 ? (int)((rec.w << 1) >> node_shift) : 0; }
+
+__global__ __launch_bounds__(256) void qdp_init_kernel(const QdpArgs a) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    if (b > a.n_bfs) return;
+    a.cnt[b] = 0;
+    if (b == 1) a.parent[1] = 0;
+    const int fc = qdp_first_child(a.nodesh[b], a.node_shift);
+    if (fc > 0 && fc + 1 <= a.n_bfs) { a.parent[fc] = b; a.parent[fc + 1] = b; }
+}
+__global__ __launch_bounds__(256) void qdp_up_kernel(const QdpArgs a) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    if (b > a.n_bfs || qdp_first_child(a.nodesh[b], a.node_shift) > 0) return;      // leaves start the climb
+    a.g[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto ld = [&](int x) {                                                            // a child's values: written by another workgroup, read past the L1
+        const float *p = reinterpret_cast<const float *>(a.g + x);
+        return make_float4(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                           __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 0.f);
+    };
+    int cur = a.parent[b];
+    for (int guard = 0; cur > 0 && guard < 4096; ++guard) {
+        __threadfence();                                                              // my values are visible before I announce myself
+        if (atomicAdd(&a.cnt[cur], 1) == 0) return;                                   // first to arrive: the sibling's thread goes on from here
+        __threadfence();
+        const uint4 rec = a.nodesh[cur];
+        const int l = qdp_first_child(rec, a.node_shift), r = l + 1;
+        const float4 gl = ld(l), gr = ld(r);
+        const float ex = (float)(rec.y >> 16) * a.sx, ey = (float)(rec.z & 0xffffu) * a.sy, ez = (float)(rec.z >> 16) * a.sz;
+        const float area = ex * ey + ey * ez + ex * ez;
+        float tot = gl.x + gr.z; unsigned char ct = 1;                                // k1 + k2 = 4: (1, 3), (2, 2), (3, 1)
+        if (gl.y + gr.y < tot) { tot = gl.y + gr.y; ct = 2; }
+        if (gl.z + gr.x < tot) { tot = gl.z + gr.x; ct = 3; }
+        const float g1 = area + tot;
+        float g2 = g1; unsigned char c2 = 0;
+        if (gl.x + gr.x < g2) { g2 = gl.x + gr.x; c2 = 1; }
+        float g3 = g1; unsigned char c3 = 0;
+        if (gl.x + gr.y < g3) { g3 = gl.x + gr.y; c3 = 1; }
+        if (gl.y + gr.x < g3) { g3 = gl.y + gr.x; c3 = 2; }
+        a.g[cur] = make_float4(g1, g2, g3, tot);
+        a.ch[cur] = make_uchar4(c2, c3, ct, 0);
+        cur = a.parent[cur];
+    }
+}
+
+// The 4-wide nodes of wf_travq<.., QW> (rt_travq.hip.h): one thread per sibling pair c = 2, 4, .. of the breadth-first array.  The quad of the pair (c, c + 1), at uint4 index
+// 2 c, holds the nodesh records of up to four nodes that cut the subtree below the pair's parent: the DP's choice (parent / ch given), or the children of c and of c + 1 (a LEAF of
+// the pair stands for itself next to an empty place).  Internal nodes come first, leaves last (a BOX step runs one push block per place and kind that some lane needs); places 0 and 2
+// are never empty.  Index 0 (what an idle lane's zero entry addresses) is four empty places.
+__global__ __launch_bounds__(256) void qquads_kernel(const uint4 *__restrict__ nodesh, int n_bfs, int node_shift, int leaf_shift, const int *__restrict__ parent,
+                                                     const uchar4 *__restrict__ ch, uint4 *__restrict__ nodesw) {
     const int c = 2 * (blockIdx.x * blockDim.x + threadIdx.x);
     if (c > n_bfs) return;
     uint4 *out = nodesw + 2 * (size_t)c;
@@ -100,24 +161,39 @@ __global__ __launch_bounds__(256) void qquads_kernel(const uint4 *__restrict__ n
         r.w = 0x80000000u | cnt << 24 | first;
         return r;
     };
-    if (sel) {
-        const int4 q = sel[c / 2];
-        const int ids[4] = {q.x, q.y, q.z, q.w};
-        if (q.x > 0 && q.z > 0) {
-            for (int j = 0; j < 4; ++j) out[j] = (ids[j] > 0 && ids[j] <= n_bfs) ? conv(nodesh[ids[j]]) : none;
-            return;
+    int cut[4], nc = 0;
+    if (parent && ch && c + 1 <= n_bfs) {
+        const int P = parent[c];
+        const int k1 = ch[P].z >= 1 && ch[P].z <= 3 ? ch[P].z : 2;
+        int sx[8], sk[8], sp = 0;
+        sx[sp] = c + 1; sk[sp++] = 4 - k1; sx[sp] = c; sk[sp++] = k1;                 // the first child's part comes out first
+        while (sp > 0 && nc < 4) {
+            const int x = sx[--sp], k = sk[sp];
+            const int fc = x <= n_bfs ? qdp_first_child(nodesh[x], node_shift) : 0;
+            const int c1 = (fc > 0 && k >= 2) ? (k == 2 ? ch[x].x : ch[x].y) : 0;
+            if (c1 <= 0 || c1 >= k || sp + 2 > 8) { cut[nc++] = x; continue; }
+            sx[sp] = fc + 1; sk[sp++] = k - c1; sx[sp] = fc; sk[sp++] = c1;
+        }
+    } else {
+        for (int s = 0; s < 2; ++s) {
+            const int x = c + s;
+            const int fc = x <= n_bfs ? qdp_first_child(nodesh[x], node_shift) : 0;
+            if (fc > 0) { cut[nc++] = fc; cut[nc++] = fc + 1; } else if (x <= n_bfs) cut[nc++] = x;
         }
     }
-    for (int s = 0; s < 2; ++s) {
-        const int x = c + s;
-        const uint4 rec = x <= n_bfs ? nodesh[x] : make_uint4(0u, 0u, 0u, 0x80000000u);
-        if ((int)rec.w > 0) {                                                   // internal: its two children
-            const int p = (int)((rec.w << 1) >> node_shift);
-            out[2 * s] = conv(nodesh[p]); out[2 * s + 1] = conv(nodesh[p + 1]);
-        } else {
-            out[2 * s] = conv(rec); out[2 * s + 1] = none;
-        }
-    }
+    // internal nodes first; then two nodes sit at places 0 and 2, three at 0, 1, 2
+    int ord[4], no = 0;
+    for (int j = 0; j < nc; ++j) if (qdp_first_child(nodesh[cut[j]], node_shift) > 0) ord[no++] = cut[j];
+    for (int j = 0; j < nc; ++j) if (qdp_first_child(nodesh[cut[j]], node_shift) <= 0) ord[no++] = cut[j];
+    uint4 recs[4] = {none, none, none, none};
+    for (int j = 0; j < no; ++j) recs[j] = conv(nodesh[ord[j]]);
+    // empty leaves (count 0) convert to nothing: keep the real ones in front, then spread
+    uint4 real[4]; int nr = 0;
+    for (int j = 0; j < no; ++j) if (recs[j].w != 0u) real[nr++] = recs[j];
+    out[0] = nr > 0 ? real[0] : none;
+    out[1] = nr > 2 ? real[1] : none;
+    out[2] = nr > 2 ? real[2] : (nr > 1 ? real[1] : none);
+    out[3] = nr > 3 ? real[3] : none;
 }
 
 }  // namespace rtk
