@@ -347,13 +347,14 @@ def test_auto_variant_is_the_lock_step_kernel_without_a_mesh_and_the_work_stack_
 @pytest.mark.parametrize("env", [{"RT_TRAVQ_CAP": "128"}, {"RT_TRAVQ_R": "32"}, {"RT_TRAVQ_R": "32", "RT_TRAVQ_CAP": "128"},
                                  {"RT_TRAVQ_LDS": "12"}, {"RT_TRAVQ_LDS": "12", "RT_TRAVQ_R": "32"}, {"RT_TRAVQ_LDS": "16"},
                                  {"RT_TRAVQ_LDS": "8", "RT_TRAVQ_CAP": "128"}, {"RT_TRAVQ_QW": "0", "RT_TRAVQ_Q16": "1"}, {"RT_TRAVQ_QW": "0", "RT_TRAVQ_Q16": "1", "RT_TRAVQ_CAP": "128"},
-                                 {"RT_TRAVQ_QW": "0"}, {"RT_TRAVQ_QW": "0", "RT_TRAVQ_CAP": "128"}, {"RT_TRAVQ_QW": "1"}, {"RT_TRAVQ_QW": "1", "RT_TRAVQ_CAP": "128"}])
+                                 {"RT_TRAVQ_QW": "0"}, {"RT_TRAVQ_QW": "0", "RT_TRAVQ_CAP": "128"}, {"RT_TRAVQ_QW": "1"}, {"RT_TRAVQ_QW": "1", "RT_TRAVQ_CAP": "128"}, {"RT_TRAVQ_QSEL": "0"}, {"RT_TRAVQ_QSEL": "0", "RT_TRAVQ_CAP": "128"}])
 def test_work_stack_traversal_bounded_stack_and_slot_counts(ctx, cat_golden, monkeypatch, env):
     """wf_travq with a 128-entry stack (forces the serial-drain path that keeps LDS bounded for any tree), with
     32 ray slots per wave, with all / the top 15 BVH nodes staged in LDS (RT_TRAVQ_LDS = waves per CU), with the BOX step reading
     16-bit fixed-point sibling pairs (RT_TRAVQ_Q16, rt_qnodes.hip.h), with the float sibling pairs the default kernel was until round 5
-    (RT_TRAVQ_QW=0) and with the 4-wide BOX step named explicitly (RT_TRAVQ_QW=1: the default for the cat; with a 128-entry stack its steps
-    predict an overflow and walk their pairs serially): same bits and same work counters as the stackless-walk kernel."""
+    (RT_TRAVQ_QW=0), with the 4-wide BOX step named explicitly (RT_TRAVQ_QW=1: the default for the cat; with a 128-entry stack its steps
+    predict an overflow and walk their pairs serially) and with its quads taking every other level of the tree instead of the cuts the surface-area DP
+    picks (RT_TRAVQ_QSEL=0: any cut is exact): same bits and same work counters as the stackless-walk kernel."""
     upload(ctx, "cpu", cat_golden)
     p = rt.make_params(640, 360, 2, 3, variant="wavefront_queue", **rt.scenes.CPU_LAUNCHER)
     ref = ctx.render(rt.make_params(640, 360, 2, 3, variant="wavefront", **rt.scenes.CPU_LAUNCHER))
