@@ -137,6 +137,7 @@ struct rt_ctx {
     rt_build_stats build{};                                          // what the last rt_mesh_rebuild_mode did
     int n_levels = 0;
     DevBuf nodesh, tri2leaf;                                        // 16-bit fixed-point sibling pairs and the triangle -> leaf table (rt_qnodes.hip.h)
+    DevBuf leaflh;                                                  // (lo, hi) of each triangle's leaf, by triangle (the flagged-leaf check of the fixed-point kernels)
     DevBuf nodesw, qdp_parent, qdp_cnt, qdp_g, qdp_ch;              // 4-wide fixed-point nodes (RT_TRAVQ_QW) and the scratch of the DP that picks which four nodes a quad holds (rt_qnodes.hip.h)
     int travq_blocks_per_cu_qw[2] = {0, 0};                         // [STATS]
     unsigned chain_nonce[8] = {};                                   // launch chains started so far, PER SUB-FRAME (WfState::nonce): every part owns its own region of the ray queue, so each
@@ -1036,18 +1037,22 @@ constexpr int kQ16AutoNodes = 16384;                                 // RT_TRAVQ
 // get later, profiles/round3/ab_hw_queues_parts.log), joined before returning.  ctx->scene must be final (root box, node arrays); trees the format does not fit keep scene.nodesh = nullptr.
 int requantize(rt_ctx *ctx, hipStream_t q) {
     rtk::Scene &sc = ctx->scene;
-    sc.nodesh = nullptr; sc.tri2leaf = nullptr; sc.nodesw = nullptr;
+    sc.nodesh = nullptr; sc.tri2leaf = nullptr; sc.nodesw = nullptr; sc.leaflh = nullptr;
     // (wherever the format fits: with flagged leaves the 4-wide step beats the fixed-point pairs on every tree measured -- 2 019 nodes -8 %, 32 889 -9 %, 358 503 -12 %: profiles/round5/ab_wide_nodes.txt)
     const bool want_qw = ctx->knobs.qw != 0 && ctx->q16_leaf_shift == 24 && sc.n_nodes + 2 < (1 << 21);   // the quad's payload word: leaves of <= 127 triangles, child << 10 positive
     if (!(ctx->knobs.q16 == 1 || (ctx->knobs.q16 < 0 && sc.n_nodes >= kQ16AutoNodes) || want_qw) || !ctx->q16_topo_ok || ctx->q16_leaf_shift == 0 || !ctx->travq_ok || !sc.fast_box || sc.mesh_slot < 0 || sc.n_nodes < 3 || sc.n_tris <= 0) return RT_OK;
     int rc;
-    if ((rc = ensure(ctx, ctx->nodesh, ((size_t)sc.n_nodes + 2) * 16)) != RT_OK || (rc = ensure(ctx, ctx->tri2leaf, (size_t)sc.n_tris * sizeof(int))) != RT_OK) return rc;
+    if ((rc = ensure(ctx, ctx->nodesh, ((size_t)sc.n_nodes + 2) * 16)) != RT_OK || (rc = ensure(ctx, ctx->tri2leaf, (size_t)sc.n_tris * sizeof(int))) != RT_OK ||
+        (rc = ensure(ctx, ctx->leaflh, (size_t)sc.n_tris * 32)) != RT_OK) return rc;
+    RT_HIP(ctx, hipMemsetAsync(ctx->tri2leaf.p, 0, (size_t)sc.n_tris * sizeof(int), q));
     const rtk::QGrid g = rtk::q16_grid(sc.root_lo, sc.root_hi);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipMemsetAsync(ctx->nodesh.p, 0, 32, q));            // nodes 0 (padding) and 1 (the root: tested when a ray is emitted)
     if (want_qw && (rc = ensure(ctx, ctx->nodesw, ((size_t)sc.n_nodes + 4) * 32)) != RT_OK) return rc;
     hipLaunchKernelGGL(rtk::qnodes_kernel, dim3((unsigned)((sc.n_nodes + 255) / 256)), dim3(256), 0, q, sc.nodesq, sc.nodesb, sc.n_nodes, g,
                        static_cast<uint4 *>(ctx->nodesh.p), static_cast<int *>(ctx->tri2leaf.p), sc.n_tris, rtk::kQLeafShift, ctx->q16_leaf_shift);
+    hipLaunchKernelGGL(rtk::leaflh_kernel, dim3((unsigned)((sc.n_tris + 255) / 256)), dim3(256), 0, q, sc.nodesq, static_cast<const int *>(ctx->tri2leaf.p), sc.n_tris, sc.n_nodes,
+                       static_cast<float4 *>(ctx->leaflh.p));
     if (want_qw) {
         const bool dp = ctx->knobs.quad_sel != 0;
         if (dp) {
@@ -1070,7 +1075,7 @@ int requantize(rt_ctx *ctx, hipStream_t q) {
     }
     RT_HIP(ctx, hipGetLastError());
     RT_HIP(ctx, hipStreamSynchronize(q));
-    sc.nodesh = static_cast<const uint4 *>(ctx->nodesh.p); sc.tri2leaf = static_cast<const int *>(ctx->tri2leaf.p);
+    sc.nodesh = static_cast<const uint4 *>(ctx->nodesh.p); sc.tri2leaf = static_cast<const int *>(ctx->tri2leaf.p); sc.leaflh = static_cast<const float4 *>(ctx->leaflh.p);
     if (want_qw) sc.nodesw = static_cast<const uint4 *>(ctx->nodesw.p);
     sc.qgx = g.gx; sc.qgy = g.gy; sc.qgz = g.gz; sc.qsx = g.sx; sc.qsy = g.sy; sc.qsz = g.sz; sc.qleaf_shift = ctx->q16_leaf_shift;
     return RT_OK;
@@ -1341,7 +1346,7 @@ int rt_ctx_destroy(rt_ctx *ctx) {
         if (ctx->slot_rendered[k]) (void)hipEventDestroy(ctx->slot_rendered[k]);
         if (ctx->slot_done[k]) (void)hipEventDestroy(ctx->slot_done[k]);
     }
-    ctx->node_lo.release(); ctx->node_hi.release(); ctx->nodes2.release(); ctx->nodesq.release(); ctx->nodesb.release(); ctx->nodesh.release(); ctx->tri2leaf.release(); ctx->nodesw.release(); ctx->qdp_parent.release(); ctx->qdp_cnt.release(); ctx->qdp_g.release(); ctx->qdp_ch.release(); ctx->q2thr.release(); ctx->left_dev.release(); ctx->lvl_nodes.release(); ctx->lvl_off.release(); ctx->nrm.release(); ctx->tri.release(); ctx->verts.release(); ctx->tidx.release();
+    ctx->node_lo.release(); ctx->node_hi.release(); ctx->nodes2.release(); ctx->nodesq.release(); ctx->nodesb.release(); ctx->nodesh.release(); ctx->tri2leaf.release(); ctx->nodesw.release(); ctx->leaflh.release(); ctx->qdp_parent.release(); ctx->qdp_cnt.release(); ctx->qdp_g.release(); ctx->qdp_ch.release(); ctx->q2thr.release(); ctx->left_dev.release(); ctx->lvl_nodes.release(); ctx->lvl_off.release(); ctx->nrm.release(); ctx->tri.release(); ctx->verts.release(); ctx->tidx.release();
     ctx->scratch_rgba.release(); ctx->scratch_rgb8.release(); ctx->work.release(); ctx->queue.release();
     ctx->wfM.release(); ctx->wfT.release(); ctx->wfLS.release(); ctx->wfSID.release(); ctx->wfSamp.release();
     ctx->wfQR.release(); ctx->accum.release(); ctx->dbgbuf.release();

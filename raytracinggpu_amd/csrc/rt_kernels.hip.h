@@ -59,6 +59,7 @@ struct Scene {
     const uint4 *nodesh;      // the sibling pairs once more in 16-bit fixed point, 32 bytes per pair (rt_travq.hip.h, QN): per child (centre.xyz, half extent.xyz) on the
                               // grid below, rounded OUTWARDS, and one payload word (rt_qnodes.hip.h); nullptr = not available for this tree
     const int *tri2leaf;      // triangle (visit order) -> breadth-first index of its leaf (the exact box of a flagged leaf: rt_qnodes.hip.h)
+    const float4 *leaflh;     // (lo, hi) of the leaf that holds triangle i (visit order) at [2 i], [2 i + 1]: what the check of a triangle accepted in a FLAGGED leaf reads in one hop (rt_travq.hip.h)
     const uint4 *nodesw;      // 4-wide fixed-point nodes (rt_travq.hip.h, QW): for the sibling pair (c, c + 1) the 64 bytes at byte offset 32 c hold the nodesh records of
                               // c's children and (c + 1)'s children (a leaf of the pair stands for itself, the free place is an empty leaf); nullptr = not in use
     float qgx, qgy, qgz;      // grid origin (the root box's lower corner) and cell size per axis

@@ -83,6 +83,16 @@ __global__ __launch_bounds__(256) void qnodes_kernel(const float4 *__restrict__ 
 // The 4-wide nodes of wf_travq<.., QW> (rt_travq.hip.h): one thread per sibling pair c = 2, 4, .. of the breadth-first array.  The quad of the pair (c, c + 1), at
 // uint4 index 2 c, is the nodesh records of the children of c and of c + 1 -- the boxes a ray meets two levels below the pair's parent -- where a LEAF of the pair
 // stands for itself next to an empty place.  Index 0 (what an idle lane's zero entry addresses) is four empty places.
+// the real box of every triangle's leaf, by triangle: the flagged-leaf check of a TRI step reads it without going through tri2leaf first
+__global__ __launch_bounds__(256) void leaflh_kernel(const float4 *__restrict__ nodesq, const int *__restrict__ tri2leaf, int n_tris, int n_bfs, float4 *__restrict__ leaflh) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_tris) return;
+    const int lf = tri2leaf[i];
+    const bool ok = lf >= 1 && lf <= n_bfs;
+    leaflh[2 * (size_t)i] = ok ? nodesq[2 * (size_t)lf] : make_float4(0, 0, 0, 0);
+    leaflh[2 * (size_t)i + 1] = ok ? nodesq[2 * (size_t)lf + 1] : make_float4(0, 0, 0, 0);
+}
+
 // WHICH four nodes a quad holds.  Any cut of at most four nodes of the subtree below a sibling pair's parent P is exact (the boxes nest; only the leaves' own boxes decide what the
 // reference reaches); "the children of c and of c + 1" is one choice.  The three kernels below pick, for every P, the cut that minimises the expected number of stack entries below
 // P under the surface-area model -- an internal node y in a cut costs area(y) + the best cost below y -- by a bottom-up DP over

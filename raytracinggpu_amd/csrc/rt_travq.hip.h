@@ -623,12 +623,9 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
                     if (STATS) n_lit++;                              // (the counter of the float pairs' literal-box blocks: they never run in this instantiation)
                     if (any) {                                       // one region for the lane's triangles: the table lookups, then the boxes, of all of them in flight together
                         WQ_MARK("lflag_begin");
-                        int lf_[NT];
                         float4 lo_[NT], hi_[NT];
 #pragma unroll
-                        for (int k = 0; k < NT; ++k) lf_[k] = sc.tri2leaf[ch_[k] ? i_[k] : 0];
-#pragma unroll
-                        for (int k = 0; k < NT; ++k) { lo_[k] = sc.nodesq[2 * (size_t)lf_[k]]; hi_[k] = sc.nodesq[2 * (size_t)lf_[k] + 1]; }
+                        for (int k = 0; k < NT; ++k) { const size_t x = 2 * (size_t)(ch_[k] ? i_[k] : 0); lo_[k] = sc.leaflh[x]; hi_[k] = sc.leaflh[x + 1]; }   // the leaf's (lo, hi), kept per triangle: one hop
 #pragma unroll
                         for (int k = 0; k < NT; ++k) {
                             const f3 Or = mk(C_[k].x, C_[k].y, C_[k].z), ur = mk(C_[k].w, D_[k].x, D_[k].y);
