@@ -127,12 +127,13 @@ __global__ __launch_bounds__(256) void qdp_up_kernel(const QdpArgs a) {
                            __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 0.f);
     };
     int cur = a.parent[b];
-    for (int guard = 0; cur > 0 && guard < 4096; ++guard) {
+    for (int guard = 0; cur > 0 && cur <= a.n_bfs && guard < 4096; ++guard) {        // (the range test and the guard only bound a corrupted tree)
         __threadfence();                                                              // my values are visible before I announce myself
         if (atomicAdd(&a.cnt[cur], 1) == 0) return;                                   // first to arrive: the sibling's thread goes on from here
         __threadfence();
         const uint4 rec = a.nodesh[cur];
         const int l = qdp_first_child(rec, a.node_shift), r = l + 1;
+        if (l <= 0 || r > a.n_bfs) return;
         const float4 gl = ld(l), gr = ld(r);
         const float ex = (float)(rec.y >> 16) * a.sx, ey = (float)(rec.z & 0xffffu) * a.sy, ez = (float)(rec.z >> 16) * a.sz;
         const float area = ex * ey + ey * ez + ex * ez;
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256) void qquads_kernel(const uint4 *__restrict__ n
     };
     int cut[4], nc = 0;
     if (parent && ch && c + 1 <= n_bfs) {
-        const int P = parent[c];
+        const int P = parent[c] >= 1 && parent[c] <= n_bfs ? parent[c] : 1;
         const int k1 = ch[P].z >= 1 && ch[P].z <= 3 ? ch[P].z : 2;
         int sx[8], sk[8], sp = 0;
         sx[sp] = c + 1; sk[sp++] = 4 - k1; sx[sp] = c; sk[sp++] = k1;                 // the first child's part comes out first
@@ -181,6 +182,7 @@ __global__ __launch_bounds__(256) void qquads_kernel(const uint4 *__restrict__ n
             const int x = sx[--sp], k = sk[sp];
             const int fc = x <= n_bfs ? qdp_first_child(nodesh[x], node_shift) : 0;
             const int c1 = (fc > 0 && k >= 2) ? (k == 2 ? ch[x].x : ch[x].y) : 0;
+            if (x < 1 || x > n_bfs) continue;
             if (c1 <= 0 || c1 >= k || sp + 2 > 8) { cut[nc++] = x; continue; }
             sx[sp] = fc + 1; sk[sp++] = k - c1; sx[sp] = fc; sk[sp++] = c1;
         }
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(256) void qquads_kernel(const uint4 *__restrict__ n
         for (int s = 0; s < 2; ++s) {
             const int x = c + s;
             const int fc = x <= n_bfs ? qdp_first_child(nodesh[x], node_shift) : 0;
-            if (fc > 0) { cut[nc++] = fc; cut[nc++] = fc + 1; } else if (x <= n_bfs) cut[nc++] = x;
+            if (fc > 0 && fc + 1 <= n_bfs) { cut[nc++] = fc; cut[nc++] = fc + 1; } else if (x <= n_bfs) cut[nc++] = x;
         }
     }
     // internal nodes first; then two nodes sit at places 0 and 2, three at 0, 1, 2
