@@ -29,8 +29,9 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 5
+#define RT_ABI_VERSION 6
 #define RT_MAX_SPHERES 16      /* reference: Geometry* objects[10], optimized.cu:663 */
+#define RT_MAX_OBJECTS 16      /* spheres + meshes of one scene (Scene::objects, cpu:538-543)                     */
 #define RT_MAX_SEGMENTS 16     /* reference: MAX_RAY_DEPTH 10, optimized.cu:22       */
 
 typedef enum rt_status {
@@ -103,6 +104,12 @@ typedef struct rt_mesh {
     float          albedo[3];      /* mesh_ptr->albedo, cpu:683                               */
     int32_t        object_slot;    /* position in Scene::objects (cpu_launcher: 6 = last,
                                       optimized.cu:690-700: 1); decides exact-tie order cpu:554 */
+    /* ABI 6: the rest of Geometry (cpu:106-118), which a TriangleMesh inherits like a Sphere does and Scene::getColor reads
+     * for WHICHEVER object was hit (cpu:573 objects[id]->mirror, cpu:580 the two indices).  A zero-initialised rt_mesh
+     * (0 / 0 / 0) is the diffuse mesh of Geometry() (cpu:110: mirror 0, indices 1 / 1): equal indices take the diffuse branch. */
+    int32_t        mirror;
+    float          in_refraction_index;
+    float          out_refraction_index;
 } rt_mesh;
 
 /* Scene::L / Scene::intensity (cpu:650-651), camera C and alpha (cpu:666,691) */
@@ -168,6 +175,17 @@ int rt_device_name(const rt_ctx *ctx, char *buf, size_t buflen);
  * (spheres only: what the reference renders when the OBJ is missing, cpu:322-325). */
 int rt_scene_upload(rt_ctx *ctx, const rt_sphere *spheres, int n_spheres, const rt_mesh *mesh,
                     const rt_light *light, const rt_camera *camera);
+/* ... with any number of meshes (ABI 6): Scene::objects is a std::vector<Geometry*> scanned in insertion order with a strict '<'
+ * (cpu:538-564; optimized.cu:663 `Geometry* objects[10]`), so a scene may hold several TriangleMesh objects at any positions.
+ * meshes[k].object_slot are distinct positions in [0, n_spheres + n_meshes); the spheres fill the remaining positions in array
+ * order.  At most RT_MAX_OBJECTS objects.  Each mesh keeps the tree its own buildBVH made (cpu:190-224) and its own root-box test
+ * (cpu:279); inside the library the trees hang below synthetic nodes whose boxes are the unions of their children, the triangles
+ * are stored mesh after mesh in object order, and one traversal finds the minimum over (t, object position, scan rank) -- the
+ * result of the reference's loop over the objects.  A mesh without triangles stays an object that is never hit (missing OBJ,
+ * cpu:322-325).  With more than one non-empty mesh: wavefront variants only (RT_ERR_UNSUPPORTED otherwise), and the per-mesh
+ * operations -- rt_mesh_set_normals, rt_mesh_rebuild* -- are refused (RT_ERR_UNSUPPORTED); rt_mesh_transform moves them all. */
+int rt_scene_upload_meshes(rt_ctx *ctx, const rt_sphere *spheres, int n_spheres, const rt_mesh *meshes, int n_meshes,
+                           const rt_light *light, const rt_camera *camera);
 
 /* --- render: replaces KernelLaunch + cudaDeviceSynchronize + D2H, optimized.cu:828-856,
  *     i.e. the pixel loop cpu:693-713.  Output: n_rows*width float4, .xyz = linear
@@ -382,6 +400,8 @@ int rt_multi_destroy(rt_multi *m);
 const char *rt_multi_last_error(const rt_multi *m);   /* m may be NULL: last global error */
 int rt_multi_scene_upload(rt_multi *m, const rt_sphere *spheres, int n_spheres, const rt_mesh *mesh,
                           const rt_light *light, const rt_camera *camera);
+int rt_multi_scene_upload_meshes(rt_multi *m, const rt_sphere *spheres, int n_spheres, const rt_mesh *meshes, int n_meshes,
+                                 const rt_light *light, const rt_camera *camera);   /* as rt_scene_upload_meshes, on every device */
 /* full frame, height*width float4, to host memory / to memory of the root device */
 int rt_render_multi(rt_multi *m, const rt_params *p, float *out_rgba_host);
 int rt_render_multi_device(rt_multi *m, const rt_params *p, void *out_rgba_dev_on_root);

@@ -144,6 +144,7 @@ struct rt_ctx {
                                                                     // region must cycle through all four values (one context-wide counter gave a part only two of them with two parts: ADVICE round 4)
     int q16_leaf_shift = 0;                                         // where a leaf's triangle count sits in its payload word (rtk::q16_leaf_shift), 0 = leaves too large
     bool q16_topo_ok = false;                                       // the tree's shape allows them (leaf sizes, node count, boxes nest)
+    int n_real_meshes = 0;                                          // meshes WITH triangles in the scene: with more than one the tree in use is a forest (install_forest) and the per-mesh operations are refused
     DevBuf node_lo, node_hi, nodes2, nodesq, nodesb, q2thr, tri, verts, tidx, scratch_rgba, scratch_rgb8, work, queue;
     int n_cus = 0;
     DevBuf wfM, wfT, wfLS, wfSID, wfSamp;                     // wavefront path state (HBM); wfSamp / wfT: per-sample colours and their running sum (num_rays > 1)
@@ -1081,7 +1082,15 @@ int requantize(rt_ctx *ctx, hipStream_t q) {
     return RT_OK;
 }
 
-int install_scene(rt_ctx *ctx, rtk::Scene sc, const rt_mesh *mesh) {
+// the triangle ranges of the scene's mesh table when at most ONE mesh has triangles (object position real_obj): a mesh without triangles is an empty range at its place in the order
+void mesh_table_single(rtk::Scene &sc, int real_obj) {
+    for (int k = 0; k < sc.n_meshes; ++k) sc.mesh[k].tri_begin = sc.mesh[k].obj <= real_obj ? 0 : sc.n_tris;
+}
+
+// sc: spheres (with their object ids), light, camera and the mesh table (object ids, materials; sc.mesh_slot = the first mesh object's position or -1) filled in by the caller.
+// mesh: the geometry to traverse -- one TriangleMesh as uploaded, or the forest install_forest made of several (tri_offsets[k] = first triangle of table entry k in mesh->indices,
+// n_meshes + 1 entries) -- or nullptr.
+int install_scene(rt_ctx *ctx, rtk::Scene sc, const rt_mesh *mesh, const std::vector<int> *tri_offsets = nullptr) {
     RT_HIP(ctx, hipSetDevice(ctx->device));
     if (ctx->stream_) RT_HIP(ctx, hipStreamSynchronize(ctx->stream_));   // (renders issued on a caller's stream are the caller's to order)
     ctx->have_scene = false;
@@ -1098,8 +1107,6 @@ int install_scene(rt_ctx *ctx, rtk::Scene sc, const rt_mesh *mesh) {
         if ((mesh->n_vertices && !mesh->vertices) || (mesh->n_triangles && !mesh->indices) || (mesh->n_nodes && !mesh->bvh_arr10))
             return fail(ctx, RT_ERR_INVALID, "mesh array pointer is NULL");
         if (mesh->n_nodes >= (1 << 24)) return fail(ctx, RT_ERR_INVALID, "node indices are stored as floats: < 2^24 nodes");
-        sc.mesh_slot = mesh->object_slot;
-        sc.mar = mesh->albedo[0]; sc.mag = mesh->albedo[1]; sc.mab = mesh->albedo[2];
         std::vector<int> perm;
         int rc = build_threaded(ctx, mesh, lo, hi, perm, left_of);
         if (rc != RT_OK) return rc;
@@ -1143,6 +1150,22 @@ int install_scene(rt_ctx *ctx, rtk::Scene sc, const rt_mesh *mesh) {
         sc.n_tris = n_int;
         if (sc.n_nodes > 0) { sc.root_lo = lo[0]; sc.root_hi = hi[0]; }
         sc.n_verts = mesh->n_vertices;
+        if (tri_offsets) {
+            // the forest is laid out so that the traversal reaches the meshes in object order (install_forest): the visit-order triangle array is mesh after mesh
+            int cur = 0;
+            for (int k = 0; k < sc.n_meshes; ++k) sc.mesh[k].tri_begin = -1;
+            for (int t = 0; t < n_int; ++t) {
+                while (cur + 1 < sc.n_meshes && perm[t] >= (*tri_offsets)[cur + 1]) ++cur;
+                if (perm[t] < (*tri_offsets)[cur]) return fail(ctx, RT_ERR_INTERNAL, "forest layout: triangle %d of an earlier mesh is visited after a later mesh's", perm[t]);
+                if (sc.mesh[cur].tri_begin < 0) sc.mesh[cur].tri_begin = t;
+            }
+            int next = n_int;
+            for (int k = sc.n_meshes - 1; k >= 0; --k) { if (sc.mesh[k].tri_begin < 0) sc.mesh[k].tri_begin = next; next = sc.mesh[k].tri_begin; }
+        } else {
+            mesh_table_single(sc, mesh->object_slot);
+        }
+    } else {
+        mesh_table_single(sc, -1);
     }
     int rc;
     if ((rc = upload(ctx, ctx->node_lo, lo.data(), lo.size() * sizeof(float4))) != RT_OK) return rc;
@@ -1375,30 +1398,151 @@ int rt_device_name(const rt_ctx *ctx, char *buf, size_t buflen) {
     return RT_OK;
 }
 
-int rt_scene_upload(rt_ctx *ctx, const rt_sphere *spheres, int n_spheres, const rt_mesh *mesh,
-                    const rt_light *light, const rt_camera *camera) {
+// Several TriangleMesh objects in one scene (cpu:538-564): ONE tree for the traversal kernels.  Every mesh keeps the tree its own buildBVH made; the roots hang below synthetic
+// internal nodes whose boxes are the unions of their children (exact: min / max of floats).  What this preserves:
+//   * a mesh's triangles are tested iff the reference's own walk of that mesh reaches their leaf: the reference enters a mesh iff its root box is hit (cpu:279) and the
+//     synthetic nodes above a root are entered whenever any root below them is -- BoundingBox::intersect is monotone along nested boxes: per axis the two plane parameters of
+//     the larger box bracket the smaller box's (one rounding each of a monotone expression), an axis with u = 0 constrains neither box or both alike (the origin lies strictly inside
+//     both intervals or the smaller box is missed), and a NaN on the first axis makes the smaller box a miss already;
+//   * the synthetic tree is shaped so that the traversal order (right child first, cpu:291-292) reaches the meshes in OBJECT order, hence the visit-order triangle array holds them
+//     mesh after mesh and min over (t, triangle index) = min over (t, object position, scan rank): the winner of the reference's loop over the objects with its strict '<' (cpu:554).
+// real[k]: index into `meshes` of the k-th mesh with triangles, in object order.  Fills the combined arrays and `out` (which points into them).
+struct Forest {
+    std::vector<float> verts, arr;
+    std::vector<int32_t> idx;
+    std::vector<int> tri_off;                                           // per real mesh: first triangle in idx (+ the total at the end)
+    rt_mesh m{};
+};
+int build_forest(rt_ctx *ctx, const rt_mesh *meshes, const std::vector<int> &real, Forest &f) {
+    const int K = (int)real.size();
+    std::vector<int> voff(K + 1, 0), noff(K + 1, 0);
+    f.tri_off.assign(K + 1, 0);
+    int64_t nv = 0, nt = 0, nn = K - 1;                                 // K - 1 synthetic nodes come first (node 0 = the forest's root)
+    for (int k = 0; k < K; ++k) {
+        const rt_mesh &m = meshes[real[k]];
+        if (m.n_vertices < 0 || m.n_triangles < 0 || m.n_nodes < 0 || m.index_stride < 3) return fail(ctx, RT_ERR_INVALID, "mesh %d: bad sizes", real[k]);
+        if ((m.n_vertices && !m.vertices) || (m.n_triangles && !m.indices) || (m.n_nodes && !m.bvh_arr10)) return fail(ctx, RT_ERR_INVALID, "mesh %d: array pointer is NULL", real[k]);
+        voff[k] = (int)nv; f.tri_off[k] = (int)nt; noff[k] = (int)nn;
+        nv += m.n_vertices; nt += m.n_triangles; nn += m.n_nodes;
+        if (nv >= ((int64_t)1 << 31) || nt >= ((int64_t)1 << 31) || nn >= (1 << 24)) return fail(ctx, RT_ERR_INVALID, "the meshes together are too large (2^31 vertices / triangles, 2^24 nodes)");
+    }
+    voff[K] = (int)nv; f.tri_off[K] = (int)nt; noff[K] = (int)nn;
+    f.verts.resize((size_t)nv * 3); f.idx.resize((size_t)nt * 3); f.arr.assign((size_t)nn * 10, 0.f);
+    for (int k = 0; k < K; ++k) {
+        const rt_mesh &m = meshes[real[k]];
+        std::copy(m.vertices, m.vertices + (size_t)m.n_vertices * 3, f.verts.begin() + (size_t)voff[k] * 3);
+        for (int t = 0; t < m.n_triangles; ++t)
+            for (int c = 0; c < 3; ++c) {
+                const int32_t v = m.indices[(size_t)t * m.index_stride + c];
+                if (v < 0 || v >= m.n_vertices) return fail(ctx, RT_ERR_INVALID, "mesh %d: triangle %d references vertex %d outside [0,%d)", real[k], t, v, m.n_vertices);
+                f.idx[3 * ((size_t)f.tri_off[k] + t) + c] = v + voff[k];
+            }
+        for (int n = 0; n < m.n_nodes; ++n) {
+            const float *a = m.bvh_arr10 + (size_t)n * 10;
+            float *o = f.arr.data() + ((size_t)noff[k] + n) * 10;
+            const int l = (int)a[0], r = (int)a[1];
+            if ((l != -1 && (l < 0 || l >= m.n_nodes)) || (r != -1 && (r < 0 || r >= m.n_nodes))) return fail(ctx, RT_ERR_INVALID, "mesh %d: bvh_arr10 node %d has a child index out of range", real[k], n);
+            const int ts = (int)a[8], te = (int)a[9];
+            if (ts < 0 || te < ts || te > m.n_triangles) return fail(ctx, RT_ERR_INVALID, "mesh %d: bvh_arr10 node %d has triangle range [%d,%d) outside [0,%d)", real[k], n, ts, te, m.n_triangles);
+            o[0] = l == -1 ? -1.f : (float)(l + noff[k]); o[1] = r == -1 ? -1.f : (float)(r + noff[k]);
+            for (int c = 2; c < 8; ++c) o[c] = a[c];
+            o[8] = (float)(ts + f.tri_off[k]); o[9] = (float)(te + f.tri_off[k]);
+        }
+    }
+    // the synthetic nodes: meshes [a, b) below node `self`; the RIGHT child holds the first half (visited first)
+    int next_syn = 1;
+    struct Job { int a, b, self; };
+    std::vector<Job> jobs{{0, K, 0}};
+    std::vector<Job> post;
+    while (!jobs.empty()) {
+        const Job j = jobs.back(); jobs.pop_back();
+        post.push_back(j);
+        const int mid = j.a + (j.b - j.a + 1) / 2;
+        auto child = [&](int a, int b) { if (b - a == 1) return noff[a]; const int id = next_syn++; jobs.push_back({a, b, id}); return id; };
+        float *o = f.arr.data() + (size_t)j.self * 10;
+        o[1] = (float)child(j.a, mid);                                  // right = the earlier meshes
+        o[0] = (float)child(mid, j.b);
+        o[8] = (float)f.tri_off[j.a]; o[9] = (float)f.tri_off[j.b];
+    }
+    for (size_t q = post.size(); q-- > 0;) {                            // children before parents: a synthetic node's index is larger than its parent's
+        float *o = f.arr.data() + (size_t)post[q].self * 10;
+        const float *l = f.arr.data() + (size_t)(int)o[0] * 10, *r = f.arr.data() + (size_t)(int)o[1] * 10;
+        for (int c = 0; c < 3; ++c) { o[2 + c] = std::min(l[2 + c], r[2 + c]); o[5 + c] = std::max(l[5 + c], r[5 + c]); }
+    }
+    f.m = rt_mesh{};
+    f.m.vertices = f.verts.data(); f.m.n_vertices = (int)nv; f.m.indices = f.idx.data(); f.m.index_stride = 3; f.m.n_triangles = (int)nt;
+    f.m.bvh_arr10 = f.arr.data(); f.m.n_nodes = (int)nn;
+    f.m.object_slot = meshes[real[0]].object_slot;
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_scene_upload_meshes(rt_ctx *ctx, const rt_sphere *spheres, int n_spheres, const rt_mesh *meshes, int n_meshes,
+                           const rt_light *light, const rt_camera *camera) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
     if (n_spheres < 0 || (n_spheres > 0 && !spheres)) return fail(ctx, RT_ERR_INVALID, "bad sphere array");
+    if (n_meshes < 0 || (n_meshes > 0 && !meshes)) return fail(ctx, RT_ERR_INVALID, "bad mesh array");
     if (!light || !camera) return fail(ctx, RT_ERR_INVALID, "light/camera is NULL");
-    const int n_objects = n_spheres + (mesh ? 1 : 0);
-    if (n_spheres > RT_MAX_SPHERES || n_objects > 16)
-        return fail(ctx, RT_ERR_INVALID, "at most %d objects (reference: Geometry* objects[10])", 16);
+    const int n_objects = n_spheres + n_meshes;
+    if (n_spheres > RT_MAX_SPHERES || n_objects > RT_MAX_OBJECTS)
+        return fail(ctx, RT_ERR_INVALID, "at most %d objects (reference: Geometry* objects[10])", RT_MAX_OBJECTS);
     rtk::Scene sc{};
+    // the meshes in object order; the spheres fill, in array order, the positions the meshes leave free (Scene::addObject numbers the objects as they come, cpu:539-542)
+    std::vector<int> order(n_meshes);
+    for (int k = 0; k < n_meshes; ++k) order[k] = k;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return meshes[a].object_slot < meshes[b].object_slot; });
+    bool taken[RT_MAX_OBJECTS] = {};
+    for (int k = 0; k < n_meshes; ++k) {
+        const rt_mesh &m = meshes[order[k]];
+        if (m.object_slot < 0 || m.object_slot >= n_objects) return fail(ctx, RT_ERR_INVALID, "mesh object_slot %d outside [0,%d]", m.object_slot, n_objects - 1);
+        if (taken[m.object_slot]) return fail(ctx, RT_ERR_INVALID, "two meshes at object_slot %d", m.object_slot);
+        taken[m.object_slot] = true;
+        sc.mesh[k] = rtk::MeshRec{0, m.object_slot, m.albedo[0], m.albedo[1], m.albedo[2], m.mirror ? 1 : 0, m.in_refraction_index, m.out_refraction_index};
+    }
+    sc.n_meshes = n_meshes;
+    int pos = 0;
     for (int i = 0; i < n_spheres; ++i) {
+        while (pos < n_objects && taken[pos]) ++pos;
         const rt_sphere &s = spheres[i];
         sc.sph[i] = {s.center[0], s.center[1], s.center[2], s.radius, s.albedo[0], s.albedo[1], s.albedo[2],
-                     s.mirror ? 1 : 0, s.in_refraction_index, s.out_refraction_index, s.radius * s.radius};   // R * R: one binary32 product (-ffp-contract=off), as cpu:513
+                     s.mirror ? 1 : 0, s.in_refraction_index, s.out_refraction_index, s.radius * s.radius, pos++};   // R * R: one binary32 product (-ffp-contract=off), as cpu:513
     }
     sc.n_spheres = n_spheres;
     sc.n_objects = n_objects;
-    sc.mesh_slot = -1;
+    sc.mesh_slot = n_meshes > 0 ? sc.mesh[0].obj : -1;
     sc.Lx = light->position[0]; sc.Ly = light->position[1]; sc.Lz = light->position[2]; sc.intensity = light->intensity;
     sc.camx = camera->position[0]; sc.camy = camera->position[1]; sc.camz = camera->position[2]; sc.fov = camera->fov;
 
     PhaseClock pc;
-    const int rc = install_scene(ctx, sc, mesh);
+    std::vector<int> real;                                               // meshes with something to traverse, in object order
+    for (int k = 0; k < n_meshes; ++k) if (meshes[order[k]].n_triangles > 0 && meshes[order[k]].n_nodes > 0) real.push_back(order[k]);
+    int rc;
+    if (real.size() <= 1) {
+        // the reference's own scenes: one mesh (or none; a mesh without triangles is an object that is never hit, cpu:322-325)
+        const rt_mesh *one = real.empty() ? (n_meshes > 0 ? &meshes[order[0]] : nullptr) : &meshes[real[0]];
+        rc = install_scene(ctx, sc, one);
+    } else {
+        Forest f;
+        if ((rc = build_forest(ctx, meshes, real, f)) != RT_OK) return rc;
+        // table entry of every mesh -> first triangle in the forest's index array (a mesh without triangles: the next real mesh's)
+        std::vector<int> offs(n_meshes + 1, f.tri_off[real.size()]);
+        for (int k = n_meshes - 1, r = (int)real.size() - 1; k >= 0; --k) {
+            if (r >= 0 && order[k] == real[r]) { offs[k] = f.tri_off[r]; --r; }
+            else offs[k] = offs[k + 1];
+        }
+        rc = install_scene(ctx, sc, &f.m, &offs);
+    }
+    if (rc == RT_OK) ctx->n_real_meshes = (int)real.size();
     pc.lap("rt_scene_upload (layouts, hipMalloc, copies)");
     return rc;
+}
+
+int rt_scene_upload(rt_ctx *ctx, const rt_sphere *spheres, int n_spheres, const rt_mesh *mesh,
+                    const rt_light *light, const rt_camera *camera) {
+    return rt_scene_upload_meshes(ctx, spheres, n_spheres, mesh, mesh ? 1 : 0, light, camera);
 }
 
 int rt_render_device(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *out_rgba_dev, void *stream) {

@@ -28,6 +28,7 @@
 namespace rtk {
 
 constexpr int kMaxSpheres = 16;
+constexpr int kMaxMeshes = 16;       // RT_MAX_OBJECTS: every object of a scene may be a mesh
 constexpr int kMaxSegments = 16;
 constexpr int kBlockThreads = 256;   // 4 waves: 32 x 8 pixels
 constexpr int kTileW = 32, kTileH = 8;
@@ -38,14 +39,28 @@ struct Sphere {           // rt_sphere, cpu:505-511
     int mirror;
     float n_in, n_out;
     float R2;             // R * R as the reference evaluates it in cpu:513 (one binary32 product), computed once by rt_scene_upload
+    int obj;              // position in Scene::objects (cpu:541): decides exact ties (strict '<', cpu:554) and names the object in the path records
+};
+
+// A TriangleMesh of the scene (Geometry's fields, cpu:106-118, and where its triangles sit in the visit-order arrays).  The meshes are stored
+// one after the other in OBJECT order, so the 64-bit minimum over bits(t) << 32 | triangle index that the traversal kernels form is the minimum
+// over (t, object position, scan rank): what the reference's loop over the objects keeps (cpu:549-558) with its strict '<'.
+struct MeshRec {
+    int tri_begin;        // first triangle (visit order) of this mesh; the next record's tri_begin (or n_tris) ends it
+    int obj;              // position in Scene::objects
+    float ar, ag, ab;
+    int mirror;
+    float n_in, n_out;
 };
 
 struct Scene {
     Sphere sph[kMaxSpheres];
     int n_spheres;
-    int n_objects;        // spheres + (mesh ? 1 : 0)
-    int mesh_slot;        // object index of the mesh, -1 = none
-    float mar, mag, mab;  // mesh albedo
+    int n_objects;        // spheres + meshes
+    int mesh_slot;        // object index of the FIRST mesh with triangles, -1 = none ("the scene has a mesh to traverse")
+    int n_meshes;         // every TriangleMesh of the scene in object order, mesh[0 .. n_meshes): one without triangles (a missing OBJ, cpu:322-325) holds
+                          // its position in Scene::objects and an empty triangle range
+    MeshRec mesh[kMaxMeshes];
     float Lx, Ly, Lz, intensity;
     float camx, camy, camz, fov;
     const float4 *node_lo, *node_hi;
@@ -332,6 +347,7 @@ __device__ __forceinline__ bool intersect_all(const Scene &sc, f3 O, f3 u, float
     int id_min = -1;
     int sph_min = -1;
     f3 Nmesh = mk(0, 0, 0);
+    // the lock-step family renders scenes with at most ONE TriangleMesh (rt_capi.hip refuses the others for these variants): objects in insertion order, the mesh at its slot
     int si = 0;
     for (int obj = 0; obj < sc.n_objects; ++obj) {
         if (obj == sc.mesh_slot) {
@@ -357,11 +373,31 @@ __device__ __forceinline__ bool intersect_all(const Scene &sc, f3 O, f3 u, float
 }
 
 struct Material { float ar, ag, ab; int mirror; float n_in, n_out; };
+// index of the sphere whose object id is `obj` (obj is a sphere's id): the spheres fill, in array order, the positions the meshes leave free
+__device__ __forceinline__ int sphere_of(const Scene &sc, int obj) {
+    int si = obj;
+    for (int k = 0; k < sc.n_meshes; ++k) si -= (sc.mesh[k].obj < obj) ? 1 : 0;   // (wave-uniform trip count: one for the reference's scenes)
+    return si;
+}
+// the mesh that holds triangle `tri` (visit order): wave-uniform loop over the scene's meshes, none for the usual single mesh
+__device__ __forceinline__ int mesh_of_tri(const Scene &sc, int tri) {
+    int m = 0;
+    for (int k = 1; k < sc.n_meshes; ++k) m = (tri >= sc.mesh[k].tri_begin) ? k : m;
+    return m;
+}
+// Geometry's fields (cpu:106-118) of object `obj`, sphere or mesh: Scene::getColor reads them for whichever object was hit (cpu:573-606)
 __device__ __forceinline__ Material material_of(const Scene &sc, int obj) {
     Material m;
-    if (obj == sc.mesh_slot) { m.ar = sc.mar; m.ag = sc.mag; m.ab = sc.mab; m.mirror = 0; m.n_in = 1.f; m.n_out = 1.f; return m; }   // cpu:110
-    const int si = (sc.mesh_slot >= 0 && obj > sc.mesh_slot) ? obj - 1 : obj;
-    const Sphere &s = sc.sph[si];
+    int mi = -1;
+    for (int k = 0; k < sc.n_meshes; ++k) mi = (sc.mesh[k].obj == obj) ? k : mi;
+    if (mi >= 0) {
+        // (k is wave-uniform: the records come out of scalar registers, the selection is a v_cndmask per field)
+        m.ar = m.ag = m.ab = 0.f; m.mirror = 0; m.n_in = m.n_out = 1.f;
+        for (int k = 0; k < sc.n_meshes; ++k)
+            if (k == mi) { m.ar = sc.mesh[k].ar; m.ag = sc.mesh[k].ag; m.ab = sc.mesh[k].ab; m.mirror = sc.mesh[k].mirror; m.n_in = sc.mesh[k].n_in; m.n_out = sc.mesh[k].n_out; }
+        return m;
+    }
+    const Sphere &s = sc.sph[sphere_of(sc, obj)];
     m.ar = s.ar; m.ag = s.ag; m.ab = s.ab; m.mirror = s.mirror; m.n_in = s.n_in; m.n_out = s.n_out;
     return m;
 }

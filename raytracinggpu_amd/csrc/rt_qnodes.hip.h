@@ -54,7 +54,10 @@ __device__ __forceinline__ void q16_axis(float lo, float hi, float g, float s, u
     const double need = (h + fabs(c - cw)) * (1.0 + 0x1p-50);            // (the sum may have rounded down by half an ulp)
     double hi_ = ceil(need / (double)s);
     if (hi_ * (double)s < need) hi_ += 1.0;                              // the quotient rounded down across an integer: hi_ s is exact (16 x 24 bits)
-    hi_ = hi_ > 65535.0 ? 65535.0 : (hi_ >= 1.0 ? hi_ : 65535.0);       // NaN or an out-of-range box: the widest box (never excluded)
+    // 0 is a legitimate value (a flat box whose centre sits on a grid point: an axis-aligned leaf on the root's minimum face): it becomes ONE cell, which is
+    // still within kQ16FaceCells of the real face and makes the box thinner than any ray's accept threshold on that axis, so the leaf is always flagged and the
+    // reference's own test of its zero-thickness box (never a hit: strict '>', cpu:156) decides.  Only NaN / out-of-range becomes the widest box (never excluded).
+    hi_ = hi_ > 65535.0 ? 65535.0 : (hi_ >= 1.0 ? hi_ : (hi_ == 0.0 ? 1.0 : 65535.0));
     cq = (unsigned int)ci; hq = (unsigned int)hi_;
 }
 

@@ -49,7 +49,7 @@ constexpr int PF_XSPHERE = 1 << 26;                         // the X ray is bloc
 constexpr unsigned long long WF_NOHIT = ~0ull;
 // the wavefront pipeline keeps the path's flag word in its continuation (Y) slot's queue record; bits 0..15 as above, then:
 constexpr int PQ_WIN_SHIFT = 16;                            // 5 bits: object id + 1 of the Y ray's nearest sphere (0 = none); its t is the record's last word
-constexpr int PQ_WINB = 1 << 21;                            // that sphere comes AFTER the mesh in object order (the mesh wins a tie; before it the sphere does: cpu:554's strict '<')
+constexpr int PQ_WINB = 1 << 21;                            // (rt_path.hip.h only) that sphere comes AFTER the mesh in object order; wf_advance compares the object ids when the query is closed
 constexpr int PQ_XSPHERE = 1 << 22;                         // PF_XSPHERE of this record
 constexpr int PQ_REFR_SHIFT = 23;                           // 6 bits: Ray::refraction_index of the Y ray: 0 = 1.0, else (object id + 1) << 1 | (0: that object's n_in, 1: its n_out)
 constexpr int PQ_TRAV = 1 << 29;                            // (either slot) the record's ray passed the mesh's root box: the traversal launch whose number (WfState::epoch) equals the
@@ -145,6 +145,20 @@ __device__ __forceinline__ void spheres_split2(const Scene &sc, f3 O, f3 uy, boo
 }
 __device__ __forceinline__ int wf_pack_wins_path(const SphereHit &h) { return ((h.winA + 1) & 31) << PF_WINS_SHIFT | ((h.winB + 1) & 31) << (PF_WINS_SHIFT + 5); }
 
+// Scene::intersect_all's running minimum over the SPHERES alone, for the two rays that leave one point: (t, object id) of the nearest sphere with the strict '<'
+// of cpu:554 (the earliest of equal t).  The meshes join when the traversal is back: a triangle at tm replaces the sphere iff tm < t, or tm == t and the
+// triangle's mesh comes before the sphere in Scene::objects -- the lexicographic minimum over (t, position) IS what the reference's loop keeps.
+struct SphereNear { float t; int obj; };
+__device__ __forceinline__ void spheres_near2(const Scene &sc, f3 O, f3 uy, bool on_y, f3 ux, bool on_x, SphereNear &hy, SphereNear &hx) {
+    hy.t = 1e9f; hy.obj = -1;
+    hx = hy;
+    for (int k = 0; k < sc.n_spheres; ++k) {
+        const SphereOrigin so = sphere_origin(sc.sph[k], O);
+        float t;
+        if (on_y && sphere_dir(sc.sph[k], so, O, uy, t)) { if (t < hy.t) { hy.t = t; hy.obj = sc.sph[k].obj; } }
+        if (on_x && sphere_dir(sc.sph[k], so, O, ux, t)) { if (t < hx.t) { hx.t = t; hx.obj = sc.sph[k].obj; } }
+    }
+}
 // inverse of wf_slot_to_path: the traversal slot of ray r
 __device__ __forceinline__ int wf_ray_to_slot(const WfState &st, int r) {
     const int g = r >> 2;
@@ -575,22 +589,24 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
             const float4 r0 = st.QR[2 * (size_t)qy];
             f3 O = mk(r0.x, r0.y, r0.z), u = mk(r0.w, y1.x, y1.y);
             int sid = 0xff;                                           // object id if the hit is diffuse
-            // Scene::intersect_all's running minimum (strict '<' in object order, cpu:554) over  spheres before the mesh, mesh, spheres after:
-            // the spheres' own winner was decided at emission (the later group wins only if strictly nearer); against it the mesh wins a
-            // tie iff the sphere comes after it in object order
+            // Scene::intersect_all's running minimum (strict '<' in object order, cpu:554) = the lexicographic minimum over (t, position in Scene::objects):
+            // the spheres' own winner was decided at emission (spheres_near2), the meshes' by the traversal; between the two a tie goes to the earlier object
             float t_min = y1.w;
             int win = ((F >> PQ_WIN_SHIFT) & 31) - 1, tri_win = -1;
             if (F & PF_MESHY) {
                 const unsigned long long m = st.M[i];
                 if (m != WF_NOHIT) {
                     const float tm = __uint_as_float((unsigned int)(m >> 32));
-                    if ((F & PQ_WINB) ? !(t_min < tm) : (tm < t_min)) { t_min = tm; win = sc.mesh_slot; tri_win = (int)(unsigned int)m; }
+                    const int mw = mesh_of_tri(sc, (int)(unsigned int)m);   // the meshes' own winner: minimum over (t, object position, scan rank) by the order the triangles are stored in
+                    int mobj = sc.mesh[0].obj;
+                    for (int k = 1; k < sc.n_meshes; ++k) mobj = (k == mw) ? sc.mesh[k].obj : mobj;
+                    if ((win > mobj) ? !(t_min < tm) : (tm < t_min)) { t_min = tm; win = mobj; tri_win = (int)(unsigned int)m; }   // a tie goes to whichever comes first in Scene::objects (no sphere: win = -1, 1e9 > tm)
                 }
             }
             if (win >= 0) {                                           // a miss is black (cpu:571): nothing to emit
                 const f3 P = O + t_min * u;                           // cpu:560
                 f3 N;
-                if (win == sc.mesh_slot && sc.nrm != nullptr) {       // get_smooth_normal, realtime_render.cu:221-245
+                if (tri_win >= 0 && sc.nrm != nullptr) {              // get_smooth_normal, realtime_render.cu:221-245
                     const float4 q0 = sc.tri[3 * tri_win], q1 = sc.tri[3 * tri_win + 1], q2 = sc.tri[3 * tri_win + 2];
                     const f3 A = mk(q0.x, q0.y, q0.z), e1 = mk(q0.w, q1.x, q1.y), e2 = mk(q1.z, q1.w, q2.x), Nt = mk(q2.y, q2.z, q2.w);
                     const float beta = dot(e2, cross(A - O, u)) / dot(u, Nt);
@@ -598,11 +614,11 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
                     const float alpha = 1 - beta - gamma;
                     const float4 na = sc.nrm[3 * tri_win], nb = sc.nrm[3 * tri_win + 1], nc = sc.nrm[3 * tri_win + 2];
                     N = normalize((alpha * mk(na.x, na.y, na.z) + beta * mk(nb.x, nb.y, nb.z)) + gamma * mk(nc.x, nc.y, nc.z));
-                } else if (win == sc.mesh_slot) {
+                } else if (tri_win >= 0) {
                     const float4 q2 = sc.tri[3 * tri_win + 2];
                     N = normalize(mk(q2.y, q2.z, q2.w));              // cpu:308
                 } else {
-                    const Sphere &sp = sc.sph[(sc.mesh_slot >= 0 && win > sc.mesh_slot) ? win - 1 : win];
+                    const Sphere &sp = sc.sph[sphere_of(sc, win)];
                     N = normalize(P - mk(sp.cx, sp.cy, sp.cz));       // cpu:524-525
                 }
                 const Material m = material_of(sc, win);
@@ -704,11 +720,11 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
 
     // ---- (3) emission: sphere tests (cpu:512-527), root-box test (cpu:279), queue records ----
     int flags = PF_ALIVE | (d << PF_DEPTH_SHIFT) | (nrays << PF_RAYS_SHIFT) | (refr_code << PQ_REFR_SHIFT) | (int)((unsigned)st.nonce << PQ_NONCE_SHIFT);
-    SphereHit h, hx;
-    spheres_split2(sc, emitX ? Ox : Oy, uy, emitY, ux, emitX, h, hx);   // a shadow ray and a bounce ray leave the same point (Oy == Ox == P_adjusted)
+    SphereNear h, hx;
+    spheres_near2(sc, emitX ? Ox : Oy, uy, emitY, ux, emitX, h, hx);   // a shadow ray and a bounce ray leave the same point (Oy == Ox == P_adjusted)
     float t_sph = 0.f;
     if (emitX) {
-        const float tS = hx.tB < hx.tA ? hx.tB : hx.tA;               // only the value of the shadow ray's nearest hit matters
+        const float tS = hx.t;                                        // only the value of the shadow ray's nearest hit matters
         const f3 Pp = Ox + tS * ux;                                   // cpu:560
         flags |= PF_HASX;
         if (norm2(Pp - Ox) <= norm2(L - Ox)) flags |= PQ_XSPHERE;      // cpu:615 holds for the sphere already (the mesh is still intersected, as intersect_all does)
@@ -719,9 +735,8 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
         }
     }
     if (emitY) {
-        const bool after = h.tB < h.tA;                               // the later group's sphere replaces the earlier one's only if strictly nearer
-        t_sph = after ? h.tB : h.tA;
-        flags |= PF_HASY | ((((after ? h.winB : h.winA) + 1) & 31) << PQ_WIN_SHIFT) | (after ? PQ_WINB : 0);
+        t_sph = h.t;
+        flags |= PF_HASY | (((h.obj + 1) & 31) << PQ_WIN_SHIFT);
         if (wf_root_test<STATS>(sc, st, i, Oy, uy, wk)) flags |= PF_MESHY | PQ_TRAV;
     }
     st.QR[2 * (size_t)qy] = make_float4(Oy.x, Oy.y, Oy.z, uy.x);    // whole sectors also when no continuation ray leaves (then nobody reads this half)

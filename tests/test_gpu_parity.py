@@ -543,18 +543,36 @@ def _synthetic_mesh(kind, rng):
         d = rng.uniform(-0.1, 0.1, (100, 3, 3)) * x[:, None, None]
         v = (c[:, None, :] + d).reshape(-1, 3).astype(np.float32)
         t = np.arange(300, dtype=np.int32).reshape(100, 3)
+    elif kind == "flat_faces":             # the six faces of an axis-aligned box, 4 x 4 quads each: every leaf of a face is a ZERO-THICKNESS box lying on a face of the
+        vs, ts = [], []                    # root box (minimum AND maximum face of every axis; ADVICE r5: half extent 0 on a grid point of the fixed-point nodes) -- which
+        lo, hi = np.array([-14.0, -9.0, -12.0]), np.array([10.0, 11.0, 8.0])   # BoundingBox::intersect never hits (strict '>', cpu:156): those triangles are invisible in
+        for ax in range(3):                # the reference, through the middle of the face as well as along its rim; 40 ordinary triangles inside give the rays something to hit
+            a, b = [(1, 2), (0, 2), (0, 1)][ax]
+            for side in (lo, hi):
+                for i in range(4):
+                    for j in range(4):
+                        q = np.zeros((4, 3)); q[:, ax] = side[ax]
+                        fa = lo[a] + (hi[a] - lo[a]) * np.array([i, i + 1, i + 1, i]) / 4
+                        fb = lo[b] + (hi[b] - lo[b]) * np.array([j, j, j + 1, j + 1]) / 4
+                        q[:, a] = fa; q[:, b] = fb
+                        base = len(vs); vs += list(q)
+                        ts += [[base, base + 1, base + 2], [base, base + 2, base + 3]]
+        inner = rng.uniform(-8, 7, (120, 3))
+        base = len(vs); vs += list(inner)
+        ts += [[base + 3 * k, base + 3 * k + 1, base + 3 * k + 2] for k in range(40)]
+        v = np.array(vs, np.float32); t = np.array(ts, np.int32)
     else:
         raise ValueError(kind)
     return v, t
 
 
-@pytest.mark.parametrize("kind", ["three_triangles", "axis_aligned_quads", "soup", "deep_strip", "geometric_chain"])
+@pytest.mark.parametrize("kind", ["three_triangles", "axis_aligned_quads", "soup", "deep_strip", "geometric_chain", "flat_faces"])
 def test_synthetic_meshes_bit_exact(ctx, oracle, kind, monkeypatch):
     """Random / degenerate / deep meshes through the product's own BVH builder: direct lighting bit-exact against the
     oracle (which builds its own BVH from the same arrays), bounces within tolerance, all traversal kernels and the
     bounded-stack / LDS-staged configurations of the work-stack kernel writing the same bits and counting the same work."""
     from raytracinggpu_amd import hostlib
-    rng = np.random.default_rng({"three_triangles": 1, "axis_aligned_quads": 2, "soup": 3, "deep_strip": 4, "geometric_chain": 5}[kind])
+    rng = np.random.default_rng({"three_triangles": 1, "axis_aligned_quads": 2, "soup": 3, "deep_strip": 4, "geometric_chain": 5, "flat_faces": 6}[kind])
     v, t = _synthetic_mesh(kind, rng)
     om = oracle.Mesh.from_arrays(v, t).build_bvh()
     osc = oracle.Scene.preset("cpu", om)
