@@ -61,8 +61,17 @@ def parse():
     ap.add_argument("--bounces", type=int, default=3)
     ap.add_argument("--scene", default="cpu", choices=["cpu", "spheres", "demo10"])
     ap.add_argument("--variant", default="auto")
-    ap.add_argument("--gather", default="f32", choices=["f32", "rgb8"],
-                    help="N > 1: what rank 0 gathers -- the float4 tiles (parity path, default) or the tonemapped RGB8 tiles (PNG path, 3 B/pixel)")
+    ap.add_argument("--gather", default="auto", choices=["auto", "f32", "rgb8"],
+                    help="N > 1: what the root gathers -- the float4 tiles (parity path) or the tonemapped RGB8 tiles (PNG path, 3 B/pixel).  auto (default): float4 unless the "
+                         "float4 tiles of ONE peer would need more than --link-budget-gbs of its xGMI link at the frame rate the ranks' compute side reaches (measured before "
+                         "the timed region), then RGB8")
+    ap.add_argument("--link-budget-gbs", type=float, default=40.0,
+                    help="--gather auto: GB/s one peer may push through its xGMI link to the root (a quarter of the link's ~153 GB/s peak: the gather is many small messages)")
+    ap.add_argument("--root", default="0", choices=["0", "rotate"],
+                    help="N > 1: the rank that assembles a frame -- always rank 0 (the reference copies every image to one host, optimized.cu:849-856) or frame k -> rank k mod N "
+                         "(one gather per frame either way; rotate spreads the inbound traffic over every rank's links)")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="N > 1: frames of a small share rendered as ONE launch chain (rt_render_device_batch); 0 = auto (the number of ranks, for shares below 0.7 Mpixel), 1 = off")
     ap.add_argument("--transport", default="torch", choices=["torch", "capi"],
                     help="N > 1: the gather goes through torch.distributed (nccl = RCCL; default) or through the product's own C-ABI "
                          "(libraytrace_rccl.so: grouped ncclSend / ncclRecv, every tile received straight into its place in rank 0's frame)")
@@ -555,7 +564,8 @@ def main():
         torch.cuda.set_stream(pool("full", 1)[1][0])
         stream = pool("full", 1)[1][0].cuda_stream
         assert stream != 0
-    rgb8 = args.gather == "rgb8" and world > 1 and not cpu_only
+    rgb8 = args.gather == "rgb8" and world > 1 and not cpu_only        # --gather auto: decided below, before the timed point is built
+    rotate = args.root == "rotate" and world > 1
 
     class Lane:
         """One frame in flight: this rank's tile buffer and the buffers of its exchange."""
@@ -565,17 +575,27 @@ def main():
             self.local8 = tiling.local_buffer(H, W, world, dev, rgb8=True) if rgb8 else None
             src = self.local8 if rgb8 else self.local
             self.xlocal = torch.empty(src.shape, dtype=src.dtype, device=xdev, pin_memory=not cpu_only) if (gloo and world > 1 and not cpu_only) else src
-            self.gathered = tiling.gather_buffer(self.xlocal, world) if (world > 1 and rank == 0 and comm is None) else None
-            self.frame = torch.empty((H, W) + tuple(src.shape[2:]), dtype=src.dtype, device=dev) if (comm is not None and rank == 0) else None
+            is_root = rank == 0 or rotate                              # a rotating root: every rank assembles its share of the frames
+            self.gathered = tiling.gather_buffer(self.xlocal, world) if (world > 1 and is_root and comm is None) else None
+            self.frame = torch.empty((H, W) + tuple(src.shape[2:]), dtype=src.dtype, device=dev) if (comm is not None and is_root) else None
 
     class Point:
-        """One timed workload: its parameters, this rank's tiles, and one Lane per frame in flight."""
-        def __init__(self, W, H, lanes=0):
+        """One timed workload: its parameters, this rank's tiles, and one Lane per frame in flight.
+        batch > 1 (small shares of an N-rank job): `batch` consecutive frames are rendered as ONE launch chain (rt_render_device_batch: frames x pixels are the chain's
+        items, so a 1/8 share fills the chip the way the whole frame does on one GPU) into `batch` lanes, two batches in flight on two contexts; every frame is still
+        exchanged and assembled on its own, one gather per frame."""
+        def __init__(self, W, H, lanes=0, batch=None):
             self.W, self.H = W, H
             self.p = rt.make_params(W, H, args.spp, args.bounces, variant=args.variant, **rt.scenes.CPU_LAUNCHER)
             self.rows, self.idx = rt.interleaved_rows(H, TILE_ROWS, rank, world)
             share_px = self.rows.n_rows * W
+            full_share = tiling.tiles_per_rank(H, world) * TILE_ROWS * W   # (the same on every rank: all ranks must batch alike, the steps hold a collective)
+            if batch is None:
+                batch = args.batch if args.batch > 0 else (min(16, max(2, round(W * H / max(full_share, 1)))) if (world > 1 and full_share <= TINY_SHARE_PX) else 1)
+            self.batch = 1 if (cpu_only or world == 1 or args.spp != 1 or lanes == 1) else max(1, min(16, batch))
             want = lanes if lanes > 0 else args.frames_in_flight if args.frames_in_flight > 0 else (2 if world == 1 else 4 if share_px <= TINY_SHARE_PX else 2 if share_px <= SMALL_SHARE_PX else 1)
+            if self.batch > 1:
+                want = 2 * self.batch
             self.n_lanes = 1 if cpu_only else want
             # one GPU renders the whole frame: the frames in flight share ONE context and stream (two buffers, rt_ctx_set_pipelining);
             # a rank with a small share keeps one context per frame in flight
@@ -586,6 +606,10 @@ def main():
                     self.ctxs, self.tstreams = [full[0][0]] * self.n_lanes, [full[1][0]] * self.n_lanes
                     if hasattr(full[0][0], "set_pipelining"):
                         full[0][0].set_pipelining(self.pipelined)
+                elif self.batch > 1:                                    # two contexts with the library's defaults (two sub-frames each): batch b on context b mod 2
+                    cs_, ts_ = pool("full", 2)
+                    self.ctxs = [cs_[(k // self.batch) % 2] for k in range(self.n_lanes)]
+                    self.tstreams = [ts_[(k // self.batch) % 2] for k in range(self.n_lanes)]
                 else:
                     if self.n_lanes > 1:
                         cs_, ts_ = pool("lanes", self.n_lanes)
@@ -595,7 +619,11 @@ def main():
             self.lanes = [Lane(k, W, H) for k in range(self.n_lanes)]
             self.local = self.lanes[0].local
             self.frame = None
-            self.n = 0
+            self.n = 0                                                # frames stepped since the point was built (decides the rotating root: the same count on every rank)
+            self.pos, self.total = 0, 1                               # position in the current run of steps and its length (a batch never renders frames the run does not step)
+
+        def begin(self, total):
+            self.pos, self.total = 0, max(int(total), 1)
 
         def render(self, ln):
             if cpu_only:
@@ -603,40 +631,57 @@ def main():
             else:
                 self.ctxs[ln.k].render_device(self.p, self.rows, ln.local.data_ptr(), self.tstreams[ln.k].cuda_stream)
 
-        def exchange(self, ln):
+        def render_batch(self, first_lane, count):
+            """`count` frames of the run into lanes first_lane .. first_lane + count - 1 as one launch chain.  Every frame of the metric is the same frame (as on one GPU, where
+            the bench renders one frame K times): same camera, same seed; the entry point takes a camera and a seed per frame (tests/test_gpu_parity.py renders a dolly with it)."""
+            lns = self.lanes[first_lane:first_lane + count]
+            frames = [(ln.local.data_ptr(), (0.0, 0.0, 55.0), None, self.p.seed) for ln in lns]
+            self.ctxs[first_lane].render_device_batch(self.p, self.rows, frames, self.tstreams[first_lane].cuda_stream)
+
+        def exchange(self, ln, root):
             src = ln.local
             if rgb8:                                                  # tonemap this rank's tiles (cpu:714-716), gather 3 bytes per pixel
                 self.ctxs[ln.k].tonemap_device(ln.local.data_ptr(), self.rows.n_rows * self.W, ln.local8.data_ptr(), self.tstreams[ln.k].cuda_stream)
                 src = ln.local8
             if comm is not None:                                      # the product's own transport: tiles land in place, nothing to assemble
-                comm.gather_tiles(src.data_ptr(), self.W, self.H, src.shape[2] * src.element_size(), ln.frame.data_ptr() if rank == 0 else None,
-                                  tile_rows=TILE_ROWS, stream=self.tstreams[ln.k].cuda_stream)
-                self.frame = ln.frame
+                comm.gather_tiles(src.data_ptr(), self.W, self.H, src.shape[2] * src.element_size(), ln.frame.data_ptr() if rank == root else None,
+                                  tile_rows=TILE_ROWS, root=root, stream=self.tstreams[ln.k].cuda_stream)
+                self.frame = ln.frame if rank == root else None
                 return
             if ln.xlocal is not src:                                  # --share-gpu: the exchange runs over gloo on host tensors
                 ln.xlocal.copy_(src, non_blocking=True)
                 torch.cuda.current_stream().synchronize()
-            self.frame = tiling.gather_frame(ln.xlocal, self.H, world, rank, ln.gathered)
+            self.frame = tiling.gather_frame(ln.xlocal, self.H, world, rank, ln.gathered, root=root)
 
         def step(self, ev=None, mode="both"):
             """mode: "both" = the metric's step; "render" / "exchange" = one side only (the compute-side / exchange-side accounting after the timed region)."""
-            ln = self.lanes[self.n % self.n_lanes]
+            root = tiling.root_of(self.n, world, args.root)
+            if self.batch > 1:
+                b, j = divmod(self.pos, self.batch)
+                ln = self.lanes[(b % 2) * self.batch + j]
+            else:
+                j, ln = 0, self.lanes[self.n % self.n_lanes]
             self.n += 1
+            self.pos += 1
             if cpu_only:
                 if mode != "exchange":
                     self.render(ln)
                 if mode != "render":
-                    self.exchange(ln)
+                    self.exchange(ln, root)
                 return
             with torch.cuda.stream(self.tstreams[ln.k]):
                 if ev:
                     ev[0].record()
                 if mode != "exchange" and not (args.gather_only and self.n > self.n_lanes):  # --gather-only: every lane's tiles are rendered once, then only exchanged
-                    self.render(ln)
+                    if self.batch > 1:
+                        if j == 0:                                    # the batch's first step issues the chain for all of its frames; the others find their frame rendered
+                            self.render_batch(ln.k, min(self.batch, self.total - (self.pos - 1)))
+                    else:
+                        self.render(ln)
                 if ev:
                     ev[1].record()
                 if mode != "render":
-                    self.exchange(ln)
+                    self.exchange(ln, root)
 
     def sync():
         if not cpu_only:
@@ -646,14 +691,18 @@ def main():
         """W warm-up steps, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
         if not cpu_only and args.prewarm_ms > 0:                        # same count on every rank (the steps hold a collective)
             est_ms = max(pt.W * pt.H / 2.0e6 / world, 0.2)
-            for _ in range(max(1, min(1000, int(args.prewarm_ms / est_ms)))):
+            n_pre = max(1, min(1000, int(args.prewarm_ms / est_ms)))
+            pt.begin(n_pre)
+            for _ in range(n_pre):
                 pt.step()
+        pt.begin(warmup)
         for _ in range(warmup):
             pt.step(mode=mode)
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)] if not cpu_only else []
         if world > 1:
             dist.barrier()
         sync()
+        pt.begin(steps)
         t0 = time.perf_counter()
         for k in range(steps):
             pt.step(ev[k] if ev else None, mode)
@@ -673,8 +722,21 @@ def main():
             dist.all_reduce(r)
         return int(r.item())
 
+    gather_choice = None
+    if args.gather == "auto" and world > 1 and not cpu_only:
+        # the exchange budget: every peer pushes its float4 tiles through ONE xGMI link into the root; at the frame rate the ranks' compute side
+        # reaches that is  W * H * 16 / N bytes x frames/s  per link.  Measured here, before the timed point exists: a few frames with the exchange skipped.
+        probe = Point(W, H)
+        e_p, _ = timed(probe, 8, 2, "render")
+        fps = 8 / max(e_p, 1e-9)
+        per_link = W * H * 16 / world * fps / 1e9
+        rgb8 = per_link > args.link_budget_gbs
+        gather_choice = {"float4_GBps_per_link_at_compute_rate": round(per_link, 2), "budget_GBps_per_link": args.link_budget_gbs, "chosen": "rgb8" if rgb8 else "f32",
+                         "compute_side_frames_per_s": round(fps, 1)}
+        del probe
     main_pt = Point(W, H)
     # exact ray count of one frame (deterministic; outside the timed region)
+    main_pt.begin(1)
     main_pt.step()
     sync()
     rays_per_frame = rays_of(main_pt)
@@ -699,6 +761,17 @@ def main():
         args.prewarm_ms = pw
         sides = {"compute_ms_per_step": round(1e3 * e_r / args.steps, 4), "exchange_ms_per_step": round(1e3 * e_x / args.steps, 4),
                  "is": "the timed steps again with the exchange skipped / with the render skipped (max over ranks, same frames in flight): the two sides of ms_per_step, which overlaps them"}
+
+    latency_ms = None
+    if world > 1 and not args.gather_only and not cpu_only:
+        # what the throughput figure does not say: ONE frame alone on this rank's share (rendered, gathered, assembled, then the next) -- the latency of a frame.  With
+        # frames batched or in flight side by side `ms_per_step` is the rate frames COMPLETE at; a single frame of a 1/8 share cannot fill the chip and takes longer than 1/8
+        lat_pt = Point(W, H, lanes=1)
+        pw, args.prewarm_ms = args.prewarm_ms, 0
+        e_l, _ = timed(lat_pt, args.steps, 2)
+        args.prewarm_ms = pw
+        latency_ms = round(1e3 * e_l / args.steps, 4)
+        del lat_pt
 
     large = None
     if args.large_steps > 0 and args.scene == "cpu" and not cpu_only and (W, H) == (1920, 1080):
@@ -745,6 +818,18 @@ def main():
             res["config"]["comm_plan"] = comm.last_plan
         if sides is not None:
             res["config"]["sides"] = sides
+        if world > 1:
+            res["config"]["root"] = "frame k is assembled on rank k mod N (one gather per frame)" if rotate else "rank 0 assembles every frame"
+            res["config"]["gather"] = "rgb8" if rgb8 else "f32"
+            if gather_choice is not None:
+                res["config"]["gather_auto"] = gather_choice
+            if main_pt.batch > 1:
+                res["config"]["batch"] = main_pt.batch
+                res["config"]["batch_is"] = (f"{main_pt.batch} consecutive frames of this rank's share are rendered as ONE launch chain (rt_render_device_batch), two batches in flight on two "
+                                             "contexts; every frame is gathered and assembled on its own.  ms_per_step is a THROUGHPUT figure: the frames of a batch finish together")
+            if latency_ms is not None:
+                res["config"]["frame_latency_ms"] = latency_ms
+                res["config"]["frame_latency_is"] = "one frame alone on the ranks' shares: rendered, gathered and assembled before the next starts (max over ranks); the other side of the batched / in-flight throughput"
         if args.gather_only and world > 1:
             px_bytes = 3 if rgb8 else 16
             moved = W * H * px_bytes * (world - 1) / world               # bytes that cross the fabric into the root per gather

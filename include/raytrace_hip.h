@@ -156,7 +156,8 @@ typedef struct rt_stats {
     float    adv_ms;               /*     summed HIP-event time, launches, paths per launch (rt_stats_enable)             */
     int32_t  adv_paths;
     int32_t  travq_mode;           /* work-stack traversal kernel of the last render: 0 = sibling pairs (64-byte float nodes), 1 = 16-bit fixed-point pairs,
-                                      2 = 4-wide fixed-point nodes (the default for trees below 16 384 nodes); -1 = another traversal kernel / no mesh */
+                                      2 = 4-wide fixed-point nodes (the default wherever the format fits: boxes nest, leaves of 1 .. 127 triangles, fewer than 2^21 nodes);
+                                      -1 = another traversal kernel / no mesh */
     int32_t  reserved;
 } rt_stats;
 
@@ -195,6 +196,23 @@ int rt_render(rt_ctx *ctx, const rt_params *p, int row_begin, int row_end, float
  * context's own stream); rows may be interleaved tiles (multi-GPU) */
 int rt_render_device(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *out_rgba_dev, void *stream);
 
+/* --- a BATCH of frames in one launch chain (ABI 6).  A process that renders a small share of every frame -- one rank of eight on 1920x1080 owns
+ *     0.26 Mpixel -- cannot fill the chip with the eleven dependent launches of ONE such frame, and a frame per stream runs out of hardware queues
+ *     (four per process).  Here n_frames (<= RT_MAX_BATCH) frames of the same size and rows are traced as the items of ONE chain -- the machinery
+ *     that traces the samples of a pixel as parallel items -- each with its OWN camera (position, fov: cpu:666, 691-699), its own seed and its own
+ *     output buffer: a sequence of frames of a moving camera / a progressive render, not one frame repeated.  Frame k's buffer holds exactly what
+ *     rt_render_device writes for the scene with that camera and p->seed = frames[k].seed (bit for bit: per-pixel arithmetic does not depend on
+ *     what else is in the launch).  num_rays == 1; wavefront variants; p->seed is ignored; asynchronous on `stream`.  Throughput, not latency: the
+ *     n frames finish together.  Replaces n x (KernelLaunch + sync, optimized.cu:828-849). */
+#define RT_MAX_BATCH 16
+typedef struct rt_frame_desc {
+    rt_camera camera;              /* this frame's camera (Camera C / alpha, cpu:666,691)      */
+    uint32_t  seed;                /* this frame's counter-RNG seed (rt_params.seed)           */
+    uint32_t  reserved;
+    void     *out_rgba_dev;        /* n_rows * width float4, as rt_render_device               */
+} rt_frame_desc;
+int rt_render_device_batch(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, const rt_frame_desc *frames, int n_frames, void *stream);
+
 /* --- tonemap: cpu:714-716 (gamma 1/2.2 in binary64, min 255, truncate) ------- */
 int rt_tonemap_device(rt_ctx *ctx, const void *rgba_dev, int64_t n_pixels, void *rgb8_dev, void *stream);
 /* render + tonemap + D2H of the interleaved RGB8 image (what stbi_write_png gets, cpu:719) */
@@ -217,7 +235,7 @@ typedef struct rt_work {
                                     * push of a BOX step; one reserved.  bench.py prices the vector-issue roofline with them. */
 } rt_work;
 /* The counters describe the REFERENCE-EQUIVALENT traversal (the binary instantiation of the kernel: every box the reference tests, cpu:284-293), whatever
- * kernel produces the frames: with the 16-bit fixed-point pairs (RT_TRAVQ_Q16, automatic for trees of 16 384 nodes and more) or the 4-wide BOX step
+ * kernel produces the frames: with the 16-bit fixed-point pairs (RT_TRAVQ_Q16) or the 4-wide BOX step
  * (RT_TRAVQ_QW) the production kernel enters a superset of the internal nodes and skips levels, and its own visits are not what box_tests / nodes
  * report -- unless RT_TRAVQ_QW_COUNT=1 asks for the 4-wide kernel's own counting instantiation (experiments). */
 int rt_count_work(rt_ctx *ctx, const rt_params *p, int row_begin, int row_end, rt_work *out);
@@ -298,6 +316,10 @@ int rt_kat_sqrt(rt_ctx *ctx, const float *in, int n, float *out);   /* out[i] = 
 int rt_kat_box(rt_ctx *ctx, const float *in, int n, int route, float *out, rt_kat_counts *counts);
 int rt_kat_triangle(rt_ctx *ctx, const float *in, int n, float *out, rt_kat_counts *counts);
 int rt_kat_mesh(rt_ctx *ctx, const float *in, int n, float tri_tmin, int route, float *out, rt_kat_counts *counts);
+/* 64-bit hashes of the device-side node layouts the upload (or a refit / rebuild) derived for the traversal kernels: [0] float sibling pairs, [1] 16-bit fixed-point
+ * pairs, [2] 4-wide quads (which four nodes a quad holds is chosen by a surface-area DP on the device), [3] leaf boxes by triangle; 0 = not in use.  Two uploads of one
+ * tree give equal hashes: the layouts -- and with them the work a frame does -- are a function of the tree alone. */
+int rt_kat_layout_hash(rt_ctx *ctx, uint64_t out[4]);
 
 /* --- device-side mesh transform: the `transform` kernel of global_launcher.cu:340-365 / transformMesh
  *     (realtime_render.cu:1151-1166) applied to the uploaded vertices -- v' = R v (row-major 3x3), then += translation --

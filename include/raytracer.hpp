@@ -318,20 +318,36 @@ public:
 // to its kernel: Vector[], TriangleIndices[] in BVH order, bvhTreeToArray's float[10] nodes).
 struct SceneArrays {
     std::vector<rt_sphere> sph;
-    std::vector<float> arr, verts;
-    rt_mesh m{};
+    std::vector<std::vector<float>> arrs, vertss;                   // per mesh: bvhTreeToArray's nodes, the vertices as 3 floats each
+    std::vector<rt_mesh> meshes;                                    // every TriangleMesh of Scene::objects, with its position (object_slot) and Geometry's fields
     rt_light lt{};
     rt_camera cm{};
-    bool has_mesh = false;
     SceneArrays(const Scene &scene, const Camera &cam) {
-        const TriangleMesh *mesh = nullptr;
-        int slot = -1;
+        if (scene.objects.size() > RT_MAX_OBJECTS) throw Error(RT_ERR_INVALID, "at most " + std::to_string(RT_MAX_OBJECTS) + " objects per Scene");
         for (size_t i = 0; i < scene.objects.size(); ++i) {
             const Geometry *g = scene.objects[i];
             if (g->is_mesh()) {
-                if (mesh) throw Error(RT_ERR_INVALID, "only one TriangleMesh per Scene is supported");
-                mesh = static_cast<const TriangleMesh *>(g);
-                slot = (int)i;
+                const TriangleMesh *mesh = static_cast<const TriangleMesh *>(g);
+                size_t nodes = 0;
+                count_nodes(&mesh->bvh, nodes);
+                arrs.emplace_back(nodes * 10);
+                size_t n = 1;
+                mesh->bvhTreeToArray(&mesh->bvh, arrs.back().data(), n);
+                vertss.emplace_back(mesh->vertices.size() * 3);
+                for (size_t v = 0; v < mesh->vertices.size(); ++v)
+                    for (int k = 0; k < 3; ++k) vertss.back()[3 * v + k] = mesh->vertices[v][k];
+                rt_mesh m{};
+                m.n_vertices = (int)mesh->vertices.size();
+                m.indices = mesh->indices.empty() ? nullptr : &mesh->indices[0].vtxi;
+                m.index_stride = (int)(sizeof(TriangleIndices) / sizeof(int32_t));
+                m.n_triangles = (int)mesh->indices.size();
+                m.n_nodes = (int)nodes;
+                for (int k = 0; k < 3; ++k) m.albedo[k] = mesh->albedo[k];
+                m.object_slot = (int)i;
+                // Geometry's other members (cpu:113-116): getColor reads them for whichever object was hit (cpu:573-606), a mesh included
+                m.mirror = mesh->mirror ? 1 : 0;
+                m.in_refraction_index = mesh->in_refraction_index; m.out_refraction_index = mesh->out_refraction_index;
+                meshes.push_back(m);
                 continue;
             }
             const Sphere *s = static_cast<const Sphere *>(g);
@@ -341,23 +357,9 @@ struct SceneArrays {
             r.in_refraction_index = s->in_refraction_index; r.out_refraction_index = s->out_refraction_index;
             sph.push_back(r);
         }
-        if (mesh) {
-            size_t nodes = 0;
-            count_nodes(&mesh->bvh, nodes);
-            arr.resize(nodes * 10);
-            size_t n = 1;
-            mesh->bvhTreeToArray(&mesh->bvh, arr.data(), n);
-            verts.resize(mesh->vertices.size() * 3);
-            for (size_t i = 0; i < mesh->vertices.size(); ++i)
-                for (int k = 0; k < 3; ++k) verts[3 * i + k] = mesh->vertices[i][k];
-            m.vertices = verts.data(); m.n_vertices = (int)mesh->vertices.size();
-            m.indices = mesh->indices.empty() ? nullptr : &mesh->indices[0].vtxi;
-            m.index_stride = (int)(sizeof(TriangleIndices) / sizeof(int32_t));
-            m.n_triangles = (int)mesh->indices.size();
-            m.bvh_arr10 = arr.data(); m.n_nodes = (int)nodes;
-            for (int k = 0; k < 3; ++k) m.albedo[k] = mesh->albedo[k];
-            m.object_slot = slot;
-            has_mesh = true;
+        for (size_t k = 0; k < meshes.size(); ++k) {                // (the vectors have stopped growing: their storage stays where it is)
+            meshes[k].vertices = vertss[k].data();
+            meshes[k].bvh_arr10 = arrs[k].data();
         }
         lt = rt_light{{scene.L[0], scene.L[1], scene.L[2]}, scene.intensity};
         cm = rt_camera{{cam.C[0], cam.C[1], cam.C[2]}, cam.alpha};
@@ -437,11 +439,11 @@ public:
     Renderer(const Renderer &) = delete;
     Renderer &operator=(const Renderer &) = delete;
 
-    // Copies the scene to the GPU.  A TriangleMesh in the scene must have its BVH built
-    // (buildBVH / buildFlatBVH); at most one mesh (as in every reference program).
+    // Copies the scene to the GPU.  Every TriangleMesh in the scene must have its BVH built (buildBVH); spheres and meshes in any number
+    // and order up to RT_MAX_OBJECTS (Scene::objects, cpu:538-543), each with Geometry's material fields.
     void upload(const Scene &scene, const Camera &cam = Camera()) {
         SceneArrays a(scene, cam);
-        check(rt_scene_upload(ctx_, a.sph.data(), (int)a.sph.size(), a.has_mesh ? &a.m : nullptr, &a.lt, &a.cm), "rt_scene_upload");
+        check(rt_scene_upload_meshes(ctx_, a.sph.data(), (int)a.sph.size(), a.meshes.data(), (int)a.meshes.size(), &a.lt, &a.cm), "rt_scene_upload_meshes");
     }
 
     // 8-bit interleaved RGB image, W*H*3 bytes, exactly what cpu:714-716 stores
@@ -572,7 +574,7 @@ public:
     MultiRenderer &operator=(const MultiRenderer &) = delete;
     void upload(const Scene &scene, const Camera &cam = Camera()) {
         SceneArrays a(scene, cam);
-        check(rt_multi_scene_upload(m_, a.sph.data(), (int)a.sph.size(), a.has_mesh ? &a.m : nullptr, &a.lt, &a.cm), "rt_multi_scene_upload");
+        check(rt_multi_scene_upload_meshes(m_, a.sph.data(), (int)a.sph.size(), a.meshes.data(), (int)a.meshes.size(), &a.lt, &a.cm), "rt_multi_scene_upload_meshes");
     }
     std::vector<float> render_float(const RenderSettings &s) {
         rt_params p = Renderer::params(s);

@@ -160,10 +160,42 @@ def make_kat_inputs(rng, verts, tris):
     return sph, box, tri, mesh
 
 
+MATERIAL_RENDERS = [  # name, scene (oracle/ref_harness.cpp add_material_scene), W, H, spp, bounce, stride
+    ("cpu_mirror_256_b3", "cpu_mirror", 256, 256, 1, 3, 2),
+    ("cpu_glass_256_b5", "cpu_glass", 256, 256, 1, 5, 2),
+    ("two_cats_256_b3", "two_cats", 256, 256, 1, 3, 2),
+    ("two_cats_512_direct", "two_cats", 512, 512, 1, 0, 4),
+    ("two_cats_diffuse_256_b1", "two_cats_diffuse", 256, 256, 1, 1, 2),
+]
+
+
+def make_materials():
+    """tests/golden/ref_materials.npz alone (`python oracle/make_golden.py materials`): mesh materials and several meshes per scene through the reference's own
+    Scene::getColor / intersect_all (single thread, mt19937(0)); the other fixtures stay as committed (ref_stat.npz is not reproducible run to run)."""
+    tmp = tempfile.mkdtemp(prefix="rt_golden_")
+    try:
+        with_cat = os.path.join(tmp, "with_cat"); os.makedirs(with_cat)
+        os.symlink(os.path.join(REF, "cadnav.com_model"), os.path.join(with_cat, "cadnav.com_model"))
+        out = {}
+        for name, scene, W, H, spp, b, stride in MATERIAL_RENDERS:
+            base = os.path.join(tmp, name)
+            run([HARNESS, "render", scene, str(W), str(H), str(spp), str(b), str(stride), base], with_cat, {"OMP_NUM_THREADS": "1"})
+            nh, nw = (H + stride - 1) // stride, (W + stride - 1) // stride
+            out[name + "_color"] = f32(base + ".color.f32").reshape(nh, nw, 3)
+            out[name + "_hit"] = f32(base + ".hit.f32").reshape(nh, nw, 7)
+            out[name + "_cfg"] = np.array([W, H, spp, b, stride], np.int32)
+            print("render", name, out[name + "_color"].shape)
+        np.savez_compressed(os.path.join(GOLD, "ref_materials.npz"), **out)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     if not (os.path.exists(CPU) and os.path.exists(HARNESS)):
         raise SystemExit("build the reference first: make -C oracle ref")
     os.makedirs(GOLD, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "materials":
+        return make_materials()
     tmp = tempfile.mkdtemp(prefix="rt_golden_")
     try:
         with_cat = os.path.join(tmp, "with_cat"); os.makedirs(with_cat)
@@ -236,6 +268,7 @@ def main():
                             sem=f32(base + ".sem.f32").reshape(nh, nw, 3),
                             cfg=np.array([W, H, spp, b, stride], np.int32))
         print("stat done")
+        make_materials()
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     for fn in sorted(os.listdir(GOLD)):

@@ -66,6 +66,7 @@ def lib():
     L.or_mesh_get_triangles.argtypes = [vp, C.POINTER(C.c_int32)]
     L.or_mesh_bvh_to_array.argtypes = [vp, fp]
     L.or_mesh_set_albedo.argtypes = [vp, C.c_float, C.c_float, C.c_float]
+    L.or_mesh_set_material.argtypes = [vp, C.c_int, C.c_float, C.c_float]
     L.or_mesh_intersect.argtypes = [vp, fp, fp, C.c_float, fp, fp, C.POINTER(Counters)]
     L.or_sphere_intersect.argtypes = [fp, C.c_float, fp, fp, fp, fp]
     L.or_box_intersect.argtypes = [fp, fp, fp, fp]
@@ -132,6 +133,11 @@ class Mesh:
     def rescale(self, scale, offset):
         o, op = _f(offset)
         lib().or_mesh_rescale(self.h, scale, op)
+
+    def set_material(self, mirror=0, n_in=1.0, n_out=1.0):
+        """Geometry's mirror / refraction indices of the mesh (cpu:113-116); call before Scene.add_mesh."""
+        lib().or_mesh_set_material(self.h, int(mirror), n_in, n_out)
+        return self
 
     def build_bvh(self):
         lib().or_mesh_build_bvh(self.h)

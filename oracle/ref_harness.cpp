@@ -84,6 +84,41 @@ static TriangleMesh *load_cat() {   /* cpu_launcher.cpp:680-684 */
     return mesh_ptr;
 }
 
+/* Scenes the reference's CLASSES accept but its main() never builds: a TriangleMesh is a Geometry, so its public mirror /
+ * refraction members are read by getColor like a sphere's (cpu_launcher.cpp:573-606), and Scene::objects takes any number of meshes at any
+ * positions (cpu_launcher.cpp:538-564).  The second cat is the first one at half size, moved in front of it: v * 0.5f + (16, -5, 20), applied
+ * to the vertices readOBJ left (float operators of the reference's Vector), before its own buildBVH. */
+static TriangleMesh *load_cat2() {
+    TriangleMesh *m = new TriangleMesh();
+    m->readOBJ(OBJ_PATH);
+    for (auto &v : m->vertices) v = v * 0.5f + Vector(16, -5, 20);
+    m->albedo = Vector(0.6, 0.3, 0.1);
+    m->buildBVH(&(m->bvh), 0, m->indices.size());
+    return m;
+}
+static bool add_material_scene(Scene &s, const std::string &scene) {
+    if (scene == "cpu_mirror") { add_walls(s); TriangleMesh *m = load_cat(); m->mirror = 1; s.addObject(m); return true; }
+    if (scene == "cpu_glass") { add_walls(s); TriangleMesh *m = load_cat(); m->in_refraction_index = 1.5; m->out_refraction_index = 1; s.addObject(m); return true; }
+    if (scene == "two_cats") {          /* objects: 3 walls, cat (diffuse), 3 walls, second cat (mirror) -- a mesh in the MIDDLE of the order and one at the end */
+        s.addObject(new Sphere(Vector(0, 0, -1000), 940, Vector(0., 1., 0.)));
+        s.addObject(new Sphere(Vector(0, -1000, 0), 990, Vector(0., 0., 1.)));
+        s.addObject(new Sphere(Vector(0, 1000, 0), 940, Vector(1., 0., 0.)));
+        s.addObject(load_cat());
+        s.addObject(new Sphere(Vector(-1000, 0, 0), 940, Vector(0., 1., 1.)));
+        s.addObject(new Sphere(Vector(1000, 0, 0), 940, Vector(1., 1., 0.)));
+        s.addObject(new Sphere(Vector(0, 0, 1000), 940, Vector(1., 0., 1.)));
+        TriangleMesh *b = load_cat2(); b->mirror = 1; s.addObject(b);
+        return true;
+    }
+    if (scene == "two_cats_diffuse") {  /* both diffuse, the SAME geometry twice at positions 0 and 7: every triangle hit is an exact tie, the earlier object wins (cpu:554) */
+        TriangleMesh *a = load_cat(); a->albedo = Vector(0.9, 0.1, 0.1); s.addObject(a);
+        add_walls(s);
+        TriangleMesh *b = load_cat(); b->albedo = Vector(0.1, 0.9, 0.1); s.addObject(b);
+        return true;
+    }
+    return false;
+}
+
 static int cmd_mesh(const std::string &out) {
     TriangleMesh *m = new TriangleMesh();
     m->readOBJ(OBJ_PATH);
@@ -177,6 +212,7 @@ static int cmd_render(const std::string &scene, int W, int H, int num_rays, int 
     if (scene == "demo10") { add_demo(s); add_walls(s); }
     else if (scene == "spheres") { add_walls(s); }
     else if (scene == "cpu") { add_walls(s); s.addObject(load_cat()); }
+    else if (add_material_scene(s, scene)) { }
     else { fprintf(stderr, "unknown scene\n"); return 2; }
     Vector C(0, 0, 55);
     float z = -W / (2 * tan(alpha / 2));

@@ -121,12 +121,14 @@ struct or_mesh {
     bvh_node *bvh;                 /* root; NULL until built */
     int n_nodes, max_depth;
     vec albedo;
+    int mirror; float in_refraction_index, out_refraction_index;   /* Geometry's other fields (cpu:106-118): a TriangleMesh inherits them like a Sphere does */
     vec *normals; int n_shading_normals;   /* smooth shading; NULL = flat, as in cpu_launcher.cpp */
 };
 
 or_mesh *or_mesh_new(void) {
     or_mesh *m = (or_mesh *)calloc(1, sizeof(or_mesh));
     m->albedo = V(0, 0, 0);
+    m->mirror = 0; m->in_refraction_index = 1; m->out_refraction_index = 1;   /* Geometry(), cpu:110 */
     return m;
 }
 static void bvh_free(bvh_node *n) {
@@ -147,6 +149,8 @@ static void push_tri(or_mesh *m, int i, int j, int k) {
     m->indices[m->nt++] = t;
 }
 void or_mesh_set_albedo(or_mesh *m, float r, float g, float b) { m->albedo = V(r, g, b); }
+/* mesh_ptr->mirror / in_refraction_index / out_refraction_index: public members of Geometry (cpu:113-116) that getColor reads for ANY object hit (cpu:573, 580) */
+void or_mesh_set_material(or_mesh *m, int mirror, float n_in, float n_out) { m->mirror = mirror; m->in_refraction_index = n_in; m->out_refraction_index = n_out; }
 
 /* vertex index resolution used all over cpu:382-479: 1-based, negative = relative */
 static inline int vidx(const or_mesh *m, int i) { return (i < 0) ? m->nv + i : i - 1; }
@@ -575,7 +579,7 @@ int or_scene_add_mesh(or_scene *s, or_mesh *m) {
     geometry *g = &s->objects[s->n];
     memset(g, 0, sizeof(*g));
     g->is_mesh = 1; g->mesh = m; g->albedo = m->albedo;
-    g->mirror = 0; g->in_refraction_index = 1; g->out_refraction_index = 1;   /* cpu:110 */
+    g->mirror = m->mirror; g->in_refraction_index = m->in_refraction_index; g->out_refraction_index = m->out_refraction_index;   /* cpu:110 unless the caller set them */
     g->id = s->n;
     return s->n++;
 }

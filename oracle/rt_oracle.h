@@ -94,6 +94,9 @@ void     or_mesh_get_triangles(const or_mesh *m, int32_t *out_vidx);
 /* bvhTreeToArray layout (optimized.cu:512-534): 10 floats per node */
 void     or_mesh_bvh_to_array(const or_mesh *m, float *out_arr10);
 void     or_mesh_set_albedo(or_mesh *m, float r, float g, float b);
+/* Geometry::mirror / in_refraction_index / out_refraction_index of the mesh (cpu:113-116; Geometry() cpu:110 = 0 / 1 / 1): Scene::getColor
+ * branches on them for whichever object was hit (cpu:573-606).  Set before or_scene_add_mesh. */
+void     or_mesh_set_material(or_mesh *m, int mirror, float n_in, float n_out);
 /* TriangleMesh::intersect (cpu:238-313, ENABLE_BVH branch). returns hit flag */
 int      or_mesh_intersect(const or_mesh *m, const float O[3], const float u[3], float tri_tmin,
                            float *t, float N[3], or_counters *cnt);

@@ -19,13 +19,13 @@ VARIANTS = {"auto": 0, "global": 1, "lds_verts": 2, "lds_top": 3, "lds_all": 4, 
 
 # every symbol include/raytrace_hip.h declares (tests check the .so exports each)
 EXPORTS = ["rt_abi_version", "rt_device_count", "rt_ctx_create", "rt_ctx_destroy", "rt_last_error",
-           "rt_device_name", "rt_scene_upload", "rt_render", "rt_render_device", "rt_tonemap_device",
+           "rt_device_name", "rt_scene_upload", "rt_scene_upload_meshes", "rt_render", "rt_render_device", "rt_render_device_batch", "rt_tonemap_device",
            "rt_render_rgb8", "rt_synchronize", "rt_get_stats", "rt_ctx_selfcheck", "rt_count_work",
            "rt_mesh_transform", "rt_mesh_set_normals", "rt_camera_basis", "rt_render_pose", "rt_render_pose_device", "rt_progressive_reset", "rt_progressive_frame",
            "rt_progressive_frames",
-           "rt_multi_create", "rt_multi_destroy", "rt_multi_last_error", "rt_multi_scene_upload", "rt_render_multi",
+           "rt_multi_create", "rt_multi_destroy", "rt_multi_last_error", "rt_multi_scene_upload", "rt_multi_scene_upload_meshes", "rt_render_multi",
            "rt_render_multi_device", "rt_render_multi_rgb8", "rt_multi_get_stats",
-           "rt_stats_enable", "rt_ctx_set_pipelining", "rt_render_async", "rt_wait", "rt_trace_rays", "rt_mesh_rebuild", "rt_mesh_rebuild_mode", "rt_mesh_build_stats", "rt_host_alloc", "rt_host_free", "rt_device_alloc", "rt_device_free", "rt_device_to_host", "rt_kat_sphere", "rt_kat_sqrt", "rt_kat_box", "rt_kat_triangle", "rt_kat_mesh"]
+           "rt_stats_enable", "rt_ctx_set_pipelining", "rt_render_async", "rt_wait", "rt_trace_rays", "rt_mesh_rebuild", "rt_mesh_rebuild_mode", "rt_mesh_build_stats", "rt_host_alloc", "rt_host_free", "rt_device_alloc", "rt_device_free", "rt_device_to_host", "rt_kat_sphere", "rt_kat_sqrt", "rt_kat_box", "rt_kat_triangle", "rt_kat_mesh", "rt_kat_layout_hash"]
 MAX_DEVICES = 16
 
 
@@ -44,7 +44,8 @@ class Mesh(C.Structure):
     _fields_ = [("vertices", C.POINTER(C.c_float)), ("n_vertices", C.c_int32),
                 ("indices", C.POINTER(C.c_int32)), ("index_stride", C.c_int32), ("n_triangles", C.c_int32),
                 ("bvh_arr10", C.POINTER(C.c_float)), ("n_nodes", C.c_int32),
-                ("albedo", C.c_float * 3), ("object_slot", C.c_int32)]
+                ("albedo", C.c_float * 3), ("object_slot", C.c_int32),
+                ("mirror", C.c_int32), ("in_refraction_index", C.c_float), ("out_refraction_index", C.c_float)]   # ABI 6: Geometry's other fields (cpu:113-116)
 
 
 class Light(C.Structure):
@@ -63,6 +64,13 @@ class Params(C.Structure):
 
 class Rows(C.Structure):
     _fields_ = [("row0", C.c_int32), ("n_rows", C.c_int32), ("tile_rows", C.c_int32), ("tile_step", C.c_int32)]
+
+
+class FrameDesc(C.Structure):
+    _fields_ = [("camera", Camera), ("seed", C.c_uint32), ("reserved", C.c_uint32), ("out_rgba_dev", C.c_void_p)]
+
+
+MAX_BATCH = 16
 
 
 class Work(C.Structure):
@@ -144,8 +152,10 @@ def load():
     L.rt_last_error.restype = C.c_char_p
     L.rt_device_name.argtypes = [vp, C.c_char_p, C.c_size_t]
     L.rt_scene_upload.argtypes = [vp, C.POINTER(Sphere), C.c_int, C.POINTER(Mesh), C.POINTER(Light), C.POINTER(Camera)]
+    L.rt_scene_upload_meshes.argtypes = [vp, C.POINTER(Sphere), C.c_int, C.POINTER(Mesh), C.c_int, C.POINTER(Light), C.POINTER(Camera)]
     L.rt_render.argtypes = [vp, C.POINTER(Params), C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.rt_render_device.argtypes = [vp, C.POINTER(Params), C.POINTER(Rows), vp, vp]
+    L.rt_render_device_batch.argtypes = [vp, C.POINTER(Params), C.POINTER(Rows), C.POINTER(FrameDesc), C.c_int, vp]
     L.rt_tonemap_device.argtypes = [vp, vp, C.c_int64, vp, vp]
     L.rt_render_rgb8.argtypes = [vp, C.POINTER(Params), C.c_int, C.c_int, C.POINTER(C.c_uint8)]
     L.rt_count_work.argtypes = [vp, C.POINTER(Params), C.c_int, C.c_int, C.POINTER(Work)]
@@ -171,6 +181,7 @@ def load():
     L.rt_multi_last_error.argtypes = [vp]
     L.rt_multi_last_error.restype = C.c_char_p
     L.rt_multi_scene_upload.argtypes = [vp, C.POINTER(Sphere), C.c_int, C.POINTER(Mesh), C.POINTER(Light), C.POINTER(Camera)]
+    L.rt_multi_scene_upload_meshes.argtypes = [vp, C.POINTER(Sphere), C.c_int, C.POINTER(Mesh), C.c_int, C.POINTER(Light), C.POINTER(Camera)]
     L.rt_render_multi.argtypes = [vp, C.POINTER(Params), C.POINTER(C.c_float)]
     L.rt_render_multi_device.argtypes = [vp, C.POINTER(Params), vp]
     L.rt_render_multi_rgb8.argtypes = [vp, C.POINTER(Params), C.POINTER(C.c_uint8)]
@@ -185,6 +196,7 @@ def load():
     L.rt_kat_box.argtypes = [vp, fp3, C.c_int, C.c_int, fp3, C.POINTER(KatCounts)]
     L.rt_kat_triangle.argtypes = [vp, fp3, C.c_int, fp3, C.POINTER(KatCounts)]
     L.rt_kat_mesh.argtypes = [vp, fp3, C.c_int, C.c_float, C.c_int, fp3, C.POINTER(KatCounts)]
+    L.rt_kat_layout_hash.argtypes = [vp, C.POINTER(C.c_uint64)]
     _lib = L
     return L
 
@@ -256,25 +268,31 @@ def _marshal_scene(spheres, mesh, light, camera):
         arr[i].mirror = int(s[3]) if len(s) > 3 else 0
         arr[i].in_refraction_index = s[4] if len(s) > 4 else 1.0
         arr[i].out_refraction_index = s[5] if len(s) > 5 else 1.0
-    m, keep = None, None
-    if mesh is not None:
-        v = np.ascontiguousarray(mesh["vertices"], np.float32).reshape(-1, 3)
-        ix = np.ascontiguousarray(mesh["indices"], np.int32)
+    meshes = [] if mesh is None else (list(mesh) if isinstance(mesh, (list, tuple)) else [mesh])
+    marr, keep = (Mesh * max(len(meshes), 1))(), []
+    taken = {d["object_slot"] for d in meshes if d.get("object_slot") is not None}
+    free = (k for k in range(len(spheres) + len(meshes)) if k not in taken)
+    for m, d in zip(marr, meshes):
+        v = np.ascontiguousarray(d["vertices"], np.float32).reshape(-1, 3)
+        ix = np.ascontiguousarray(d["indices"], np.int32)
         stride = ix.shape[1] if ix.ndim == 2 else 3
-        bv = np.ascontiguousarray(mesh["bvh_arr10"], np.float32).reshape(-1, 10)
-        m = Mesh()
+        bv = np.ascontiguousarray(d["bvh_arr10"], np.float32).reshape(-1, 10)
         m.vertices = v.ctypes.data_as(C.POINTER(C.c_float)); m.n_vertices = len(v)
         m.indices = ix.ctypes.data_as(C.POINTER(C.c_int32)); m.index_stride = stride
         m.n_triangles = ix.size // stride
         m.bvh_arr10 = bv.ctypes.data_as(C.POINTER(C.c_float)); m.n_nodes = len(bv)
-        m.albedo[:] = mesh.get("albedo", (0.25, 0.25, 0.25))
-        m.object_slot = mesh.get("object_slot", len(spheres))
-        keep = (v, ix, bv)
+        m.albedo[:] = d.get("albedo", (0.25, 0.25, 0.25))
+        # a lone mesh without a slot is added last (cpu:685); several meshes without slots follow the spheres in list order
+        m.object_slot = d["object_slot"] if d.get("object_slot") is not None else (len(spheres) if len(meshes) == 1 else next(free))
+        m.mirror = int(d.get("mirror", 0))
+        m.in_refraction_index = d.get("in_refraction_index", 1.0)
+        m.out_refraction_index = d.get("out_refraction_index", 1.0)
+        keep.append((v, ix, bv))
     lt = Light(); lt.position[:] = light[0]; lt.intensity = light[1]
     cam = Camera(); cam.position[:] = camera[0]
     # float alpha = PI/3 (cpu:666)
     cam.fov = np.float32(np.pi / 3) if camera[1] is None else np.float32(camera[1])
-    return arr, len(spheres), m, lt, cam, keep
+    return arr, len(spheres), marr, len(meshes), lt, cam, keep
 
 
 class Context:
@@ -309,9 +327,13 @@ class Context:
 
     def scene_upload(self, spheres, mesh=None, light=((-10.0, 20.0, 40.0), 3e10), camera=((0.0, 0.0, 55.0), None)):
         """spheres: iterable of (center, radius, albedo[, mirror, n_in, n_out]);
-        mesh: dict(vertices, indices, bvh_arr10, albedo, object_slot) with the reference's array layouts."""
-        arr, n, m, lt, cam, self._keep = _marshal_scene(spheres, mesh, light, camera)
-        self._check(self._L.rt_scene_upload(self._h, arr, n, C.byref(m) if m is not None else None, C.byref(lt), C.byref(cam)))
+        mesh: dict(vertices, indices, bvh_arr10, albedo, object_slot[, mirror, in_refraction_index, out_refraction_index]) with the reference's array
+        layouts, or a list of such dicts (several TriangleMesh objects in Scene::objects: rt_scene_upload_meshes)."""
+        arr, n, marr, nm, lt, cam, self._keep = _marshal_scene(spheres, mesh, light, camera)
+        if nm <= 1 and not isinstance(mesh, (list, tuple)):
+            self._check(self._L.rt_scene_upload(self._h, arr, n, marr if nm else None, C.byref(lt), C.byref(cam)))
+        else:
+            self._check(self._L.rt_scene_upload_meshes(self._h, arr, n, marr, nm, C.byref(lt), C.byref(cam)))
 
     def render(self, params, row_begin=0, row_end=None, out=None):
         """out: optional preallocated [rows, W, 4] float32 array (e.g. PinnedArray(...).array)."""
@@ -332,6 +354,17 @@ class Context:
         """Asynchronous render into device memory (e.g. a torch tensor's data_ptr())."""
         self._check(self._L.rt_render_device(self._h, C.byref(params), C.byref(rows), C.c_void_p(out_ptr),
                                              C.c_void_p(stream) if stream else None))
+
+    def render_device_batch(self, params, rows, frames, stream=None):
+        """rt_render_device_batch: `frames` = iterable of (out_ptr, camera_position, fov or None, seed); ONE launch chain traces them all (num_rays == 1)."""
+        frames = list(frames)
+        arr = (FrameDesc * max(len(frames), 1))()
+        for d, (ptr, pos, fov, seed) in zip(arr, frames):
+            d.camera.position[:] = pos
+            d.camera.fov = np.float32(np.pi / 3) if fov is None else np.float32(fov)
+            d.seed = int(seed)
+            d.out_rgba_dev = int(ptr)
+        self._check(self._L.rt_render_device_batch(self._h, C.byref(params), C.byref(rows), arr, len(frames), C.c_void_p(stream) if stream else None))
 
     def render_async(self, params, out, slot=0, rgb8=False):
         """rt_render_async: whole frame into device buffer `slot` (0 / 1), device-to-host copy into `out` on the copy stream;
@@ -472,6 +505,12 @@ class Context:
     def kat_mesh(self, rows, tri_tmin=1e-4, route=0):
         return self._kat(self._L.rt_kat_mesh, rows, 6, 5, C.c_float(tri_tmin), int(route))
 
+    def layout_hash(self):
+        """rt_kat_layout_hash -> dict(pairs, fixed_pairs, quads, leaf_boxes) of 64-bit hashes (0 = that layout is not in use)."""
+        h = (C.c_uint64 * 4)()
+        self._check(self._L.rt_kat_layout_hash(self._h, h))
+        return dict(zip(("pairs", "fixed_pairs", "quads", "leaf_boxes"), (int(x) for x in h)))
+
     def stats_after_render(self, params):
         """Render one frame with `params` and return rt_get_stats of it (which traversal kernel ran: travq_mode)."""
         self.render(params)
@@ -507,8 +546,11 @@ class MultiContext:
             raise RtError(rc, self._L.rt_multi_last_error(self._h).decode())
 
     def scene_upload(self, spheres, mesh=None, light=((-10.0, 20.0, 40.0), 3e10), camera=((0.0, 0.0, 55.0), None)):
-        arr, n, m, lt, cam, self._keep = _marshal_scene(spheres, mesh, light, camera)
-        self._check(self._L.rt_multi_scene_upload(self._h, arr, n, C.byref(m) if m is not None else None, C.byref(lt), C.byref(cam)))
+        arr, n, marr, nm, lt, cam, self._keep = _marshal_scene(spheres, mesh, light, camera)
+        if nm <= 1 and not isinstance(mesh, (list, tuple)):
+            self._check(self._L.rt_multi_scene_upload(self._h, arr, n, marr if nm else None, C.byref(lt), C.byref(cam)))
+        else:
+            self._check(self._L.rt_multi_scene_upload_meshes(self._h, arr, n, marr, nm, C.byref(lt), C.byref(cam)))
 
     def render(self, params):
         out = np.empty((params.height, params.width, 4), np.float32)

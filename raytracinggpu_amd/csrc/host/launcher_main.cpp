@@ -5,6 +5,7 @@
 // optional flag after the two positionals:
 //   --program cpu|optimized   scene/constants of cpu_launcher.cpp (default) or optimized.cu
 //   --scene cat|spheres|demo10   --width W --height H --out FILE --obj FILE --device N --variant N
+//   --mesh-material mirror|glass   --second-cat 1      (scenes the reference's classes accept and its main() never builds: cpu:106-118, 538-606)
 //   --devices 0,1,2,...          several GPUs from this one process (interleaved row tiles, rt_render_multi_rgb8)
 //   --tile-rank R --tile-world G --tiles FILE   one process per GPU: render only rank R's interleaved 8-row tiles and write
 //                                them (raw RGB8) to FILE; the processes' exchange is the caller's (RCCL / MPI / files)
@@ -59,6 +60,8 @@ int main(int argc, char *argv[]) {
     std::string rccl_nonce = getenv("RT_RCCL_NONCE") ? getenv("RT_RCCL_NONCE") : std::to_string((long)getppid());   // one launch = one nonce (the ranks' common parent by default)
     int rccl_timeout_s = 120;
     std::vector<std::string> assemble;
+    std::string mesh_material;
+    bool second_cat = false;
     for (int i = 3; i + 1 < argc; i += 2) {
         const std::string k = argv[i], v = argv[i + 1];
         if (k == "--program") program = v;
@@ -69,6 +72,8 @@ int main(int argc, char *argv[]) {
         else if (k == "--obj") obj = v;
         else if (k == "--device") device = atoi(v.c_str());
         else if (k == "--variant") variant = atoi(v.c_str());
+        else if (k == "--mesh-material") mesh_material = v;
+        else if (k == "--second-cat") second_cat = atoi(v.c_str()) != 0;
         else if (k == "--tile-rank") tile_rank = atoi(v.c_str());
         else if (k == "--tile-world") tile_world = atoi(v.c_str());
         else if (k == "--tiles") tiles_file = v;
@@ -118,6 +123,19 @@ int main(int argc, char *argv[]) {
             mesh_ptr->albedo = Vector(0.25, 0.25, 0.25);                  // cpu:683
             mesh_ptr->buildBVH(&(mesh_ptr->bvh), 0, (int)mesh_ptr->indices.size());   // cpu:684
         }
+        // --mesh-material mirror | glass: Geometry's public members on the mesh (cpu:113-116), as a user of the reference's classes would set them
+        if (mesh_ptr && mesh_material == "mirror") mesh_ptr->mirror = true;
+        if (mesh_ptr && mesh_material == "glass") { mesh_ptr->in_refraction_index = 1.5f; mesh_ptr->out_refraction_index = 1.f; }
+        // --second-cat 1: a second TriangleMesh in the same Scene::objects (cpu:538-543), the cat at half size in front of the first: v * 0.5 + (16, -5, 20), mirror, added last
+        TriangleMesh *mesh2_ptr = nullptr;
+        if (mesh_ptr && second_cat) {
+            mesh2_ptr = new TriangleMesh();
+            mesh2_ptr->readOBJ(obj.c_str());
+            for (auto &v : mesh2_ptr->vertices) v = v * 0.5f + Vector(16, -5, 20);
+            mesh2_ptr->albedo = Vector(0.6f, 0.3f, 0.1f);
+            mesh2_ptr->mirror = true;
+            mesh2_ptr->buildBVH(&(mesh2_ptr->bvh), 0, (int)mesh2_ptr->indices.size());
+        }
         lap("readOBJ + buildBVH (host)");
         if (scene_name == "demo10") {                                     // the commented objects, cpu:669-672
             s.addObject(new Sphere(Vector(0, 0, 0), 10, Vector(0., 0., 0.), 0, 1.5, 1));
@@ -133,6 +151,7 @@ int main(int argc, char *argv[]) {
         s.addObject(new Sphere(Vector(1000, 0, 0), 940, Vector(1., 1., 0.)));
         s.addObject(new Sphere(Vector(0, 0, 1000), 940, Vector(1., 0., 1.)));
         if (mesh_ptr && !optimized) s.addObject(mesh_ptr);                         // cpu:685: mesh is object 6
+        if (mesh2_ptr) s.addObject(mesh2_ptr);
 
         RenderSettings rs = optimized ? RenderSettings::optimized_cu() : RenderSettings::cpu_launcher();
         rs.W = W; rs.H = H; rs.num_rays = num_rays; rs.num_bounce = num_bounce; rs.variant = variant;

@@ -144,6 +144,8 @@ struct rt_ctx {
                                                                     // region must cycle through all four values (one context-wide counter gave a part only two of them with two parts: ADVICE round 4)
     int q16_leaf_shift = 0;                                         // where a leaf's triangle count sits in its payload word (rtk::q16_leaf_shift), 0 = leaves too large
     bool q16_topo_ok = false;                                       // the tree's shape allows them (leaf sizes, node count, boxes nest)
+    bool qw_topo_ok = false;                                        // ... and no leaf is empty: places 0 and 2 of a quad must hold a node (the pairs cope with an empty leaf)
+    int real_obj = -1;                                              // object position of the (first) mesh with triangles, -1 = none
     int n_real_meshes = 0;                                          // meshes WITH triangles in the scene: with more than one the tree in use is a forest (install_forest) and the per-mesh operations are refused
     DevBuf node_lo, node_hi, nodes2, nodesq, nodesb, q2thr, tri, verts, tidx, scratch_rgba, scratch_rgb8, work, queue;
     int n_cus = 0;
@@ -151,6 +153,8 @@ struct rt_ctx {
     DevBuf wfQR;                                                    // traversal queue in slot order: the rays (32 B each)
     DevBuf pathSamp, pathT;                                         // wf_path with num_rays > 1: per-sample colours, running sum
     DevBuf dbgbuf;                                                  // -DRT_DEBUG builds: per-wave traversal records
+    DevBuf batch_dev;                                               // rt_render_device_batch: the frames' descriptors (two slots)
+    int batch_slot = 0;
     DevBuf accum;                                                   // progressive mode: sum of the frames so far (float4 per pixel)
     int prog_frames = 0, prog_w = 0, prog_h = 0;
     uint64_t qf_sig = 0;                                            // layout the queue flags were last zeroed for
@@ -456,7 +460,7 @@ inline bool auto_is_lockstep(const rt_ctx *ctx, const rt_camera_pose *pose) {
 }
 
 int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void *out_dev, hipStream_t stream,
-                        unsigned long long *work_dev, const rt_camera_pose *pose, bool rec_begin, bool rec_end) {
+                        unsigned long long *work_dev, const rt_camera_pose *pose, bool rec_begin, bool rec_end, const rtk::Batch *batch = nullptr) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
     if (!ctx->have_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_scene_upload has not been called");
     int segs = 0;
@@ -479,7 +483,7 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
     // ... when there is a mesh.  A scene of spheres alone has no traversal to feed and no divergence to sort out: one lane per pixel for the whole frame (the reference's
     // own structure, the lock-step kernel) keeps a path in registers instead of streaming it through HBM once per bounce -- BASELINE config 2, 1920x1080 b 3: 0.198 against
     // 0.220 ms per frame (profiles/round5/ab_spheres_only.txt).  A posed camera exists in the wavefront family only.
-    if (variant == RT_VARIANT_AUTO) variant = auto_is_lockstep(ctx, pose) ? RT_VARIANT_LOCKSTEP : RT_VARIANT_WAVEFRONT_QUEUE;
+    if (variant == RT_VARIANT_AUTO) variant = (auto_is_lockstep(ctx, pose) && !batch) ? RT_VARIANT_LOCKSTEP : RT_VARIANT_WAVEFRONT_QUEUE;
     // BASELINE config 4 / north star: "hot triangle vertices and top BVH levels staged in LDS" = the work-stack traversal kernel
     // with the vertex array (LDS_VERTS), the breadth-first top of the node array (LDS_TOP) or both (LDS_ALL) staged per workgroup
     const int variant_req = variant;
@@ -511,6 +515,11 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
     rtk::Scene scn = ctx->scene;                                      // per-launch copy: a pose moves the camera
     fr.cam_mode = 0; fr.inv_n = 1.f;
     const bool wf_family = variant == RT_VARIANT_WAVEFRONT || variant == RT_VARIANT_WAVEFRONT_LDS || variant == RT_VARIANT_WAVEFRONT_QUEUE || variant == RT_VARIANT_PATH;
+    // several TriangleMesh objects: the object-order replay across meshes lives in wf_advance (rt_wavefront.hip.h); the other kernels keep the reference programs' one mesh
+    if (scn.n_meshes > 1 && !(wf_family && variant != RT_VARIANT_PATH))
+        return fail(ctx, RT_ERR_UNSUPPORTED, "a scene with %d meshes needs a wavefront variant (auto, wavefront, wavefront_lds, wavefront_queue, lds_*)", scn.n_meshes);
+    if (batch && !(wf_family && variant != RT_VARIANT_PATH))
+        return fail(ctx, RT_ERR_UNSUPPORTED, "a batch of frames needs a wavefront variant (auto, wavefront, wavefront_lds, wavefront_queue, lds_*)");
     if (scn.nrm != nullptr && !wf_family)
         return fail(ctx, RT_ERR_UNSUPPORTED, "smooth normals need a wavefront or path variant");
     if (pose) {                                                       // realtime_render.cu's camera
@@ -718,6 +727,7 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
         // samples of a pixel are independent paths: a launch chain traces `chunk` of them at once (bigger launches, fewer tails) as
         // long as the chain's state (~130 bytes per item) stays around the size of the Infinity Cache (RT_PATH_SAMP_MB, default 400)
         int chunk = 1;
+        if (batch) chunk = batch->n;                                  // the chain's items are (frame, pixel slot) pairs: num_rays == 1 (rt_render_device_batch checks)
         if (fr.spp > 1) {
             const int64_t px_all = (int64_t)tiles_x * ((rows->n_rows + 7) / 8 + parts) * 64;
             const int64_t per_item = 16 + 16 + 64 + 16 + 5 * (int64_t)nseg;
@@ -800,6 +810,17 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
             st.samp_out = fr.spp > 1 ? static_cast<float4 *>(ctx->wfSamp.p) + pt.base : nullptr;
             st.LS = static_cast<float *>(ctx->wfLS.p) + pt.base * (size_t)nseg;   // LS[d * n_paths + i] inside the part's block
             st.SID = static_cast<unsigned char *>(ctx->wfSID.p) + pt.base * (size_t)nseg;
+            st.batch = nullptr; st.n_batch = 0;
+        }
+        if (batch) {
+            // the frames' descriptors go to device memory on the caller's stream, ahead of the fork below: every chain of this call starts behind them.  Two slots, alternating:
+            // a batch call never takes the relaxed start of rt_ctx_set_pipelining (its chains must not overtake this store), so the previous call's chains have been joined
+            // into the stream before this kernel runs; the second slot only keeps that argument local
+            if ((rc2 = ensure(ctx, ctx->batch_dev, 2 * rtk::kMaxBatch * sizeof(rtk::BatchFrame))) != RT_OK) return rc2;
+            ctx->batch_slot ^= 1;
+            rtk::BatchFrame *dst = static_cast<rtk::BatchFrame *>(ctx->batch_dev.p) + ctx->batch_slot * rtk::kMaxBatch;
+            hipLaunchKernelGGL(rtk::batch_store_kernel, dim3(1), dim3(64), 0, stream, *batch, dst);
+            for (Part &pt : pv) { pt.st.batch = dst; pt.st.n_batch = batch->n; }
         }
         ctx->stats.lds_bytes = (int)trav_lds;
         ctx->stats.block_threads = tb;
@@ -828,7 +849,7 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
                     return fail(ctx, RT_ERR_INVALID, "pipelining rule broken: work submitted to this stream after the previous render call (rt_tonemap_device) touches the buffer "
                                                      "this frame renders into; with rt_ctx_set_pipelining the frame would not wait for it (raytrace_hip.h)");
 #endif
-                const bool relaxed = pl.on && pl.prev_valid && pl.stream == stream && pl.sig == layout_sig && disjoint && !zeroed && !hazard;
+                const bool relaxed = pl.on && pl.prev_valid && pl.stream == stream && pl.sig == layout_sig && disjoint && !zeroed && !hazard && !batch;
                 pl.cur ^= 1;
                 RT_HIP(ctx, hipEventRecord(pl.fork2[pl.cur], stream));
                 start_ev = pl.fork2[relaxed ? pl.cur ^ 1 : pl.cur];
@@ -1040,7 +1061,7 @@ int requantize(rt_ctx *ctx, hipStream_t q) {
     rtk::Scene &sc = ctx->scene;
     sc.nodesh = nullptr; sc.tri2leaf = nullptr; sc.nodesw = nullptr; sc.leaflh = nullptr;
     // (wherever the format fits: with flagged leaves the 4-wide step beats the fixed-point pairs on every tree measured -- 2 019 nodes -8 %, 32 889 -9 %, 358 503 -12 %: profiles/round5/ab_wide_nodes.txt)
-    const bool want_qw = ctx->knobs.qw != 0 && ctx->q16_leaf_shift == 24 && sc.n_nodes + 2 < (1 << 21);   // the quad's payload word: leaves of <= 127 triangles, child << 10 positive
+    const bool want_qw = ctx->knobs.qw != 0 && ctx->qw_topo_ok && ctx->q16_leaf_shift == 24 && sc.n_nodes + 2 < (1 << 21);   // the quad's payload word: leaves of <= 127 triangles, child << 10 positive; no empty leaf
     if (!(ctx->knobs.q16 == 1 || (ctx->knobs.q16 < 0 && sc.n_nodes >= kQ16AutoNodes) || want_qw) || !ctx->q16_topo_ok || ctx->q16_leaf_shift == 0 || !ctx->travq_ok || !sc.fast_box || sc.mesh_slot < 0 || sc.n_nodes < 3 || sc.n_tris <= 0) return RT_OK;
     int rc;
     if ((rc = ensure(ctx, ctx->nodesh, ((size_t)sc.n_nodes + 2) * 16)) != RT_OK || (rc = ensure(ctx, ctx->tri2leaf, (size_t)sc.n_tris * sizeof(int))) != RT_OK ||
@@ -1076,6 +1097,8 @@ int requantize(rt_ctx *ctx, hipStream_t q) {
     }
     RT_HIP(ctx, hipGetLastError());
     RT_HIP(ctx, hipStreamSynchronize(q));
+    // the DP's scratch (28 bytes per node) is needed while this function runs only: big trees give it back (a cat-sized one keeps it for the next refit)
+    if ((size_t)sc.n_nodes * 28 > (16u << 20)) { ctx->qdp_parent.release(); ctx->qdp_cnt.release(); ctx->qdp_g.release(); ctx->qdp_ch.release(); }
     sc.nodesh = static_cast<const uint4 *>(ctx->nodesh.p); sc.tri2leaf = static_cast<const int *>(ctx->tri2leaf.p); sc.leaflh = static_cast<const float4 *>(ctx->leaflh.p);
     if (want_qw) sc.nodesw = static_cast<const uint4 *>(ctx->nodesw.p);
     sc.qgx = g.gx; sc.qgy = g.gy; sc.qgz = g.gz; sc.qsx = g.sx; sc.qsy = g.sy; sc.qsz = g.sz; sc.qleaf_shift = ctx->q16_leaf_shift;
@@ -1091,6 +1114,7 @@ void mesh_table_single(rtk::Scene &sc, int real_obj) {
 // mesh: the geometry to traverse -- one TriangleMesh as uploaded, or the forest install_forest made of several (tri_offsets[k] = first triangle of table entry k in mesh->indices,
 // n_meshes + 1 entries) -- or nullptr.
 int install_scene(rt_ctx *ctx, rtk::Scene sc, const rt_mesh *mesh, const std::vector<int> *tri_offsets = nullptr) {
+    PhaseClock pc;
     RT_HIP(ctx, hipSetDevice(ctx->device));
     if (ctx->stream_) RT_HIP(ctx, hipStreamSynchronize(ctx->stream_));   // (renders issued on a caller's stream are the caller's to order)
     ctx->have_scene = false;
@@ -1100,8 +1124,8 @@ int install_scene(rt_ctx *ctx, rtk::Scene sc, const rt_mesh *mesh, const std::ve
     std::vector<int4> tidx;
     std::vector<int> left_of;
     if (mesh) {
-        if (mesh->object_slot < 0 || mesh->object_slot > sc.n_spheres)
-            return fail(ctx, RT_ERR_INVALID, "mesh object_slot %d outside [0,%d]", mesh->object_slot, sc.n_spheres);
+        if (mesh->object_slot < 0 || mesh->object_slot >= RT_MAX_OBJECTS)   // (validated against the scene's objects by rt_scene_upload_meshes)
+            return fail(ctx, RT_ERR_INVALID, "mesh object_slot %d outside [0,%d)", mesh->object_slot, RT_MAX_OBJECTS);
         if (mesh->n_vertices < 0 || mesh->n_triangles < 0 || mesh->n_nodes < 0 || mesh->index_stride < 3)
             return fail(ctx, RT_ERR_INVALID, "bad mesh sizes");
         if ((mesh->n_vertices && !mesh->vertices) || (mesh->n_triangles && !mesh->indices) || (mesh->n_nodes && !mesh->bvh_arr10))
@@ -1168,7 +1192,9 @@ int install_scene(rt_ctx *ctx, rtk::Scene sc, const rt_mesh *mesh, const std::ve
         mesh_table_single(sc, -1);
     }
     int rc;
+    pc.lap("  scene: traversal order, triangle records (host)");
     if ((rc = upload(ctx, ctx->node_lo, lo.data(), lo.size() * sizeof(float4))) != RT_OK) return rc;
+    pc.lap("  scene: first hipMalloc + copy");
     if ((rc = upload(ctx, ctx->node_hi, hi.data(), hi.size() * sizeof(float4))) != RT_OK) return rc;
     std::vector<float4> inter(lo.size() * 2);
     for (size_t k = 0; k < lo.size(); ++k) { inter[2 * k] = lo[k]; inter[2 * k + 1] = hi[k]; }
@@ -1224,13 +1250,13 @@ int install_scene(rt_ctx *ctx, rtk::Scene sc, const rt_mesh *mesh, const std::ve
         }
         if ((rc = upload(ctx, ctx->nodesb, qb.data(), qb.size() * sizeof(float4))) != RT_OK) return rc;
         {   // may this tree use the 16-bit fixed-point pairs (rt_qnodes.hip.h)?  Leaf sizes and counts fit the payload word, and every box nests inside its parent's
-            bool topo = order.size() >= 3;
+            bool topo = order.size() >= 3, empty_leaf = false;
             int max_leaf = 0;
             for (size_t x = 0; topo && x < n; ++x) {
                 if (left_of[x] < 0) {
                     const int cnt = __builtin_bit_cast(int, hi[x].w) - __builtin_bit_cast(int, lo[x].w);
                     max_leaf = std::max(max_leaf, cnt);
-                    if (cnt <= 0) topo = false;                       // an empty leaf: the quads' places 0 and 2 must hold a node (the float pairs cope with it)
+                    if (cnt <= 0) empty_leaf = true;                  // the quads' places 0 and 2 must hold a node; the fixed-point and the float pairs cope with an empty leaf
                     continue;
                 }
                 for (const int c : {(int)x + 1, left_of[x]}) {
@@ -1239,6 +1265,7 @@ int install_scene(rt_ctx *ctx, rtk::Scene sc, const rt_mesh *mesh, const std::ve
                 }
             }
             ctx->q16_topo_ok = topo;
+            ctx->qw_topo_ok = topo && !empty_leaf;
             ctx->q16_leaf_shift = rtk::q16_leaf_shift(max_leaf, (long long)(tri.size() / 3));
         }
         sc.bmx = bm[0]; sc.bmy = bm[1]; sc.bmz = bm[2];
@@ -1274,7 +1301,10 @@ int install_scene(rt_ctx *ctx, rtk::Scene sc, const rt_mesh *mesh, const std::ve
     sc.tidx = static_cast<const int4 *>(ctx->tidx.p);
     ctx->scene = sc;
     ctx->have_scene = true;
-    return requantize(ctx, nullptr);
+    pc.lap("  scene: layouts (host) + the other hipMallocs and copies");
+    rc = requantize(ctx, nullptr);
+    pc.lap("  scene: fixed-point nodes on the device (first kernel launch: code object load)");
+    return rc;
 }
 
 // tri_perm / up_indices (host copies of the mesh's orders) after a device-side install: fetched when a host-side path needs them
@@ -1289,112 +1319,6 @@ int refresh_host_mesh(rt_ctx *ctx) {
     ctx->up_indices.resize(nt * 3);
     for (size_t t = 0; t < nt; ++t) { ctx->up_indices[3 * t] = up[t].x; ctx->up_indices[3 * t + 1] = up[t].y; ctx->up_indices[3 * t + 2] = up[t].z; }
     ctx->host_mesh_stale = false;
-    return RT_OK;
-}
-
-}  // namespace
-
-extern "C" {
-
-int rt_abi_version(void) { return RT_ABI_VERSION; }
-
-int rt_device_count(int *count) {
-    if (!count) return fail(nullptr, RT_ERR_INVALID, "count is NULL");
-    int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess) { *count = 0; return fail(nullptr, RT_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
-    *count = n;
-    return RT_OK;
-}
-
-int rt_ctx_create(rt_ctx **out, int device_id) {
-    if (!out) return fail(nullptr, RT_ERR_INVALID, "ctx out-pointer is NULL");
-    *out = nullptr;
-    int n = 0;
-    PhaseClock pc;
-    int rc = rt_device_count(&n);
-    pc.lap("hipGetDeviceCount (runtime initialisation)");
-    if (rc != RT_OK) return rc;
-    if (n == 0) return fail(nullptr, RT_ERR_NO_DEVICE, "no HIP device visible");
-    if (device_id < 0 || device_id >= n) return fail(nullptr, RT_ERR_INVALID, "device %d out of range [0,%d)", device_id, n);
-    rt_ctx *ctx = new (std::nothrow) rt_ctx();
-    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "out of host memory");
-    ctx->device = device_id;
-    ctx->knobs = read_knobs();
-    { const char *e = getenv("RT_LBVH_HOST_INSTALL"); ctx->lbvh_host_install = (e && *e && atoi(e) != 0) ? 1 : 0; }
-    hipDeviceProp_t prop;
-    hipError_t e = hipSetDevice(device_id);
-    pc.lap("hipSetDevice");
-    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device_id);
-    pc.lap("hipGetDeviceProperties");
-    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_k0);
-    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_k1);
-    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_t0);
-    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_t1);
-    for (hipEvent_t &ev : ctx->ev_trav) if (e == hipSuccess) e = hipEventCreate(&ev);
-    for (hipEvent_t &ev : ctx->ev_adv) if (e == hipSuccess) e = hipEventCreate(&ev);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming);
-    for (int k = 0; k < rt_ctx::kSlots; ++k) if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->slot_half[k], hipEventDisableTiming);
-    for (int k = 0; k < rt_ctx::kSlots; ++k) {
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->slot_rendered[k], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->slot_done[k], hipEventDisableTiming);
-    }
-    if (e != hipSuccess) {
-        int code = fail(nullptr, RT_ERR_HIP, "context creation: %s", hipGetErrorString(e));
-        rt_ctx_destroy(ctx);
-        return code;
-    }
-    pc.lap("events");
-    snprintf(ctx->name, sizeof(ctx->name), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
-    ctx->n_cus = prop.multiProcessorCount;
-    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
-        int code = fail(nullptr, RT_ERR_NO_DEVICE, "device %d is %s; this library contains gfx950 code only", device_id, prop.gcnArchName);
-        rt_ctx_destroy(ctx);
-        return code;
-    }
-    *out = ctx;
-    return RT_OK;
-}
-
-int rt_ctx_destroy(rt_ctx *ctx) {
-    if (!ctx) return RT_OK;
-    (void)hipSetDevice(ctx->device);
-    if (ctx->stream_) (void)hipStreamSynchronize(ctx->stream_);
-    for (hipStream_t q : ctx->part_stream) if (q) (void)hipStreamSynchronize(q);   // sub-frame chains of frames issued on a caller's stream
-    if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
-    if (ctx->copy_stream2) { (void)hipStreamSynchronize(ctx->copy_stream2); (void)hipStreamDestroy(ctx->copy_stream2); }
-    for (int k = 0; k < rt_ctx::kSlots; ++k) if (ctx->slot_half[k]) (void)hipEventDestroy(ctx->slot_half[k]);
-    for (int k = 0; k < rt_ctx::kSlots; ++k) {
-        ctx->slot_rgba[k].release(); ctx->slot_rgb8[k].release();
-        if (ctx->slot_rendered[k]) (void)hipEventDestroy(ctx->slot_rendered[k]);
-        if (ctx->slot_done[k]) (void)hipEventDestroy(ctx->slot_done[k]);
-    }
-    ctx->node_lo.release(); ctx->node_hi.release(); ctx->nodes2.release(); ctx->nodesq.release(); ctx->nodesb.release(); ctx->nodesh.release(); ctx->tri2leaf.release(); ctx->nodesw.release(); ctx->leaflh.release(); ctx->qdp_parent.release(); ctx->qdp_cnt.release(); ctx->qdp_g.release(); ctx->qdp_ch.release(); ctx->q2thr.release(); ctx->left_dev.release(); ctx->lvl_nodes.release(); ctx->lvl_off.release(); ctx->nrm.release(); ctx->tri.release(); ctx->verts.release(); ctx->tidx.release();
-    ctx->scratch_rgba.release(); ctx->scratch_rgb8.release(); ctx->work.release(); ctx->queue.release();
-    ctx->wfM.release(); ctx->wfT.release(); ctx->wfLS.release(); ctx->wfSID.release(); ctx->wfSamp.release();
-    ctx->wfQR.release(); ctx->accum.release(); ctx->dbgbuf.release();
-    ctx->pathSamp.release(); ctx->pathT.release(); ctx->tidx_up.release();
-    for (DevBuf *b : {&ctx->bb_idx, &ctx->bb_cnt, &ctx->bb_pa, &ctx->bb_pb, &ctx->bb_tmp, &ctx->bb_nodes_i, &ctx->bb_nodes_f, &ctx->bb_counter, &ctx->bb_lvl, &ctx->bb_size, &ctx->bb_pre, &ctx->bb_arr, &ctx->lb_pool, &ctx->lb_pool2, &ctx->perm_dev}) b->release();
-    for (hipEvent_t &e : ctx->ev_trav) if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t &e : ctx->ev_adv) if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t &e : ctx->part_ev) if (e) (void)hipEventDestroy(e);
-    for (hipStream_t &q : ctx->part_stream) if (q) (void)hipStreamDestroy(q);
-    if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
-    for (hipEvent_t &e : ctx->pipe.fork2) if (e) (void)hipEventDestroy(e);
-    if (ctx->ev_k0) (void)hipEventDestroy(ctx->ev_k0);
-    if (ctx->ev_k1) (void)hipEventDestroy(ctx->ev_k1);
-    if (ctx->ev_t0) (void)hipEventDestroy(ctx->ev_t0);
-    if (ctx->ev_t1) (void)hipEventDestroy(ctx->ev_t1);
-    if (ctx->stream_) (void)hipStreamDestroy(ctx->stream_);
-    delete ctx;
-    return RT_OK;
-}
-
-const char *rt_last_error(const rt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
-
-int rt_device_name(const rt_ctx *ctx, char *buf, size_t buflen) {
-    if (!ctx || !buf || buflen == 0) return fail(nullptr, RT_ERR_INVALID, "bad arguments");
-    snprintf(buf, buflen, "%s", ctx->name);
     return RT_OK;
 }
 
@@ -1480,6 +1404,108 @@ int build_forest(rt_ctx *ctx, const rt_mesh *meshes, const std::vector<int> &rea
 
 extern "C" {
 
+int rt_abi_version(void) { return RT_ABI_VERSION; }
+
+int rt_device_count(int *count) {
+    if (!count) return fail(nullptr, RT_ERR_INVALID, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(nullptr, RT_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = n;
+    return RT_OK;
+}
+
+int rt_ctx_create(rt_ctx **out, int device_id) {
+    if (!out) return fail(nullptr, RT_ERR_INVALID, "ctx out-pointer is NULL");
+    *out = nullptr;
+    int n = 0;
+    PhaseClock pc;
+    int rc = rt_device_count(&n);
+    pc.lap("hipGetDeviceCount (runtime initialisation)");
+    if (rc != RT_OK) return rc;
+    if (n == 0) return fail(nullptr, RT_ERR_NO_DEVICE, "no HIP device visible");
+    if (device_id < 0 || device_id >= n) return fail(nullptr, RT_ERR_INVALID, "device %d out of range [0,%d)", device_id, n);
+    rt_ctx *ctx = new (std::nothrow) rt_ctx();
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "out of host memory");
+    ctx->device = device_id;
+    ctx->knobs = read_knobs();
+    { const char *e = getenv("RT_LBVH_HOST_INSTALL"); ctx->lbvh_host_install = (e && *e && atoi(e) != 0) ? 1 : 0; }
+    hipDeviceProp_t prop;
+    hipError_t e = hipSetDevice(device_id);
+    pc.lap("hipSetDevice");
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device_id);
+    pc.lap("hipGetDeviceProperties");
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_k0);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_k1);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_t0);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_t1);
+    for (hipEvent_t &ev : ctx->ev_trav) if (e == hipSuccess) e = hipEventCreate(&ev);
+    for (hipEvent_t &ev : ctx->ev_adv) if (e == hipSuccess) e = hipEventCreate(&ev);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming);
+    for (int k = 0; k < rt_ctx::kSlots; ++k) if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->slot_half[k], hipEventDisableTiming);
+    for (int k = 0; k < rt_ctx::kSlots; ++k) {
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->slot_rendered[k], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->slot_done[k], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) {
+        int code = fail(nullptr, RT_ERR_HIP, "context creation: %s", hipGetErrorString(e));
+        rt_ctx_destroy(ctx);
+        return code;
+    }
+    pc.lap("events");
+    snprintf(ctx->name, sizeof(ctx->name), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    ctx->n_cus = prop.multiProcessorCount;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        int code = fail(nullptr, RT_ERR_NO_DEVICE, "device %d is %s; this library contains gfx950 code only", device_id, prop.gcnArchName);
+        rt_ctx_destroy(ctx);
+        return code;
+    }
+    *out = ctx;
+    return RT_OK;
+}
+
+int rt_ctx_destroy(rt_ctx *ctx) {
+    if (!ctx) return RT_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream_) (void)hipStreamSynchronize(ctx->stream_);
+    for (hipStream_t q : ctx->part_stream) if (q) (void)hipStreamSynchronize(q);   // sub-frame chains of frames issued on a caller's stream
+    if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
+    if (ctx->copy_stream2) { (void)hipStreamSynchronize(ctx->copy_stream2); (void)hipStreamDestroy(ctx->copy_stream2); }
+    for (int k = 0; k < rt_ctx::kSlots; ++k) if (ctx->slot_half[k]) (void)hipEventDestroy(ctx->slot_half[k]);
+    for (int k = 0; k < rt_ctx::kSlots; ++k) {
+        ctx->slot_rgba[k].release(); ctx->slot_rgb8[k].release();
+        if (ctx->slot_rendered[k]) (void)hipEventDestroy(ctx->slot_rendered[k]);
+        if (ctx->slot_done[k]) (void)hipEventDestroy(ctx->slot_done[k]);
+    }
+    ctx->node_lo.release(); ctx->node_hi.release(); ctx->nodes2.release(); ctx->nodesq.release(); ctx->nodesb.release(); ctx->nodesh.release(); ctx->tri2leaf.release(); ctx->nodesw.release(); ctx->leaflh.release(); ctx->qdp_parent.release(); ctx->qdp_cnt.release(); ctx->qdp_g.release(); ctx->qdp_ch.release(); ctx->q2thr.release(); ctx->left_dev.release(); ctx->lvl_nodes.release(); ctx->lvl_off.release(); ctx->nrm.release(); ctx->tri.release(); ctx->verts.release(); ctx->tidx.release();
+    ctx->scratch_rgba.release(); ctx->scratch_rgb8.release(); ctx->work.release(); ctx->queue.release();
+    ctx->wfM.release(); ctx->wfT.release(); ctx->wfLS.release(); ctx->wfSID.release(); ctx->wfSamp.release();
+    ctx->wfQR.release(); ctx->accum.release(); ctx->dbgbuf.release(); ctx->batch_dev.release();
+    ctx->pathSamp.release(); ctx->pathT.release(); ctx->tidx_up.release();
+    for (DevBuf *b : {&ctx->bb_idx, &ctx->bb_cnt, &ctx->bb_pa, &ctx->bb_pb, &ctx->bb_tmp, &ctx->bb_nodes_i, &ctx->bb_nodes_f, &ctx->bb_counter, &ctx->bb_lvl, &ctx->bb_size, &ctx->bb_pre, &ctx->bb_arr, &ctx->lb_pool, &ctx->lb_pool2, &ctx->perm_dev}) b->release();
+    for (hipEvent_t &e : ctx->ev_trav) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t &e : ctx->ev_adv) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t &e : ctx->part_ev) if (e) (void)hipEventDestroy(e);
+    for (hipStream_t &q : ctx->part_stream) if (q) (void)hipStreamDestroy(q);
+    if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
+    for (hipEvent_t &e : ctx->pipe.fork2) if (e) (void)hipEventDestroy(e);
+    if (ctx->ev_k0) (void)hipEventDestroy(ctx->ev_k0);
+    if (ctx->ev_k1) (void)hipEventDestroy(ctx->ev_k1);
+    if (ctx->ev_t0) (void)hipEventDestroy(ctx->ev_t0);
+    if (ctx->ev_t1) (void)hipEventDestroy(ctx->ev_t1);
+    if (ctx->stream_) (void)hipStreamDestroy(ctx->stream_);
+    delete ctx;
+    return RT_OK;
+}
+
+const char *rt_last_error(const rt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+int rt_device_name(const rt_ctx *ctx, char *buf, size_t buflen) {
+    if (!ctx || !buf || buflen == 0) return fail(nullptr, RT_ERR_INVALID, "bad arguments");
+    snprintf(buf, buflen, "%s", ctx->name);
+    return RT_OK;
+}
+
 int rt_scene_upload_meshes(rt_ctx *ctx, const rt_sphere *spheres, int n_spheres, const rt_mesh *meshes, int n_meshes,
                            const rt_light *light, const rt_camera *camera) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
@@ -1500,15 +1526,23 @@ int rt_scene_upload_meshes(rt_ctx *ctx, const rt_sphere *spheres, int n_spheres,
         if (m.object_slot < 0 || m.object_slot >= n_objects) return fail(ctx, RT_ERR_INVALID, "mesh object_slot %d outside [0,%d]", m.object_slot, n_objects - 1);
         if (taken[m.object_slot]) return fail(ctx, RT_ERR_INVALID, "two meshes at object_slot %d", m.object_slot);
         taken[m.object_slot] = true;
-        sc.mesh[k] = rtk::MeshRec{0, m.object_slot, m.albedo[0], m.albedo[1], m.albedo[2], m.mirror ? 1 : 0, m.in_refraction_index, m.out_refraction_index};
+        sc.mesh[k] = rtk::MeshRec{0, m.object_slot};
+        sc.obj_a[m.object_slot] = make_float4(0.f, 0.f, 0.f, __builtin_bit_cast(float, (int)(m.mirror ? 1 : 0)));
+        sc.obj_b[m.object_slot] = make_float4(m.albedo[0], m.albedo[1], m.albedo[2], 0.f);
+        // Geometry() (cpu:110) gives a mesh the indices 1 / 1; a zero-initialised rt_mesh (ABI 5 callers) says 0 / 0: the same diffuse object, stored as 1 / 1
+        const bool unset = m.in_refraction_index == 0.f && m.out_refraction_index == 0.f;
+        sc.obj_n[m.object_slot] = make_float2(unset ? 1.f : m.in_refraction_index, unset ? 1.f : m.out_refraction_index);
     }
     sc.n_meshes = n_meshes;
     int pos = 0;
     for (int i = 0; i < n_spheres; ++i) {
         while (pos < n_objects && taken[pos]) ++pos;
         const rt_sphere &s = spheres[i];
-        sc.sph[i] = {s.center[0], s.center[1], s.center[2], s.radius, s.albedo[0], s.albedo[1], s.albedo[2],
-                     s.mirror ? 1 : 0, s.in_refraction_index, s.out_refraction_index, s.radius * s.radius, pos++};   // R * R: one binary32 product (-ffp-contract=off), as cpu:513
+        sc.sph[i] = {s.center[0], s.center[1], s.center[2], s.radius, s.radius * s.radius, pos};   // R * R: one binary32 product (-ffp-contract=off), as cpu:513
+        sc.obj_a[pos] = make_float4(s.center[0], s.center[1], s.center[2], __builtin_bit_cast(float, (int)(s.mirror ? 1 : 0)));
+        sc.obj_b[pos] = make_float4(s.albedo[0], s.albedo[1], s.albedo[2], 0.f);
+        sc.obj_n[pos] = make_float2(s.in_refraction_index, s.out_refraction_index);
+        ++pos;
     }
     sc.n_spheres = n_spheres;
     sc.n_objects = n_objects;
@@ -1535,7 +1569,7 @@ int rt_scene_upload_meshes(rt_ctx *ctx, const rt_sphere *spheres, int n_spheres,
         }
         rc = install_scene(ctx, sc, &f.m, &offs);
     }
-    if (rc == RT_OK) ctx->n_real_meshes = (int)real.size();
+    if (rc == RT_OK) { ctx->n_real_meshes = (int)real.size(); ctx->real_obj = real.empty() ? -1 : meshes[real[0]].object_slot; }
     pc.lap("rt_scene_upload (layouts, hipMalloc, copies)");
     return rc;
 }
@@ -1550,6 +1584,40 @@ int rt_render_device(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, void 
     const hipStream_t q_ = stream ? static_cast<hipStream_t>(stream) : own_stream(ctx);
     if (!q_) return fail(ctx, RT_ERR_HIP, "the context's stream: %s", ctx->err.c_str());
     return launch_render(ctx, p, rows, out_rgba_dev, q_);
+}
+
+int rt_render_device_batch(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, const rt_frame_desc *frames, int n_frames, void *stream) {
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    const hipStream_t q_ = stream ? static_cast<hipStream_t>(stream) : own_stream(ctx);
+    if (!q_) return fail(ctx, RT_ERR_HIP, "the context's stream: %s", ctx->err.c_str());
+    if (!p || !rows || !frames) return fail(ctx, RT_ERR_INVALID, "params / rows / frames is NULL");
+    if (n_frames < 1 || n_frames > RT_MAX_BATCH) return fail(ctx, RT_ERR_INVALID, "n_frames %d outside [1,%d]", n_frames, RT_MAX_BATCH);
+    if (p->num_rays != 1) return fail(ctx, RT_ERR_UNSUPPORTED, "a batch renders one sample per pixel and frame (num_rays = %d)", p->num_rays);
+    if (p->width <= 0 || p->height <= 0) return fail(ctx, RT_ERR_INVALID, "width/height must be positive");
+    rtk::Batch bt{};
+    bt.n = n_frames;
+    const uint8_t *lo = nullptr, *hi = nullptr;
+    const size_t bytes = (size_t)std::max(rows->n_rows, 0) * p->width * sizeof(float4);
+    for (int k = 0; k < n_frames; ++k) {
+        const rt_frame_desc &f = frames[k];
+        if (!f.out_rgba_dev) return fail(ctx, RT_ERR_INVALID, "frame %d: output pointer is NULL", k);
+        const uint8_t *o = static_cast<const uint8_t *>(f.out_rgba_dev);
+        for (int j = 0; j < k; ++j) {
+            const uint8_t *oj = static_cast<const uint8_t *>(frames[j].out_rgba_dev);
+            if (o < oj + bytes && oj < o + bytes) return fail(ctx, RT_ERR_INVALID, "frames %d and %d render into overlapping buffers", j, k);
+        }
+        lo = (!lo || o < lo) ? o : lo; hi = (!hi || o + bytes > hi) ? o + bytes : hi;
+        // cpu:694 `-W / (2 * tan(alpha/2))` for this frame's camera (evaluated as launch_render_chunk evaluates the uploaded camera's)
+        bt.f[k] = rtk::BatchFrame{f.camera.position[0], f.camera.position[1], f.camera.position[2],
+                                  -(float)p->width / (2 * (float)std::tan((double)(f.camera.fov / 2))), f.seed, 0, static_cast<float4 *>(f.out_rgba_dev)};
+    }
+    // one chunk: the batch exists for SMALL shares (a share too big for one chunk fills the chip by itself: render its frames one by one)
+    rt_ctx::Pipe &pl = ctx->pipe;
+    pl.prev_valid = pl.valid; pl.valid = false;
+    pl.call_chunk = 0; pl.call_chunks = 1; pl.open_parts = 0;
+    struct ClearBetween { rt_ctx::Pipe &p; ~ClearBetween() { p.between.clear(); p.between_overflow = false; } } clear_between{pl};
+    pl.call_lo = lo; pl.call_hi = hi;                                // (the frames' buffers and whatever lies between them: conservative for the pipelining rule)
+    return launch_render_chunk(ctx, p, rows, frames[0].out_rgba_dev, q_, nullptr, nullptr, true, true, &bt);
 }
 
 int rt_render(rt_ctx *ctx, const rt_params *p, int row_begin, int row_end, float *out_rgba_host) {
@@ -1704,6 +1772,7 @@ int rt_mesh_set_normals(rt_ctx *ctx, const float *normals_xyz, int n_normals, co
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipStreamSynchronize(own_stream(ctx)));
     if (!normals_xyz || !nidx) { ctx->scene.nrm = nullptr; return RT_OK; }          // back to flat shading
+    if (ctx->n_real_meshes > 1) return fail(ctx, RT_ERR_UNSUPPORTED, "the scene holds %d meshes: smooth normals are set for ONE TriangleMesh", ctx->n_real_meshes);
     if (int rr = refresh_host_mesh(ctx); rr != RT_OK) return rr;
     if (ctx->scene.mesh_slot < 0) return fail(ctx, RT_ERR_INVALID, "the scene has no mesh");
     if (n_normals <= 0 || index_stride < 3) return fail(ctx, RT_ERR_INVALID, "bad normal array sizes");
@@ -1976,6 +2045,7 @@ static int install_lbvh_device(rt_ctx *ctx, const rtk::Scene &old, const int n_n
     rtk::Scene sc = old;
     sc.nrm = nullptr;
     sc.n_nodes = n_nodes; sc.n_tris = (int)n;
+    mesh_table_single(sc, ctx->real_obj);
     sc.root_lo = root[0]; sc.root_hi = root[1];
     bool fast = true;
     const float rv[6] = {root[0].x, root[0].y, root[0].z, root[1].x, root[1].y, root[1].z};
@@ -1994,6 +2064,7 @@ static int install_lbvh_device(rt_ctx *ctx, const rtk::Scene &old, const int n_n
     ctx->host_mesh_stale = true;                                                 // tri_perm / up_indices: on the device now (perm_dev, tidx_up)
     ctx->have_scene = true;
     ctx->q16_topo_ok = true;                                                     // boxes are unions, bottom-up: they nest
+    ctx->qw_topo_ok = true;                                                      // (an LBVH leaf holds at least one triangle)
     ctx->q16_leaf_shift = rtk::q16_leaf_shift(rtk::kLbvhLeaf, n);                // leaves of at most kLbvhLeaf triangles
     return requantize(ctx, q);
 }
@@ -2006,7 +2077,8 @@ int rt_mesh_rebuild_mode(rt_ctx *ctx, int mode, float *bvh_arr10_out, int32_t *t
     if (n_nodes_out) *n_nodes_out = 0;
     const rtk::Scene old = ctx->scene;
     const int nt = ctx->n_up_tris, nv = old.n_verts;
-    if (old.mesh_slot < 0 || nt <= 0 || nv <= 0) return RT_OK;                     // no mesh: nothing to build
+    if (ctx->n_real_meshes > 1) return fail(ctx, RT_ERR_UNSUPPORTED, "the scene holds %d meshes: a rebuild works on ONE TriangleMesh (upload the rebuilt meshes again)", ctx->n_real_meshes);
+    if (old.mesh_slot < 0 || ctx->real_obj < 0 || nt <= 0 || nv <= 0) return RT_OK;  // no mesh: nothing to build
     RT_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t q = own_stream(ctx);
     int rc;
@@ -2059,7 +2131,7 @@ int rt_mesh_rebuild_mode(rt_ctx *ctx, int mode, float *bvh_arr10_out, int32_t *t
     rt_mesh m{};
     m.vertices = vx.data(); m.n_vertices = nv; m.indices = ix.data(); m.index_stride = 3; m.n_triangles = nt;
     m.bvh_arr10 = arr.data(); m.n_nodes = n_nodes;
-    m.albedo[0] = old.mar; m.albedo[1] = old.mag; m.albedo[2] = old.mab; m.object_slot = old.mesh_slot;
+    m.object_slot = ctx->real_obj;                                                  // (albedo and material stay in the scene's mesh table, which `sc` carries over)
     rtk::Scene sc = old;
     sc.n_nodes = sc.n_tris = sc.n_verts = 0; sc.nrm = nullptr;
     if ((rc = install_scene(ctx, sc, &m)) != RT_OK) return rc;

@@ -244,4 +244,28 @@ int rt_kat_mesh(rt_ctx *ctx, const float *in, int n, float tri_tmin, int route, 
     });
 }
 
+// FNV-1a over the device arrays the traversal kernels read: out[0] the float sibling pairs (nodesb), [1] the 16-bit fixed-point pairs (nodesh), [2] the 4-wide quads
+// (nodesw: WHICH four nodes a quad holds is the surface-area DP's choice, rt_qnodes.hip.h), [3] the leaf boxes by triangle (leaflh); 0 = the array is not in use.
+int rt_kat_layout_hash(rt_ctx *ctx, uint64_t out[4]) {
+    if (!ctx || !out) return fail(ctx, RT_ERR_INVALID, "bad arguments");
+    if (!ctx->have_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_scene_upload has not been called");
+    RT_OWN_STREAM(ctx);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const rtk::Scene &sc = ctx->scene;
+    const void *src[4] = {sc.nodesb, sc.nodesh, sc.nodesw, sc.leaflh};
+    const size_t bytes[4] = {2 * ((size_t)sc.n_nodes + 1) * 16, ((size_t)sc.n_nodes + 1) * 16, ((size_t)(sc.n_nodes & ~1) + 2) * 32 /* quads of the pairs c = 0, 2, .. <= n_nodes */, (size_t)sc.n_tris * 32};
+    std::vector<unsigned char> h;
+    for (int k = 0; k < 4; ++k) {
+        out[k] = 0;
+        if (!src[k] || sc.n_nodes <= 0) continue;
+        h.resize(bytes[k]);
+        RT_HIP(ctx, hipMemcpyAsync(h.data(), src[k], bytes[k], hipMemcpyDeviceToHost, own_stream(ctx)));
+        RT_HIP(ctx, hipStreamSynchronize(own_stream(ctx)));
+        uint64_t x = 0xcbf29ce484222325ull;
+        for (unsigned char c : h) x = (x ^ c) * 0x100000001b3ull;
+        out[k] = x ? x : 1;
+    }
+    return RT_OK;
+}
+
 }  // extern "C"

@@ -33,24 +33,18 @@ constexpr int kMaxSegments = 16;
 constexpr int kBlockThreads = 256;   // 4 waves: 32 x 8 pixels
 constexpr int kTileW = 32, kTileH = 8;
 
-struct Sphere {           // rt_sphere, cpu:505-511
+struct Sphere {           // the geometry of rt_sphere, cpu:505-511 (its material sits in the per-object tables of Scene)
     float cx, cy, cz, R;
-    float ar, ag, ab;
-    int mirror;
-    float n_in, n_out;
     float R2;             // R * R as the reference evaluates it in cpu:513 (one binary32 product), computed once by rt_scene_upload
     int obj;              // position in Scene::objects (cpu:541): decides exact ties (strict '<', cpu:554) and names the object in the path records
 };
 
-// A TriangleMesh of the scene (Geometry's fields, cpu:106-118, and where its triangles sit in the visit-order arrays).  The meshes are stored
-// one after the other in OBJECT order, so the 64-bit minimum over bits(t) << 32 | triangle index that the traversal kernels form is the minimum
-// over (t, object position, scan rank): what the reference's loop over the objects keeps (cpu:549-558) with its strict '<'.
+// A TriangleMesh of the scene: where its triangles sit in the visit-order arrays.  The meshes are stored one after the other in OBJECT order, so the
+// 64-bit minimum over bits(t) << 32 | triangle index that the traversal kernels form is the minimum over (t, object position, scan rank): what the
+// reference's loop over the objects keeps (cpu:549-558) with its strict '<'.
 struct MeshRec {
     int tri_begin;        // first triangle (visit order) of this mesh; the next record's tri_begin (or n_tris) ends it
     int obj;              // position in Scene::objects
-    float ar, ag, ab;
-    int mirror;
-    float n_in, n_out;
 };
 
 struct Scene {
@@ -61,6 +55,11 @@ struct Scene {
     int n_meshes;         // every TriangleMesh of the scene in object order, mesh[0 .. n_meshes): one without triangles (a missing OBJ, cpu:322-325) holds
                           // its position in Scene::objects and an empty triangle range
     MeshRec mesh[kMaxMeshes];
+    // Geometry's fields (cpu:106-118) by OBJECT id, sphere or mesh alike -- Scene::getColor reads objects[id]->mirror / the indices / the albedo of whichever
+    // object was hit (cpu:573-606, 624, 642): one dynamically indexed read each, no search
+    float4 obj_a[kMaxSpheres];   // (sphere centre xyz | 0 for a mesh, mirror as an int's bits)
+    float4 obj_b[kMaxSpheres];   // (albedo rgb, -)
+    float2 obj_n[kMaxSpheres];   // (in_refraction_index, out_refraction_index)
     float Lx, Ly, Lz, intensity;
     float camx, camy, camz, fov;
     const float4 *node_lo, *node_hi;
@@ -75,8 +74,9 @@ struct Scene {
                               // grid below, rounded OUTWARDS, and one payload word (rt_qnodes.hip.h); nullptr = not available for this tree
     const int *tri2leaf;      // triangle (visit order) -> breadth-first index of its leaf (the exact box of a flagged leaf: rt_qnodes.hip.h)
     const float4 *leaflh;     // (lo, hi) of the leaf that holds triangle i (visit order) at [2 i], [2 i + 1]: what the check of a triangle accepted in a FLAGGED leaf reads in one hop (rt_travq.hip.h)
-    const uint4 *nodesw;      // 4-wide fixed-point nodes (rt_travq.hip.h, QW): for the sibling pair (c, c + 1) the 64 bytes at byte offset 32 c hold the nodesh records of
-                              // c's children and (c + 1)'s children (a leaf of the pair stands for itself, the free place is an empty leaf); nullptr = not in use
+    const uint4 *nodesw;      // 4-wide fixed-point nodes (rt_travq.hip.h, QW): for the sibling pair (c, c + 1) the 64 bytes at byte offset 32 c hold the nodesh records of up to
+                              // four nodes that cut the subtree below the pair's parent -- the cut a surface-area DP picks (rt_qnodes.hip.h; RT_TRAVQ_QSEL=0: the children of c
+                              // and of c + 1), internal nodes first, a free place = 0; nullptr = not in use
     float qgx, qgy, qgz;      // grid origin (the root box's lower corner) and cell size per axis
     float qsx, qsy, qsz;
     int qleaf_shift;          // a leaf's payload word in nodesh = 1 << 31 | count << qleaf_shift | first triangle (20 or 24: rt_qnodes.hip.h)
@@ -373,34 +373,22 @@ __device__ __forceinline__ bool intersect_all(const Scene &sc, f3 O, f3 u, float
 }
 
 struct Material { float ar, ag, ab; int mirror; float n_in, n_out; };
-// index of the sphere whose object id is `obj` (obj is a sphere's id): the spheres fill, in array order, the positions the meshes leave free
-__device__ __forceinline__ int sphere_of(const Scene &sc, int obj) {
-    int si = obj;
-    for (int k = 0; k < sc.n_meshes; ++k) si -= (sc.mesh[k].obj < obj) ? 1 : 0;   // (wave-uniform trip count: one for the reference's scenes)
-    return si;
-}
-// the mesh that holds triangle `tri` (visit order): wave-uniform loop over the scene's meshes, none for the usual single mesh
+// the mesh that holds triangle `tri` (visit order): wave-uniform loop over the scene's meshes, no iteration for the usual single mesh
 __device__ __forceinline__ int mesh_of_tri(const Scene &sc, int tri) {
     int m = 0;
     for (int k = 1; k < sc.n_meshes; ++k) m = (tri >= sc.mesh[k].tri_begin) ? k : m;
     return m;
 }
-// Geometry's fields (cpu:106-118) of object `obj`, sphere or mesh: Scene::getColor reads them for whichever object was hit (cpu:573-606)
+// Geometry's fields (cpu:106-118) of object `obj`, sphere or mesh: Scene::getColor reads them for whichever object was hit (cpu:573-606).  (Callers use a
+// part of the record: the loads of the rest are dropped.)
 __device__ __forceinline__ Material material_of(const Scene &sc, int obj) {
     Material m;
-    int mi = -1;
-    for (int k = 0; k < sc.n_meshes; ++k) mi = (sc.mesh[k].obj == obj) ? k : mi;
-    if (mi >= 0) {
-        // (k is wave-uniform: the records come out of scalar registers, the selection is a v_cndmask per field)
-        m.ar = m.ag = m.ab = 0.f; m.mirror = 0; m.n_in = m.n_out = 1.f;
-        for (int k = 0; k < sc.n_meshes; ++k)
-            if (k == mi) { m.ar = sc.mesh[k].ar; m.ag = sc.mesh[k].ag; m.ab = sc.mesh[k].ab; m.mirror = sc.mesh[k].mirror; m.n_in = sc.mesh[k].n_in; m.n_out = sc.mesh[k].n_out; }
-        return m;
-    }
-    const Sphere &s = sc.sph[sphere_of(sc, obj)];
-    m.ar = s.ar; m.ag = s.ag; m.ab = s.ab; m.mirror = s.mirror; m.n_in = s.n_in; m.n_out = s.n_out;
+    const float4 a = sc.obj_a[obj], b = sc.obj_b[obj];
+    const float2 n = sc.obj_n[obj];
+    m.ar = b.x; m.ag = b.y; m.ab = b.z; m.mirror = __float_as_int(a.w); m.n_in = n.x; m.n_out = n.y;
     return m;
 }
+__device__ __forceinline__ f3 sphere_centre_of(const Scene &sc, int obj) { const float4 a = sc.obj_a[obj]; return mk(a.x, a.y, a.z); }
 
 // Scene::getColor, cpu:566-648, made iterative: the path is walked front to back recording for each
 // diffuse segment the scalar l (cpu:623) and the object id, then folded back to front exactly as the

@@ -326,14 +326,19 @@ int rt_multi_destroy(rt_multi *m) {
 
 const char *rt_multi_last_error(const rt_multi *m) { return m ? m->err.c_str() : g_last_error.c_str(); }
 
-int rt_multi_scene_upload(rt_multi *m, const rt_sphere *spheres, int n_spheres, const rt_mesh *mesh,
-                          const rt_light *light, const rt_camera *camera) {
+int rt_multi_scene_upload_meshes(rt_multi *m, const rt_sphere *spheres, int n_spheres, const rt_mesh *meshes, int n_meshes,
+                                 const rt_light *light, const rt_camera *camera) {
     if (!m) return mfail(nullptr, RT_ERR_INVALID, "multi context is NULL");
     for (int k = 0; k < m->n; ++k) {
-        const int rc = rt_scene_upload(m->ctx[k], spheres, n_spheres, mesh, light, camera);
+        const int rc = rt_scene_upload_meshes(m->ctx[k], spheres, n_spheres, meshes, n_meshes, light, camera);
         if (rc != RT_OK) { m->err = m->ctx[k]->err; return rc; }
     }
     return RT_OK;
+}
+
+int rt_multi_scene_upload(rt_multi *m, const rt_sphere *spheres, int n_spheres, const rt_mesh *mesh,
+                          const rt_light *light, const rt_camera *camera) {
+    return rt_multi_scene_upload_meshes(m, spheres, n_spheres, mesh, mesh ? 1 : 0, light, camera);
 }
 
 int rt_render_multi(rt_multi *m, const rt_params *p, float *out_rgba_host) {

@@ -253,8 +253,7 @@ __global__ __launch_bounds__(kQBlock, 2) void wf_path(const Scene sc, const Fram
                                 const float4 q2 = sc.tri[3 * tri_win + 2];
                                 N = normalize(mk(q2.y, q2.z, q2.w));          // cpu:308
                             } else {
-                                const Sphere &sp = sc.sph[(sc.mesh_slot >= 0 && win > sc.mesh_slot) ? win - 1 : win];
-                                N = normalize(Pt - mk(sp.cx, sp.cy, sp.cz));  // cpu:524-525
+                                N = normalize(Pt - sphere_centre_of(sc, win));  // cpu:524-525
                             }
                             const Material m = material_of(sc, win);
                             bool cont = false;                                // a continuation ray of segment d+1 was built in (O,u)

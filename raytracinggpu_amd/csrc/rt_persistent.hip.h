@@ -178,8 +178,7 @@ __global__ __launch_bounds__(kPBlock) void render_persistent(const Scene sc, con
                     f3 N;
                     if (win == mesh_slot) N = normalize(Nb);             // cpu:308
                     else {
-                        const Sphere &s = sc.sph[(mesh_slot >= 0 && win > mesh_slot) ? win - 1 : win];
-                        N = normalize(P - mk(s.cx, s.cy, s.cz));         // cpu:524-525
+                        N = normalize(P - sphere_centre_of(sc, win));    // cpu:524-525
                     }
                     const Material m = material_of(sc, win);
                     bool next_segment = true;

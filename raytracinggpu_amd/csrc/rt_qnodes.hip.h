@@ -83,9 +83,6 @@ __global__ __launch_bounds__(256) void qnodes_kernel(const float4 *__restrict__ 
     nodesh[b] = make_uint4(cx | cy << 16, cz | hx << 16, hy | hz << 16, pay);
 }
 
-// The 4-wide nodes of wf_travq<.., QW> (rt_travq.hip.h): one thread per sibling pair c = 2, 4, .. of the breadth-first array.  The quad of the pair (c, c + 1), at
-// uint4 index 2 c, is the nodesh records of the children of c and of c + 1 -- the boxes a ray meets two levels below the pair's parent -- where a LEAF of the pair
-// stands for itself next to an empty place.  Index 0 (what an idle lane's zero entry addresses) is four empty places.
 // the real box of every triangle's leaf, by triangle: the flagged-leaf check of a TRI step reads it without going through tri2leaf first
 __global__ __launch_bounds__(256) void leaflh_kernel(const float4 *__restrict__ nodesq, const int *__restrict__ tri2leaf, int n_tris, int n_bfs, float4 *__restrict__ leaflh) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -100,8 +97,10 @@ __global__ __launch_bounds__(256) void leaflh_kernel(const float4 *__restrict__ 
 // reference reaches); "the children of c and of c + 1" is one choice.  The three kernels below pick, for every P, the cut that minimises the expected number of stack entries below
 // P under the surface-area model -- an internal node y in a cut costs area(y) + the best cost below y -- by a bottom-up DP over
 //     g(x, k) = the least cost of covering x's subtree with at most k nodes          (k = 1, 2, 3;  a leaf costs nothing;  tot(x) = min over k1 + k2 = 4 of g(l, k1) + g(r, k2))
-// one thread per leaf climbing towards the root, the second arrival at a node computing it (the first one's values are behind a fence; a stale value could only cost optimality:
-// every recorded choice describes a valid cut whatever the numbers were).  On the cat the model says 7.05 -> 6.69 entries per root hit; measured: BOX steps -3.3 %, frame -1.0 %
+// one thread per leaf climbing towards the root, the SECOND arrival at a node computing it.  The result is a function of the tree alone (tests hash the quads of two uploads):
+// the first arrival wrote its values, fenced (release at agent scope) and then announced itself with the atomic add; the second one sees the count, fences, and reads both
+// children's values with agent-scope atomic loads, i.e. from L2 where the fence put them -- the usual bottom-up reduction (Karras 2012).  (And every recorded choice
+// describes a valid cut whatever the numbers were: the DP can only cost optimality, never a result.)  On the cat the model says 7.05 -> 6.69 entries per root hit; measured: BOX steps -3.3 %, frame -1.0 %
 // (profiles/round5/ab_wide_nodes.txt).  Areas are taken from the fixed-point half extents (a model needs no more).
 struct QdpArgs {
     const uint4 *nodesh; int n_bfs, node_shift;
@@ -130,7 +129,7 @@ __global__ __launch_bounds__(256) void qdp_up_kernel(const QdpArgs a) {
                            __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 0.f);
     };
     int cur = a.parent[b];
-    for (int guard = 0; cur > 0 && cur <= a.n_bfs && guard < 4096; ++guard) {        // (the range test and the guard only bound a corrupted tree)
+    for (int guard = 0; cur > 0 && cur <= a.n_bfs && guard <= a.n_bfs; ++guard) {    // (a climb is at most the tree's depth long; the range test and the guard only bound a corrupted tree)
         __threadfence();                                                              // my values are visible before I announce myself
         if (atomicAdd(&a.cnt[cur], 1) == 0) return;                                   // first to arrive: the sibling's thread goes on from here
         __threadfence();

@@ -64,6 +64,19 @@ __device__ __forceinline__ bool wq_live(int w0, int epoch, int nonce) {
     return (w0 & PQ_LIVE_MASK) == (int)((unsigned)PQ_TRAV | (unsigned)epoch << PF_DEPTH_SHIFT | (unsigned)nonce << PQ_NONCE_SHIFT);
 }
 
+// A BATCH of frames in one launch chain (rt_render_device_batch): the items of a chain are (frame f, pixel slot) pairs -- the machinery that traces several samples of a pixel
+// as parallel items (n_paths = n_px x items per pixel), with a camera, a seed and an output buffer PER FRAME instead of per-sample colours to reduce.  A rank that renders a
+// small share of a frame (1/8 of 1920x1080 = 0.26 Mpixel) fills the chip with K frames' worth of paths per launch instead of K chains on K streams.  Only wf_advance reads it.
+// The descriptors live in device memory (WfState::batch; written by batch_store_kernel on the caller's stream before the chain starts) and are read with a wave-uniform
+// index through the scalar cache: as kernel arguments a dynamically indexed array is copied to scratch by the compiler (2 KB per lane, measured).
+constexpr int kMaxBatch = 16;
+struct BatchFrame { float camx, camy, camz, z; uint32_t seed; int pad; float4 *out; };
+struct Batch { int n; int pad; BatchFrame f[kMaxBatch]; };
+__global__ void batch_store_kernel(const Batch bt, BatchFrame *__restrict__ dst) {
+    const int k = threadIdx.x;
+    if (k < kMaxBatch) dst[k] = bt.f[k < bt.n ? k : 0];               // (constant trip structure: one lane per descriptor)
+}
+
 // Path state of the wavefront pipeline, in HBM.  A ray lives in ONE place: its 32-byte record in the traversal queue (slot order;
 // the four rays of a group are one 128-byte line), which the uniform kernel writes when it emits the ray, the traversal kernel
 // reads, and the next uniform launch reads back to compute the hit point.  The record's two spare words hold the PATH's state as
@@ -87,6 +100,8 @@ struct WfState {
     int epoch;                // index of the traversal launch inside its chain (0 after wf_advance<FIRST>): a queue record is live iff its flag word carries PQ_TRAV and this number
     int init_m;               // the traversal kernel merges partial results with atomicMin (wf_trav's work splitting): emitters initialise M
     unsigned long long *dbg;  // optional per-wave debug record (-DRT_DEBUG)
+    const BatchFrame *batch;  // rt_render_device_batch: n_batch frame descriptors in device memory (item i belongs to frame i / n_px); nullptr / 0 = the launch's own camera, seed, output
+    int n_batch;
     // traversal queue: the rays in TRAVERSAL-SLOT order, so that the slots a traversal workgroup owns are contiguous and one
     // round trip brings flag and record
     float4 *QR;               // [2 slots] record of slot q: QR[2q] = (O.xyz, u.x), QR[2q+1] = (u.y, u.z, bits(W0), W1).  Y slot (ray r < n_paths): W0 = the path's
@@ -530,9 +545,22 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
     int px, lrow; bool valid;
     int s_rel = 0;
     if (st.n_paths != st.n_px) s_rel = wf_div(i, st.n_px, st.n_px_m);
-    const int samp = st.samp0 + s_rel;
+    // a batch: item i belongs to frame s_rel (a wave's 64 items share it: n_px is a multiple of 64), whose camera, seed and output replace the launch's -- from scalar registers
+    float camx = sc.camx, camy = sc.camy, camz = sc.camz, fr_z = fr.z;
+    uint32_t fr_seed = fr.seed;
+    float4 *fr_out = fr.out;
+    int samp = st.samp0 + s_rel;
+    bool in_batch = true;
+    if (st.n_batch > 0) {
+        const int f = __builtin_amdgcn_readfirstlane(s_rel);
+        in_batch = f < st.n_batch;
+        const BatchFrame b = st.batch[f & (kMaxBatch - 1)];             // wave-uniform address: scalar loads
+        camx = b.camx; camy = b.camy; camz = b.camz;
+        fr_z = b.z; fr_seed = b.seed; fr_out = b.out;
+        samp = 0;
+    }
     wf_decode(st, fr, i - s_rel * st.n_px, px, lrow, valid);
-    valid = valid && samp < fr.spp;                                   // the last chain of a frame may be short of samples
+    valid = valid && samp < fr.spp && in_batch;                       // the last chain of a frame may be short of samples
     const int row = fr.row0 + (lrow / fr.tile_rows) * fr.tile_rows * fr.tile_step + (lrow % fr.tile_rows);
 
     if (FIRST) {
@@ -542,17 +570,17 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
         } else {
             // cpu:699: +0.5/-0.5 are double literals, narrowed by the Vector constructor
             const f3 uc = mk((float)((double)((float)px - (float)fr.W / 2) + 0.5),
-                             (float)((double)((float)fr.H / 2 - (float)row) - 0.5), fr.z);
+                             (float)((double)((float)fr.H / 2 - (float)row) - 0.5), fr_z);
             f3 ucm = uc;
             if (fr.cam_mode == 1) {   // realtime:1115: cam.C + cam.bz * z + cam.bx * X + cam.by * Y (the position is part of the direction there)
-                const f3 Cc = mk(sc.camx, sc.camy, sc.camz), Bx = mk(fr.bx[0], fr.bx[1], fr.bx[2]), By = mk(fr.by[0], fr.by[1], fr.by[2]), Bz = mk(fr.bz[0], fr.bz[1], fr.bz[2]);
-                const f3 a = Cc + mk(Bz.x * fr.z, Bz.y * fr.z, Bz.z * fr.z);
+                const f3 Cc = mk(camx, camy, camz), Bx = mk(fr.bx[0], fr.bx[1], fr.bx[2]), By = mk(fr.by[0], fr.by[1], fr.by[2]), Bz = mk(fr.bz[0], fr.bz[1], fr.bz[2]);
+                const f3 a = Cc + mk(Bz.x * fr_z, Bz.y * fr_z, Bz.z * fr_z);
                 const f3 b = a + mk(Bx.x * uc.x, Bx.y * uc.x, Bx.z * uc.x);
                 ucm = b + mk(By.x * uc.y, By.y * uc.y, By.z * uc.y);
             }
             f3 uu = ucm;
             if (fr.sigma != 0.f) {   // cpu:705-707; with sigma == 0 the jitter is exactly +-0
-                const uint32_t hp = mix32(((uint32_t)row * (uint32_t)fr.W + (uint32_t)px) ^ mix32(fr.seed));
+                const uint32_t hp = mix32(((uint32_t)row * (uint32_t)fr.W + (uint32_t)px) ^ mix32(fr_seed));
                 const uint32_t hs = mix32(hp ^ ((uint32_t)samp * 0x9E3779B1U));
                 const float r1 = uniform01(hs, 0, 2), r2 = uniform01(hs, 0, 3);
                 const float bm = fr.sigma * rt_sqrtf(-2 * logf(r1));
@@ -560,7 +588,7 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
                 rt_sincos_2pi(2 * 3.14159265358979323846 * (double)r2, sn, cs);
                 uu = ucm + mk((float)((double)bm * cs), (float)((double)bm * sn), 0.f);
             }
-            Oy = mk(sc.camx, sc.camy, sc.camz);
+            Oy = mk(camx, camy, camz);
             uy = normalize(uu);
             emitY = true;                                             // continuation ray of segment 0
             nrays = 1;
@@ -618,8 +646,7 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
                     const float4 q2 = sc.tri[3 * tri_win + 2];
                     N = normalize(mk(q2.y, q2.z, q2.w));              // cpu:308
                 } else {
-                    const Sphere &sp = sc.sph[sphere_of(sc, win)];
-                    N = normalize(P - mk(sp.cx, sp.cy, sp.cz));       // cpu:524-525
+                    N = normalize(P - sphere_centre_of(sc, win));     // cpu:524-525
                 }
                 const Material m = material_of(sc, win);
                 bool cont = false;                                    // a continuation ray of segment d+1 was built in (O,u)
@@ -659,7 +686,7 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
                     st.LS[(size_t)d * st.n_paths + i] = (float)((double)sc.intensity / (4 * PI_D * (double)norm2(L - P)) * (double)mx);
                     sid = win;
                     if (d + 1 < fr.segs) {                            // the bounce ray (cpu:627-642): needs r1, r2 and N only
-                        const uint32_t hp = mix32(((uint32_t)row * (uint32_t)fr.W + (uint32_t)px) ^ mix32(fr.seed));
+                        const uint32_t hp = mix32(((uint32_t)row * (uint32_t)fr.W + (uint32_t)px) ^ mix32(fr_seed));
                         const uint32_t hs = mix32(hp ^ ((uint32_t)samp * 0x9E3779B1U));
                         const float r1u = uniform01(hs, (uint32_t)d, 0);
                         const float r2u = uniform01(hs, (uint32_t)d, 1);
@@ -712,7 +739,7 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
             else { t.x += ans.x; t.y += ans.y; t.z += ans.z; }
             t.w += (float)nrays;
             const float n = fr.cam_mode == 1 ? 1.f : (float)fr.spp;
-            fr.out[out_index(fr, lrow, px)] = make_float4(t.x / n, t.y / n, t.z / n, t.w);
+            fr_out[out_index(fr, lrow, px)] = make_float4(t.x / n, t.y / n, t.z / n, t.w);
         }
         st.QR[2 * (size_t)qy + 1] = kDead;                            // the path is over; its X slot keeps a record of an older launch, which no later one takes for its own
         return;

@@ -40,15 +40,22 @@ def gather_buffer(local, world):
     return torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
 
 
-def gather_frame(local, height, world, rank, gathered=None, tile_rows=TILE_ROWS):
-    """One gather of the float4 tiles to rank 0 (a grouped send/recv under RCCL: each peer uses its own xGMI
-    link to the root).  `gathered`: rank 0's gather_buffer (allocated here if None).  Returns the assembled
-    [H, W, 4] frame on rank 0, None elsewhere."""
+def gather_frame(local, height, world, rank, gathered=None, tile_rows=TILE_ROWS, root=0):
+    """One gather of the float4 tiles to rank `root` (a grouped send/recv under RCCL: each peer uses its own xGMI
+    link to the root).  `gathered`: the root's gather_buffer (allocated here if None).  Returns the assembled
+    [H, W, 4] frame on the root, None elsewhere.  A caller that renders frame after frame may ROTATE the root
+    (frame k -> rank k mod G): every frame is still one gather into one device, but the inbound traffic and the
+    assembly are spread over all ranks' links instead of loading rank 0's seven."""
     if world == 1:
         return local[:height]
-    if rank == 0 and gathered is None:
+    if rank == root and gathered is None:
         gathered = gather_buffer(local, world)
-    dist.gather(local, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
-    if rank != 0:
+    dist.gather(local, list(gathered.unbind(0)) if rank == root else None, dst=root)
+    if rank != root:
         return None
     return assemble(gathered, height, tile_rows)
+
+
+def root_of(frame_index, world, policy="0"):
+    """Which rank assembles frame `frame_index`: "0" = always rank 0 (the reference copies every image to ONE host, optimized.cu:849-856); "rotate" = rank k mod G."""
+    return frame_index % world if policy == "rotate" else 0

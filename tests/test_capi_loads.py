@@ -26,13 +26,15 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_capi.EXPORTS) == names
-    assert lib.rt_abi_version() == 5
+    assert lib.rt_abi_version() == 6
 
 
 def test_struct_sizes_match_header():
     assert ctypes.sizeof(_capi.Sphere) == 40
+    assert ctypes.sizeof(_capi.Mesh) == 72                              # ABI 6: + mirror, in / out refraction index (Geometry, cpu:113-116)
     assert ctypes.sizeof(_capi.Params) == 40
     assert ctypes.sizeof(_capi.Rows) == 16
+    assert ctypes.sizeof(_capi.FrameDesc) == 32
     assert ctypes.sizeof(_capi.Light) == 16 and ctypes.sizeof(_capi.Camera) == 16
     assert ctypes.sizeof(_capi.Stats) == 64 and ctypes.sizeof(_capi.Work) == 32 + 16 + 12 * 8 and ctypes.sizeof(_capi.CameraPose) == 24 and ctypes.sizeof(_capi.KatCounts) == 40
     assert ctypes.sizeof(_capi.MultiStats) == 4 + 64 + 64 + 4 + 4 + 4 + 8 + 8 + 64 + 4 + 4     # incl. 4 bytes of padding before `rays`, submit_ms + tail padding

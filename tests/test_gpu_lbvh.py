@@ -276,3 +276,34 @@ def test_lbvh_device_install_equals_host_install(oracle, cat_golden, monkeypatch
     np.testing.assert_array_equal(o0, o1)
     np.testing.assert_array_equal(dev.render(p).view(np.uint32), host.render(p).view(np.uint32))
     dev.close(); host.close()
+
+
+@pytest.mark.parametrize("kind", ["cat", "deep_strip", "geometric_chain", "lbvh_524288"])
+def test_node_layouts_are_a_function_of_the_tree_alone(oracle, cat_golden, kind):
+    """The quads of the 4-wide BOX step hold the cut a surface-area DP picks ON THE DEVICE (rt_qnodes.hip.h: one thread per leaf climbing, the second arrival at a node computes it
+    from values the first one published behind a fence).  Two contexts given the same tree must end with byte-identical layouts -- float pairs, fixed-point pairs, quads, leaf boxes --
+    so that the work a frame does (BOX steps, and with them the headline's ms) does not vary from upload to upload; and a second upload into the SAME context reproduces them too.
+    deep_strip / geometric_chain: chains far deeper than a wave is wide (the climb's guard is the tree's size, not a constant)."""
+    if kind == "cat":
+        mesh = dict(vertices=cat_golden["vertices"], indices=cat_golden["tri_bvh_order"], bvh_arr10=cat_golden["bvh_arr10"], albedo=rt.scenes.CAT_ALBEDO, object_slot=6)
+    elif kind == "lbvh_524288":
+        v, t = _displaced_grid(513)
+        mesh, first = None, hostlib.build_mesh(v, t, albedo=rt.scenes.CAT_ALBEDO, object_slot=6)
+    else:
+        v, t = _synthetic_mesh(kind, np.random.default_rng(4))
+        mesh = hostlib.build_mesh(v, t, albedo=rt.scenes.CAT_ALBEDO, object_slot=6)
+    hashes = []
+    for rep in range(2):
+        c = rt.Context(0)
+        if mesh is None:                                               # the LBVH builder's tree (Morton sort + parallel hierarchy + SAH leaf cut, all on the device) and its device-side install
+            c.scene_upload(rt.scenes.spheres("cpu"), first)
+            c.mesh_rebuild(len(t), mode="lbvh")
+            hashes.append(c.layout_hash())
+        else:
+            c.scene_upload(rt.scenes.spheres("cpu"), mesh)
+            hashes.append(c.layout_hash())
+            c.scene_upload(rt.scenes.spheres("cpu"), mesh)
+            hashes.append(c.layout_hash())
+        c.close()
+    assert all(h == hashes[0] for h in hashes), hashes
+    assert hashes[0]["quads"] != 0 and hashes[0]["fixed_pairs"] != 0 and hashes[0]["pairs"] != 0

@@ -869,3 +869,60 @@ def test_large_mesh_bit_exact(ctx, oracle, n):
     got3 = ctx.render(rt.make_params(W, H, 1, 0, **rt.scenes.CPU_LAUNCHER))
     assert values_equal(got3[..., :3], exp0[..., :3]).all()
     ctx.selfcheck()
+
+
+def test_batched_frames_are_bitwise_the_lone_frames(ctx, oracle, oracle_cat, cat_golden):
+    """rt_render_device_batch (ABI 6): K frames of a rank's share -- interleaved 8-row tiles of rank 3 of 8 at 1920x1080, the share a rank of the 8-GPU job owns -- traced as the
+    items of ONE launch chain, each frame with its OWN camera (a dolly along x and z, one with another field of view), its own seed and its own buffer.  Every batched frame is, word
+    for word, the frame rt_render_device writes for the scene uploaded with that camera and that seed (per-pixel arithmetic does not depend on what else is in the launch); one of
+    them is held against the oracle rendering the same rows with that camera.  Also: a batch of one, the full 16, whole small frames (contiguous rows), and the refusals."""
+    import torch
+    mesh = dict(vertices=cat_golden["vertices"], indices=cat_golden["tri_bvh_order"], bvh_arr10=cat_golden["bvh_arr10"], albedo=rt.scenes.CAT_ALBEDO, object_slot=6)
+    W, H, b = 1920, 1080, 3
+    rows, idx = rt.interleaved_rows(H, 8, 3, 8)
+    st = torch.cuda.Stream()
+    cams = [((0.5 * k - 1.0, 0.25 * (k % 3), 55.0 - 0.75 * k), None if k != 2 else 1.2, 1000 + 17 * k) for k in range(5)]
+    outs = [torch.zeros((rows.n_rows, W, 4), dtype=torch.float32, device="cuda:0") for _ in cams]
+    p = rt.make_params(W, H, 1, b, **rt.scenes.CPU_LAUNCHER)
+    ctx.scene_upload(rt.scenes.spheres("cpu"), mesh)
+    torch.cuda.synchronize()
+    ctx.render_device_batch(p, rows, [(o.data_ptr(), c[0], c[1], c[2]) for o, c in zip(outs, cams)], st.cuda_stream)
+    st.synchronize()
+    got = [o.cpu().numpy() for o in outs]
+    assert ctx.stats()["travq_mode"] == 2
+    lone = torch.zeros_like(outs[0])
+    for k, (pos, fov, seed) in enumerate(cams):
+        ctx.scene_upload(rt.scenes.spheres("cpu"), mesh, camera=(pos, fov))
+        pk = rt.make_params(W, H, 1, b, seed=seed, **rt.scenes.CPU_LAUNCHER)
+        ctx.render_device(pk, rows, lone.data_ptr(), st.cuda_stream)
+        st.synchronize()
+        np.testing.assert_array_equal(got[k].view(np.uint32), lone.cpu().numpy().view(np.uint32), err_msg=f"frame {k}")
+        assert k == 0 or (got[k][..., :3] != got[0][..., :3]).any()     # a sequence of different frames, not one frame K times
+    exp, _, _ = oracle.Scene.preset("cpu", oracle_cat).render(W, H, 1, b, rows=(3 * 8, H), tile_rows=8, tile_step=8, cam=cams[2][0], fov=cams[2][1], seed=cams[2][2], want_rgb8=False)
+    np.testing.assert_array_equal(got[2][..., :3].view(np.uint32), exp[..., :3].view(np.uint32))
+    # whole small frames, 16 of them and one alone; then what a batch cannot be
+    ctx.scene_upload(rt.scenes.spheres("cpu"), mesh)
+    W2, H2 = 256, 144
+    rows2, _ = rt.interleaved_rows(H2, 8, 0, 1)
+    p2 = rt.make_params(W2, H2, 1, 2, **rt.scenes.CPU_LAUNCHER)
+    bufs = [torch.zeros((H2, W2, 4), dtype=torch.float32, device="cuda:0") for _ in range(16)]
+    torch.cuda.synchronize()
+    ctx.render_device_batch(p2, rows2, [(o.data_ptr(), (0.0, 0.0, 55.0), None, 500 + k) for k, o in enumerate(bufs)], st.cuda_stream)
+    st.synchronize()
+    for k in (0, 7, 15):
+        np.testing.assert_array_equal(bufs[k].cpu().numpy().view(np.uint32), ctx.render(rt.make_params(W2, H2, 1, 2, seed=500 + k, **rt.scenes.CPU_LAUNCHER)).view(np.uint32))
+    one = torch.zeros_like(bufs[0])
+    ctx.render_device_batch(p2, rows2, [(one.data_ptr(), (0.0, 0.0, 55.0), None, 507)], st.cuda_stream)
+    st.synchronize()
+    np.testing.assert_array_equal(one.cpu().numpy().view(np.uint32), bufs[7].cpu().numpy().view(np.uint32))
+    for bad, code in (([(bufs[0].data_ptr(), (0, 0, 55), None, 1)] * 2, -1),                                   # two frames into one buffer
+                      ([(o.data_ptr(), (0, 0, 55), None, 1) for o in bufs] + [(one.data_ptr(), (0, 0, 55), None, 1)], -1),   # 17 frames
+                      ([], -1)):
+        with pytest.raises(rt.RtError) as e:
+            ctx.render_device_batch(p2, rows2, bad, st.cuda_stream)
+        assert e.value.code == code
+    for kw in (dict(num_rays=2), dict(variant="lockstep"), dict(variant="path")):
+        with pytest.raises(rt.RtError) as e:
+            q = rt.make_params(W2, H2, kw.get("num_rays", 1), 2, variant=kw.get("variant", "auto"), **rt.scenes.CPU_LAUNCHER)
+            ctx.render_device_batch(q, rows2, [(one.data_ptr(), (0, 0, 55), None, 1)], st.cuda_stream)
+        assert e.value.code == -5

@@ -73,6 +73,59 @@ def test_gathered_tiles_equal_full_frame_gloo_cpu(oracle, oracle_cat, tmp_path, 
     np.testing.assert_array_equal(got.view(np.uint32), exp.view(np.uint32))
 
 
+def _worker_rotating_root(rank, world, port, W, H, b, out_dir):
+    """frames 0 .. world: frame k is gathered to and assembled on rank k mod world (tiling.root_of), each frame with its own seed so that a frame landing on the wrong rank shows"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import raytracinggpu_amd as rt
+    from raytracinggpu_amd import tiling
+    from oracle import oracle_py as orc
+    g = np.load(rt.scenes.CAT_FIXTURE, allow_pickle=False)
+    sc = orc.Scene.preset("cpu", orc.Mesh.from_arrays(g["vertices"], g["tri_obj_order"]).build_bvh())
+    rows, idx = rt.interleaved_rows(H, tiling.TILE_ROWS, rank, world)
+    for k in range(world + 1):
+        local = tiling.local_buffer(H, W, world, "cpu")
+        if rows.n_rows:
+            part, _, _ = sc.render(W, H, 1, b, rows=(rank * tiling.TILE_ROWS, H), tile_rows=tiling.TILE_ROWS, tile_step=world, threads=2, seed=100 + k, want_rgb8=False)
+            local[:rows.n_rows] = torch.from_numpy(part)
+        root = tiling.root_of(k, world, "rotate")
+        frame = tiling.gather_frame(local, H, world, rank, root=root)
+        assert (frame is not None) == (rank == root)
+        if frame is not None:
+            np.save(os.path.join(out_dir, f"frame{k}_rank{rank}.npy"), frame.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_rotating_root_assembles_frame_k_on_rank_k_mod_world_gloo_cpu(oracle, oracle_cat, tmp_path, world):
+    """bench.py --root rotate / tiling.root_of: one gather per frame, the root moving over the ranks frame by frame (the inbound traffic of a stream of frames is spread over
+    every rank's links instead of rank 0's).  Every frame, wherever it was assembled, is bit for bit the full frame."""
+    W, H, b = 64, 42, 1
+    mp.spawn(_worker_rotating_root, args=(world, _free_port(), W, H, b, str(tmp_path)), nprocs=world, join=True)
+    from raytracinggpu_amd import tiling
+    assert [tiling.root_of(k, world, "rotate") for k in range(world + 1)] == [k % world for k in range(world + 1)] and tiling.root_of(5, world, "0") == 0
+    for k in range(world + 1):
+        exp, _, _ = oracle.Scene.preset("cpu", oracle_cat).render(W, H, 1, b, seed=100 + k, want_rgb8=False)
+        got = np.load(tmp_path / f"frame{k}_rank{k % world}.npy")
+        np.testing.assert_array_equal(got.view(np.uint32), exp.view(np.uint32))
+        assert not (tmp_path / f"frame{k}_rank{(k + 1) % world}.npy").exists()
+
+
+def test_bench_rotating_root_and_batch_arguments_gloo_cpu(oracle, oracle_cat, tmp_path):
+    """`bench.py --gpus 2 --root rotate` over gloo with the CPU stand-in: three steps, three roots (0, 1, 0), the line says which policy ran; frame 0 (root 0) is dumped and equal."""
+    W, H, b = 96, 50, 1
+    out = str(tmp_path / "frame.npy")
+    r, line = _bench("--gpus", "2", "--renderer", "oracle", "--root", "rotate", "--width", str(W), "--height", str(H), "--bounces", str(b), "--steps", "3", "--warmup", "0",
+                     "--large-steps", "0", "--dump-frame", out)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line["steps"] == 3 and "rank k mod N" in line["config"]["root"] and line["config"]["gather"] == "f32" and line["value"] is None
+    exp, _, _ = oracle.Scene.preset("cpu", oracle_cat).render(W, H, 1, b, want_rgb8=False)
+    np.testing.assert_array_equal(np.load(out).view(np.uint32), exp.view(np.uint32))
+
+
 def _worker_rgb8(rank, world, port, W, H, out_path):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"

@@ -148,6 +148,44 @@ def test_float_render_matches_reference_getColor(oracle, oracle_cat, name, scene
     assert np.isfinite(exp).all() and exp.max() > 1.0
 
 
+@pytest.mark.parametrize("name", ["cpu_mirror_256_b3", "cpu_glass_256_b5", "two_cats_256_b3", "two_cats_512_direct", "two_cats_diffuse_256_b1"])
+def test_mesh_materials_and_several_meshes_match_reference_getColor(oracle, cat_golden, name):
+    """Scenes the reference's classes accept and its main() never builds: a TriangleMesh with mirror = 1 / with refraction indices 1.5 / 1 (Geometry's public members,
+    cpu:113-116, read by getColor for whichever object was hit, cpu:573-606) and TWO meshes in one Scene::objects, one of them in the middle of the order (cpu:538-564).
+    Golden: the reference TU itself with those members set (oracle/ref_harness.cpp add_material_scene), mt19937(0) replayed: colours bit-exact, primary hit ids equal."""
+    from . import material_scenes as ms
+    g = load_golden("ref_materials.npz")
+    W, H, spp, b, stride = (int(x) for x in g[name + "_cfg"])
+    scene = name.rsplit("_", 2)[0]                                  # "two_cats_256_b3" -> "two_cats"
+    s = ms.oracle_scene(oracle, scene, cat_golden["vertices"], cat_golden["tri_obj_order"])
+    rgba, _, _ = s.render(W, H, spp, b, rng_mode=1, stride=stride, threads=1, want_rgb8=False)
+    exp = g[name + "_color"]
+    np.testing.assert_array_equal(bits(rgba[..., :3]), bits(exp))
+    assert np.isfinite(exp).all() and exp.max() > 1.0
+    rec = g[name + "_hit"]
+    tan_h = np.float32(np.tan(np.float64(np.float32(np.float32(np.pi / 3) / np.float32(2)))))
+    z = np.float32(np.float32(-W) / np.float32(np.float32(2) * tan_h))
+    ids = set()
+    for ii in range(0, rec.shape[0], 5):
+        for jj in range(0, rec.shape[1], 5):
+            i, j = ii * stride, jj * stride
+            u = np.array([np.float32(j) - np.float32(W) / 2 + 0.5, np.float32(H) / 2 - i - 0.5, z], np.float32)
+            n = np.sqrt(np.float32(np.float32(u[0] * u[0] + u[1] * u[1]) + u[2] * u[2]))
+            u = (u / n).astype(np.float32)
+            hit, oid, P, N = s.intersect_all([0, 0, 55], u)
+            assert oid == int(rec[ii, jj, 0])
+            np.testing.assert_array_equal(bits(P), bits(rec[ii, jj, 1:4]))
+            if hit:
+                np.testing.assert_array_equal(bits(N), bits(rec[ii, jj, 4:7]))
+            ids.add(oid)
+    n_meshes = sum(1 for o in ms.describe(scene, cat_golden["vertices"]) if o[0] == "mesh")
+    mesh_ids = {k for k, o in enumerate(ms.describe(scene, cat_golden["vertices"])) if o[0] == "mesh"}
+    if scene == "two_cats_diffuse":
+        assert 0 in ids and 7 not in ids                            # the same geometry twice: every hit is an exact tie and the EARLIER object keeps it (strict '<', cpu:554)
+    else:
+        assert mesh_ids <= ids, (ids, n_meshes)                     # every mesh is seen by some primary ray
+
+
 @pytest.mark.parametrize("name,scene", [("cpu_512_direct", "cpu"), ("demo10_256_direct", "demo10")])
 def test_primary_hit_records(oracle, oracle_cat, name, scene):
     g = load_golden("ref_render.npz")
