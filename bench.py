@@ -606,16 +606,17 @@ def main():
                     self.ctxs, self.tstreams = [full[0][0]] * self.n_lanes, [full[1][0]] * self.n_lanes
                     if hasattr(full[0][0], "set_pipelining"):
                         full[0][0].set_pipelining(self.pipelined)
-                elif self.batch > 1:                                    # two contexts with the library's defaults (two sub-frames each): batch b on context b mod 2
-                    cs_, ts_ = pool("full", 2)
-                    self.ctxs = [cs_[(k // self.batch) % 2] for k in range(self.n_lanes)]
-                    self.tstreams = [ts_[(k // self.batch) % 2] for k in range(self.n_lanes)]
+                elif self.batch > 1:                                    # ONE context with the library's defaults (two sub-frames, each taking half of a batch's frames), batches alternating
+                    full = pool("full", 1)                              # between two sets of buffers on one stream with rt_ctx_set_pipelining: batch b + 1's chains follow batch b's directly
+                    self.ctxs, self.tstreams = [full[0][0]] * self.n_lanes, [full[1][0]] * self.n_lanes
+                    full[0][0].set_pipelining(True)
                 else:
                     if self.n_lanes > 1:
                         cs_, ts_ = pool("lanes", self.n_lanes)
                         self.ctxs, self.tstreams = cs_[:self.n_lanes], ts_[:self.n_lanes]
                     else:
                         self.ctxs, self.tstreams = pool("full", 1)
+                        self.ctxs[0].set_pipelining(False)
             self.lanes = [Lane(k, W, H) for k in range(self.n_lanes)]
             self.local = self.lanes[0].local
             self.frame = None
@@ -825,8 +826,8 @@ def main():
                 res["config"]["gather_auto"] = gather_choice
             if main_pt.batch > 1:
                 res["config"]["batch"] = main_pt.batch
-                res["config"]["batch_is"] = (f"{main_pt.batch} consecutive frames of this rank's share are rendered as ONE launch chain (rt_render_device_batch), two batches in flight on two "
-                                             "contexts; every frame is gathered and assembled on its own.  ms_per_step is a THROUGHPUT figure: the frames of a batch finish together")
+                res["config"]["batch_is"] = (f"{main_pt.batch} consecutive frames of this rank's share are rendered as ONE launch chain (rt_render_device_batch), two batches in flight on one context and two "
+                                             "sets of buffers (rt_ctx_set_pipelining); every frame is gathered and assembled on its own.  ms_per_step is a THROUGHPUT figure: the frames of a batch finish together")
             if latency_ms is not None:
                 res["config"]["frame_latency_ms"] = latency_ms
                 res["config"]["frame_latency_is"] = "one frame alone on the ranks' shares: rendered, gathered and assembled before the next starts (max over ranks); the other side of the batched / in-flight throughput"

@@ -153,8 +153,7 @@ struct rt_ctx {
     DevBuf wfQR;                                                    // traversal queue in slot order: the rays (32 B each)
     DevBuf pathSamp, pathT;                                         // wf_path with num_rays > 1: per-sample colours, running sum
     DevBuf dbgbuf;                                                  // -DRT_DEBUG builds: per-wave traversal records
-    DevBuf batch_dev;                                               // rt_render_device_batch: the frames' descriptors (two slots)
-    int batch_slot = 0;
+    DevBuf batch_dev;                                               // rt_render_device_batch: the frames' descriptors, one copy per sub-frame
     DevBuf accum;                                                   // progressive mode: sum of the frames so far (float4 per pixel)
     int prog_frames = 0, prog_w = 0, prog_h = 0;
     uint64_t qf_sig = 0;                                            // layout the queue flags were last zeroed for
@@ -268,6 +267,9 @@ int ensure(rt_ctx *ctx, DevBuf &b, size_t bytes) {
     return RT_OK;
 }
 
+// Host -> device, complete on return.  (hipMemcpy = the NULL stream.  Round 6 tried the context's own stream instead, to spare a C++ program one hardware queue: the ~27 ms the
+// FIRST copy of a process costs -- the runtime creating a queue and its staging -- just moved to that stream, and the headline frame read 1 % slower:
+// profiles/round6/launcher_timing.txt.)
 int upload(rt_ctx *ctx, DevBuf &b, const void *src, size_t bytes) {
     int rc = ensure(ctx, b, bytes);
     if (rc != RT_OK) return rc;
@@ -673,6 +675,7 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
         if (G == 1) R = 8;                                            // contiguous rows: any tile height describes them
         const int T = (rows->n_rows + R - 1) / R;                     // local tiles of this call
         if (R % 8 != 0 || work_dev || kn.debug_trav != -2) parts = 1;
+        // (one sub-frame for SMALL frames was measured in round 6: 512x512 back to back 0.297 -> 0.328 ms at one sample, 0.82 -> 1.03 ms at eight: two stay, profiles/round6/small_frame_parts.txt)
         if (parts > T) parts = T > 0 ? T : 1;
         const int tiles_x = (p->width + 7) / 8;
         const int tb = qlds ? 64 * qW : queue ? travq_block_threads(qR) : ldsn ? rtk::kTravBlockLds : rtk::kTravBlock;
@@ -735,22 +738,34 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
             const int64_t chains = (fr.spp + cmax - 1) / cmax;
             chunk = (int)((fr.spp + chains - 1) / chains);            // chains of (almost) equal size: 64 samples at 15 per chain = 4 x 13 + 12
         }
-        // per-part geometry
-        struct Part { rtk::Frame fr; rtk::WfState st; int64_t tblocks; unsigned pblocks; size_t base; size_t qbase; size_t pxbase; };
+        // per-part geometry.  A batch of an even number of frames is cut by FRAMES, not by tiles: both sub-frames hold every pixel of the call and half of the frames, so they are
+        // exactly as long as each other (a 1/8 share of 1080p is 17 tiles: 9 + 8 would leave one chain 12 % longer than the other)
+        struct Part { rtk::Frame fr; rtk::WfState st; int64_t tblocks; unsigned pblocks; size_t base; size_t qbase; size_t pxbase; int batch0, batch_n; };
         std::vector<Part> pv(parts);
         size_t np_total = 0, px_total = 0;
+        const bool by_frames = batch && parts > 1 && batch->n % parts == 0;
         for (int j = 0; j < parts; ++j) {
             Part &pt = pv[j];
             const int Tj = (T - j + parts - 1) / parts;               // local tiles j, j+parts, ...
             int nrows_j = Tj * R;
             if (Tj > 0 && (T - 1) % parts == j) nrows_j -= T * R - rows->n_rows;   // the last local tile may be partial
             pt.fr = fr;
+            pt.batch0 = 0; pt.batch_n = batch ? batch->n : 0;
+            int chunk_j = chunk;
+            if (by_frames) {
+                nrows_j = rows->n_rows;
+                pt.fr.row0 = rows->row0; pt.fr.n_rows = nrows_j; pt.fr.tile_rows = R; pt.fr.tile_step = G;
+                pt.fr.out_tile0 = 0; pt.fr.out_tile_step = 1;
+                chunk_j = batch->n / parts;
+                pt.batch0 = j * chunk_j; pt.batch_n = chunk_j;
+            } else {
             pt.fr.row0 = rows->row0 + j * R * G; pt.fr.n_rows = nrows_j; pt.fr.tile_rows = R; pt.fr.tile_step = G * parts;
             pt.fr.out_tile0 = j; pt.fr.out_tile_step = parts;
+            }
             pt.st = rtk::WfState{};
             pt.st.tiles_x = tiles_x; pt.st.tiles_x_m = rtk::wf_div_magic(tiles_x);
             const int64_t n_px64 = (int64_t)tiles_x * ((nrows_j + 7) / 8) * 64;
-            const int64_t n_paths64 = n_px64 * chunk;
+            const int64_t n_paths64 = n_px64 * chunk_j;
             // slot arithmetic is 32-bit: ((col << log2S | a) << 2) and 2 * n_paths / 4 must stay below 2^31
             if (n_paths64 >= ((int64_t)1 << 29)) return fail(ctx, RT_ERR_INVALID, "image too large: %lld paths per sub-frame (limit 2^29)", (long long)n_paths64);
             pt.st.n_paths = (int)n_paths64;
@@ -813,14 +828,14 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
             st.batch = nullptr; st.n_batch = 0;
         }
         if (batch) {
-            // the frames' descriptors go to device memory on the caller's stream, ahead of the fork below: every chain of this call starts behind them.  Two slots, alternating:
-            // a batch call never takes the relaxed start of rt_ctx_set_pipelining (its chains must not overtake this store), so the previous call's chains have been joined
-            // into the stream before this kernel runs; the second slot only keeps that argument local
-            if ((rc2 = ensure(ctx, ctx->batch_dev, 2 * rtk::kMaxBatch * sizeof(rtk::BatchFrame))) != RT_OK) return rc2;
-            ctx->batch_slot ^= 1;
-            rtk::BatchFrame *dst = static_cast<rtk::BatchFrame *>(ctx->batch_dev.p) + ctx->batch_slot * rtk::kMaxBatch;
-            hipLaunchKernelGGL(rtk::batch_store_kernel, dim3(1), dim3(64), 0, stream, *batch, dst);
-            for (Part &pt : pv) { pt.st.batch = dst; pt.st.n_batch = batch->n; }
+            // the frames' descriptors live in device memory, one copy PER SUB-FRAME, written by a one-wave kernel at the head of that sub-frame's own chain (below): a chain is
+            // ordered behind the previous chain of its stream, so the copy is never rewritten under a running kernel, and nothing has to wait on the caller's stream -- a batch
+            // takes the relaxed start of rt_ctx_set_pipelining like a frame does
+            if ((rc2 = ensure(ctx, ctx->batch_dev, rt_ctx::kMaxParts * rtk::kMaxBatch * sizeof(rtk::BatchFrame))) != RT_OK) return rc2;
+            for (int j = 0; j < parts; ++j) {
+                pv[j].st.batch = static_cast<rtk::BatchFrame *>(ctx->batch_dev.p) + j * rtk::kMaxBatch;
+                pv[j].st.n_batch = pv[j].batch_n;
+            }
         }
         ctx->stats.lds_bytes = (int)trav_lds;
         ctx->stats.block_threads = tb;
@@ -849,7 +864,7 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
                     return fail(ctx, RT_ERR_INVALID, "pipelining rule broken: work submitted to this stream after the previous render call (rt_tonemap_device) touches the buffer "
                                                      "this frame renders into; with rt_ctx_set_pipelining the frame would not wait for it (raytrace_hip.h)");
 #endif
-                const bool relaxed = pl.on && pl.prev_valid && pl.stream == stream && pl.sig == layout_sig && disjoint && !zeroed && !hazard && !batch;
+                const bool relaxed = pl.on && pl.prev_valid && pl.stream == stream && pl.sig == layout_sig && disjoint && !zeroed && !hazard;
                 pl.cur ^= 1;
                 RT_HIP(ctx, hipEventRecord(pl.fork2[pl.cur], stream));
                 start_ev = pl.fork2[relaxed ? pl.cur ^ 1 : pl.cur];
@@ -878,6 +893,12 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
                 pt.st.samp0 = s;
                 pt.st.epoch = 0;
                 pt.st.nonce = (int)(++ctx->chain_nonce[j] & (unsigned)rtk::PQ_NONCE_MASK);
+                if (batch) {                                          // this sub-frame's frames, at the head of its chain
+                    rtk::Batch bj{};
+                    bj.n = pt.batch_n;
+                    for (int k = 0; k < pt.batch_n; ++k) bj.f[k] = batch->f[pt.batch0 + k];
+                    hipLaunchKernelGGL(rtk::batch_store_kernel, dim3(1), dim3(64), 0, q, bj, const_cast<rtk::BatchFrame *>(pt.st.batch));
+                }
                 if (work_dev) hipLaunchKernelGGL((rtk::wf_advance<true, true>), dim3(pt.pblocks), dim3(kn.adv_block), 0, q, scn, pt.fr, pt.st);
                 else hipLaunchKernelGGL((rtk::wf_advance<false, true>), dim3(pt.pblocks), dim3(kn.adv_block), 0, q, scn, pt.fr, pt.st);
                 for (int it = 0; it < (segs > 0 ? segs + 1 : 0); ++it) {
@@ -1192,9 +1213,9 @@ int install_scene(rt_ctx *ctx, rtk::Scene sc, const rt_mesh *mesh, const std::ve
         mesh_table_single(sc, -1);
     }
     int rc;
-    pc.lap("  scene: traversal order, triangle records (host)");
+    pc.lap("  scene: traversal order, triangle records (host) + the FIRST hipMalloc / copy of the process (runtime: stream = hardware queue, staging)");
     if ((rc = upload(ctx, ctx->node_lo, lo.data(), lo.size() * sizeof(float4))) != RT_OK) return rc;
-    pc.lap("  scene: first hipMalloc + copy");
+    pc.lap("  scene: one more hipMalloc + copy");
     if ((rc = upload(ctx, ctx->node_hi, hi.data(), hi.size() * sizeof(float4))) != RT_OK) return rc;
     std::vector<float4> inter(lo.size() * 2);
     for (size_t k = 0; k < lo.size(); ++k) { inter[2 * k] = lo[k]; inter[2 * k + 1] = hi[k]; }

@@ -527,6 +527,12 @@ finished:
 // FIRST: the launch that opens the chain's samples -- camera rays (cpu:699-709) instead of closing queries.
 // The samples of a pixel are independent paths (the reference's loop cpu:701-712 carries nothing but the sum): a chain traces
 // several of them at once as items, each writes its colour, and path_reduce adds the colours in sample order.
+// code-object markers (labels, not instructions): tools/static_counts.py cuts the production instantiation into regions at them -- what a path pays for, region by region
+#ifdef RT_NO_MARKS
+#define ADV_MARK(name) do { } while (0)
+#else
+#define ADV_MARK(name) asm volatile("rt_mark_adv_" name "_%=:" ::)
+#endif
 template <bool STATS, bool FIRST>
 __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr, const WfState &st, const int i, Work &wk) {
     const float4 kDead = make_float4(0, 0, 0, 0);                     // second half of a queue record without a ray (and, in a Y slot, without a path)
@@ -594,6 +600,7 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
             nrays = 1;
         }
     } else {
+        ADV_MARK("closex_begin");
         d = (F >> PF_DEPTH_SHIFT) & PF_DEPTH_MASK;                    // segment of the continuation ray in flight
         nrays = (F >> PF_RAYS_SHIFT) & PF_RAYS_MASK;
         // ---- (1) the shadow ray of segment d-1's hit came back: direct light or not (cpu:615) ----
@@ -612,8 +619,10 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
             }
             if (shadowed) st.LS[(size_t)(d - 1) * st.n_paths + i] = 0.f;               // the l stored when the segment was shaded does not count
         }
+        ADV_MARK("closex_end");
         // ---- (2) the continuation ray of segment d came back: Scene::getColor's branch for its hit (cpu:570-614) ----
         if (F & PF_HASY) {
+            ADV_MARK("closey_begin");
             const float4 r0 = st.QR[2 * (size_t)qy];
             f3 O = mk(r0.x, r0.y, r0.z), u = mk(r0.w, y1.x, y1.y);
             int sid = 0xff;                                           // object id if the hit is diffuse
@@ -649,6 +658,7 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
                     N = normalize(P - sphere_centre_of(sc, win));     // cpu:524-525
                 }
                 const Material m = material_of(sc, win);
+                ADV_MARK("closey_end");
                 bool cont = false;                                    // a continuation ray of segment d+1 was built in (O,u)
                 if (m.mirror) {                                       // cpu:573-579
                     O = P + fr.eps * N;
@@ -674,6 +684,7 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
                     }
                     cont = true;
                 } else {                                              // cpu:605-642: diffuse
+                    ADV_MARK("diffuse_begin");
                     const f3 Pa = P + fr.eps * N;
                     const f3 toL = L - Pa;
                     Ox = Pa; ux = normalize(toL);   // = toL / sqrt(norm2(toL))         // NORMED_VEC, cpu:614: the shadow ray of segment d
@@ -685,7 +696,9 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
                     const float mx = (dn < 0.f) ? 0.f : dn;
                     st.LS[(size_t)d * st.n_paths + i] = (float)((double)sc.intensity / (4 * PI_D * (double)norm2(L - P)) * (double)mx);
                     sid = win;
+                    ADV_MARK("diffuse_end");
                     if (d + 1 < fr.segs) {                            // the bounce ray (cpu:627-642): needs r1, r2 and N only
+                        ADV_MARK("bounce_begin");
                         const uint32_t hp = mix32(((uint32_t)row * (uint32_t)fr.W + (uint32_t)px) ^ mix32(fr_seed));
                         const uint32_t hs = mix32(hp ^ ((uint32_t)samp * 0x9E3779B1U));
                         const float r1u = uniform01(hs, (uint32_t)d, 0);
@@ -706,6 +719,7 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
                         O = Pa;
                         refr_code = 0;                                // Ray(P_adjusted, random_direction): index 1
                         cont = true;
+                        ADV_MARK("bounce_end");
                     }
                 }
                 if (cont && d + 1 < fr.segs) {
@@ -720,6 +734,7 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
     }
 
     if (finished) {   // nothing in flight: fold the path back to front (cpu:642-644), accumulate the sample (cpu:711)
+        ADV_MARK("fold_begin");
         f3 ans = mk(0, 0, 0);
         const int nseg = d < fr.segs ? d : fr.segs;
         for (int k = nseg - 1; k >= 0; --k) {
@@ -742,13 +757,16 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
             fr_out[out_index(fr, lrow, px)] = make_float4(t.x / n, t.y / n, t.z / n, t.w);
         }
         st.QR[2 * (size_t)qy + 1] = kDead;                            // the path is over; its X slot keeps a record of an older launch, which no later one takes for its own
+        ADV_MARK("fold_end");
         return;
     }
 
     // ---- (3) emission: sphere tests (cpu:512-527), root-box test (cpu:279), queue records ----
     int flags = PF_ALIVE | (d << PF_DEPTH_SHIFT) | (nrays << PF_RAYS_SHIFT) | (refr_code << PQ_REFR_SHIFT) | (int)((unsigned)st.nonce << PQ_NONCE_SHIFT);
     SphereNear h, hx;
+    ADV_MARK("spheres_begin");
     spheres_near2(sc, emitX ? Ox : Oy, uy, emitY, ux, emitX, h, hx);   // a shadow ray and a bounce ray leave the same point (Oy == Ox == P_adjusted)
+    ADV_MARK("spheres_end");
     float t_sph = 0.f;
     if (emitX) {
         const float tS = hx.t;                                        // only the value of the shadow ray's nearest hit matters

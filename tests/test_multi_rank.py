@@ -198,6 +198,12 @@ def test_bench_two_ranks_on_the_one_gpu_frame_equals_single_device_frame(tmp_pat
     assert r.returncode == 0, r.stderr[-2000:]
     assert line["n_gpus"] == 2 and line["config"]["ranks"] == 2 and line["config"]["frame_equals_single_device_frame"] is True
     assert line["value"] > 0 and "roofline" in line
+    # a share this small is rendered as batches of `ranks` frames in one launch chain (rt_render_device_batch); the line says so and carries the latency of a lone frame beside it
+    assert line["config"]["batch"] == 2 and line["config"]["frame_latency_ms"] > 0 and line["config"]["gather"] in ("f32", "rgb8")
+    # three ranks, a rotating root, a step count that is no multiple of the batch (7 = 3 + 3 + 1): frame 0 (root 0) still equals the single-device frame
+    r, line = _bench("--gpus", "3", "--share-gpu", "--check-frame", "--root", "rotate", "--gather", "f32", "--width", "640", "--height", "356", "--steps", "7", "--warmup", "2", "--large-steps", "0")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line["config"]["batch"] == 3 and line["steps"] == 7 and line["config"]["frame_equals_single_device_frame"] is True and "rank k mod N" in line["config"]["root"]
 
 
 def test_assemble_is_the_inverse_of_the_partition():

@@ -1,6 +1,7 @@
 """GPU box: the compute side of the N-rank job on ONE GPU, with the denominators bench.py's own lines use.
 For world = 2, 4, 8 at 1920x1080 (and 3840x2160): rank 0's share of the frame (interleaved 8-row tiles)
-  * as bench.py --gpus N renders it since round 6: `world` consecutive frames as ONE launch chain (rt_render_device_batch), two batches in flight on two contexts;
+  * as bench.py --gpus N renders it since round 6: `world` consecutive frames as ONE launch chain (rt_render_device_batch), batches alternating between two sets of buffers on one
+    context and stream with rt_ctx_set_pipelining (and the same with every batch joined before the next starts);
   * as round 5 rendered it: four frames in flight on four contexts (RT_PARTS=1, RT_TRAV_MIN_GROUPS=64);
   * one frame alone (the latency of a frame on that share);
 against the WHOLE frame rendered the way bench.py --gpus 1 renders it (two frames alternating on one context and stream, rt_ctx_set_pipelining) -- the `ms_per_step` a
@@ -61,13 +62,17 @@ for W, H in sizes:
         K = min(16, world)
         lb = [tiling.local_buffer(H, W, world, "cuda:0") for _ in range(2 * K)]
 
-        def batch(k):
-            b = k & 1
-            full[b].render_device_batch(p, rows, [(lb[b * K + j].data_ptr(), (0.0, 0.0, 55.0), None, 123456) for j in range(K)], st[b].cuda_stream)
+        descs = [[(lb[b * K + j].data_ptr(), (0.0, 0.0, 55.0), None, 123456) for j in range(K)] for b in range(2)]
+
+        def batch(k):                                                 # as bench.py --gpus N: one context, one stream, batches alternating between two sets of buffers, pipelining on
+            full[0].render_device_batch(p, rows, descs[k & 1], st[0].cuda_stream)
         nb = max(8, (N if W <= 1920 else 32) // K)
+        full[0].set_pipelining(True)
         t_batch = run(batch, nb, 4) / K
+        full[0].set_pipelining(False)
+        t_batch_alone = run(lambda k: full[0].render_device_batch(p, rows, descs[0], st[0].cuda_stream), nb, 4) / K
         t_four = run(lambda k: lanes4[k & 3].render_device(p, rows, lb[k & 3].data_ptr(), st[k & 3].cuda_stream), N if W <= 1920 else 32, 12)
         t_alone = run(lambda k: full[0].render_device(p, rows, lb[0].data_ptr(), st[0].cuda_stream), N if W <= 1920 else 32, 6)
-        print(f"{W}x{H} world {world}: batch of {K} frames in one chain {t_batch:.4f} ms per frame = {n1 / t_batch:.2f}x of bench --gpus 1 (ideal {world}x) | "
+        print(f"{W}x{H} world {world}: batch of {K} frames in one chain {t_batch:.4f} ms per frame = {n1 / t_batch:.2f}x of bench --gpus 1 (ideal {world}x; one batch at a time {t_batch_alone:.4f} ms per frame) | "
               f"four frames in flight (round 5) {t_four:.4f} ms = {n1 / t_four:.2f}x | one frame alone (latency) {t_alone:.4f} ms = {n1_alone / t_alone:.2f}x of a lone whole frame", flush=True)
         del lb

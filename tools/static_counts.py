@@ -166,6 +166,27 @@ def travq_qw_counts(lines):
     }
 
 
+def advance_counts(lines):
+    """wf_advance<false, false>: what a path pays for per launch, region by region (ADV_MARK labels of rt_wavefront.hip.h).  A region's instructions execute for the lanes
+    (paths) that take its branch; `rest` = decode, record reads and writes, the emission's root-box tests and flag words."""
+    marks = regions(lines)
+    pos = {}
+    for i, name in marks:
+        pos.setdefault(name, []).append(i)
+    out, covered = {}, count([])
+    for name in ("closex", "closey", "diffuse", "bounce", "fold", "spheres"):
+        b, e = pos.get("adv_" + name + "_begin"), pos.get("adv_" + name + "_end")
+        if not b or not e or e[0] < b[0]:
+            out[name] = None
+            continue
+        out[name] = count(lines[b[0]:e[0]])
+        covered = {k: covered[k] + out[name][k] for k in covered}
+    whole = count(lines)
+    out["rest"] = sub(whole, covered)
+    out["whole_kernel"] = whole
+    return out
+
+
 def main():
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     sys.path.insert(0, ROOT)
@@ -186,13 +207,16 @@ def main():
                           ("wf_advance_first", "_ZN3rtk10wf_advanceILb0ELb1EEEvNS_5SceneENS_5FrameENS_7WfStateE")):
         t = kernel_text(asm, mangled)
         if t:
-            res[name] = {"whole_kernel": count(t)}
+            res[name] = advance_counts(t) if name == "wf_advance" else {"whole_kernel": count(t)}
     m = re.search(r"\.name:\s+_ZN3rtk8wf_travqILb0ELi64ELb0ELb0EEE.*?\n(.*?)\.wavefront_size", asm, re.S)
     with open(OUT, "w") as f:
         json.dump(res, f, indent=1)
     w = res["wf_travq_qw"]
     print("static_counts: wf_travq 4-wide per step: BOX %d valu (weight %d) %d salu + %.1f per internal push block + %.1f per leaf push block | TRI %d (%d) %d | round %d | fetch %d" % (
         w["box"]["valu"], w["box"]["valu_weight"], w["box"]["salu"], w["lpush2"]["valu"], w["lpush"]["valu"], w["tri"]["valu"], w["tri"]["valu_weight"], w["tri"]["salu"], w["round"]["valu"], w["fetch"]["valu"]))
+    a = res.get("wf_advance", {})
+    if a:
+        print("static_counts: wf_advance regions (valu / weight): " + ", ".join(f"{k} {v['valu']}/{v['valu_weight']}" for k, v in a.items() if v))
     t = res["wf_travq"]
     print("static_counts: wf_travq per step: BOX %d valu (weight %d) %d salu + leaf pushes %d / %d | TRI %d (%d) %d + %.0f per t-division block | round %d (%d) %d | fetch %d | retire %d | head+dispatch %d" % (
         t["box"]["valu"], t["box"]["valu_weight"], t["box"]["salu"], t["lpush"]["valu"], t["lpush2"]["valu"], t["tri"]["valu"], t["tri"]["valu_weight"], t["tri"]["salu"], t["tdiv"]["valu"],
