@@ -399,21 +399,34 @@ def roofline(rt, ctx, args, p, rows, local, stream, counts, world, W, H, kernel_
                 "algorithmic_bytes_per_launch": int(trav_bytes / launches), "nominal_hbm_GBps": round(hbm_ach, 1), "nominal_hbm_frac": round(hbm_ach / HBM_PEAK_GBS, 4),
                 "nominal_hbm_frac_is": "SURVEY 8d: 24 B/box test + 16 B/node + 48 B/triangle test of a cache-resident scene over 8 TB/s; may exceed 1, NOT a utilisation"})
     # measured HBM traffic of the same launch: only from a PMC summary taken from THIS library
-    rnd = "round5"
-    for rnd in ("round5", "round4", "round3", "round2"):
-        spath = os.path.join(ROOT, "profiles", rnd, "summary.json")
-        if os.path.exists(spath) and workload == "cat_1920x1080_spp1_b3":
+    # the committed PMC summary of THIS code: every profiles/roundN/summary.json is looked at, newest round first, and the one whose code_hash equals the hash of the sources
+    # being run is quoted; if none matches, the newest one is named as stale and no traffic is quoted
+    import glob
+    import re as _re
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", "summary.json")), key=lambda q: -int((_re.search(r"round(\d+)", q) or [0, 0])[1]))
+    rnd, match, newest = None, None, None
+    for spath in cands:
+        try:
             summ = json.load(open(spath))
-            if summ.get("code_hash") and summ.get("code_hash") == code_hash():
-                t = summ["kernels"]["wf_travq"]
-                out["traffic"] = int(t["hbm_read_bytes_per_launch"] + t["hbm_write_bytes_per_launch"])
-                out["traffic_source"] = f"profiles/{rnd}/summary.json (rocprofv3 --pmc, RT_PARTS=1, same source hash)"
-                out["pmc"] = {"valu_wave_insts_per_launch": t.get("valu_wave_insts_per_launch"), "salu_wave_insts_per_launch": t.get("salu_wave_insts_per_launch"),
-                              "valu_lane_utilization": t.get("valu_lane_utilization"), "l2_hit_rate": t.get("l2_hit_rate"),
-                              "rocprof_avg_us_single_stream": t.get("rocprof_avg_us_single_stream"), "rocprof_avg_us_two_streams": t.get("rocprof_avg_us_two_streams")}
-            else:
-                out["traffic_note"] = f"profiles/{rnd}/summary.json was taken from other code (hash differs): profile stale, traffic not quoted"
+        except (OSError, ValueError):
+            continue
+        newest = newest or os.path.basename(os.path.dirname(spath))
+        if summ.get("code_hash") == code_hash() and workload == "cat_1920x1080_spp1_b3":   # (the profile is of the headline workload)
+            rnd, match = os.path.basename(os.path.dirname(spath)), summ
             break
+    if match is not None:
+        t = match["kernels"]["wf_travq"]
+        out["traffic"] = int(t["hbm_read_bytes_per_launch"] + t["hbm_write_bytes_per_launch"])
+        out["traffic_source"] = f"profiles/{rnd}/summary.json (rocprofv3 --pmc, RT_PARTS=1, same source hash)"
+        out["pmc"] = {"valu_wave_insts_per_launch": t.get("valu_wave_insts_per_launch"), "salu_wave_insts_per_launch": t.get("salu_wave_insts_per_launch"),
+                      "valu_lane_utilization": t.get("valu_lane_utilization"), "l2_hit_rate": t.get("l2_hit_rate"),
+                      "rocprof_avg_us_single_stream": t.get("rocprof_avg_us_single_stream"), "rocprof_avg_us_two_streams": t.get("rocprof_avg_us_two_streams")}
+        if t.get("valu_wave_insts_per_launch") and t.get("rocprof_avg_us_single_stream"):
+            out["pmc"]["frac_pmc"] = round(t["valu_wave_insts_per_launch"] / (t["rocprof_avg_us_single_stream"] * 1e-6) / 1e9 / VALU_PEAK_GINST, 4)
+            out["pmc"]["frac_pmc_is"] = "SQ_INSTS_VALU per launch / rocprofv3's average launch duration (one sub-frame at a time) over the same 1228.8 G wave-inst/s: the unweighted hardware count"
+    else:
+        rnd = newest or "round0"
+        out["traffic_note"] = f"no profiles/round*/summary.json carries the hash of the sources being run (newest: {rnd}): profile stale, traffic not quoted"
     # both hot kernels, each against the roofline that bounds it
     kern = [{"kernel": "wf_travq", "bound": "valu_issue", "kernel_ms": out.get("kernel_ms"), "launches_per_frame": out.get("launches_per_frame"),
              "achieved": out.get("achieved"), "peak": out["peak"], "unit": out["unit"], "frac": out.get("frac"), "traffic": out.get("traffic")}]

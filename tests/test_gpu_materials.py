@@ -85,6 +85,29 @@ def test_two_meshes_full_size_and_samples(ctx, oracle, cat_golden):
     _frames_equal(got, exp)
 
 
+def test_two_meshes_move_together_under_the_device_transform(ctx, oracle, cat_golden):
+    """rt_mesh_transform on a forest: every mesh's vertices move, every node is refitted bottom-up (the synthetic nodes above the roots become the unions of the moved roots' boxes).
+    Against the oracle transforming and refitting each mesh (or_mesh_transform + or_mesh_refit: same trees, boxes by compute_bbox): direct lighting and two bounces bit for bit."""
+    v, t = cat_golden["vertices"], cat_golden["tri_obj_order"]
+    R = np.array([[0.9553365, 0, 0.29552022], [0, 1, 0], [-0.29552022, 0, 0.9553365]], np.float32)
+    tr = (0.5, 0.25, -0.5)
+    osc = oracle.Scene()
+    desc = ms.describe("two_cats", v)
+    for o in desc:
+        if o[0] == "sphere":
+            osc.add_sphere(o[1], o[2], o[3])
+        else:
+            m = oracle.Mesh.from_arrays(o[1], t, albedo=o[2]).set_material(o[3], o[4], o[5]).build_bvh()
+            m.transform(R, tr).refit()
+            osc.add_mesh(m)
+    ctx.scene_upload(*ms.capi_scene("two_cats", v, t))
+    ctx.mesh_transform(R, tr)
+    for b in (0, 2):
+        exp, _, _ = osc.render(448, 256, 1, b, want_rgb8=False)
+        _frames_equal(ctx.render(rt.make_params(448, 256, 1, b, **rt.scenes.CPU_LAUNCHER)), exp)
+    assert ctx.stats()["travq_mode"] == 2
+
+
 def _f32_point(O, t, u):
     return (O + (np.float32(t) * u).astype(np.float32)).astype(np.float32)
 

@@ -900,6 +900,26 @@ def test_batched_frames_are_bitwise_the_lone_frames(ctx, oracle, oracle_cat, cat
         assert k == 0 or (got[k][..., :3] != got[0][..., :3]).any()     # a sequence of different frames, not one frame K times
     exp, _, _ = oracle.Scene.preset("cpu", oracle_cat).render(W, H, 1, b, rows=(3 * 8, H), tile_rows=8, tile_step=8, cam=cams[2][0], fov=cams[2][1], seed=cams[2][2], want_rgb8=False)
     np.testing.assert_array_equal(got[2][..., :3].view(np.uint32), exp[..., :3].view(np.uint32))
+    # an EVEN number of frames on the same interleaved rows (the two sub-frames then take half of the frames each, not half of the tiles), with pixel jitter (sigma 0.2: the
+    # frames' seeds reach the jitter's random numbers too), against the lone frames of the uploaded camera
+    ctx.scene_upload(rt.scenes.spheres("cpu"), mesh)
+    pj = rt.make_params(W, H, 1, 2, **dict(rt.scenes.CPU_LAUNCHER, sigma=0.2))
+    ctx.render_device_batch(pj, rows, [(o.data_ptr(), (0.0, 0.0, 55.0), None, 2000 + k) for k, o in enumerate(outs[:4])], st.cuda_stream)
+    st.synchronize()
+    for k in range(4):
+        ctx.render_device(rt.make_params(W, H, 1, 2, seed=2000 + k, **dict(rt.scenes.CPU_LAUNCHER, sigma=0.2)), rows, lone.data_ptr(), st.cuda_stream)
+        st.synchronize()
+        np.testing.assert_array_equal(outs[k].cpu().numpy().view(np.uint32), lone.cpu().numpy().view(np.uint32), err_msg=f"jittered frame {k}")
+    # a scene without a mesh: the batch keeps the wavefront pipeline (the lock-step kernel that AUTO picks for lone frames of such scenes has no batch form); same frames
+    ctx.scene_upload(rt.scenes.spheres("demo10"), None)
+    pd = rt.make_params(W, H, 1, 5, **rt.scenes.CPU_LAUNCHER)
+    ctx.render_device_batch(pd, rows, [(o.data_ptr(), (0.0, 0.0, 55.0), None, 77) for o in outs[:2]], st.cuda_stream)
+    st.synchronize()
+    ctx.render_device(rt.make_params(W, H, 1, 5, seed=77, **rt.scenes.CPU_LAUNCHER), rows, lone.data_ptr(), st.cuda_stream)
+    st.synchronize()
+    assert ctx.stats()["variant"] == 5                                 # the lone frame: lock-step
+    for k in range(2):
+        np.testing.assert_array_equal(outs[k].cpu().numpy().view(np.uint32), lone.cpu().numpy().view(np.uint32))
     # whole small frames, 16 of them and one alone; then what a batch cannot be
     ctx.scene_upload(rt.scenes.spheres("cpu"), mesh)
     W2, H2 = 256, 144
