@@ -71,7 +71,7 @@ def parse():
                     help="N > 1: the rank that assembles a frame -- always rank 0 (the reference copies every image to one host, optimized.cu:849-856) or frame k -> rank k mod N "
                          "(one gather per frame either way; rotate spreads the inbound traffic over every rank's links)")
     ap.add_argument("--batch", type=int, default=0,
-                    help="N > 1: frames of a small share rendered as ONE launch chain (rt_render_device_batch); 0 = auto (the number of ranks, for shares below 0.7 Mpixel), 1 = off")
+                    help="N > 1: frames of a small share rendered as ONE launch chain (rt_render_device_batch); 0 = auto (about a whole frame's worth: the number of ranks, for shares of at most 1.3 Mpixel), 1 = off")
     ap.add_argument("--transport", default="torch", choices=["torch", "capi"],
                     help="N > 1: the gather goes through torch.distributed (nccl = RCCL; default) or through the product's own C-ABI "
                          "(libraytrace_rccl.so: grouped ncclSend / ncclRecv, every tile received straight into its place in rank 0's frame)")
@@ -92,7 +92,7 @@ def parse():
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="whole frames kept in flight (0 = auto).  One GPU: 2 = frames alternate between two device buffers on ONE context and "
                          "stream with rt_ctx_set_pipelining (frame k+1's sub-frames follow frame k's directly; default), 1 = every frame joined before "
-                         "the next starts.  Several ranks: one context per frame in flight (default 2 for small shares, else 1)")
+                         "the next starts.  Several ranks: see --batch")
     ap.add_argument("--dump-frame", default="", help="rank 0 saves the (gathered) float4 frame of the first step as .npy (tests)")
     ap.add_argument("--check-frame", action="store_true", help="rank 0 renders the whole frame alone as well and reports whether the gathered frame equals it bit for bit")
     return ap.parse_args()
@@ -526,46 +526,28 @@ def main():
         comm.set_plan(args.comm_plan)                                  # the same on every rank: both sides derive their message sizes from it
 
     W, H = args.width, args.height
-    # Frames in flight.  One GPU renders a whole 1080p frame as two concurrent sub-frames (the library's default) and a second frame
-    # would only queue behind it.  A small share of a frame no longer fills the chip with its eleven dependent launches; there the
-    # bench keeps two whole frames in flight instead -- one context per lane (own streams, own path state, sub-frames off), frames
-    # dealt round-robin, every frame still rendered, gathered and assembled in full.  Measured on one MI355X for rank 0's share
-    # (tools/share_scaling.py, profiles/round3/share_scaling.txt): 1/8 of 1080p 0.323 -> 0.234 ms, 1/8 of 3840x2160 0.620 -> 0.538 ms;
-    # a share above ~1.3 Mpixel is faster as ONE frame with two sub-frames (two frames' path state would overflow the Infinity Cache).
-    # Round 5 (tools/share_frames.py, profiles/round5/share_frames.txt): a share below ~0.7 Mpixel wants FOUR frames in flight, and every lane's launches
-    # cut into fewer, fuller workgroups (RT_TRAV_MIN_GROUPS=64: 256 ray slots per wave instead of 64 -- a lone small launch is slower that way, four of them
-    # side by side fill the chip with waves whose stacks stay full): 1/8 of 1080p 0.204 -> 0.130 ms per frame and rank, 1/4 0.315 -> 0.248 ms.
-    # Five and more streams fall off the runtime's hardware queues (0.17 ms).
+    # Frames in flight.  One GPU renders a whole frame as two concurrent sub-frames (the library's default) and keeps two frames pipelined on one context and stream
+    # (rt_ctx_set_pipelining).  A rank of an N-rank job owns a SHARE of every frame; a share of at most ~1.3 Mpixel no longer fills the chip with its eleven dependent launches,
+    # so the bench renders `batch` consecutive frames of the share as ONE launch chain (rt_render_device_batch: about one whole frame's worth of paths per chain), batches
+    # pipelined like frames, every frame still gathered and assembled on its own.  Measured on one MI355X for rank 0's share (tools/share_batch.py,
+    # profiles/round6/share_batch.txt): 1/8 of 1080p 0.282 ms one frame at a time -> 0.109 ms per frame in batches of 8 (round 5: four contexts with four frames in flight,
+    # 0.13-0.19 ms); 1/8 of 3840x2160 0.536 -> 0.489 ms; a share above ~1.3 Mpixel is fastest one frame at a time (1/4 of 3840x2160: 0.878 ms alone, 0.973 in batches).
     SMALL_SHARE_PX = 1.3e6
-    TINY_SHARE_PX = 0.7e6
-    LANE_MIN_GROUPS = "64"
     ctx = None
-    pools = {}                                                         # "full": [context with the default knobs]; "lanes": contexts with sub-frames off
-
-    if world > 1:
-        os.environ.setdefault("RT_PART_PRIO", "1")                    # this process will hold several contexts: keep their sub-frame streams off each other's hardware queues
+    pools = {}                                                         # "full": [contexts with the default knobs], each with a stream of its own
 
     def pool(kind, n):
-        if kind in pools and len(pools[kind][0]) < n:                 # a later point wants more lanes: build the pool again
+        if kind in pools and len(pools[kind][0]) < n:                 # a later point wants more contexts: build the pool again
             del pools[kind]
         if kind not in pools:
-            old_parts, old_mg = os.environ.get("RT_PARTS"), os.environ.get("RT_TRAV_MIN_GROUPS")
-            if kind == "lanes" and old_parts is None:
-                os.environ["RT_PARTS"] = "1"                          # knobs are read when a context is created
-            if kind == "lanes" and old_mg is None:
-                os.environ["RT_TRAV_MIN_GROUPS"] = LANE_MIN_GROUPS    # fuller workgroups for launches that run beside other frames' launches
             cs, ts = [], []
             for _ in range(n):
                 c = rt.Context(dev_index)
                 build_scene(rt, c, args.scene)
                 cs.append(c)
-                # a non-default torch stream per lane: its handle is non-NULL (NULL means "the context's own stream" in the C-ABI),
-                # so the lane's render kernels, torch's timing events and its gather are all ordered on ONE stream
-                ts.append(torch.cuda.Stream(device=dev, priority=-1 if (len(ts) & 1) else 0))   # odd lanes in the high-priority queue pool: never the even lane's hardware queue
-            if kind == "lanes" and old_parts is None:
-                del os.environ["RT_PARTS"]
-            if kind == "lanes" and old_mg is None:
-                del os.environ["RT_TRAV_MIN_GROUPS"]
+                # a non-default torch stream per context: its handle is non-NULL (NULL means "the context's own stream" in the C-ABI),
+                # so the render kernels, torch's timing events and the gather are all ordered on ONE stream
+                ts.append(torch.cuda.Stream(device=dev, priority=-1 if (len(ts) & 1) else 0))
             pools[kind] = (cs, ts)
         return pools[kind]
 
@@ -601,12 +583,11 @@ def main():
             self.W, self.H = W, H
             self.p = rt.make_params(W, H, args.spp, args.bounces, variant=args.variant, **rt.scenes.CPU_LAUNCHER)
             self.rows, self.idx = rt.interleaved_rows(H, TILE_ROWS, rank, world)
-            share_px = self.rows.n_rows * W
             full_share = tiling.tiles_per_rank(H, world) * TILE_ROWS * W   # (the same on every rank: all ranks must batch alike, the steps hold a collective)
             if batch is None:
-                batch = args.batch if args.batch > 0 else (min(16, max(2, round(W * H / max(full_share, 1)))) if (world > 1 and full_share <= TINY_SHARE_PX) else 1)
+                batch = args.batch if args.batch > 0 else (min(16, max(2, round(W * H / max(full_share, 1)))) if (world > 1 and full_share <= SMALL_SHARE_PX) else 1)
             self.batch = 1 if (cpu_only or world == 1 or args.spp != 1 or lanes == 1) else max(1, min(16, batch))
-            want = lanes if lanes > 0 else args.frames_in_flight if args.frames_in_flight > 0 else (2 if world == 1 else 4 if share_px <= TINY_SHARE_PX else 2 if share_px <= SMALL_SHARE_PX else 1)
+            want = lanes if lanes > 0 else (args.frames_in_flight if (args.frames_in_flight > 0 and world == 1) else 2 if world == 1 else 1)
             if self.batch > 1:
                 want = 2 * self.batch
             self.n_lanes = 1 if cpu_only else want
@@ -623,13 +604,9 @@ def main():
                     full = pool("full", 1)                              # between two sets of buffers on one stream with rt_ctx_set_pipelining: batch b + 1's chains follow batch b's directly
                     self.ctxs, self.tstreams = [full[0][0]] * self.n_lanes, [full[1][0]] * self.n_lanes
                     full[0][0].set_pipelining(True)
-                else:
-                    if self.n_lanes > 1:
-                        cs_, ts_ = pool("lanes", self.n_lanes)
-                        self.ctxs, self.tstreams = cs_[:self.n_lanes], ts_[:self.n_lanes]
-                    else:
-                        self.ctxs, self.tstreams = pool("full", 1)
-                        self.ctxs[0].set_pipelining(False)
+                else:                                                   # a big share: one frame at a time, two sub-frames
+                    self.ctxs, self.tstreams = pool("full", 1)
+                    self.ctxs[0].set_pipelining(False)
             self.lanes = [Lane(k, W, H) for k in range(self.n_lanes)]
             self.local = self.lanes[0].local
             self.frame = None

@@ -1,7 +1,11 @@
 #!/bin/bash
-# final validation batch: the whole GPU suite, the big-mesh table, the round profile (kernel stats, PMC, bench) -- on the final sources
+# GPU box, final validation batch of a round: the whole GPU suite, the compute side of the N-rank job, the launcher's timing laps, then the round's profile (kernel stats, PMC, bench)
+# on the final sources.  usage: bash tools/validate_gpu.sh <round tag, e.g. round6>   (copy gpurun_out/<tag>/ and gpurun_out/<tag>_v/ into profiles/<tag>/ afterwards)
 cd "$GRAFT_REPO_ROOT"
-mkdir -p gpurun_out/x16
-python -m pytest tests -m gpu -x -q > gpurun_out/x16/pytest.log 2>&1; tail -4 gpurun_out/x16/pytest.log
-python3 tools/big_mesh_bench.py > gpurun_out/x16/big.txt 2>&1; grep -c triangles gpurun_out/x16/big.txt
-bash tools/round_profile.sh round5 > gpurun_out/x16/profile.log 2>&1; tail -3 gpurun_out/x16/profile.log | cut -c1-600
+tag=${1:-round6}
+v=gpurun_out/${tag}_v
+mkdir -p $v
+timeout -k 10 900 python -m pytest tests -m gpu -q > $v/pytest.log 2>&1; tail -4 $v/pytest.log | cut -c1-300
+timeout -k 10 300 python tools/share_batch.py > $v/share_batch.txt 2> $v/share_batch.err; cut -c1-330 $v/share_batch.txt
+timeout -k 10 200 python tools/launcher_timing.py > $v/launcher_timing.txt 2>&1; grep -E "run |scene:|rt_scene_upload" $v/launcher_timing.txt | cut -c1-200 | head -12
+bash tools/round_profile.sh $tag > $v/profile.log 2>&1; tail -3 $v/profile.log | cut -c1-700
