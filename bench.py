@@ -70,6 +70,9 @@ def parse():
     ap.add_argument("--root", default="0", choices=["0", "rotate"],
                     help="N > 1: the rank that assembles a frame -- always rank 0 (the reference copies every image to one host, optimized.cu:849-856) or frame k -> rank k mod N "
                          "(one gather per frame either way; rotate spreads the inbound traffic over every rank's links)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "frame", "batch"],
+                    help="N > 1 with batches: one gather per FRAME, or one per BATCH (the tiles of a peer's `batch` frames travel as one message: an eighth of the collectives, the same "
+                         "bytes; every frame is still assembled).  auto = batch whenever frames are batched and the exchange is torch.distributed's")
     ap.add_argument("--batch", type=int, default=0,
                     help="N > 1: frames of a small share rendered as ONE launch chain (rt_render_device_batch); 0 = auto (about a whole frame's worth: the number of ranks, for shares of at most 1.3 Mpixel), 1 = off")
     ap.add_argument("--transport", default="torch", choices=["torch", "capi"],
@@ -564,10 +567,13 @@ def main():
 
     class Lane:
         """One frame in flight: this rank's tile buffer and the buffers of its exchange."""
-        def __init__(self, k, W, H):
+        def __init__(self, k, W, H, local=None, local8=None):
             self.k = k
-            self.local = tiling.local_buffer(H, W, world, dev)
-            self.local8 = tiling.local_buffer(H, W, world, dev, rgb8=True) if rgb8 else None
+            self.local = tiling.local_buffer(H, W, world, dev) if local is None else local
+            self.local8 = (tiling.local_buffer(H, W, world, dev, rgb8=True) if local8 is None else local8) if rgb8 else None
+            if local is not None:                                      # a frame of a batch whose exchange moves the whole batch: the batch owns the exchange buffers
+                self.xlocal = self.gathered = self.frame = None
+                return
             src = self.local8 if rgb8 else self.local
             self.xlocal = torch.empty(src.shape, dtype=src.dtype, device=xdev, pin_memory=not cpu_only) if (gloo and world > 1 and not cpu_only) else src
             is_root = rank == 0 or rotate                              # a rotating root: every rank assembles its share of the frames
@@ -607,7 +613,20 @@ def main():
                 else:                                                   # a big share: one frame at a time, two sub-frames
                     self.ctxs, self.tstreams = pool("full", 1)
                     self.ctxs[0].set_pipelining(False)
-            self.lanes = [Lane(k, W, H) for k in range(self.n_lanes)]
+            # one gather per batch: the frames of a batch live in ONE tensor [batch, rows, W, C], so a peer's tiles of all of them are one contiguous message
+            self.bx = self.batch > 1 and comm is None and args.exchange != "frame"
+            if self.bx:
+                K, rows_pad = self.batch, tiling.tiles_per_rank(H, world) * TILE_ROWS
+                self.bbuf = [torch.zeros((K, rows_pad, W, 4), dtype=torch.float32, device=dev) for _ in range(2)]
+                self.bbuf8 = [torch.zeros((K, rows_pad, W, 3), dtype=torch.uint8, device=dev) for _ in range(2)] if rgb8 else None
+                src = self.bbuf8 if rgb8 else self.bbuf
+                self.bhost = [torch.empty(src[0].shape, dtype=src[0].dtype, device=xdev, pin_memory=True) for _ in range(2)] if gloo else None
+                is_root = rank == 0 or rotate
+                self.bgath = [torch.empty((world,) + tuple(src[0].shape), dtype=src[0].dtype, device=xdev) for _ in range(2)] if is_root else None
+                self.lanes = [Lane(k, W, H, local=self.bbuf[k // K][k % K], local8=self.bbuf8[k // K][k % K] if rgb8 else None) for k in range(self.n_lanes)]
+                self.nb = 0                                           # batches exchanged since the point was built (decides the rotating root of a batch)
+            else:
+                self.lanes = [Lane(k, W, H) for k in range(self.n_lanes)]
             self.local = self.lanes[0].local
             self.frame = None
             self.n = 0                                                # frames stepped since the point was built (decides the rotating root: the same count on every rank)
@@ -644,6 +663,30 @@ def main():
                 torch.cuda.current_stream().synchronize()
             self.frame = tiling.gather_frame(ln.xlocal, self.H, world, rank, ln.gathered, root=root)
 
+        def exchange_batch(self, b, count):
+            """ONE gather for the `count` frames of batch buffer b: every peer sends the tiles of all of them as one message; the root assembles each frame."""
+            root = tiling.root_of(self.nb, world, args.root)
+            self.nb += 1
+            k0 = b * self.batch
+            if rgb8:
+                for j in range(count):
+                    ln = self.lanes[k0 + j]
+                    self.ctxs[ln.k].tonemap_device(ln.local.data_ptr(), self.rows.n_rows * self.W, ln.local8.data_ptr(), self.tstreams[ln.k].cuda_stream)
+            src = (self.bbuf8 if rgb8 else self.bbuf)[b][:count]      # contiguous: the leading frames of the batch tensor
+            if self.bhost is not None:                                # --share-gpu: the exchange runs over gloo on host tensors
+                host = self.bhost[b][:count]
+                host.copy_(src, non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+                src = host
+            g = self.bgath[b][:, :count] if rank == root else None
+            dist.gather(src, [g[r] for r in range(world)] if rank == root else None, dst=root)
+            self.frame = None
+            if rank == root:
+                for j in range(count):
+                    self.frame = tiling.assemble(g[:, j], self.H)
+                if count > 1:
+                    self.frame = tiling.assemble(g[:, 0], self.H)     # (--dump-frame / --check-frame look at the batch's first frame)
+
         def step(self, ev=None, mode="both"):
             """mode: "both" = the metric's step; "render" / "exchange" = one side only (the compute-side / exchange-side accounting after the timed region)."""
             root = tiling.root_of(self.n, world, args.root)
@@ -672,7 +715,13 @@ def main():
                 if ev:
                     ev[1].record()
                 if mode != "render":
-                    self.exchange(ln, root)
+                    if self.bx:                                       # the batch's LAST step moves the whole batch
+                        b_, j_ = divmod(self.pos - 1, self.batch)
+                        cnt = min(self.batch, self.total - b_ * self.batch)
+                        if j_ == cnt - 1:
+                            self.exchange_batch(b_ % 2, cnt)
+                    else:
+                        self.exchange(ln, root)
 
     def sync():
         if not cpu_only:
@@ -800,7 +849,8 @@ def main():
                                                      "follows the same sub-frame of frame k without a join in between (rt_ctx_set_pipelining); every frame is rendered in full",
                               "ms_per_step_one_frame_in_flight": one_in_flight_ms} if one_in_flight_ms is not None else {}),
                           "tiling": f"{TILE_ROWS}-row tiles interleaved over {world} rank(s)"
-                          + (f", one gather ({backend}) of the {'RGB8' if rgb8 else 'float4'} tiles to rank 0 per frame" if world > 1 else ""),
+                          + (f", one gather ({backend}) of the {'RGB8' if rgb8 else 'float4'} tiles to {'a rotating root' if rotate else 'rank 0'} per "
+                             f"{'batch of ' + str(main_pt.batch) + ' frames' if getattr(main_pt, 'bx', False) else 'frame'}" if world > 1 else ""),
                           "variant": ctx.stats()["variant"] if ctx else None, "device": ctx.device_name if ctx else "cpu (oracle stand-in: not a measurement)",
                           "primary_Msamples_per_s": round(W * H * args.spp / (elapsed / args.steps) / 1e6, 1)}}
         if frame_ok is not None:
@@ -816,8 +866,10 @@ def main():
                 res["config"]["gather_auto"] = gather_choice
             if main_pt.batch > 1:
                 res["config"]["batch"] = main_pt.batch
+                res["config"]["exchange"] = ("one gather per BATCH: a peer's tiles of the batch's frames travel as one message, the root assembles every frame" if main_pt.bx
+                                             else "one gather per frame")
                 res["config"]["batch_is"] = (f"{main_pt.batch} consecutive frames of this rank's share are rendered as ONE launch chain (rt_render_device_batch), two batches in flight on one context and two "
-                                             "sets of buffers (rt_ctx_set_pipelining); every frame is gathered and assembled on its own.  ms_per_step is a THROUGHPUT figure: the frames of a batch finish together")
+                                             "sets of buffers (rt_ctx_set_pipelining); every frame is assembled on its own.  ms_per_step is a THROUGHPUT figure: the frames of a batch finish together")
             if latency_ms is not None:
                 res["config"]["frame_latency_ms"] = latency_ms
                 res["config"]["frame_latency_is"] = "one frame alone on the ranks' shares: rendered, gathered and assembled before the next starts (max over ranks); the other side of the batched / in-flight throughput"

@@ -200,6 +200,10 @@ def test_bench_two_ranks_on_the_one_gpu_frame_equals_single_device_frame(tmp_pat
     assert line["value"] > 0 and "roofline" in line
     # a share this small is rendered as batches of `ranks` frames in one launch chain (rt_render_device_batch); the line says so and carries the latency of a lone frame beside it
     assert line["config"]["batch"] == 2 and line["config"]["frame_latency_ms"] > 0 and line["config"]["gather"] in ("f32", "rgb8")
+    assert line["config"]["exchange"].startswith("one gather per BATCH")          # ... and its frames' tiles travel in one gather per batch (--exchange auto)
+    r, line = _bench("--gpus", "2", "--share-gpu", "--check-frame", "--exchange", "frame", "--gather", "rgb8", "--width", "640", "--height", "356", "--steps", "5", "--warmup", "1", "--large-steps", "0")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line["config"]["exchange"] == "one gather per frame" and line["config"]["gather"] == "rgb8" and line["config"]["batch"] == 2
     # three ranks, a rotating root, a step count that is no multiple of the batch (7 = 3 + 3 + 1): frame 0 (root 0) still equals the single-device frame
     r, line = _bench("--gpus", "3", "--share-gpu", "--check-frame", "--root", "rotate", "--gather", "f32", "--width", "640", "--height", "356", "--steps", "7", "--warmup", "2", "--large-steps", "0")
     assert r.returncode == 0, r.stderr[-2000:]
