@@ -89,27 +89,32 @@ static Knobs read_knobs() {
     Knobs k;
     auto geti = [](const char *name, int &out) { const char *e = getenv(name); if (e && *e) { out = atoi(e); return true; } return false; };
     int v;
+    // --- knobs a caller or a test may set: which (bit-identical) kernel form runs, how a call is cut up.  INTEGRATION.md section 4 lists them.
     if (geti("RT_TRAVQ_R", v) && (v == 32 || v == 64)) k.travq_R = v;
     if (geti("RT_TRAVQ_CAP", v) && v >= 128) k.travq_cap = v;
     if (geti("RT_TRAVQ_LDS", v) && v >= 1 && v <= 16) k.travq_lds = v;
-    if (geti("RT_TRAVQ_LOW", v) && v >= 32 && v <= 320) k.q_low = v;
-    if (geti("RT_TRAVQ_MINFREE", v) && v >= 1 && v <= 64) k.q_minfree = v;
-    if (const char *e = std::getenv("RT_LBVH_CT")) { const float f = (float)std::atof(e); if (f > 0.f && f < 100.f) k.lbvh_ct = f; }
     if (geti("RT_TRAVQ_Q16", v) && v >= -1 && v <= 1) k.q16 = v;
     if (geti("RT_TRAVQ_QW", v) && v >= -1 && v <= 1) k.qw = v;
     if (geti("RT_TRAVQ_QW_COUNT", v)) k.qw_count = v != 0;
     if (geti("RT_AUTO_LOCKSTEP", v)) k.auto_lockstep = v != 0;
     if (geti("RT_TRAVQ_QSEL", v)) k.quad_sel = v != 0;
     if (geti("RT_PARTS", v) && v >= 1 && v <= 8) k.parts = v;
-    if (geti("RT_TRAV_WAVES", v) && v >= 1) k.trav_waves = v;
-    if (geti("RT_TRAVQ_OVERSUB", v) && v >= 1 && v <= 16) k.oversub = v;
-    if (geti("RT_TRAV_MIN_GROUPS", v) && v >= 4) k.min_groups = v;
-    if (geti("RT_TRAV_LOG2S", v) && v >= 0) k.log2S = v;
     if (geti("RT_PART_PRIO", v)) k.part_prio = v != 0;
     { const char *e = getenv("RT_CHUNK_MPX"); if (e && *e) { const double d = atof(e); if (d >= 0 && d < 1e4) k.chunk_mpx = d; } }
     if (geti("RT_ASYNC_PIPELINE", v)) k.async_pipeline = v != 0;
-    if (geti("RT_ADV_BLOCK", v) && (v == 64 || v == 128 || v == 256)) k.adv_block = v;
     if (geti("RT_PATH_SAMP_MB", v) && v >= 1) k.path_samp_bytes = (long long)v << 20;
+    // --- launch-geometry knobs of the A/B tools (tools/ab_variants.sh, share_*.py): honoured only under RT_EXPERIMENT=1, so that a stray variable in a
+    //     caller's environment cannot move a product frame off its measured optimum
+    if (geti("RT_EXPERIMENT", v) && v != 0) {
+        if (geti("RT_TRAVQ_LOW", v) && v >= 32 && v <= 320) k.q_low = v;
+        if (geti("RT_TRAVQ_MINFREE", v) && v >= 1 && v <= 64) k.q_minfree = v;
+        if (const char *e = std::getenv("RT_LBVH_CT")) { const float f = (float)std::atof(e); if (f > 0.f && f < 100.f) k.lbvh_ct = f; }
+        if (geti("RT_TRAV_WAVES", v) && v >= 1) k.trav_waves = v;
+        if (geti("RT_TRAVQ_OVERSUB", v) && v >= 1 && v <= 16) k.oversub = v;
+        if (geti("RT_TRAV_MIN_GROUPS", v) && v >= 4) k.min_groups = v;
+        if (geti("RT_TRAV_LOG2S", v) && v >= 0) k.log2S = v;
+        if (geti("RT_ADV_BLOCK", v) && (v == 64 || v == 128 || v == 256)) k.adv_block = v;
+    }
 #ifdef RT_DEBUG
     if (geti("RT_DEBUG_TRAV", v)) k.debug_trav = v;
 #endif

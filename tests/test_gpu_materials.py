@@ -80,9 +80,13 @@ def test_two_meshes_full_size_and_samples(ctx, oracle, cat_golden):
     ctx.scene_upload(*ms.capi_scene("two_cats", v, t))
     exp, _, _ = osc.render(1920, 1080, 1, 3, want_rgb8=False)
     _frames_equal(ctx.render(rt.make_params(1920, 1080, 1, 3, **rt.scenes.CPU_LAUNCHER)), exp)
-    exp, _, _ = osc.render(640, 360, 4, 2, want_rgb8=False)
+    exp, _, cnt = osc.render(640, 360, 4, 2, want_rgb8=False)
     got = ctx.render(rt.make_params(640, 360, 4, 2, **rt.scenes.CPU_LAUNCHER))
     _frames_equal(got, exp)
+    # the counting instantiation on the forest: rays and triangle tests are the reference's (a mesh's triangles are tested iff the reference's own walk of THAT mesh reaches their
+    # leaf); the box / node counts include the synthetic union nodes above the two roots and are not compared (raytrace_hip.h, rt_count_work)
+    work = ctx.count_work(rt.make_params(640, 360, 4, 2, **rt.scenes.CPU_LAUNCHER))
+    assert work["rays"] == cnt["rays"] and work["tri_tests"] == cnt["tri_tests"]
 
 
 def test_two_meshes_move_together_under_the_device_transform(ctx, oracle, cat_golden):

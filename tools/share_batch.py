@@ -8,6 +8,7 @@ against the WHOLE frame rendered the way bench.py --gpus 1 renders it (two frame
 scaling run divides by -- and against one whole frame alone.  No exchange: this is the compute side only.
 usage: python tools/share_batch.py [> profiles/roundN/share_batch.txt]"""
 import os, sys, time
+os.environ.setdefault("RT_EXPERIMENT", "1")   # the launch-geometry knobs below are honoured only under it
 os.environ.setdefault("RT_PART_PRIO", "1")
 sys.path.insert(0, os.getcwd())
 import torch

@@ -3,6 +3,7 @@ slot, sub-frames off), next to one frame cut into two sub-frames: how many frame
 (VERDICT round 4 item 2).  The environment of the calling shell applies to every context (RT_TRAVQ_QW, GPU_MAX_HW_QUEUES ...).
 usage: python tools/share_frames.py [> profiles/roundN/share_frames.txt]"""
 import os, sys, time
+os.environ.setdefault("RT_EXPERIMENT", "1")   # the launch-geometry knobs below are honoured only under it
 os.environ.setdefault("RT_PART_PRIO", "1")
 sys.path.insert(0, os.getcwd())
 import torch
