@@ -151,7 +151,7 @@ struct rt_ctx {
     bool q16_topo_ok = false;                                       // the tree's shape allows them (leaf sizes, node count, boxes nest)
     bool qw_topo_ok = false;                                        // ... and no leaf is empty: places 0 and 2 of a quad must hold a node (the pairs cope with an empty leaf)
     int real_obj = -1;                                              // object position of the (first) mesh with triangles, -1 = none
-    int n_real_meshes = 0;                                          // meshes WITH triangles in the scene: with more than one the tree in use is a forest (install_forest) and the per-mesh operations are refused
+    int n_real_meshes = 0;                                          // meshes WITH triangles in the scene: with more than one the tree in use is a forest (build_forest) and the per-mesh operations are refused
     DevBuf node_lo, node_hi, nodes2, nodesq, nodesb, q2thr, tri, verts, tidx, scratch_rgba, scratch_rgb8, work, queue;
     int n_cus = 0;
     DevBuf wfM, wfT, wfLS, wfSID, wfSamp;                     // wavefront path state (HBM); wfSamp / wfT: per-sample colours and their running sum (num_rays > 1)
@@ -1137,7 +1137,7 @@ void mesh_table_single(rtk::Scene &sc, int real_obj) {
 }
 
 // sc: spheres (with their object ids), light, camera and the mesh table (object ids, materials; sc.mesh_slot = the first mesh object's position or -1) filled in by the caller.
-// mesh: the geometry to traverse -- one TriangleMesh as uploaded, or the forest install_forest made of several (tri_offsets[k] = first triangle of table entry k in mesh->indices,
+// mesh: the geometry to traverse -- one TriangleMesh as uploaded, or the forest build_forest made of several (tri_offsets[k] = first triangle of table entry k in mesh->indices,
 // n_meshes + 1 entries) -- or nullptr.
 int install_scene(rt_ctx *ctx, rtk::Scene sc, const rt_mesh *mesh, const std::vector<int> *tri_offsets = nullptr) {
     PhaseClock pc;
@@ -1201,7 +1201,7 @@ int install_scene(rt_ctx *ctx, rtk::Scene sc, const rt_mesh *mesh, const std::ve
         if (sc.n_nodes > 0) { sc.root_lo = lo[0]; sc.root_hi = hi[0]; }
         sc.n_verts = mesh->n_vertices;
         if (tri_offsets) {
-            // the forest is laid out so that the traversal reaches the meshes in object order (install_forest): the visit-order triangle array is mesh after mesh
+            // the forest is laid out so that the traversal reaches the meshes in object order (build_forest): the visit-order triangle array is mesh after mesh
             int cur = 0;
             for (int k = 0; k < sc.n_meshes; ++k) sc.mesh[k].tri_begin = -1;
             for (int t = 0; t < n_int; ++t) {
@@ -1356,7 +1356,7 @@ int refresh_host_mesh(rt_ctx *ctx) {
 //     both intervals or the smaller box is missed), and a NaN on the first axis makes the smaller box a miss already;
 //   * the synthetic tree is shaped so that the traversal order (right child first, cpu:291-292) reaches the meshes in OBJECT order, hence the visit-order triangle array holds them
 //     mesh after mesh and min over (t, triangle index) = min over (t, object position, scan rank): the winner of the reference's loop over the objects with its strict '<' (cpu:554).
-// real[k]: index into `meshes` of the k-th mesh with triangles, in object order.  Fills the combined arrays and `out` (which points into them).
+// real[k]: index into `meshes` of the k-th mesh with triangles, in object order.  Fills the combined arrays and f.m (which points into them).
 struct Forest {
     std::vector<float> verts, arr;
     std::vector<int32_t> idx;

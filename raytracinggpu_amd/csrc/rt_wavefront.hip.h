@@ -67,8 +67,8 @@ __device__ __forceinline__ bool wq_live(int w0, int epoch, int nonce) {
 // A BATCH of frames in one launch chain (rt_render_device_batch): the items of a chain are (frame f, pixel slot) pairs -- the machinery that traces several samples of a pixel
 // as parallel items (n_paths = n_px x items per pixel), with a camera, a seed and an output buffer PER FRAME instead of per-sample colours to reduce.  A rank that renders a
 // small share of a frame (1/8 of 1920x1080 = 0.26 Mpixel) fills the chip with K frames' worth of paths per launch instead of K chains on K streams.  Only wf_advance reads it.
-// The descriptors live in device memory (WfState::batch; written by batch_store_kernel on the caller's stream before the chain starts) and are read with a wave-uniform
-// index through the scalar cache: as kernel arguments a dynamically indexed array is copied to scratch by the compiler (2 KB per lane, measured).
+// The descriptors live in device memory (WfState::batch: one copy per sub-frame, written by batch_store_kernel at the head of that sub-frame's own chain) and are read with
+// a wave-uniform index: as kernel arguments a dynamically indexed array is copied to scratch by the compiler (2 KB per lane, measured).
 constexpr int kMaxBatch = 16;
 struct BatchFrame { float camx, camy, camz, z; uint32_t seed; int pad; float4 *out; };
 struct Batch { int n; int pad; BatchFrame f[kMaxBatch]; };
@@ -128,7 +128,7 @@ __device__ __forceinline__ void wf_decode(const WfState &st, const Frame &fr, in
 struct SphereHit { float tA; int winA; float tB; int winB; };
 
 // ray/sphere tests of Scene::intersect_all for one ray, split at the mesh's slot so that the strict '<'
-// of cpu:554 can be replayed later as  A, mesh, B  (see wf_advance).
+// of cpu:554 can be replayed later as  A, mesh, B  (wf_path, rt_path.hip.h: scenes with at most one mesh; wf_advance uses spheres_near2 below).
 __device__ __forceinline__ SphereHit spheres_split(const Scene &sc, f3 O, f3 u) {
     SphereHit h; h.tA = 1e9f; h.winA = -1; h.tB = 1e9f; h.winB = -1;
     const int nb = sc.mesh_slot < 0 ? sc.n_spheres : sc.mesh_slot;
@@ -140,28 +140,10 @@ __device__ __forceinline__ SphereHit spheres_split(const Scene &sc, f3 O, f3 u) 
     }
     return h;
 }
-// the same for the two rays that leave one point (origins equal bit for bit): the origin part of every sphere test is shared
-__device__ __forceinline__ void spheres_split2(const Scene &sc, f3 O, f3 uy, bool on_y, f3 ux, bool on_x, SphereHit &hy, SphereHit &hx) {
-    hy.tA = 1e9f; hy.winA = -1; hy.tB = 1e9f; hy.winB = -1;
-    hx = hy;
-    const int nb = sc.mesh_slot < 0 ? sc.n_spheres : sc.mesh_slot;
-    for (int k = 0; k < sc.n_spheres; ++k) {
-        const SphereOrigin so = sphere_origin(sc.sph[k], O);
-        float t;
-        if (on_y && sphere_dir(sc.sph[k], so, O, uy, t)) {
-            if (k < nb) { if (t < hy.tA) { hy.tA = t; hy.winA = k; } }
-            else        { if (t < hy.tB) { hy.tB = t; hy.winB = k + 1; } }
-        }
-        if (on_x && sphere_dir(sc.sph[k], so, O, ux, t)) {
-            if (k < nb) { if (t < hx.tA) { hx.tA = t; hx.winA = k; } }
-            else        { if (t < hx.tB) { hx.tB = t; hx.winB = k + 1; } }
-        }
-    }
-}
 __device__ __forceinline__ int wf_pack_wins_path(const SphereHit &h) { return ((h.winA + 1) & 31) << PF_WINS_SHIFT | ((h.winB + 1) & 31) << (PF_WINS_SHIFT + 5); }
 
-// Scene::intersect_all's running minimum over the SPHERES alone, for the two rays that leave one point: (t, object id) of the nearest sphere with the strict '<'
-// of cpu:554 (the earliest of equal t).  The meshes join when the traversal is back: a triangle at tm replaces the sphere iff tm < t, or tm == t and the
+// Scene::intersect_all's running minimum over the SPHERES alone, for the two rays that leave one point (origins equal bit for bit: the origin part of every sphere test
+// is shared): (t, object id) of the nearest sphere with the strict '<' of cpu:554 (the earliest of equal t).  The meshes join when the traversal is back: a triangle at tm replaces the sphere iff tm < t, or tm == t and the
 // triangle's mesh comes before the sphere in Scene::objects -- the lexicographic minimum over (t, position) IS what the reference's loop keeps.
 struct SphereNear { float t; int obj; };
 __device__ __forceinline__ void spheres_near2(const Scene &sc, f3 O, f3 uy, bool on_y, f3 ux, bool on_x, SphereNear &hy, SphereNear &hx) {
