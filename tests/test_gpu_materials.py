@@ -211,3 +211,56 @@ def test_launcher_renders_the_material_scenes_through_the_cpp_host_api(tmp_path,
     assert r.returncode == 0, r.stderr
     _, rgb8, _ = osc.render(512, 512, 1, 3)
     np.testing.assert_array_equal(np.array(Image.open(tmp_path / "two.png").convert("RGB")), rgb8)
+
+
+def test_sixteen_objects_three_meshes_every_material_and_the_rare_traversal_paths(oracle, cat_golden, monkeypatch):
+    """The full house: 16 objects (RT_MAX_OBJECTS) -- thirteen spheres (the demo scene's mirror, glass, nested glass and walls + three more) and three meshes at positions 0, 8 and 15: a GLASS
+    single-leaf mesh of three triangles (its root is a leaf hanging directly below a synthetic node), a mirror soup with duplicated and degenerate triangles, the diffuse cat.
+    Frames of 5 bounces equal the oracle's in every channel and ray count through the default pipeline, the per-lane walk, the LDS-staged work-stack kernel, and the work-stack
+    kernel with a stack so small that popped pairs are walked serially (RT_TRAVQ_CAP=128: the drain crosses the synthetic nodes); 4 samples per pixel as parallel items too."""
+    from raytracinggpu_amd import hostlib
+    from .test_gpu_parity import _synthetic_mesh
+    v, t = np.asarray(cat_golden["vertices"], np.float32), np.asarray(cat_golden["tri_obj_order"], np.int32)
+    v3, t3 = _synthetic_mesh("three_triangles", np.random.default_rng(1))
+    v3 = (v3 * np.float32(0.6) + np.float32([-14, 4, 14])).astype(np.float32)
+    vs, ts = _synthetic_mesh("soup", np.random.default_rng(3))
+    vs = (vs * np.float32(0.35) + np.float32([15, 2, 10])).astype(np.float32)
+    spheres = rt.scenes.spheres("demo10") + [((-8.0, -6.0, 18.0), 3.0, (0.8, 0.8, 0.1)), ((6.0, 12.0, 5.0), 2.5, (0.1, 0.1, 0.1), 1, 1.0, 1.0),
+                                             ((0.0, -7.0, 28.0), 2.0, (1.0, 1.0, 1.0), 0, 1.3, 1.0)]   # 4 demo spheres + 6 walls + a diffuse, a mirror and a glass ball: 13
+    geo = [(v3, t3, (0.9, 0.9, 0.9), 0, 1.5, 1.0, 0), (vs, ts, (0.2, 0.7, 0.3), 1, 1.0, 1.0, 8), (v, t, rt.scenes.CAT_ALBEDO, 0, 1.0, 1.0, 15)]
+    meshes = []
+    for vv, tt, alb, mir, ni, no, slot in geo:
+        d = hostlib.build_mesh(vv, tt, albedo=alb, object_slot=slot)
+        d.update(mirror=mir, in_refraction_index=ni, out_refraction_index=no)
+        meshes.append(d)
+    osc = oracle.Scene()
+    it, n_obj = iter(spheres), len(spheres) + len(geo)
+    slots = {g[6]: g for g in geo}
+    for pos in range(n_obj):
+        if pos in slots:
+            vv, tt, alb, mir, ni, no, _ = slots[pos]
+            osc.add_mesh(oracle.Mesh.from_arrays(vv, tt, albedo=alb).set_material(mir, ni, no).build_bvh())
+        else:
+            s = next(it)
+            osc.add_sphere(s[0], s[1], s[2], *(s[3:] if len(s) > 3 else ()))
+    W, H = 416, 240
+    exp5, _, _ = osc.render(W, H, 1, 5, want_rgb8=False)
+    exp4, _, _ = osc.render(W, H, 4, 2, want_rgb8=False)
+    assert n_obj == 16
+    for env, variants in (({}, ("auto", "wavefront", "lds_all", "wavefront_lds")), ({"RT_TRAVQ_CAP": "128"}, ("auto",)), ({"RT_TRAVQ_CAP": "128", "RT_TRAVQ_QW": "0"}, ("auto",))):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        c = rt.Context(0)
+        for k_ in env:
+            monkeypatch.delenv(k_)
+        c.scene_upload(spheres, meshes)
+        for variant in variants:
+            _frames_equal(c.render(rt.make_params(W, H, 1, 5, variant=variant, **rt.scenes.CPU_LAUNCHER)), exp5)
+        _frames_equal(c.render(rt.make_params(W, H, 4, 2, **rt.scenes.CPU_LAUNCHER)), exp4)
+        if env:
+            assert c.count_work(rt.make_params(W, H, 1, 5, **rt.scenes.CPU_LAUNCHER), detail=True)["steps"]["serial_drains"] > 0
+        c.close()
+    with pytest.raises(rt.RtError) as e:                              # a seventeenth object
+        c = rt.Context(0)
+        c.scene_upload(spheres + [((0, 0, 0), 1, (1, 1, 1))], meshes)
+    assert e.value.code == -1
