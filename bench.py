@@ -9,7 +9,10 @@ One "step" = one frame of the workload: the cat scene of cpu_launcher.cpp (walls
 1920x1080, num_rays=1, num_bounce=3 (CPU convention: 4 segments), rendered by the HIP kernel through the
 C-ABI with the scene already resident in HBM.  With N > 1 the frame is split into interleaved 8-row tiles
 (tile k -> rank k mod N), every rank renders its tiles, and ONE RCCL gather per frame brings the float4
-tiles to rank 0, which de-interleaves them (all inside the timed region).  Total work is fixed => "strong".
+tiles to the root, which de-interleaves them (all inside the timed region).  Total work is fixed => "strong".
+A rank whose share is small (<= 1.3 Mpixel: every share of the 1080p frame) renders N consecutive frames of its
+share as ONE launch chain (rt_render_device_batch) and, by default, ships them in one gather per batch; the line
+then carries the single-frame latency beside the throughput (config.frame_latency_ms, config.batch, config.exchange).
 
 Rank 0 prints one JSON line.  `value` = rays traced per second (1 ray = 1 Scene::intersect_all call:
 primary, shadow or bounce segment; counted exactly by the kernel in the framebuffer's .w channel).
