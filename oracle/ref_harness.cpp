@@ -62,14 +62,14 @@ static void flatten(const BVH *cur, std::vector<float> &arr, size_t &n, size_t i
 
 static const char *OBJ_PATH = "cadnav.com_model/Models_F0202A090/cat.obj";   /* cpu_launcher.cpp:681 */
 
-static void add_walls(Scene &s) {   /* cpu_launcher.cpp:673-678 */
-    s.addObject(new Sphere(Vector(0, 0, -1000), 940, Vector(0., 1., 0.)));
-    s.addObject(new Sphere(Vector(0, -1000, 0), 990, Vector(0., 0., 1.)));
-    s.addObject(new Sphere(Vector(0, 1000, 0), 940, Vector(1., 0., 0.)));
-    s.addObject(new Sphere(Vector(-1000, 0, 0), 940, Vector(0., 1., 1.)));
-    s.addObject(new Sphere(Vector(1000, 0, 0), 940, Vector(1., 1., 0.)));
-    s.addObject(new Sphere(Vector(0, 0, 1000), 940, Vector(1., 0., 1.)));
+/* the six wall spheres of cpu_launcher.cpp:673-678 as data: centre, radius, albedo, in the reference's order */
+static const float WALLS[6][7] = {{0, 0, -1000, 940, 0, 1, 0}, {0, -1000, 0, 990, 0, 0, 1}, {0, 1000, 0, 940, 1, 0, 0},
+                                  {-1000, 0, 0, 940, 0, 1, 1}, {1000, 0, 0, 940, 1, 1, 0}, {0, 0, 1000, 940, 1, 0, 1}};
+static void add_wall(Scene &s, int k) {
+    const float *w = WALLS[k];
+    s.addObject(new Sphere(Vector(w[0], w[1], w[2]), w[3], Vector(w[4], w[5], w[6])));
 }
+static void add_walls(Scene &s, int first = 0, int last = 6) { for (int k = first; k < last; ++k) add_wall(s, k); }
 static void add_demo(Scene &s) {    /* the commented-out objects, cpu_launcher.cpp:669-672 */
     s.addObject(new Sphere(Vector(0, 0, 0), 10, Vector(0., 0., 0.), 0, 1.5, 1));
     s.addObject(new Sphere(Vector(-20, 0, 0), 10, Vector(0., 0., 0.), 1));
@@ -100,13 +100,9 @@ static bool add_material_scene(Scene &s, const std::string &scene) {
     if (scene == "cpu_mirror") { add_walls(s); TriangleMesh *m = load_cat(); m->mirror = 1; s.addObject(m); return true; }
     if (scene == "cpu_glass") { add_walls(s); TriangleMesh *m = load_cat(); m->in_refraction_index = 1.5; m->out_refraction_index = 1; s.addObject(m); return true; }
     if (scene == "two_cats") {          /* objects: 3 walls, cat (diffuse), 3 walls, second cat (mirror) -- a mesh in the MIDDLE of the order and one at the end */
-        s.addObject(new Sphere(Vector(0, 0, -1000), 940, Vector(0., 1., 0.)));
-        s.addObject(new Sphere(Vector(0, -1000, 0), 990, Vector(0., 0., 1.)));
-        s.addObject(new Sphere(Vector(0, 1000, 0), 940, Vector(1., 0., 0.)));
+        add_walls(s, 0, 3);
         s.addObject(load_cat());
-        s.addObject(new Sphere(Vector(-1000, 0, 0), 940, Vector(0., 1., 1.)));
-        s.addObject(new Sphere(Vector(1000, 0, 0), 940, Vector(1., 1., 0.)));
-        s.addObject(new Sphere(Vector(0, 0, 1000), 940, Vector(1., 0., 1.)));
+        add_walls(s, 3, 6);
         TriangleMesh *b = load_cat2(); b->mirror = 1; s.addObject(b);
         return true;
     }
