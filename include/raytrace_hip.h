@@ -183,8 +183,8 @@ int rt_scene_upload(rt_ctx *ctx, const rt_sphere *spheres, int n_spheres, const 
  * (cpu:279); inside the library the trees hang below synthetic nodes whose boxes are the unions of their children, the triangles
  * are stored mesh after mesh in object order, and one traversal finds the minimum over (t, object position, scan rank) -- the
  * result of the reference's loop over the objects.  A mesh without triangles stays an object that is never hit (missing OBJ,
- * cpu:322-325).  With more than one mesh object in the scene: wavefront variants only (RT_ERR_UNSUPPORTED otherwise); with more than one mesh that has triangles the per-mesh
- * operations -- rt_mesh_set_normals, rt_mesh_rebuild* -- are refused (RT_ERR_UNSUPPORTED); rt_mesh_transform moves them all. */
+ * cpu:322-325).  Every kernel variant renders such scenes.  With more than one mesh that has triangles the per-mesh operations -- rt_mesh_set_normals, rt_mesh_rebuild* --
+ * are refused (RT_ERR_UNSUPPORTED); rt_mesh_transform moves them all. */
 int rt_scene_upload_meshes(rt_ctx *ctx, const rt_sphere *spheres, int n_spheres, const rt_mesh *meshes, int n_meshes,
                            const rt_light *light, const rt_camera *camera);
 

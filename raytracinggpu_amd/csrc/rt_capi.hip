@@ -522,9 +522,6 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
     rtk::Scene scn = ctx->scene;                                      // per-launch copy: a pose moves the camera
     fr.cam_mode = 0; fr.inv_n = 1.f;
     const bool wf_family = variant == RT_VARIANT_WAVEFRONT || variant == RT_VARIANT_WAVEFRONT_LDS || variant == RT_VARIANT_WAVEFRONT_QUEUE || variant == RT_VARIANT_PATH;
-    // several TriangleMesh objects: the object-order replay across meshes lives in wf_advance (rt_wavefront.hip.h); the other kernels keep the reference programs' one mesh
-    if (scn.n_meshes > 1 && !(wf_family && variant != RT_VARIANT_PATH))
-        return fail(ctx, RT_ERR_UNSUPPORTED, "a scene with %d meshes needs a wavefront variant (auto, wavefront, wavefront_lds, wavefront_queue, lds_*)", scn.n_meshes);
     if (batch && !(wf_family && variant != RT_VARIANT_PATH))
         return fail(ctx, RT_ERR_UNSUPPORTED, "a batch of frames needs a wavefront variant (auto, wavefront, wavefront_lds, wavefront_queue, lds_*)");
     if (scn.nrm != nullptr && !wf_family)

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void kat_mesh_kernel(const Scene sc, const flo
         if (route == 1) {
             Work wk;
             f3 Nr;
-            hit = mesh_intersect<false>(sc, O, u, tri_tmin, t, Nr, wk);
+            int tri_; hit = mesh_intersect<false>(sc, O, u, tri_tmin, t, Nr, tri_, wk);
             if (hit) N = normalize(Nr);
         } else if (sc.n_nodes > 0) {
             bool dec;

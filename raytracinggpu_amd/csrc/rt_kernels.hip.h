@@ -278,9 +278,11 @@ __device__ __forceinline__ bool sphere_test(const Sphere &s, f3 O, f3 u, float &
 // TriangleMesh::intersect, cpu:277-311.  Returns true iff some triangle was accepted
 // (SURVEY H4); t/Nraw are the nearest accepted t and its unnormalised e1 x e2.
 template <bool STATS>
-__device__ __forceinline__ bool mesh_intersect(const Scene &sc, f3 O, f3 u, float tri_tmin, float &t_out, f3 &N_out, Work &wk) {
+__device__ __forceinline__ bool mesh_intersect(const Scene &sc, f3 O, f3 u, float tri_tmin, float &t_out, f3 &N_out, int &tri_out, Work &wk) {
     float t_min = 1e9f;   // INF (1e9+9) narrowed to float, cpu:283
     bool any = false;
+    int tri_best = 0;     // the winning triangle (visit order): with several meshes in the tree it names the mesh -- the walk reaches the meshes in object order, so the strict '<'
+                          // below keeps, among equal t, the earliest object and inside it the earliest triangle of the reference's scan
     f3 Nb = mk(0, 0, 0);
     int node = 0;
     const int n_nodes = sc.n_nodes;
@@ -325,7 +327,7 @@ __device__ __forceinline__ bool mesh_intersect(const Scene &sc, f3 O, f3 u, floa
                     }
                     const float t = dot(AO, N) / det;   // exact: t is compared and returned
                     if (!(t > 0)) continue;
-                    if (t > tri_tmin && t < t_min) { t_min = t; Nb = N; any = true; }   // cpu:301
+                    if (t > tri_tmin && t < t_min) { t_min = t; Nb = N; any = true; tri_best = i; }   // cpu:301
                 }
             }
             node = node + 1;
@@ -335,30 +337,48 @@ __device__ __forceinline__ bool mesh_intersect(const Scene &sc, f3 O, f3 u, floa
     }
     t_out = t_min;
     N_out = Nb;
+    tri_out = tri_best;
     return any;
 }
 
 // Scene::intersect_all, cpu:545-564.  Objects are visited in insertion order with a
 // strict '<' (exact-tie behaviour); the winner's normal is evaluated once at the end
 // (it is a pure function of the winner, so this is bit-identical to cpu:524-525/308).
+// the mesh that holds triangle `tri` (visit order): wave-uniform loop over the scene's meshes, no iteration for the usual single mesh
+__device__ __forceinline__ int mesh_of_tri(const Scene &sc, int tri) {
+    int m = 0;
+    for (int k = 1; k < sc.n_meshes; ++k) m = (tri >= sc.mesh[k].tri_begin) ? k : m;
+    return m;
+}
+__device__ __forceinline__ int mesh_obj_of_tri(const Scene &sc, int tri) {   // ... and its position in Scene::objects
+    const int mw = mesh_of_tri(sc, tri);
+    int mobj = sc.mesh[0].obj;
+    for (int k = 1; k < sc.n_meshes; ++k) mobj = (k == mw) ? sc.mesh[k].obj : mobj;
+    return mobj;
+}
+// Scene::intersect_all's running minimum with the strict '<' of cpu:554 is the lexicographic minimum over (t, position in Scene::objects).  Given the spheres' own winner
+// (t_s, object id; -1 = none) and the meshes' (t_m, object id of the winning triangle's mesh): does the mesh win?  A tie goes to whichever comes first.
+__device__ __forceinline__ bool mesh_beats_sphere(float t_s, int obj_s, float t_m, int obj_m) { return (obj_s > obj_m) ? !(t_s < t_m) : (t_m < t_s); }
+
 template <bool STATS>
 __device__ __forceinline__ bool intersect_all(const Scene &sc, f3 O, f3 u, float tri_tmin, f3 &P, f3 &N, int &objectId, Work &wk) {
     float t_min = 1e9f;
     int id_min = -1;
     int sph_min = -1;
     f3 Nmesh = mk(0, 0, 0);
-    // the lock-step family renders scenes with at most ONE TriangleMesh (rt_capi.hip refuses the others for these variants): objects in insertion order, the mesh at its slot
-    int si = 0;
-    for (int obj = 0; obj < sc.n_objects; ++obj) {
-        if (obj == sc.mesh_slot) {
-            float t; f3 Nr;
-            if (mesh_intersect<STATS>(sc, O, u, tri_tmin, t, Nr, wk) && t < t_min) { t_min = t; id_min = obj; sph_min = -1; Nmesh = Nr; }
-            continue;
-        }
-        const Sphere &s = sc.sph[si++];
+    // the spheres in insertion order (strict '<': the earliest of equal t), then the mesh(es): the lexicographic minimum over (t, position) either way round
+    for (int k = 0; k < sc.n_spheres; ++k) {
+        const Sphere &s = sc.sph[k];
         float t;
         if (!sphere_test(s, O, u, t)) continue;
-        if (t < t_min) { t_min = t; id_min = obj; sph_min = si - 1; }
+        if (t < t_min) { t_min = t; id_min = s.obj; sph_min = k; }
+    }
+    if (sc.mesh_slot >= 0 && sc.n_nodes > 0) {
+        float t; f3 Nr; int tri;
+        if (mesh_intersect<STATS>(sc, O, u, tri_tmin, t, Nr, tri, wk)) {
+            const int mobj = mesh_obj_of_tri(sc, tri);
+            if (mesh_beats_sphere(t_min, id_min, t, mobj)) { t_min = t; id_min = mobj; sph_min = -1; Nmesh = Nr; }
+        }
     }
     P = O + t_min * u;   // cpu:560 (also on a miss)
     objectId = id_min;
@@ -373,12 +393,6 @@ __device__ __forceinline__ bool intersect_all(const Scene &sc, f3 O, f3 u, float
 }
 
 struct Material { float ar, ag, ab; int mirror; float n_in, n_out; };
-// the mesh that holds triangle `tri` (visit order): wave-uniform loop over the scene's meshes, no iteration for the usual single mesh
-__device__ __forceinline__ int mesh_of_tri(const Scene &sc, int tri) {
-    int m = 0;
-    for (int k = 1; k < sc.n_meshes; ++k) m = (tri >= sc.mesh[k].tri_begin) ? k : m;
-    return m;
-}
 // Geometry's fields (cpu:106-118) of object `obj`, sphere or mesh: Scene::getColor reads them for whichever object was hit (cpu:573-606).  (Callers use a
 // part of the record: the loads of the rest are dropped.)
 __device__ __forceinline__ Material material_of(const Scene &sc, int obj) {

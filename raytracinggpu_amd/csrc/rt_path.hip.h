@@ -225,21 +225,22 @@ __global__ __launch_bounds__(kQBlock, 2) void wf_path(const Scene sc, const Fram
                         const float4 r0 = tabC[lane];
                         const float2 r1 = tabD[lane];
                         f3 O = mk(r0.x, r0.y, r0.z), u = mk(r0.w, r1.x, r1.y);
-                        // Scene::intersect_all's running minimum replayed in object order: spheres before the mesh, mesh, spheres after
+                        // Scene::intersect_all's running minimum (strict '<' in object order, cpu:554) = the lexicographic minimum over (t, position in Scene::objects): the spheres'
+                        // own winner was decided at emission, the meshes' by the traversal; between the two a tie goes to the earlier object (rt_kernels.hip.h mesh_beats_sphere)
                         float t_min = S.x;
                         int win = ((F.x >> PF_WINS_SHIFT) & 31) - 1, tri_win = -1;
                         if (F.x & PF_MESHY) {
                             const unsigned long long m = best[lane];
                             if (m != WF_NOHIT) {
                                 const float tm = __uint_as_float((unsigned int)(m >> 32));
-                                if (tm < t_min) { t_min = tm; win = sc.mesh_slot; tri_win = (int)(unsigned int)m; }
+                                const int mobj = mesh_obj_of_tri(sc, (int)(unsigned int)m);
+                                if (mesh_beats_sphere(t_min, win, tm, mobj)) { t_min = tm; win = mobj; tri_win = (int)(unsigned int)m; }
                             }
                         }
-                        if (S.y < t_min) { t_min = S.y; win = ((F.x >> (PF_WINS_SHIFT + 5)) & 31) - 1; }
                         if (win >= 0) {                                       // a miss is black (cpu:571): nothing to emit
                             const f3 Pt = O + t_min * u;                      // cpu:560
                             f3 N;
-                            if (win == sc.mesh_slot && sc.nrm != nullptr) {   // get_smooth_normal, realtime_render.cu:221-245
+                            if (tri_win >= 0 && sc.nrm != nullptr) {          // get_smooth_normal, realtime_render.cu:221-245
                                 PQ_CHECK(tri_win >= 0 && tri_win < sc.n_tris, 2, tri_win = 0);
                                 const float4 q0 = sc.tri[3 * tri_win], q1 = sc.tri[3 * tri_win + 1], q2 = sc.tri[3 * tri_win + 2];
                                 const f3 A = mk(q0.x, q0.y, q0.z), e1 = mk(q0.w, q1.x, q1.y), e2 = mk(q1.z, q1.w, q2.x), Nt = mk(q2.y, q2.z, q2.w);
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(kQBlock, 2) void wf_path(const Scene sc, const Fram
                                 const float alpha = 1 - beta - gamma;
                                 const float4 na = sc.nrm[3 * tri_win], nb = sc.nrm[3 * tri_win + 1], nc = sc.nrm[3 * tri_win + 2];
                                 N = normalize((alpha * mk(na.x, na.y, na.z) + beta * mk(nb.x, nb.y, nb.z)) + gamma * mk(nc.x, nc.y, nc.z));
-                            } else if (win == sc.mesh_slot) {
+                            } else if (tri_win >= 0) {
                                 PQ_CHECK(tri_win >= 0 && tri_win < sc.n_tris, 2, tri_win = 0);
                                 const float4 q2 = sc.tri[3 * tri_win + 2];
                                 N = normalize(mk(q2.y, q2.z, q2.w));          // cpu:308
@@ -411,14 +412,14 @@ __global__ __launch_bounds__(kQBlock, 2) void wf_path(const Scene sc, const Fram
                     const int slot = k * P + lane;
                     bool need = false;
                     if (on) {
-                        const SphereHit h = spheres_split(sc, O, u);                     // Sphere::intersect x n (cpu:512-527)
+                        const SphereNear h = spheres_near1(sc, O, u);                   // Sphere::intersect x n (cpu:512-527)
                         tabC[slot] = make_float4(O.x, O.y, O.z, u.x);
                         tabD[slot] = make_float2(u.y, u.z);
                         if (k == 0) {
-                            S.x = h.tA; S.y = h.tB;
-                            F.x = (F.x & ~(1023 << PF_WINS_SHIFT)) | wf_pack_wins_path(h);
+                            S.x = h.t;
+                            F.x = (F.x & ~(1023 << PF_WINS_SHIFT)) | (((h.obj + 1) & 31) << PF_WINS_SHIFT);
                         } else {
-                            S.z = h.tB < h.tA ? h.tB : h.tA;                             // only the value of the shadow ray's nearest hit matters
+                            S.z = h.t;                                                   // only the value of the shadow ray's nearest hit matters
                         }
                         if (have_mesh) {                                                 // root-box test (cpu:279)
                             if (STATS) wk.box++;

@@ -36,9 +36,10 @@ struct PFrame {
 
 constexpr int kPBlock = 256;
 
-// spheres [s0, s1) of Scene::sph with the strict '<' of cpu:554; object ids follow insertion order
-__device__ __forceinline__ void spheres_range(const Scene &sc, int s0, int s1, int obj0, f3 O, f3 u, float &t_min, int &win) {
-    for (int k = s0; k < s1; ++k) {
+// every sphere of Scene::sph in insertion order with the strict '<' of cpu:554 (the earliest of equal t); win = its position in Scene::objects.  The mesh(es) join after the
+// traversal: intersect_all's running minimum is the lexicographic minimum over (t, position), whichever way round it is formed (mesh_beats_sphere)
+__device__ __forceinline__ void spheres_all(const Scene &sc, f3 O, f3 u, float &t_min, int &win) {
+    for (int k = 0; k < sc.n_spheres; ++k) {
         const Sphere &s = sc.sph[k];
         const f3 C = mk(s.cx, s.cy, s.cz);
         const f3 OC = O - C;
@@ -50,7 +51,7 @@ __device__ __forceinline__ void spheres_range(const Scene &sc, int s0, int s1, i
         const float t1 = b - sq, t2 = b + sq;                      // cpu:516-517
         if (t2 < 0) continue;
         const float t = t1 < 0 ? t2 : t1;
-        if (t < t_min) { t_min = t; win = obj0 + (k - s0); }
+        if (t < t_min) { t_min = t; win = s.obj; }
     }
 }
 
@@ -67,7 +68,6 @@ __global__ __launch_bounds__(kPBlock) void render_persistent(const Scene sc, con
     const f3 Cam = mk(sc.camx, sc.camy, sc.camz);
     const int n_nodes = sc.n_nodes;
     const int mesh_slot = sc.mesh_slot;
-    const int n_sph_before = mesh_slot < 0 ? sc.n_spheres : mesh_slot;   // spheres with object id < mesh_slot
 
     // ---- lane state ----
     int phase = PH_NEXT;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kPBlock) void render_persistent(const Scene sc, con
     f3 O = mk(0, 0, 0), u = mk(0, 0, 1);
     RayInv ri = ray_inv(u);
     float t_min = 1e9f; int win = -1;
-    int node = 0, ti = 0, te = 0; float tm = 1e9f; f3 Nb = mk(0, 0, 0); bool many = false;
+    int node = 0, ti = 0, te = 0; float tm = 1e9f; f3 Nb = mk(0, 0, 0); bool many = false; int tbest = 0;   // tbest: the winning triangle (names its mesh: rt_kernels.hip.h mesh_obj_of_tri)
     f3 Ps = mk(0, 0, 0), Ns = mk(0, 0, 0); int sid = 0;             // surface being shaded (shadow query in flight)
     float refr = 1.f; uint64_t ids = 0; uint32_t dmask = 0;
     f3 total = mk(0, 0, 0); float rays = 0.f;
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(kPBlock) void render_persistent(const Scene sc, con
                         }
                         if (ok) {
                             const float t = dot(AO, N) / det;
-                            if (t > 0 && t > fr.tri_tmin && t < tm) { tm = t; Nb = N; many = true; }   // cpu:235,301
+                            if (t > 0 && t > fr.tri_tmin && t < tm) { tm = t; Nb = N; many = true; tbest = i; }   // cpu:235,301
                         }
                     }
                 }
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(kPBlock) void render_persistent(const Scene sc, con
                 rays += 1.f;
                 if (STATS) wk.rays++;
                 t_min = 1e9f; win = -1;                                  // cpu:546-547
-                spheres_range(sc, 0, n_sph_before, 0, O, u, t_min, win);
+                spheres_all(sc, O, u, t_min, win);
                 tm = 1e9f; many = false;                                 // cpu:283
                 node = 0;
                 ri = ray_inv(u);
@@ -169,14 +169,14 @@ __global__ __launch_bounds__(kPBlock) void render_persistent(const Scene sc, con
             }
         } else if (sel == PH_HIT) {
             if (phase == PH_HIT) {
-                if (many && tm < t_min) { t_min = tm; win = mesh_slot; } // the mesh's turn in cpu:549-558
-                if (mesh_slot >= 0) spheres_range(sc, n_sph_before, sc.n_spheres, mesh_slot + 1, O, u, t_min, win);
+                bool mesh_won = false;
+                if (many) { const int mobj = mesh_obj_of_tri(sc, tbest); if (mesh_beats_sphere(t_min, win, tm, mobj)) { t_min = tm; win = mobj; mesh_won = true; } }   // the meshes' turn in cpu:549-558
                 if (win < 0) {
                     phase = PH_NEXT;                                     // miss: black (cpu:571)
                 } else {
                     const f3 P = O + t_min * u;                          // cpu:560
                     f3 N;
-                    if (win == mesh_slot) N = normalize(Nb);             // cpu:308
+                    if (mesh_won) N = normalize(Nb);                     // cpu:308
                     else {
                         N = normalize(P - sphere_centre_of(sc, win));    // cpu:524-525
                     }
@@ -219,8 +219,7 @@ __global__ __launch_bounds__(kPBlock) void render_persistent(const Scene sc, con
             }
         } else if (sel == PH_SHADE) {
             if (phase == PH_SHADE) {
-                if (many && tm < t_min) { t_min = tm; win = mesh_slot; }
-                if (mesh_slot >= 0) spheres_range(sc, n_sph_before, sc.n_spheres, mesh_slot + 1, O, u, t_min, win);
+                if (many && tm < t_min) t_min = tm;                      // (a shadow ray needs the nearest hit's value only: ties do not matter)
                 const f3 Pp = O + t_min * u;                             // cpu:560 (O is P_adjusted)
                 float l = 0.f;
                 if (!(norm2(Pp - O) <= norm2(L - O))) {                  // cpu:615

@@ -49,7 +49,7 @@ constexpr int PF_XSPHERE = 1 << 26;                         // the X ray is bloc
 constexpr unsigned long long WF_NOHIT = ~0ull;
 // the wavefront pipeline keeps the path's flag word in its continuation (Y) slot's queue record; bits 0..15 as above, then:
 constexpr int PQ_WIN_SHIFT = 16;                            // 5 bits: object id + 1 of the Y ray's nearest sphere (0 = none); its t is the record's last word
-constexpr int PQ_WINB = 1 << 21;                            // (rt_path.hip.h only) that sphere comes AFTER the mesh in object order; wf_advance compares the object ids when the query is closed
+// (bit 21 is free: until round 5 it said whether that sphere comes after the mesh in object order; the object ids are compared when the query is closed)
 constexpr int PQ_XSPHERE = 1 << 22;                         // PF_XSPHERE of this record
 constexpr int PQ_REFR_SHIFT = 23;                           // 6 bits: Ray::refraction_index of the Y ray: 0 = 1.0, else (object id + 1) << 1 | (0: that object's n_in, 1: its n_out)
 constexpr int PQ_TRAV = 1 << 29;                            // (either slot) the record's ray passed the mesh's root box: the traversal launch whose number (WfState::epoch) equals the
@@ -125,27 +125,18 @@ __device__ __forceinline__ void wf_decode(const WfState &st, const Frame &fr, in
     valid = px < fr.W && lrow < fr.n_rows;
 }
 
-struct SphereHit { float tA; int winA; float tB; int winB; };
-
-// ray/sphere tests of Scene::intersect_all for one ray, split at the mesh's slot so that the strict '<'
-// of cpu:554 can be replayed later as  A, mesh, B  (wf_path, rt_path.hip.h: scenes with at most one mesh; wf_advance uses spheres_near2 below).
-__device__ __forceinline__ SphereHit spheres_split(const Scene &sc, f3 O, f3 u) {
-    SphereHit h; h.tA = 1e9f; h.winA = -1; h.tB = 1e9f; h.winB = -1;
-    const int nb = sc.mesh_slot < 0 ? sc.n_spheres : sc.mesh_slot;
-    for (int k = 0; k < sc.n_spheres; ++k) {
-        float t;
-        if (!sphere_test(sc.sph[k], O, u, t)) continue;
-        if (k < nb) { if (t < h.tA) { h.tA = t; h.winA = k; } }
-        else        { if (t < h.tB) { h.tB = t; h.winB = k + 1; } }   // object id = sphere index + 1 after the mesh
-    }
-    return h;
-}
-__device__ __forceinline__ int wf_pack_wins_path(const SphereHit &h) { return ((h.winA + 1) & 31) << PF_WINS_SHIFT | ((h.winB + 1) & 31) << (PF_WINS_SHIFT + 5); }
-
 // Scene::intersect_all's running minimum over the SPHERES alone, for the two rays that leave one point (origins equal bit for bit: the origin part of every sphere test
 // is shared): (t, object id) of the nearest sphere with the strict '<' of cpu:554 (the earliest of equal t).  The meshes join when the traversal is back: a triangle at tm replaces the sphere iff tm < t, or tm == t and the
 // triangle's mesh comes before the sphere in Scene::objects -- the lexicographic minimum over (t, position) IS what the reference's loop keeps.
 struct SphereNear { float t; int obj; };
+__device__ __forceinline__ SphereNear spheres_near1(const Scene &sc, f3 O, f3 u) {   // ... for one ray (wf_path)
+    SphereNear h; h.t = 1e9f; h.obj = -1;
+    for (int k = 0; k < sc.n_spheres; ++k) {
+        float t;
+        if (sphere_test(sc.sph[k], O, u, t) && t < h.t) { h.t = t; h.obj = sc.sph[k].obj; }
+    }
+    return h;
+}
 __device__ __forceinline__ void spheres_near2(const Scene &sc, f3 O, f3 uy, bool on_y, f3 ux, bool on_x, SphereNear &hy, SphereNear &hx) {
     hy.t = 1e9f; hy.obj = -1;
     hx = hy;
@@ -616,10 +607,8 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
                 const unsigned long long m = st.M[i];
                 if (m != WF_NOHIT) {
                     const float tm = __uint_as_float((unsigned int)(m >> 32));
-                    const int mw = mesh_of_tri(sc, (int)(unsigned int)m);   // the meshes' own winner: minimum over (t, object position, scan rank) by the order the triangles are stored in
-                    int mobj = sc.mesh[0].obj;
-                    for (int k = 1; k < sc.n_meshes; ++k) mobj = (k == mw) ? sc.mesh[k].obj : mobj;
-                    if ((win > mobj) ? !(t_min < tm) : (tm < t_min)) { t_min = tm; win = mobj; tri_win = (int)(unsigned int)m; }   // a tie goes to whichever comes first in Scene::objects (no sphere: win = -1, 1e9 > tm)
+                    const int mobj = mesh_obj_of_tri(sc, (int)(unsigned int)m);   // the meshes' own winner: minimum over (t, object position, scan rank) by the order the triangles are stored in
+                    if (mesh_beats_sphere(t_min, win, tm, mobj)) { t_min = tm; win = mobj; tri_win = (int)(unsigned int)m; }   // a tie goes to whichever comes first in Scene::objects (no sphere: win = -1, 1e9 > tm)
                 }
             }
             if (win >= 0) {                                           // a miss is black (cpu:571): nothing to emit
