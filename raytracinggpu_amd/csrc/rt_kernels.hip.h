@@ -7,7 +7,7 @@
 // operation is the same single rounding the reference performs (DESIGN.md
 // "Numerics").  No MFMA: there is no dense contraction on this path.
 //
-// Data layout (built by rt_scene_upload, rt_capi.hip):
+// Data layout (built by rt_scene_upload: install_scene, rt_host_scene.hip.h):
 //   node_lo[n], node_hi[n]  float4 SoA, nodes in TRAVERSAL order (pre-order,
 //        right child first = the order cpu_launcher.cpp:284-293 pops them).
 //        lo = (mn.x, mn.y, mn.z, bits(next-on-miss | tri_start))

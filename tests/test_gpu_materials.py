@@ -117,7 +117,7 @@ def _f32_point(O, t, u):
 
 
 def test_rays_through_a_forest_of_two_meshes(ctx, oracle, cat_golden):
-    """rt_trace_rays over the forest of two cats (rt_capi.hip build_forest) against the oracle's loop over the two meshes in object order (intersect_all of a scene
+    """rt_trace_rays over the forest of two cats (rt_host_scene.hip.h build_forest) against the oracle's loop over the two meshes in object order (intersect_all of a scene
     holding only them): hit flag, P = O + t u and the normal bit for bit -- camera-like rays, rays between the cats, and the degenerate ones (zero / denormal / huge
     components, axis-parallel) for which the box test is least forgiving (the synthetic union nodes above the two roots must never hide a root the reference enters)."""
     v, t = np.asarray(cat_golden["vertices"], np.float32), cat_golden["tri_obj_order"]

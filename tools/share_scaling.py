@@ -5,7 +5,7 @@ small shares until round 4), and round 5's rule for small shares: FOUR frames in
 usage: python tools/share_scaling.py [> profiles/roundN/share_scaling.txt]"""
 import os, sys, time
 os.environ.setdefault("RT_EXPERIMENT", "1")   # the launch-geometry knobs below are honoured only under it
-os.environ.setdefault("RT_PART_PRIO", "1")       # three contexts live in this process (as in a bench.py rank with N > 1): see Knobs::part_prio in rt_capi.hip
+os.environ.setdefault("RT_PART_PRIO", "1")       # three contexts live in this process (as in a bench.py rank with N > 1): see Knobs::part_prio in rt_host_ctx.hip.h
 sys.path.insert(0, os.getcwd())
 import torch
 import raytracinggpu_amd as rt
