@@ -232,7 +232,8 @@ typedef struct rt_work {
                                     * refill rounds, queue fetches, TRI steps (128 triangle tests), BOX steps (64 sibling pairs),
                                     * literal-box fall-backs, serial drains; then blocks a step enters only when some lane needs them:
                                     * t-division blocks of the triangle tests (2 per TRI step at most), first and second leaf-queue
-                                    * push of a BOX step; one reserved.  bench.py prices the vector-issue roofline with them. */
+                                    * push of a BOX step; TRI steps in which a shadow ray stopped at a hit that certainly shades (any-hit; 0 for the
+                                    * binary instantiation, which never stops early).  bench.py prices the vector-issue roofline with them. */
 } rt_work;
 /* The counters describe the REFERENCE-EQUIVALENT traversal (the binary instantiation of the kernel: every box the reference tests, cpu:284-293), whatever
  * kernel produces the frames: with the 16-bit fixed-point pairs (RT_TRAVQ_Q16) or the 4-wide BOX step

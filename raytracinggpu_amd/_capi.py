@@ -417,7 +417,7 @@ class Context:
             return out
         out.update(box_literal=int(w.box_literal), tri_literal=int(w.tri_literal))
         out["steps"] = dict(zip(("iterations", "refill_passes", "refill_rounds", "fetches", "tri_steps", "box_steps", "literal_box_fallbacks", "serial_drains",
-                                 "tdiv_blocks", "leaf_push_blocks", "leaf_push2_blocks", "reserved"),
+                                 "tdiv_blocks", "leaf_push_blocks", "leaf_push2_blocks", "anyhit_stop_steps"),
                                 (int(v) for v in w.steps)))
         return out
 

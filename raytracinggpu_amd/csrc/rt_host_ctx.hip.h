@@ -30,6 +30,8 @@ struct Knobs {
                                // skipped; leaves flagged and decided as the fixed-point pairs decide them; rt_travq.hip.h, QW).  -1 (default) = 1 = on where the tree allows the format (boxes nest, leaves of
                                // at most 127 triangles, fewer than 2^21 nodes), 0 = off.  Bit-exact either way; cat 1920x1080: 0.934 -> 0.861 ms per frame (profiles/round5/ab_wide_nodes.txt)
     int quad_sel = 1;          // RT_TRAVQ_QSEL=0: the quads of the 4-wide step take every other level of the tree (A/B; default: the four nodes a surface-area DP picks, rt_qnodes.hip.h)
+    int anyhit = 1;            // RT_TRAVQ_ANYHIT=0: shadow rays are traced to the end like every other ray (A/B, cross-check; default: the fixed-point traversal kernels stop a shadow ray at the
+                               // first accepted triangle that certainly shades, rt_wavefront.hip.h wf_anyhit_bound).  Bit-exact either way
     int auto_lockstep = 1;     // RT_AUTO_LOCKSTEP=0: RT_VARIANT_AUTO stays the wavefront pipeline for scenes without a mesh (A/B; default: the lock-step kernel renders them)
     int qw_count = 0;          // RT_TRAVQ_QW_COUNT=1: rt_count_work runs the 4-wide kernel's counting instantiation (its own step counters; the box / node counts then describe
                                // THAT kernel, not the reference's traversal)
@@ -79,6 +81,7 @@ static Knobs read_knobs() {
     if (geti("RT_TRAVQ_QW_COUNT", v)) k.qw_count = v != 0;
     if (geti("RT_AUTO_LOCKSTEP", v)) k.auto_lockstep = v != 0;
     if (geti("RT_TRAVQ_QSEL", v)) k.quad_sel = v != 0;
+    if (geti("RT_TRAVQ_ANYHIT", v)) k.anyhit = v != 0;
     if (geti("RT_PARTS", v) && v >= 1 && v <= 8) k.parts = v;
     if (geti("RT_PART_PRIO", v)) k.part_prio = v != 0;
     { const char *e = getenv("RT_CHUNK_MPX"); if (e && *e) { const double d = atof(e); if (d >= 0 && d < 1e4) k.chunk_mpx = d; } }

@@ -97,7 +97,7 @@ struct Frame {
     float4 *out;
     unsigned long long *work;   // STATS kernels only: [24] {rays, box_tests, nodes, tri_tests, invariant mask, literal box tests, literal triangle tests, -,
                                 // wf_travq step counters [8..19]: loop iterations, refill passes, refill rounds, queue fetches, TRI steps, BOX steps, literal-box fall-backs,
-                                // serial drains, t-division blocks, first / second leaf pushes, -}
+                                // serial drains, t-division blocks, first / second leaf pushes, TRI steps that stopped a shadow ray (any-hit)}
     int out_tile0, out_tile_step;   // local row r is stored at output row ((r / tile_rows) * out_tile_step + out_tile0) * tile_rows + r % tile_rows
     // cam_mode 1 = realtime_render.cu's camera and sample averaging (KernelLaunch realtime:1100-1134; wavefront variants only):
     // u_center = C + bz * z + bx * X + by * Y, every sample weighted by inv_n = (float)(1. / num_rays) as it is added
@@ -148,8 +148,9 @@ __device__ __forceinline__ float norm2(f3 a) { return a.x * a.x + a.y * a.y + a.
 // cpu:58-63: three divisions by sqrt(norm2).  The three quotients share one reciprocal (rt_div.h: the compiler's own correctly rounded
 // sequence with its denominator part done once); lanes with a component or a norm outside [2^-60, 2^60] -- zero, denormal, overflowed,
 // NaN -- take the literal divisions behind a wave-uniform branch.
-__device__ __forceinline__ f3 normalize(f3 a) {
+__device__ __forceinline__ f3 normalize(f3 a, float &n_out) {         // n_out: the norm the components were divided by
     const float n = rt_sqrtf(norm2(a));
+    n_out = n;
     float mn, mx;
     asm("v_min3_f32 %0, |%1|, |%2|, |%3|" : "=v"(mn) : "v"(a.x), "v"(a.y), "v"(a.z));
     const bool fast = mn >= kDivLo && n <= kDivHi;                     // n >= every |component| >= 2^-60 then; false for NaN
@@ -161,6 +162,7 @@ __device__ __forceinline__ f3 normalize(f3 a) {
     }
     return q;
 }
+__device__ __forceinline__ f3 normalize(f3 a) { float n; return normalize(a, n); }
 // the same for a vector whose THIRD listed component is the literal +0 (T1 of cpu:634-636: (-Ny, Nx, 0) or (-Nz, 0, Nx)): +0 / n = +0
 // for every n the fast range admits, so only two quotients are formed; (p, q) are the other two components
 __device__ __forceinline__ void normalize_pq0(float p, float q, float &op, float &oq, float &ozero) {

@@ -291,6 +291,12 @@ __device__ __forceinline__ bool qtri_test(const float4 q0, const float4 q1, cons
 // real box of EVERY leaf entry in the TRI step, two gathers and 26 vector instructions per step: 8 % of the cat's frame and a third of a frame of 524 288 triangles,
 // profiles/round5/ab_wide_nodes.txt.)  Work counters of this instantiation differ from the oracle's by construction (no test of the skipped level, a superset of
 // internal nodes entered): the counter tests use the binary instantiation, this one is held to frames and ray counts.
+//
+// ANY-HIT (round 6; the fixed-point instantiations QN / QW).  A shadow ray's record carries a bound (PQ_ANYHIT, wf_anyhit_bound): an ACCEPTED triangle with t at or below
+// it settles cpu:615 whatever else the ray would hit.  The TRI step that accepts such a triangle marks the slot dead by writing -inf over the ray's band (row A, .w): every
+// later BOX step then excludes all boxes of the ray's remaining entries with the comparison it makes anyway (d < -band = +inf), nothing is pushed, the entries drain and
+// the slot retires with what it has -- a hit at or below the bound, which is all the closing launch looks at.  Leaf entries of a dead slot that are already queued
+// shrink to one position (their first triangle).  The bound lives in a register of the lane that owns the slot.  The float-pair instantiation (the counting one: its work counters are the oracle's) never stops early; frames are bit-identical either way.
 template <bool STATS, int R, bool LDSN, bool LDSV, bool QN = false, bool QW = false>
 __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || kQBlock != 256 || QPairs<R>::value > 1 || (QW && kQwTris > 2)) ? 4 : 5) void wf_travq(const Scene sc, const Frame fr, const WfState st, const int cap, const int n_lds, const int kLow, const int kMinFree) {
     // kLow: refill while the stack holds fewer entries (sibling pairs) than this (default 48); kMinFree: ... and at least this
@@ -321,6 +327,7 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
     auto rowD = [&](unsigned int sb) -> float4 & { return *reinterpret_cast<float4 *>(wl + Carve::kTabD + sb); };
     auto pend = [&](unsigned int sb) -> int * { return reinterpret_cast<int *>(wl + Carve::kTabO + sb + 12); };
     auto best = [&](unsigned int sb) -> unsigned long long * { return reinterpret_cast<unsigned long long *>(wl + Carve::kTabD + sb + 8); };
+    auto bandw = [&](unsigned int sb) -> float & { return *reinterpret_cast<float *>(wl + Carve::kTabA + sb + 12); };      // row A's .w: the ray's band; -inf = the slot is dead (any-hit)
     const unsigned int my_sb0 = (unsigned int)lane << 4;           // lane l owns ray slot l (bank 0) and l + 64 (bank 1, R = 128): row offsets
     if (tid == 0) *blk_cur = 0;
     for (int k = 0; k < NT; ++k) marks[lane + 64 * k] = 0;
@@ -339,14 +346,18 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
     float4 sp0 = make_float4(0, 0, 0, 0);         // staged record of this lane (registers; sidx[k] = lane of the k-th staged record)
     float2 sp1 = make_float2(0, 0);
     int spf = 0;
+    float spb = -__builtin_inff();                // ... and its any-hit bound
     const int root_hiw = __float_as_int(sc.root_hi.w);
     int path_[NB];                                // the path index of the ray in each of the lane's slots, -1 = free
     for (int b = 0; b < NB; ++b) path_[b] = -1;
+    float bound_[NB];                             // ... and its any-hit bound (-inf: none; only shadow rays carry one)
+    for (int b = 0; b < NB; ++b) bound_[b] = -__builtin_inff();
     int top = 0;                                  // wave-uniform: entries on the stack
     unsigned int lhead = 0, ltail = 0;            // wave-uniform: leaf-queue cursors (monotonic)
     bool drained = false;
     Work wk;
     unsigned int n_iter = 0, n_refill = 0, n_round = 0, n_fetch = 0, n_tri = 0, n_box = 0, n_lit = 0, n_serial = 0;   // STATS: step counters (wave-uniform)
+    unsigned int n_stop = 0;                                        // STATS: TRI steps in which some lane stopped its ray (any-hit)
     unsigned int n_tdiv = 0, n_lpush = 0, n_lpush2 = 0;             // STATS: conditionally executed blocks of the steps (entered when any lane needs them)
     // optional per-wave record (-DRT_DEBUG builds with RT_DEBUG_TRAV set; tools/dbg_travq.py): st.dbg[16 * wave + k]
 #ifdef RT_DEBUG
@@ -428,6 +439,7 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
                     if (*pend(sbk) == 0) {
                         st.M[path_[b]] = *best(sbk);  // always: the emitter does not initialise M (WF_NOHIT = no triangle accepted)
                         path_[b] = -1;
+                        if (QN) bound_[b] = -__builtin_inff();
                     }
                 }
             }
@@ -452,7 +464,8 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
                         const size_t q = (size_t)blk_base + (size_t)(base + lane);
                         const float4 qb = st.QR[2 * q + 1];             // the slot's 32-byte record: flag and ray in one round trip
                         sp0 = st.QR[2 * q]; sp1 = make_float2(qb.x, qb.y);
-                        spf = wq_live(__float_as_int(qb.z), st.epoch, st.nonce) ? wf_slot_to_path(st, (int)q) + 1 : 0;   // ray + 1 if the slot's record is live for this launch   // ray + 1 if the slot's ray needs traversal
+                        spf = wq_live(__float_as_int(qb.z), st.epoch, st.nonce) ? wf_slot_to_path(st, (int)q) + 1 : 0;   // ray + 1 if the slot's record is live for this launch
+                        if (QN) spb = (__float_as_int(qb.z) & PQ_ANYHIT) ? qb.w : -__builtin_inff();
                     }
                     const unsigned long long am = __ballot(spf != 0);
                     if (spf != 0) sidx[lanes_below(am)] = (unsigned char)lane;
@@ -484,6 +497,7 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
                     const float4 r0 = make_float4(__shfl(sp0.x, src, 64), __shfl(sp0.y, src, 64), __shfl(sp0.z, src, 64), __shfl(sp0.w, src, 64));
                     const float2 r1 = make_float2(__shfl(sp1.x, src, 64), __shfl(sp1.y, src, 64));
                     const int rf = __shfl(spf, src, 64);
+                    const float rb_any = QN ? __shfl(spb, src, 64) : 0.f;
                     if (got) {
                         const f3 O = mk(r0.x, r0.y, r0.z), u = mk(r0.w, r1.x, r1.y);
                         const RayBoxC rb = ray_box_c(O, u, mk(sc.bmx, sc.bmy, sc.bmz), sc.fast_box != 0);
@@ -505,6 +519,7 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
                         rowO(sbk) = make_float4(rb.ox, rb.oy, rb.oz, __int_as_float(work ? 1 : 0));      // .w: one outstanding entry
                         }
                         rowC(sbk) = r0;
+                        if (QN) bound_[b] = rb_any;
                         rowD(sbk) = make_float4(r1.x, r1.y, __uint_as_float(0xffffffffu), __uint_as_float(0xffffffffu));   // .zw: WF_NOHIT
                         path_[b] = rf - 1;
                         WQ_CHECK(path_[b] >= 0 && path_[b] < 2 * st.n_paths, 1, path_[b] = 0);
@@ -546,14 +561,24 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
         // from 736 K to 425 K per frame -- measured SLOWER twice (profiles/round5/ab_wide_nodes.txt): nine / twelve triangle records per lane want 101 / 124 registers (68 spills at a
         // 64-register limit), the launch owns the register file and the other sub-frame's wf_advance no longer fits beside it: the launch alone 0.173 -> 0.167 ms, the frame 0.866 -> 0.882 / 0.953 ms.
         const unsigned int lcount = ltail - lhead;
-        if (lcount >= 64u || (top == 0 && lcount > 0u)) {
+        // a TRI step as soon as 32 leaf entries wait (about the 128 triangles a step takes: the cat's leaves hold 3.9 on average).  Until round 6 it waited for 64: the same frame
+        // time without any-hit (0.848 vs 0.844 ms), but a shadow ray stops the sooner its leaves are tested -- with any-hit 0.830 (64), 0.825 (48), 0.822 (32), 0.829 (24), 0.845 (16)
+#ifndef RT_TRAVQ_TRI_MIN
+#define RT_TRAVQ_TRI_MIN 32
+#endif
+        if (lcount >= (unsigned int)RT_TRAVQ_TRI_MIN || (top == 0 && lcount > 0u)) {
             if (STATS) n_tri++;
             WQ_MARK("tri_begin");
             constexpr unsigned int LIM = 64u * NT;                   // triangles a step takes
             const unsigned int m = lcount < 64u ? lcount : 64u;
             uint2 E = make_uint2(0u, 0u);
             if ((unsigned int)lane < m) E = leafq[(lhead + (unsigned int)lane) & (LCAP - 1)];
-            const unsigned int c = QW ? (E.x >> kQwLeafShift) & 0x7fu : E.y >> kQLeafShift;               // >= 1 for queued entries, 0 beyond them (QW: the entry is (payload word, slot << 4 | flag))
+            unsigned int c = QW ? (E.x >> kQwLeafShift) & 0x7fu : E.y >> kQLeafShift;               // >= 1 for queued entries, 0 beyond them (QW: the entry is (payload word, slot << 4 | flag))
+            if (QN) {              // any-hit: the entry of a dead slot (band = -inf: the only negative one) shrinks to ONE position -- the expansion below wants every entry to own one; what that
+                                   // position accepts joins the slot's minimum, which stays at or below the bound
+                const int band_bits = *reinterpret_cast<const int *>(wl + Carve::kTabA + (E.y & kQSlotMask) + 12);
+                c = band_bits < 0 ? (c < 1u ? c : 1u) : c;
+            }
             if (QW) E.x &= (1u << kQwLeafShift) - 1u;
             const unsigned int incl = wave_incl_scan(c);
             const unsigned int P = incl - c;                         // position of this entry's first triangle
@@ -638,6 +663,19 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
             }
 #pragma unroll
             for (int k = 0; k < NT; ++k) if (ok_[k]) atomicMin(best(o_[k]), (unsigned long long)__float_as_uint(tt_[k]) << 32 | (unsigned int)i_[k]);
+            if (QN) {              // any-hit: every lane looks at ITS slot's nearest accepted hit (after the mins above: LDS operations stay in order); at or below the ray's bound ends the ray
+                WQ_MARK("stop_begin");   // (false for a ray without a bound, -inf, and for a slot without a hit: the high word of WF_NOHIT is a NaN)
+                bool any = false;
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const unsigned int sbk = my_sb0 + 1024u * b;
+                    const bool stop = __uint_as_float(reinterpret_cast<const unsigned int *>(best(sbk))[1]) <= bound_[b];   // (a lane without a ray in the slot holds -inf)
+                    if (stop) bandw(sbk) = -__builtin_inff();
+                    any = any || stop;
+                }
+                if (STATS) n_stop += __ballot(any) != 0ull ? 1u : 0u;
+                WQ_MARK("stop_end");
+            }
             const bool full = part && P + c <= LIM;
             if (part && !full) {                                     // at most one entry straddles position LIM - 1: keep its rest
                 const unsigned int took = LIM - P;
@@ -944,8 +982,8 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
         d[14] = d_fetch; d[15] = d_maxtop;
     }
     if (STATS && lane == 0) {
-        const unsigned int v[11] = {n_iter, n_refill, n_round, n_fetch, n_tri, n_box, n_lit, n_serial, n_tdiv, n_lpush, n_lpush2};
-        for (int k = 0; k < 11; ++k) if (v[k]) atomicAdd(&fr.work[8 + k], (unsigned long long)v[k]);
+        const unsigned int v[12] = {n_iter, n_refill, n_round, n_fetch, n_tri, n_box, n_lit, n_serial, n_tdiv, n_lpush, n_lpush2, n_stop};
+        for (int k = 0; k < 12; ++k) if (v[k]) atomicAdd(&fr.work[8 + k], (unsigned long long)v[k]);
     }
     wf_flush_work<STATS>(fr, wk);
 }

@@ -49,7 +49,7 @@ constexpr int PF_XSPHERE = 1 << 26;                         // the X ray is bloc
 constexpr unsigned long long WF_NOHIT = ~0ull;
 // the wavefront pipeline keeps the path's flag word in its continuation (Y) slot's queue record; bits 0..15 as above, then:
 constexpr int PQ_WIN_SHIFT = 16;                            // 5 bits: object id + 1 of the Y ray's nearest sphere (0 = none); its t is the record's last word
-// (bit 21 is free: until round 5 it said whether that sphere comes after the mesh in object order; the object ids are compared when the query is closed)
+constexpr int PQ_ANYHIT = 1 << 21;                          // (X slot only) the record's last word is the shadow ray's ANY-HIT bound: see wf_anyhit_bound
 constexpr int PQ_XSPHERE = 1 << 22;                         // PF_XSPHERE of this record
 constexpr int PQ_REFR_SHIFT = 23;                           // 6 bits: Ray::refraction_index of the Y ray: 0 = 1.0, else (object id + 1) << 1 | (0: that object's n_in, 1: its n_out)
 constexpr int PQ_TRAV = 1 << 29;                            // (either slot) the record's ray passed the mesh's root box: the traversal launch whose number (WfState::epoch) equals the
@@ -62,6 +62,19 @@ constexpr int PQ_LIVE_MASK = (int)((unsigned)PQ_TRAV | ((unsigned)PF_DEPTH_MASK 
 // ray went to the mesh (PF_MESHX)
 __device__ __forceinline__ bool wq_live(int w0, int epoch, int nonce) {
     return (w0 & PQ_LIVE_MASK) == (int)((unsigned)PQ_TRAV | (unsigned)epoch << PF_DEPTH_SHIFT | (unsigned)nonce << PQ_NONCE_SHIFT);
+}
+
+// ANY-HIT bound of a shadow ray.  cpu:615 asks whether |P' - Pa|^2 <= |L - Pa|^2 for P' = Pa + t_min u, the NEAREST hit of the shadow ray (Pa = P_adjusted, u = (L - Pa) /
+// |L - Pa|), and uses nothing else of that hit.  Every rounding on the left is monotone in t (fl(t u_k), fl(Pa_k + .), fl(. - Pa_k), the squares, the sums: the magnitude of
+// each component grows with t, see the comment at the close of the X query in wf_advance_path), so the comparison holds for the nearest hit iff it holds for SOME accepted
+// hit: a traversal that has accepted one triangle whose t certainly passes may stop -- the frame cannot tell.  "Certainly": with nl = fl(sqrt(fl|L - Pa|^2)) (the value
+// normalize() divides by), g_k = fl(fl(Pa_k + fl(t u_k)) - Pa_k) obeys |g_k| <= t |u_k| (1 + 3 * 2^-24) + 2^-24 (1 + 2^-23) |Pa_k|, |u| <= 1 + 2^-22, so the left side's
+// square root is at most t (1 + 2^-20) + 2^-22 |Pa|_1, while the right side's is at least nl (1 - 2^-24).  Any t <= nl (1 - 2^-15) - 2^-20 |Pa|_1 is therefore inside with
+// a margin of more than 2^-16 nl (the bound's own two roundings are 2^-24 each); hits between this bound and the light (a band 3e-5 of the distance wide) simply do not stop
+// the traversal, whose complete result then decides as before.  -inf = never (a light at the surface or beyond 1e30, NaN anywhere: every comparison with it is false).
+__device__ __forceinline__ float wf_anyhit_bound(f3 Pa, float nl) {
+    const float b = fmaf(nl, 1.f - 0x1p-15f, -0x1p-20f * ((fabsf(Pa.x) + fabsf(Pa.y)) + fabsf(Pa.z)));
+    return (nl > 1e-18f && nl < 1e30f) ? b : -__builtin_inff();
 }
 
 // A BATCH of frames in one launch chain (rt_render_device_batch): the items of a chain are (frame f, pixel slot) pairs -- the machinery that traces several samples of a pixel
@@ -100,12 +113,13 @@ struct WfState {
     int epoch;                // index of the traversal launch inside its chain (0 after wf_advance<FIRST>): a queue record is live iff its flag word carries PQ_TRAV and this number
     int init_m;               // the traversal kernel merges partial results with atomicMin (wf_trav's work splitting): emitters initialise M
     unsigned long long *dbg;  // optional per-wave debug record (-DRT_DEBUG)
+    int anyhit;               // shadow rays carry their any-hit bound (PQ_ANYHIT): the fixed-point instantiations of wf_travq stop a shadow ray at the first accepted triangle that certainly shades
     const BatchFrame *batch;  // rt_render_device_batch: n_batch frame descriptors in device memory (item i belongs to frame i / n_px); nullptr / 0 = the launch's own camera, seed, output
     int n_batch;
     // traversal queue: the rays in TRAVERSAL-SLOT order, so that the slots a traversal workgroup owns are contiguous and one
     // round trip brings flag and record
     float4 *QR;               // [2 slots] record of slot q: QR[2q] = (O.xyz, u.x), QR[2q+1] = (u.y, u.z, bits(W0), W1).  Y slot (ray r < n_paths): W0 = the path's
-                              // flag word (PF_* | PQ_*; 0 = no path), W1 = t of the Y ray's nearest sphere; X slot: W0 = PQ_TRAV | depth | chain number, written only when the ray needs traversal
+                              // flag word (PF_* | PQ_*; 0 = no path), W1 = t of the Y ray's nearest sphere; X slot: W0 = PQ_TRAV | depth | chain number (| PQ_ANYHIT: W1 = the any-hit bound), written only when the ray needs traversal
 };
 
 // n / d for 0 <= n < 2^32 with m = floor(2^32 / d) from the host: the estimate mulhi(n, m) is the quotient or one below it
@@ -520,6 +534,7 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
     int refr_code = FIRST ? 0 : (F >> PQ_REFR_SHIFT) & 63;            // Ray::refraction_index = 1 (cpu:100)
     int d = 0, nrays = 0;
     bool emitY = false, emitX = false, finished = false;
+    float x_bound = -__builtin_inff();                                // any-hit bound of the shadow ray (wf_anyhit_bound)
     f3 Oy = mk(0, 0, 0), uy = mk(0, 0, 1), Ox = mk(0, 0, 0), ux = mk(0, 0, 1);
     int px, lrow; bool valid;
     int s_rel = 0;
@@ -658,7 +673,9 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
                     ADV_MARK("diffuse_begin");
                     const f3 Pa = P + fr.eps * N;
                     const f3 toL = L - Pa;
-                    Ox = Pa; ux = normalize(toL);   // = toL / sqrt(norm2(toL))         // NORMED_VEC, cpu:614: the shadow ray of segment d
+                    float nl;
+                    Ox = Pa; ux = normalize(toL, nl);   // = toL / nl, nl = sqrt(norm2(toL))     // NORMED_VEC, cpu:614: the shadow ray of segment d
+                    x_bound = wf_anyhit_bound(Pa, nl);
                     emitX = true;
                     nrays += 1;
                     // the segment's direct term if the light turns out to be visible (cpu:620-623); kept until the shadow ray is back
@@ -747,7 +764,7 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
         if (wf_root_test<STATS>(sc, st, rx, Ox, ux, wk)) {             // only then does anybody read the record: the traversal, and this kernel if the mesh is hit
             flags |= PF_MESHX;
             st.QR[2 * (size_t)qx] = make_float4(Ox.x, Ox.y, Ox.z, ux.x);
-            st.QR[2 * (size_t)qx + 1] = make_float4(ux.y, ux.z, __int_as_float((int)((unsigned)(PQ_TRAV | (d << PF_DEPTH_SHIFT)) | (unsigned)st.nonce << PQ_NONCE_SHIFT)), 0.f);
+            st.QR[2 * (size_t)qx + 1] = make_float4(ux.y, ux.z, __int_as_float((int)((unsigned)(PQ_TRAV | (st.anyhit ? PQ_ANYHIT : 0) | (d << PF_DEPTH_SHIFT)) | (unsigned)st.nonce << PQ_NONCE_SHIFT)), x_bound);
         }
     }
     if (emitY) {
