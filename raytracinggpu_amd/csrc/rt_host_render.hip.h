@@ -480,7 +480,7 @@ int launch_render_chunk(rt_ctx *ctx, const rt_params *p, const rt_rows *rows, vo
             st.LS = static_cast<float *>(ctx->wfLS.p) + pt.base * (size_t)nseg;   // LS[d * n_paths + i] inside the part's block
             st.SID = static_cast<unsigned char *>(ctx->wfSID.p) + pt.base * (size_t)nseg;
             st.batch = nullptr; st.n_batch = 0;
-            st.anyhit = ctx->knobs.anyhit;
+            st.anyhit = (kn.anyhit && (work_dev == nullptr || qw)) ? 1 : 0;   // a run that counts the REFERENCE's work (the float-pair counting instantiation) traces every shadow ray to the end
         }
         if (batch) {
             // the frames' descriptors live in device memory, one copy PER SUB-FRAME, written by a one-wave kernel at the head of that sub-frame's own chain (below): a chain is

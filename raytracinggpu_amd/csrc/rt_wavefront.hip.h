@@ -113,7 +113,8 @@ struct WfState {
     int epoch;                // index of the traversal launch inside its chain (0 after wf_advance<FIRST>): a queue record is live iff its flag word carries PQ_TRAV and this number
     int init_m;               // the traversal kernel merges partial results with atomicMin (wf_trav's work splitting): emitters initialise M
     unsigned long long *dbg;  // optional per-wave debug record (-DRT_DEBUG)
-    int anyhit;               // shadow rays carry their any-hit bound (PQ_ANYHIT): the fixed-point instantiations of wf_travq stop a shadow ray at the first accepted triangle that certainly shades
+    int anyhit;               // shadow rays carry their any-hit bound (PQ_ANYHIT): the fixed-point instantiations of wf_travq stop a shadow ray at the first accepted triangle that certainly
+                              // shades, and a shadow ray that a sphere shades already is not traced through the mesh
     const BatchFrame *batch;  // rt_render_device_batch: n_batch frame descriptors in device memory (item i belongs to frame i / n_px); nullptr / 0 = the launch's own camera, seed, output
     int n_batch;
     // traversal queue: the rays in TRAVERSAL-SLOT order, so that the slots a traversal workgroup owns are contiguous and one
@@ -760,8 +761,9 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
         const float tS = hx.t;                                        // only the value of the shadow ray's nearest hit matters
         const f3 Pp = Ox + tS * ux;                                   // cpu:560
         flags |= PF_HASX;
-        if (norm2(Pp - Ox) <= norm2(L - Ox)) flags |= PQ_XSPHERE;      // cpu:615 holds for the sphere already (the mesh is still intersected, as intersect_all does)
-        if (wf_root_test<STATS>(sc, st, rx, Ox, ux, wk)) {             // only then does anybody read the record: the traversal, and this kernel if the mesh is hit
+        if (norm2(Pp - Ox) <= norm2(L - Ox)) flags |= PQ_XSPHERE;      // cpu:615 holds for the sphere already: whatever the mesh says, the segment is shaded (the comparison is monotone in t)
+        // ... so with any-hit on that ray is not traced through the mesh at all (intersect_all does: a run that counts the reference's work has any-hit off)
+        if ((!(flags & PQ_XSPHERE) || !st.anyhit) && wf_root_test<STATS>(sc, st, rx, Ox, ux, wk)) {   // only then does anybody read the record: the traversal, and this kernel if the mesh is hit
             flags |= PF_MESHX;
             st.QR[2 * (size_t)qx] = make_float4(Ox.x, Ox.y, Ox.z, ux.x);
             st.QR[2 * (size_t)qx + 1] = make_float4(ux.y, ux.z, __int_as_float((int)((unsigned)(PQ_TRAV | (st.anyhit ? PQ_ANYHIT : 0) | (d << PF_DEPTH_SHIFT)) | (unsigned)st.nonce << PQ_NONCE_SHIFT)), x_bound);

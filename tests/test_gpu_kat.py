@@ -340,13 +340,15 @@ def test_kat_error_paths(ctx):
     assert out.shape == (0,) and cnt["n"] == 0
 
 
-@pytest.mark.parametrize("light", [(-10.0, 20.0, 40.0), (0.0, 6.0, 9.0), (3.0, -9.5, 12.0), (0.0, 3e18, 0.0)], ids=["reference", "beside_the_cat", "on_the_floor", "far_away"])
-def test_shadow_rays_stop_at_the_first_hit_that_certainly_shades(oracle, cat_golden, monkeypatch, light):
+@pytest.mark.parametrize("light,ball", [((-10.0, 20.0, 40.0), None), ((0.0, 6.0, 9.0), None), ((3.0, -9.5, 12.0), None), ((0.0, 3e18, 0.0), None), ((-10.0, 20.0, 40.0), ((-6.0, 9.0, 24.0), 5.0))],
+                         ids=["reference", "beside_the_cat", "on_the_floor", "far_away", "ball_before_the_cat"])
+def test_shadow_rays_stop_at_the_first_hit_that_certainly_shades(oracle, cat_golden, monkeypatch, light, ball):
     """Any-hit (round 6): cpu:615 looks at nothing but whether the shadow ray's NEAREST hit lies before the light, a comparison that is monotone in t -- so the fixed-point
     traversal kernels stop a shadow ray at the first accepted triangle whose t is certainly inside (wf_anyhit_bound) instead of tracing it to the end.  For four lights -- the
-    reference's, one beside the cat (many triangles BEHIND the light: they must not shade), one a hand above the floor, one 3e18 away -- the frames are word for word those of
+    reference's, one beside the cat (many triangles BEHIND the light: they must not shade), one a hand above the floor, one 3e18 away (outside the room: the ceiling shades everything) -- the frames are word for word those of
     a context that never stops early (RT_TRAVQ_ANYHIT=0) through the 4-wide step and through the fixed-point pairs, the direct-lighting frame is the oracle's bit for bit, and
-    the step counters say the rays did stop (and never do with the knob off, nor in the float-pair kernel whose work counters are the oracle's)."""
+    the step counters say the rays did stop (and never do with the knob off, nor in the float-pair kernel whose work counters are the oracle's).  Fifth case: a ball between
+    the light and the cat -- shadow rays the ball shades already are not traced through the mesh at all with any-hit on (the reference-equivalent work counters still count them)."""
     mesh = dict(vertices=cat_golden["vertices"], indices=cat_golden["tri_bvh_order"], bvh_arr10=cat_golden["bvh_arr10"], albedo=rt.scenes.CAT_ALBEDO, object_slot=6)
     monkeypatch.setenv("RT_TRAVQ_QW_COUNT", "1")                       # rt_count_work reports the production kernel's own steps
     on = rt.Context(0)
@@ -357,10 +359,13 @@ def test_shadow_rays_stop_at_the_first_hit_that_certainly_shades(oracle, cat_gol
     off = rt.Context(0)
     monkeypatch.delenv("RT_TRAVQ_ANYHIT"); monkeypatch.delenv("RT_TRAVQ_QW_COUNT")
     W, H = 480, 270
+    spheres = list(rt.scenes.spheres("cpu")) + ([(ball[0], ball[1], (0.6, 0.5, 0.4))] if ball else [])
     for c in (on, pairs, off):
-        c.scene_upload(rt.scenes.spheres("cpu"), mesh, light=(light, 3e10))
+        c.scene_upload(spheres, mesh, light=(light, 3e10))
     om = oracle.Mesh.from_arrays(cat_golden["vertices"], cat_golden["tri_obj_order"]).build_bvh()
     osc = oracle.Scene.preset("cpu", om); osc.set_light(light, 3e10)
+    if ball:
+        osc.add_sphere(ball[0], ball[1], (0.6, 0.5, 0.4))               # object 7, after the walls (0-5) and the mesh (6): the order scene_upload gives it too
     exp0, _, _ = osc.render(W, H, 1, 0, want_rgb8=False)
     p0 = rt.make_params(W, H, 1, 0, **rt.scenes.CPU_LAUNCHER)
     p3 = rt.make_params(W, H, 2, 3, **rt.scenes.CPU_LAUNCHER)
@@ -374,6 +379,17 @@ def test_shadow_rays_stop_at_the_first_hit_that_certainly_shades(oracle, cat_gol
     assert on.stats()["travq_mode"] == 2 and pairs.stats()["travq_mode"] == 1 and off.stats()["travq_mode"] == 2
     s_on, s_off = on.count_work(p3, detail=True)["steps"], off.count_work(p3, detail=True)["steps"]
     assert s_off["anyhit_stop_steps"] == 0
-    assert s_on["anyhit_stop_steps"] > 0 and s_on["tri_steps"] < s_off["tri_steps"]
+    if ball:                                                            # the reference's work on this scene, whatever the product skips
+        plain = rt.Context(0)                                           # (the knobs are read when a context is created: this one counts the reference-equivalent traversal)
+        plain.scene_upload(spheres, mesh, light=(light, 3e10))
+        _, _, cnt = osc.render(W, H, 1, 1, want_rgb8=False)
+        assert plain.count_work(rt.make_params(W, H, 1, 1, **rt.scenes.CPU_LAUNCHER)) == {k: cnt[k] for k in ("rays", "box_tests", "nodes", "tri_tests")}
+        np.testing.assert_array_equal(plain.render(p3).view(np.uint32), ref3.view(np.uint32))
+        plain.close()
+        assert s_on["fetches"] > 0 and s_on["box_steps"] < s_off["box_steps"]
+    if light[1] > 1e6:                                                  # a light outside the room: the ceiling shades every shadow ray, none is traced through the mesh
+        assert s_on["anyhit_stop_steps"] == 0 and s_on["box_steps"] < s_off["box_steps"] and s_on["tri_steps"] < s_off["tri_steps"]
+    else:
+        assert s_on["anyhit_stop_steps"] > 0 and s_on["tri_steps"] < s_off["tri_steps"]
     for c in (on, pairs, off):
         c.close()

@@ -152,14 +152,21 @@ def test_lbvh_large_mesh_bit_exact_and_much_less_work(ctx, oracle, n, monkeypatc
     assert st["device_build_ms"] < 50.0
     # the 4-wide kernel's OWN counting instantiation on this tree (RT_TRAVQ_QW_COUNT=1: every index that reaches an address is checked, rt_count_work fails if one is out of range):
     # the rays it retires are the frame's, its BOX steps are four boxes wide (fewer than a quarter of the reference-equivalent box tests per 64 lanes), nothing was walked serially
+    # (with shadow rays traced to the end, RT_TRAVQ_ANYHIT=0: it enters a superset of the reference's leaves; with any-hit, the default, it queues fewer triangles than that)
     monkeypatch.setenv("RT_TRAVQ_QW_COUNT", "1")
-    c2 = rt.Context(0)
-    c2.scene_upload(rt.scenes.spheres("cpu"), first)
-    c2.mesh_rebuild(len(up), mode="lbvh")
-    own = c2.count_work(p0, detail=True)
-    c2.close()
+    owns = {}
+    for anyhit in ("0", "1"):
+        monkeypatch.setenv("RT_TRAVQ_ANYHIT", anyhit)
+        c2 = rt.Context(0)
+        c2.scene_upload(rt.scenes.spheres("cpu"), first)
+        c2.mesh_rebuild(len(up), mode="lbvh")
+        owns[anyhit] = c2.count_work(p0, detail=True)
+        c2.close()
+    monkeypatch.delenv("RT_TRAVQ_ANYHIT")
+    own = owns["0"]
     assert own["rays"] == work["rays"] and own["tri_tests"] >= work["tri_tests"]
     assert 0 < own["steps"]["box_steps"] * 64 * 4 < 2 * work["box_tests"] and own["steps"]["serial_drains"] == 0
+    assert owns["1"]["rays"] == work["rays"] and owns["1"]["tri_tests"] <= own["tri_tests"] and owns["1"]["steps"]["serial_drains"] == 0
 
 
 def _displaced_grid(n, seed=11):
