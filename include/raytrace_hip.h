@@ -237,7 +237,9 @@ typedef struct rt_work {
 } rt_work;
 /* The counters describe the REFERENCE-EQUIVALENT traversal (the binary instantiation of the kernel: every box the reference tests, cpu:284-293), whatever
  * kernel produces the frames: with the 16-bit fixed-point pairs (RT_TRAVQ_Q16) or the 4-wide BOX step
- * (RT_TRAVQ_QW) the production kernel enters a superset of the internal nodes and skips levels, and its own visits are not what box_tests / nodes
+ * (RT_TRAVQ_QW) the production kernel enters a superset of the internal nodes and skips levels, stops a shadow ray at the first accepted triangle that certainly
+ * shades and does not trace a shadow ray that a sphere shades already (any-hit, RT_TRAVQ_ANYHIT=0 turns both off: cpu:615 is monotone in the nearest hit's t, so the
+ * frame is the same bit for bit), and its own visits are not what box_tests / nodes / tri_tests
  * report -- unless RT_TRAVQ_QW_COUNT=1 asks for the 4-wide kernel's own counting instantiation (experiments).
  * With several meshes (rt_scene_upload_meshes) the tree in use holds synthetic union nodes above the meshes' roots: box_tests / nodes count those too (one test of the
  * forest's root where the reference tests every mesh's root, cpu:279), tri_tests are the reference's. */

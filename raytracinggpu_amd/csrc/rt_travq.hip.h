@@ -574,10 +574,10 @@ __global__ __launch_bounds__((LDSN || LDSV) ? 1024 : kQBlock, (LDSN || LDSV || k
             uint2 E = make_uint2(0u, 0u);
             if ((unsigned int)lane < m) E = leafq[(lhead + (unsigned int)lane) & (LCAP - 1)];
             unsigned int c = QW ? (E.x >> kQwLeafShift) & 0x7fu : E.y >> kQLeafShift;               // >= 1 for queued entries, 0 beyond them (QW: the entry is (payload word, slot << 4 | flag))
-            if (QN) {              // any-hit: the entry of a dead slot (band = -inf: the only negative one) shrinks to ONE position -- the expansion below wants every entry to own one; what that
-                                   // position accepts joins the slot's minimum, which stays at or below the bound
-                const int band_bits = *reinterpret_cast<const int *>(wl + Carve::kTabA + (E.y & kQSlotMask) + 12);
-                c = band_bits < 0 ? (c < 1u ? c : 1u) : c;
+            if (QN) {              // any-hit: the entry of a dead slot (band = -inf, nothing else writes that value: bands are positive, +inf or -- a ray with a NaN -- NaN) shrinks to ONE
+                                   // position -- the expansion below wants every entry to own one; what that position accepts joins the slot's minimum, which stays at or below the bound
+                const unsigned int band_bits = *reinterpret_cast<const unsigned int *>(wl + Carve::kTabA + (E.y & kQSlotMask) + 12);
+                c = band_bits == 0xff800000u ? (c < 1u ? c : 1u) : c;
             }
             if (QW) E.x &= (1u << kQwLeafShift) - 1u;
             const unsigned int incl = wave_incl_scan(c);
