@@ -855,7 +855,10 @@ def main():
                           + (f", one gather ({backend}) of the {'RGB8' if rgb8 else 'float4'} tiles to {'a rotating root' if rotate else 'rank 0'} per "
                              f"{'batch of ' + str(main_pt.batch) + ' frames' if getattr(main_pt, 'bx', False) else 'frame'}" if world > 1 else ""),
                           "variant": ctx.stats()["variant"] if ctx else None, "device": ctx.device_name if ctx else "cpu (oracle stand-in: not a measurement)",
-                          "primary_Msamples_per_s": round(W * H * args.spp / (elapsed / args.steps) / 1e6, 1)}}
+                          "primary_Msamples_per_s": round(W * H * args.spp / (elapsed / args.steps) / 1e6, 1),
+                          "shadow_rays": ("traced to the end (RT_TRAVQ_ANYHIT=0)" if os.environ.get("RT_TRAVQ_ANYHIT", "1") == "0" else
+                                          "any-hit: a shadow ray stops at the first accepted triangle that certainly lies before the light (cpu:615 is monotone in the nearest hit's t: "
+                                          "frames bit-identical to RT_TRAVQ_ANYHIT=0, which costs +3 %: profiles/round6/ab_anyhit.txt); every ray is still one intersect_all call of the count")}}
         if frame_ok is not None:
             res["config"]["frame_equals_single_device_frame"] = frame_ok
         if comm is not None:
