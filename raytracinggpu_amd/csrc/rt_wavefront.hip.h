@@ -71,10 +71,11 @@ __device__ __forceinline__ bool wq_live(int w0, int epoch, int nonce) {
 // normalize() divides by), g_k = fl(fl(Pa_k + fl(t u_k)) - Pa_k) obeys |g_k| <= t |u_k| (1 + 3 * 2^-24) + 2^-24 (1 + 2^-23) |Pa_k|, |u| <= 1 + 2^-22, so the left side's
 // square root is at most t (1 + 2^-20) + 2^-22 |Pa|_1, while the right side's is at least nl (1 - 2^-24).  Any t <= nl (1 - 2^-15) - 2^-20 |Pa|_1 is therefore inside with
 // a margin of more than 2^-16 nl (the bound's own two roundings are 2^-24 each); hits between this bound and the light (a band 3e-5 of the distance wide) simply do not stop
-// the traversal, whose complete result then decides as before.  -inf = never (a light at the surface or beyond 1e30, NaN anywhere: every comparison with it is false).
+// the traversal, whose complete result then decides as before.  -inf = never (a light within 1e-12 of the surface or so far that the squared distance overflows; with a NaN
+// anywhere the bound is a NaN or -inf: every comparison with it is false).
 __device__ __forceinline__ float wf_anyhit_bound(f3 Pa, float nl) {
     const float b = fmaf(nl, 1.f - 0x1p-15f, -0x1p-20f * ((fabsf(Pa.x) + fabsf(Pa.y)) + fabsf(Pa.z)));
-    return (nl > 1e-18f && nl < 1e30f) ? b : -__builtin_inff();
+    return (nl > 1e-12f && nl < 1e30f) ? b : -__builtin_inff();      // (above 1e-12 no square that matters to the budget is denormal; a finite nl is below 1.9e19 anyway: beyond it |L - Pa|^2 is +inf)
 }
 
 // A BATCH of frames in one launch chain (rt_render_device_batch): the items of a chain are (frame f, pixel slot) pairs -- the machinery that traces several samples of a pixel
