@@ -393,3 +393,35 @@ def test_shadow_rays_stop_at_the_first_hit_that_certainly_shades(oracle, cat_gol
         assert s_on["anyhit_stop_steps"] > 0 and s_on["tri_steps"] < s_off["tri_steps"]
     for c in (on, pairs, off):
         c.close()
+
+
+def test_any_hit_changes_no_bit_on_random_scenes(monkeypatch):
+    """Differential run of the any-hit rule: twelve random scenes -- the synthetic meshes of test_gpu_parity (single-leaf trees, zero-thickness boxes, triangle soups, deep
+    chains, flat faces), a light anywhere in the room including inside the mesh's box and a hair above a wall, sometimes a ball in the way, sometimes a mirror or glass mesh
+    (then few shadow rays leave it) -- each rendered at 2 samples, 3 bounces by a default context and by one created under RT_TRAVQ_ANYHIT=0: every word of every frame equal."""
+    from .test_gpu_parity import _synthetic_mesh
+    on = rt.Context(0)
+    monkeypatch.setenv("RT_TRAVQ_ANYHIT", "0")
+    off = rt.Context(0)
+    monkeypatch.delenv("RT_TRAVQ_ANYHIT")
+    rng = np.random.default_rng(20261005)
+    kinds = ["three_triangles", "axis_aligned_quads", "soup", "deep_strip", "geometric_chain", "flat_faces"]
+    p = rt.make_params(256, 144, 2, 3, **rt.scenes.CPU_LAUNCHER)
+    differing_lights, modes = 0, []
+    for k in range(12):
+        v, t = _synthetic_mesh(kinds[k % 6], np.random.default_rng(100 + k))
+        mesh = hostlib.build_mesh(v, t, albedo=(0.3, 0.4, 0.5), object_slot=6)
+        if k % 4 == 3:
+            mesh.update(mirror=int(k % 8 == 3), in_refraction_index=1.0 if k % 8 == 3 else 1.4, out_refraction_index=1.0)
+        light = [(-10.0, 20.0, 40.0), tuple(rng.uniform(-8, 8, 3)), (float(rng.uniform(-20, 20)), -9.99, float(rng.uniform(0, 30))), tuple(v[rng.integers(len(v))] + np.float32(0.01))][k % 4]
+        spheres = list(rt.scenes.spheres("cpu")) + ([(tuple(rng.uniform(-10, 10, 3)), float(rng.uniform(1, 4)), (0.5, 0.5, 0.5))] if k % 3 == 0 else [])
+        for c in (on, off):
+            c.scene_upload(spheres, mesh, light=(tuple(float(x) for x in light), 3e10))
+        a, b = on.render(p), off.render(p)
+        np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32), err_msg=f"scene {k}: {kinds[k % 6]}, light {light}")
+        differing_lights += int(np.isfinite(a[..., :3]).all())
+        modes.append(on.stats()["travq_mode"])
+    print("traversal kernel form per scene (2 = 4-wide fixed-point step, 1 = fixed-point pairs, 0 = float pairs: no any-hit there):", modes)
+    assert differing_lights >= 8                                        # (a light ON a vertex may give inf / NaN pixels in both: still equal word for word)
+    assert sum(m >= 1 for m in modes) >= 8                              # the rule was in play: only the single-leaf trees run the float pairs
+    on.close(); off.close()
