@@ -115,7 +115,7 @@ struct WfState {
     int init_m;               // the traversal kernel merges partial results with atomicMin (wf_trav's work splitting): emitters initialise M
     unsigned long long *dbg;  // optional per-wave debug record (-DRT_DEBUG)
     int anyhit;               // shadow rays carry their any-hit bound (PQ_ANYHIT): the fixed-point instantiations of wf_travq stop a shadow ray at the first accepted triangle that certainly
-                              // shades, and a shadow ray that a sphere shades already is not traced through the mesh
+                              // shades; a shadow ray that a sphere shades already is not traced through the mesh; a shadow ray whose segment has the direct term +0 either way is not traced
     const BatchFrame *batch;  // rt_render_device_batch: n_batch frame descriptors in device memory (item i belongs to frame i / n_px); nullptr / 0 = the launch's own camera, seed, output
     int n_batch;
     // traversal queue: the rays in TRAVERSAL-SLOT order, so that the slots a traversal workgroup owns are contiguous and one
@@ -537,6 +537,7 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
     int d = 0, nrays = 0;
     bool emitY = false, emitX = false, finished = false;
     float x_bound = -__builtin_inff();                                // any-hit bound of the shadow ray (wf_anyhit_bound)
+    bool x_moot = false;                                              // the shadow ray's answer cannot reach the pixel (direct term +0 either way)
     f3 Oy = mk(0, 0, 0), uy = mk(0, 0, 1), Ox = mk(0, 0, 0), ux = mk(0, 0, 1);
     int px, lrow; bool valid;
     int s_rel = 0;
@@ -678,13 +679,21 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
                     float nl;
                     Ox = Pa; ux = normalize(toL, nl);   // = toL / nl, nl = sqrt(norm2(toL))     // NORMED_VEC, cpu:614: the shadow ray of segment d
                     x_bound = wf_anyhit_bound(Pa, nl);
-                    emitX = true;
                     nrays += 1;
                     // the segment's direct term if the light turns out to be visible (cpu:620-623); kept until the shadow ray is back
                     const f3 wl = normalize(L - P);
                     const float dn = dot(N, wl);
                     const float mx = (dn < 0.f) ? 0.f : dn;
-                    st.LS[(size_t)d * st.n_paths + i] = (float)((double)sc.intensity / (4 * PI_D * (double)norm2(L - P)) * (double)mx);
+                    const float lvis = (float)((double)sc.intensity / (4 * PI_D * (double)norm2(L - P)) * (double)mx);
+                    st.LS[(size_t)d * st.n_paths + i] = lvis;
+                    // A surface that faces away from the light (mx = 0) has the direct term +0 whether the light is visible or not: shaded, cpu:616 stores the literal 0; lit,
+                    // cpu:623 computes l = +0 -- the same 32 bits (a NaN or a -0 from a degenerate light is not +0 and keeps its ray).  The reference still calls intersect_all
+                    // for it (the ray is counted), but nothing of its answer can reach the pixel: with any-hit on the ray is neither set up nor traced.  These are the shadow
+                    // rays that start on the mesh's far side and run through its whole body: 4.7 % of a headline frame's traversal work.
+                    // (The path still spends a launch on the ray -- PF_HASX without PF_MESHX, closed as a ray that missed the mesh -- so that it finishes in the launch it always
+                    // finished in: folding a launch early costs the uniform kernel more than the traversal saves.)
+                    emitX = true;
+                    x_moot = st.anyhit && __float_as_uint(lvis) == 0u;
                     sid = win;
                     ADV_MARK("diffuse_end");
                     if (d + 1 < fr.segs) {                            // the bounce ray (cpu:627-642): needs r1, r2 and N only
@@ -755,16 +764,16 @@ __device__ __forceinline__ void wf_advance_path(const Scene &sc, const Frame &fr
     int flags = PF_ALIVE | (d << PF_DEPTH_SHIFT) | (nrays << PF_RAYS_SHIFT) | (refr_code << PQ_REFR_SHIFT) | (int)((unsigned)st.nonce << PQ_NONCE_SHIFT);
     SphereNear h, hx;
     ADV_MARK("spheres_begin");
-    spheres_near2(sc, emitX ? Ox : Oy, uy, emitY, ux, emitX, h, hx);   // a shadow ray and a bounce ray leave the same point (Oy == Ox == P_adjusted)
+    spheres_near2(sc, emitX ? Ox : Oy, uy, emitY, ux, emitX && !x_moot, h, hx);   // a shadow ray and a bounce ray leave the same point (Oy == Ox == P_adjusted)
     ADV_MARK("spheres_end");
     float t_sph = 0.f;
     if (emitX) {
         const float tS = hx.t;                                        // only the value of the shadow ray's nearest hit matters
         const f3 Pp = Ox + tS * ux;                                   // cpu:560
         flags |= PF_HASX;
-        if (norm2(Pp - Ox) <= norm2(L - Ox)) flags |= PQ_XSPHERE;      // cpu:615 holds for the sphere already: whatever the mesh says, the segment is shaded (the comparison is monotone in t)
+        if (!x_moot && norm2(Pp - Ox) <= norm2(L - Ox)) flags |= PQ_XSPHERE;      // cpu:615 holds for the sphere already: whatever the mesh says, the segment is shaded (the comparison is monotone in t)
         // ... so with any-hit on that ray is not traced through the mesh at all (intersect_all does: a run that counts the reference's work has any-hit off)
-        if ((!(flags & PQ_XSPHERE) || !st.anyhit) && wf_root_test<STATS>(sc, st, rx, Ox, ux, wk)) {   // only then does anybody read the record: the traversal, and this kernel if the mesh is hit
+        if (!x_moot && (!(flags & PQ_XSPHERE) || !st.anyhit) && wf_root_test<STATS>(sc, st, rx, Ox, ux, wk)) {   // only then does anybody read the record: the traversal, and this kernel if the mesh is hit
             flags |= PF_MESHX;
             st.QR[2 * (size_t)qx] = make_float4(Ox.x, Ox.y, Ox.z, ux.x);
             st.QR[2 * (size_t)qx + 1] = make_float4(ux.y, ux.z, __int_as_float((int)((unsigned)(PQ_TRAV | (st.anyhit ? PQ_ANYHIT : 0) | (d << PF_DEPTH_SHIFT)) | (unsigned)st.nonce << PQ_NONCE_SHIFT)), x_bound);
