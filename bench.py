@@ -858,7 +858,7 @@ def main():
                           "primary_Msamples_per_s": round(W * H * args.spp / (elapsed / args.steps) / 1e6, 1),
                           "shadow_rays": ("traced to the end (RT_TRAVQ_ANYHIT=0)" if os.environ.get("RT_TRAVQ_ANYHIT", "1") == "0" else
                                           "any-hit: a shadow ray stops at the first accepted triangle that certainly lies before the light (cpu:615 is monotone in the nearest hit's t: "
-                                          "frames bit-identical to RT_TRAVQ_ANYHIT=0, which costs +3 %: profiles/round6/ab_anyhit.txt); every ray is still one intersect_all call of the count")}}
+                                          "and a shadow ray whose answer cannot reach the pixel -- a sphere shades it already, or the segment's direct term is +0 either way -- is not traced through the mesh; frames bit-identical to RT_TRAVQ_ANYHIT=0, which costs +4.5 %: profiles/round6/ab_anyhit.txt); every ray is still one intersect_all call of the count")}}
         if frame_ok is not None:
             res["config"]["frame_equals_single_device_frame"] = frame_ok
         if comm is not None:
